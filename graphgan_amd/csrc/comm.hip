@@ -1,0 +1,126 @@
+// comm.hip -- C1: gradient exchange between the per-GPU replicas over RCCL / xGMI.
+//
+// The reference is single-device (one tf.Session, src/GraphGAN/graph_gan.py:57-61); sharding
+// roots over GPUs is new.  One process per GPU; every optimizer step sums
+// the dense gradient accumulators (gradE [n_node*ld], gradb [n_node]) of all ranks with
+// ncclAllReduce on the context's own HIP stream, so the update kernels that follow on the
+// same stream see the global gradient and every replica applies the identical update.
+//
+// librccl is dlopen'ed on first use: a single-GPU run never loads it.
+#include <dlfcn.h>
+#include <string.h>
+
+#include "gg_internal.h"
+
+namespace gg {
+
+typedef struct { char internal[128]; } RcclUniqueId;
+typedef int (*fn_GetUniqueId)(RcclUniqueId *);
+typedef int (*fn_CommInitRank)(void **, int, RcclUniqueId, int);
+typedef int (*fn_CommDestroy)(void *);
+typedef int (*fn_AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t);
+typedef const char *(*fn_GetErrorString)(int);
+
+struct RcclApi {
+    void *handle = nullptr;
+    fn_GetUniqueId GetUniqueId = nullptr;
+    fn_CommInitRank CommInitRank = nullptr;
+    fn_CommDestroy CommDestroy = nullptr;
+    fn_AllReduce AllReduce = nullptr;
+    fn_GetErrorString GetErrorString = nullptr;
+};
+
+static RcclApi g_rccl;
+constexpr int NCCL_FLOAT32 = 7;  // ncclFloat32
+constexpr int NCCL_SUM = 0;      // ncclSum
+
+static int load_rccl(gg_ctx *ctx) {
+    if (g_rccl.handle) return GG_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return fail(ctx, GG_ECOMM, "cannot dlopen librccl: %s", dlerror());
+    RcclApi api;
+    api.handle = h;
+    api.GetUniqueId = (fn_GetUniqueId)dlsym(h, "ncclGetUniqueId");
+    api.CommInitRank = (fn_CommInitRank)dlsym(h, "ncclCommInitRank");
+    api.CommDestroy = (fn_CommDestroy)dlsym(h, "ncclCommDestroy");
+    api.AllReduce = (fn_AllReduce)dlsym(h, "ncclAllReduce");
+    api.GetErrorString = (fn_GetErrorString)dlsym(h, "ncclGetErrorString");
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.GetErrorString)
+        return fail(ctx, GG_ECOMM, "librccl is missing a required symbol");
+    g_rccl = api;
+    return GG_OK;
+}
+
+#define GG_NCCL(ctx, call)                                                                              \
+    do {                                                                                                \
+        int r__ = (call);                                                                               \
+        if (r__ != 0) return fail(ctx, GG_ECOMM, "%s -> %s", #call, g_rccl.GetErrorString(r__));        \
+    } while (0)
+
+int comm_allreduce_grads(gg_ctx *ctx) {
+    if (ctx->world <= 1 || !ctx->comm) return GG_OK;
+    const size_t ne = (size_t)ctx->n_node * ctx->ld;
+    GG_NCCL(ctx, g_rccl.AllReduce(ctx->gradE, ctx->gradE, ne, NCCL_FLOAT32, NCCL_SUM, ctx->comm, ctx->stream));
+    GG_NCCL(ctx, g_rccl.AllReduce(ctx->gradb, ctx->gradb, (size_t)ctx->n_node, NCCL_FLOAT32, NCCL_SUM, ctx->comm, ctx->stream));
+    return GG_OK;
+}
+
+void comm_destroy(gg_ctx *ctx) {
+    if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+    ctx->world = 1;
+    ctx->rank = 0;
+}
+
+}  // namespace gg
+
+using namespace gg;
+
+extern "C" {
+
+int gg_comm_unique_id(void *id128) {
+    if (!id128) return fail(nullptr, GG_EINVAL, "gg_comm_unique_id: NULL");
+    int rc = load_rccl(nullptr);
+    if (rc != GG_OK) return rc;
+    RcclUniqueId id;
+    GG_NCCL(nullptr, g_rccl.GetUniqueId(&id));
+    memcpy(id128, &id, sizeof(id));
+    return GG_OK;
+}
+
+int gg_comm_init(gg_ctx *ctx, const void *id128, int32_t rank, int32_t world) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    GG_CHECK(ctx, id128 && world >= 1 && rank >= 0 && rank < world, GG_EINVAL, "gg_comm_init: bad argument");
+    GG_CHECK(ctx, !ctx->comm, GG_EINVAL, "gg_comm_init: already initialised");
+    if (world == 1) return GG_OK;
+    int rc = load_rccl(ctx);
+    if (rc != GG_OK) return rc;
+    GG_HIP(ctx, hipSetDevice(ctx->device));
+    RcclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    void *comm = nullptr;
+    GG_NCCL(ctx, g_rccl.CommInitRank(&comm, world, id, rank));
+    ctx->comm = comm;
+    ctx->rank = rank;
+    ctx->world = world;
+    return GG_OK;
+}
+
+int gg_comm_barrier(gg_ctx *ctx) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    GG_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->world > 1 && ctx->comm) {
+        // a 4-byte all-reduce on the (idle) touched_cnt scratch word [3]
+        float *w = (float *)(ctx->touched_cnt + 3);
+        GG_NCCL(ctx, g_rccl.AllReduce(w, w, 1, NCCL_FLOAT32, NCCL_SUM, ctx->comm, ctx->stream));
+    }
+    GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,465 @@
+// gg_api.hip -- context life cycle, graph / tree residency, walk_sample entry point,
+// variable fetch / restore.  The C ABI is include/graphgan_hip.h; each function there cites
+// the reference interface it replaces.
+#include <stdarg.h>
+#include <string.h>
+
+#include <algorithm>
+#include <thread>
+
+#include "gg_internal.h"
+
+namespace gg {
+
+thread_local std::string g_last_error;
+
+int fail(gg_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+int64_t host_tree_sizes(int32_t n, const int64_t *rowptr, const int32_t *col, const int32_t *roots, int32_t n_roots,
+                        int64_t *nbr_base);
+void host_fill_trees(int32_t n, const int64_t *rowptr, const int32_t *col, const int32_t *roots, int32_t r0, int32_t r1,
+                     const int64_t *nbr_base, int32_t *off, int32_t off_row0, int32_t *nbr, int64_t nbr_origin,
+                     int32_t n_threads, int32_t *max_depth_out, int32_t *max_list_out);
+
+static void free_trees(gg_ctx *ctx) {
+    if (ctx->t_root) (void)hipFree(ctx->t_root);
+    if (ctx->t_off) (void)hipFree(ctx->t_off);
+    if (ctx->t_nbr) (void)hipFree(ctx->t_nbr);
+    if (ctx->t_base) (void)hipFree(ctx->t_base);
+    ctx->t_root = ctx->t_off = ctx->t_nbr = nullptr;
+    ctx->t_base = nullptr;
+    ctx->n_tree_roots = 0;
+    ctx->tree_entries = 0;
+    ctx->tree_max_depth = ctx->tree_max_list = 0;
+    ctx->h_troot.clear();
+}
+
+static int alloc_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int64_t *nbr_base) {
+    free_trees(ctx);
+    const int64_t entries = nbr_base[n_roots];
+    GG_HIP(ctx, hipMalloc((void **)&ctx->t_root, sizeof(int32_t) * std::max(n_roots, 1)));
+    GG_HIP(ctx, hipMalloc((void **)&ctx->t_off, sizeof(int32_t) * (size_t)std::max(n_roots, 1) * (ctx->n_node + 1)));
+    GG_HIP(ctx, hipMalloc((void **)&ctx->t_nbr, sizeof(int32_t) * (size_t)std::max<int64_t>(entries, 1)));
+    GG_HIP(ctx, hipMalloc((void **)&ctx->t_base, sizeof(int64_t) * (n_roots + 1)));
+    GG_HIP(ctx, hipMemcpyAsync(ctx->t_root, roots, sizeof(int32_t) * n_roots, hipMemcpyHostToDevice, ctx->stream));
+    GG_HIP(ctx, hipMemcpyAsync(ctx->t_base, nbr_base, sizeof(int64_t) * (n_roots + 1), hipMemcpyHostToDevice, ctx->stream));
+    GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_tree_roots = n_roots;
+    ctx->tree_entries = entries;
+    ctx->h_troot.assign(roots, roots + n_roots);
+    return GG_OK;
+}
+
+static int upload_table(gg_ctx *ctx, float *dst, const float *src) {
+    const int n = ctx->n_node, d = ctx->n_emb, ld = ctx->ld;
+    if (ld == d) {
+        GG_HIP(ctx, hipMemcpy(dst, src, sizeof(float) * (size_t)n * d, hipMemcpyHostToDevice));
+    } else {
+        GG_HIP(ctx, hipMemset(dst, 0, sizeof(float) * (size_t)n * ld));
+        GG_HIP(ctx, hipMemcpy2D(dst, sizeof(float) * ld, src, sizeof(float) * d, sizeof(float) * d, n, hipMemcpyHostToDevice));
+    }
+    return GG_OK;
+}
+
+}  // namespace gg
+
+using namespace gg;
+
+// Shared by gg_walk_sample and gg_prepare_*: stage the launch on device, run, leave the
+// results resident.  n_walks == NULL: CSR degree of each slot's root (D-mode, graph_gan.py:190-191).
+int gg::walk_resident(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, int32_t uniform_walks, int32_t n_slots,
+                  int32_t for_d, uint64_t seed, uint32_t stream, int32_t stride) {
+    GG_CHECK(ctx, ctx->n_tree_roots > 0, GG_EINVAL, "walk: no trees loaded (gg_build_trees / gg_set_trees)");
+    GG_CHECK(ctx, n_slots >= 0 && (slots || n_slots == 0), GG_EINVAL, "walk: bad slots");
+    GG_CHECK(ctx, stride >= 2, GG_ECAPACITY, "walk: stride %d < 2", stride);
+    std::vector<int64_t> ptr(n_slots + 1, 0);
+    for (int i = 0; i < n_slots; ++i) {
+        GG_CHECK(ctx, slots[i] >= 0 && slots[i] < ctx->n_tree_roots, GG_EINVAL, "walk: slot %d out of range", slots[i]);
+        int64_t nw;
+        if (n_walks) nw = n_walks[i];
+        else if (uniform_walks >= 0) nw = uniform_walks;
+        else {
+            GG_CHECK(ctx, !ctx->h_rowptr.empty(), GG_EINVAL, "walk: graph CSR needed for D-mode degrees");
+            const int r = ctx->h_troot[slots[i]];
+            nw = ctx->h_rowptr[r + 1] - ctx->h_rowptr[r];
+        }
+        GG_CHECK(ctx, nw >= 0, GG_EINVAL, "walk: negative n_walks");
+        ptr[i + 1] = ptr[i] + nw;
+    }
+    const int64_t total = ptr[n_slots];
+    GG_HIP(ctx, hipSetDevice(ctx->device));
+    GG_HIP(ctx, ctx->w_slots.reserve(sizeof(int32_t) * (n_slots + 1)));
+    GG_HIP(ctx, ctx->w_ptr.reserve(sizeof(int64_t) * (n_slots + 1)));
+    GG_HIP(ctx, ctx->w_status.reserve(sizeof(int32_t) * (n_slots + 1)));
+    GG_HIP(ctx, ctx->w_abort.reserve(sizeof(int32_t) * (n_slots + 1)));
+    GG_HIP(ctx, ctx->w_samples.reserve(sizeof(int32_t) * (total + 1)));
+    GG_HIP(ctx, ctx->w_len.reserve(sizeof(int32_t) * (total + 1)));
+    GG_HIP(ctx, ctx->w_first.reserve(sizeof(int32_t) * (total + 1)));
+    GG_HIP(ctx, ctx->w_paths.reserve(sizeof(int32_t) * ((size_t)total * stride + 1)));
+    if (n_slots) GG_HIP(ctx, hipMemcpyAsync(ctx->w_slots.p, slots, sizeof(int32_t) * n_slots, hipMemcpyHostToDevice, ctx->stream));
+    GG_HIP(ctx, hipMemcpyAsync(ctx->w_ptr.p, ptr.data(), sizeof(int64_t) * (n_slots + 1), hipMemcpyHostToDevice, ctx->stream));
+    GG_HIP(ctx, hipStreamSynchronize(ctx->stream));  // ptr is a local
+    ctx->w_total = total;
+    ctx->w_stride = stride;
+    ctx->w_nslots = n_slots;
+    if (n_slots == 0) return GG_OK;
+    int rc = launch_walk_sample(ctx, n_slots, total, for_d, seed, stream, stride);
+    if (rc != GG_OK) return rc;
+    GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long c[4];
+    GG_HIP(ctx, hipMemcpy(c, ctx->dev_ctr, sizeof(c), hipMemcpyDeviceToHost));
+    ctx->ctr.hops = (int64_t)c[0];
+    ctx->ctr.nbr_reads = (int64_t)c[1];
+    ctx->ctr.walks += total;
+    if (total) {
+        float ms = 0.f;
+        GG_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        ctx->ctr.last_kernel_ms = ms;
+        ctx->ctr.walk_kernel_ms += ms;
+        ctx->ctr.walk_launches += 1;
+    }
+    if (c[3]) {
+        unsigned long long z = 0;
+        (void)hipMemcpy(ctx->dev_ctr + 3, &z, sizeof(z), hipMemcpyHostToDevice);
+        return fail(ctx, GG_ECAPACITY, "walk: a path needed more than stride=%d entries", stride);
+    }
+    return GG_OK;
+}
+
+
+extern "C" {
+
+int gg_abi_version(void) { return GG_ABI_VERSION; }
+
+const char *gg_last_error(const gg_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int gg_create(int32_t n_node, int32_t n_emb, const float *emb_gen, const float *emb_dis, const gg_config *cfg,
+              gg_ctx **out) {
+    if (!out) return fail(nullptr, GG_EINVAL, "gg_create: out is NULL");
+    *out = nullptr;
+    if (n_node <= 0 || n_emb <= 0 || n_emb > 512 || !emb_gen || !emb_dis || !cfg)
+        return fail(nullptr, GG_EINVAL, "gg_create: bad argument (n_node=%d n_emb=%d)", n_node, n_emb);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, GG_EHIP, "gg_create: no HIP device (%s); this engine has no CPU fallback",
+                    e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, GG_EINVAL, "gg_create: device %d of %d", cfg->device, ndev);
+    hipDeviceProp_t prop;
+    GG_HIP(nullptr, hipGetDeviceProperties(&prop, cfg->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, GG_EHIP, "gg_create: device %d is %s; kernels are built for gfx950 only", cfg->device, prop.gcnArchName);
+    GG_HIP(nullptr, hipSetDevice(cfg->device));
+
+    gg_ctx *ctx = new gg_ctx();
+    ctx->n_node = n_node;
+    ctx->n_emb = n_emb;
+    ctx->ld = (n_emb + 3) / 4 * 4;
+    ctx->cfg = *cfg;
+    ctx->device = cfg->device;
+#define GG_TRY(call)                        \
+    do {                                    \
+        int rc__ = (call);                  \
+        if (rc__ != GG_OK) {                \
+            g_last_error = ctx->err;        \
+            gg_destroy(ctx);                \
+            return rc__;                    \
+        }                                   \
+    } while (0)
+    auto body = [&]() -> int {
+        GG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        GG_HIP(ctx, hipEventCreate(&ctx->ev0));
+        GG_HIP(ctx, hipEventCreate(&ctx->ev1));
+        const size_t tb = sizeof(float) * (size_t)n_node * ctx->ld, vb = sizeof(float) * (size_t)n_node;
+        for (int m = 0; m < 2; ++m) {
+            Model &M = ctx->model[m];
+            GG_HIP(ctx, hipMalloc((void **)&M.E, tb));
+            GG_HIP(ctx, hipMalloc((void **)&M.b, vb));
+            GG_HIP(ctx, hipMemset(M.b, 0, vb));
+            if (cfg->optimizer != GG_OPT_SGD) {
+                GG_HIP(ctx, hipMalloc((void **)&M.mE, tb));
+                GG_HIP(ctx, hipMalloc((void **)&M.vE, tb));
+                GG_HIP(ctx, hipMalloc((void **)&M.mb, vb));
+                GG_HIP(ctx, hipMalloc((void **)&M.vb, vb));
+                GG_HIP(ctx, hipMemset(M.mE, 0, tb));
+                GG_HIP(ctx, hipMemset(M.vE, 0, tb));
+                GG_HIP(ctx, hipMemset(M.mb, 0, vb));
+                GG_HIP(ctx, hipMemset(M.vb, 0, vb));
+            }
+            M.b1p = cfg->adam_beta1;
+            M.b2p = cfg->adam_beta2;
+            M.lr = m == 0 ? cfg->lr_gen : cfg->lr_dis;
+            M.lambda = m == 0 ? cfg->lambda_gen : cfg->lambda_dis;
+            int rc = upload_table(ctx, M.E, m == 0 ? emb_gen : emb_dis);
+            if (rc != GG_OK) return rc;
+        }
+        GG_HIP(ctx, hipMalloc((void **)&ctx->gradE, tb));
+        GG_HIP(ctx, hipMalloc((void **)&ctx->gradb, vb));
+        GG_HIP(ctx, hipMemset(ctx->gradE, 0, tb));
+        GG_HIP(ctx, hipMemset(ctx->gradb, 0, vb));
+        GG_HIP(ctx, hipMalloc((void **)&ctx->touched, sizeof(int32_t) * n_node));
+        GG_HIP(ctx, hipMalloc((void **)&ctx->touched_list, sizeof(int32_t) * n_node));
+        GG_HIP(ctx, hipMalloc((void **)&ctx->touched_cnt, sizeof(int32_t) * 4));
+        GG_HIP(ctx, hipMemset(ctx->touched, 0, sizeof(int32_t) * n_node));
+        GG_HIP(ctx, hipMemset(ctx->touched_cnt, 0, sizeof(int32_t) * 4));
+        GG_HIP(ctx, hipMalloc((void **)&ctx->dev_ctr, sizeof(unsigned long long) * 8));
+        GG_HIP(ctx, hipMemset(ctx->dev_ctr, 0, sizeof(unsigned long long) * 8));
+        GG_HIP(ctx, hipDeviceSynchronize());
+        return GG_OK;
+    };
+    GG_TRY(body());
+#undef GG_TRY
+    *out = ctx;
+    return GG_OK;
+}
+
+int gg_destroy(gg_ctx *ctx) {
+    if (!ctx) return GG_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    comm_destroy(ctx);
+    for (int m = 0; m < 2; ++m) {
+        Model &M = ctx->model[m];
+        float *ps[] = {M.E, M.b, M.mE, M.vE, M.mb, M.vb};
+        for (float *p : ps)
+            if (p) (void)hipFree(p);
+    }
+    void *ps[] = {ctx->gradE, ctx->gradb, ctx->touched, ctx->touched_list, ctx->touched_cnt, ctx->g_rowptr, ctx->g_col, ctx->dev_ctr};
+    for (void *p : ps)
+        if (p) (void)hipFree(p);
+    free_trees(ctx);
+    DevBuf *bufs[] = {&ctx->w_slots, &ctx->w_nwalks, &ctx->w_ptr, &ctx->w_samples, &ctx->w_paths, &ctx->w_len, &ctx->w_status,
+                      &ctx->w_first, &ctx->w_abort, &ctx->w_scratch, &ctx->d_center, &ctx->d_neighbor, &ctx->d_label, &ctx->d_cnt,
+                      &ctx->d_ptr, &ctx->g_node1, &ctx->g_node2, &ctx->g_reward, &ctx->g_cnt, &ctx->g_ptr, &ctx->scan_tmp,
+                      &ctx->step_u, &ctx->step_v, &ctx->step_x, &ctx->starts_buf, &ctx->misc};
+    for (DevBuf *b : bufs) b->release();
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return GG_OK;
+}
+
+int gg_set_graph_csr(gg_ctx *ctx, const int64_t *rowptr, const int32_t *col) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    GG_CHECK(ctx, rowptr && rowptr[0] == 0, GG_EINVAL, "gg_set_graph_csr: rowptr[0] must be 0");
+    const int n = ctx->n_node;
+    const int64_t nnz = rowptr[n];
+    GG_CHECK(ctx, nnz >= 0 && (col || nnz == 0), GG_EINVAL, "gg_set_graph_csr: col is NULL");
+    for (int v = 0; v < n; ++v) GG_CHECK(ctx, rowptr[v + 1] >= rowptr[v], GG_EINVAL, "gg_set_graph_csr: rowptr not monotone at %d", v);
+    for (int64_t e = 0; e < nnz; ++e) GG_CHECK(ctx, col[e] >= 0 && col[e] < n, GG_EINVAL, "gg_set_graph_csr: col[%lld]=%d out of range", (long long)e, col[e]);
+    GG_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->g_rowptr) (void)hipFree(ctx->g_rowptr);
+    if (ctx->g_col) (void)hipFree(ctx->g_col);
+    ctx->g_rowptr = nullptr;
+    ctx->g_col = nullptr;
+    GG_HIP(ctx, hipMalloc((void **)&ctx->g_rowptr, sizeof(int64_t) * (n + 1)));
+    GG_HIP(ctx, hipMalloc((void **)&ctx->g_col, sizeof(int32_t) * std::max<int64_t>(nnz, 1)));
+    GG_HIP(ctx, hipMemcpy(ctx->g_rowptr, rowptr, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
+    if (nnz) GG_HIP(ctx, hipMemcpy(ctx->g_col, col, sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
+    ctx->g_nnz = nnz;
+    ctx->h_rowptr.assign(rowptr, rowptr + n + 1);
+    ctx->h_col.assign(col, col + nnz);
+    return GG_OK;
+}
+
+int gg_build_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, int32_t n_threads) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    GG_CHECK(ctx, !ctx->h_rowptr.empty(), GG_EINVAL, "gg_build_trees: call gg_set_graph_csr first");
+    GG_CHECK(ctx, n_roots >= 0 && (roots || n_roots == 0), GG_EINVAL, "gg_build_trees: bad roots");
+    const int n = ctx->n_node;
+    for (int r = 0; r < n_roots; ++r) GG_CHECK(ctx, roots[r] >= 0 && roots[r] < n, GG_EINVAL, "gg_build_trees: root %d out of range", roots[r]);
+    GG_HIP(ctx, hipSetDevice(ctx->device));
+    if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    std::vector<int64_t> base(n_roots + 1);
+    host_tree_sizes(n, ctx->h_rowptr.data(), ctx->h_col.data(), roots, n_roots, base.data());
+    int rc = alloc_trees(ctx, roots, n_roots, base.data());
+    if (rc != GG_OK) return rc;
+    // batches of roots bounded by ~256 MiB of host staging
+    const int64_t budget = 64ll << 20;  // int32 entries
+    int32_t md = 0, ml = 0;
+    std::vector<int32_t> off_h, nbr_h;
+    for (int r0 = 0; r0 < n_roots;) {
+        int r1 = r0 + 1;
+        while (r1 < n_roots && (base[r1 + 1] - base[r0]) + (int64_t)(r1 + 1 - r0) * (n + 1) <= budget) ++r1;
+        off_h.resize((size_t)(r1 - r0) * (n + 1));
+        nbr_h.resize((size_t)(base[r1] - base[r0]));
+        host_fill_trees(n, ctx->h_rowptr.data(), ctx->h_col.data(), roots, r0, r1, base.data(), off_h.data(), r0, nbr_h.data(),
+                        base[r0], n_threads, &md, &ml);
+        GG_HIP(ctx, hipMemcpy(ctx->t_off + (size_t)r0 * (n + 1), off_h.data(), sizeof(int32_t) * off_h.size(), hipMemcpyHostToDevice));
+        if (!nbr_h.empty())
+            GG_HIP(ctx, hipMemcpy(ctx->t_nbr + base[r0], nbr_h.data(), sizeof(int32_t) * nbr_h.size(), hipMemcpyHostToDevice));
+        r0 = r1;
+    }
+    ctx->tree_max_depth = md;
+    ctx->tree_max_list = ml;
+    return GG_OK;
+}
+
+int gg_set_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int32_t *off, const int32_t *nbr,
+                 const int64_t *nbr_base, int32_t max_depth) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    GG_CHECK(ctx, n_roots >= 0 && roots && off && nbr_base && (nbr || nbr_base[n_roots] == 0), GG_EINVAL, "gg_set_trees: bad argument");
+    const int n = ctx->n_node;
+    GG_HIP(ctx, hipSetDevice(ctx->device));
+    int32_t ml = 0;
+    for (int r = 0; r < n_roots; ++r) {
+        GG_CHECK(ctx, roots[r] >= 0 && roots[r] < n, GG_EINVAL, "gg_set_trees: root out of range");
+        const int32_t *o = off + (size_t)r * (n + 1);
+        GG_CHECK(ctx, o[0] == 0 && o[n] == nbr_base[r + 1] - nbr_base[r], GG_EINVAL, "gg_set_trees: offsets of slot %d inconsistent", r);
+        for (int v = 0; v < n; ++v) {
+            GG_CHECK(ctx, o[v + 1] >= o[v], GG_EINVAL, "gg_set_trees: offsets not monotone");
+            ml = std::max(ml, o[v + 1] - o[v]);
+        }
+    }
+    int rc = alloc_trees(ctx, roots, n_roots, nbr_base);
+    if (rc != GG_OK) return rc;
+    GG_HIP(ctx, hipMemcpy(ctx->t_off, off, sizeof(int32_t) * (size_t)n_roots * (n + 1), hipMemcpyHostToDevice));
+    if (nbr_base[n_roots])
+        GG_HIP(ctx, hipMemcpy(ctx->t_nbr, nbr, sizeof(int32_t) * (size_t)nbr_base[n_roots], hipMemcpyHostToDevice));
+    ctx->tree_max_depth = max_depth > 0 ? max_depth : n;
+    ctx->tree_max_list = ml;
+    return GG_OK;
+}
+
+int gg_tree_info(const gg_ctx *ctx, int32_t *n_roots, int64_t *n_entries, int32_t *max_depth) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    if (n_roots) *n_roots = ctx->n_tree_roots;
+    if (n_entries) *n_entries = ctx->tree_entries;
+    if (max_depth) *max_depth = ctx->tree_max_depth;
+    return GG_OK;
+}
+
+int gg_get_trees(gg_ctx *ctx, int32_t *off, int32_t *nbr, int64_t *nbr_base) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    GG_CHECK(ctx, ctx->n_tree_roots > 0, GG_EINVAL, "gg_get_trees: no trees loaded");
+    GG_HIP(ctx, hipSetDevice(ctx->device));
+    GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (off) GG_HIP(ctx, hipMemcpy(off, ctx->t_off, sizeof(int32_t) * (size_t)ctx->n_tree_roots * (ctx->n_node + 1), hipMemcpyDeviceToHost));
+    if (nbr && ctx->tree_entries) GG_HIP(ctx, hipMemcpy(nbr, ctx->t_nbr, sizeof(int32_t) * (size_t)ctx->tree_entries, hipMemcpyDeviceToHost));
+    if (nbr_base) GG_HIP(ctx, hipMemcpy(nbr_base, ctx->t_base, sizeof(int64_t) * (ctx->n_tree_roots + 1), hipMemcpyDeviceToHost));
+    return GG_OK;
+}
+
+int gg_walk_sample(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, int32_t n_slots, int32_t for_d,
+                   uint64_t seed, uint32_t stream, int32_t *samples, int32_t *paths, int32_t *path_len, int32_t stride,
+                   int32_t *root_status) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    GG_CHECK(ctx, n_walks || n_slots == 0, GG_EINVAL, "gg_walk_sample: n_walks is NULL");
+    int rc = walk_resident(ctx, slots, n_walks, -1, n_slots, for_d ? 1 : 0, seed, stream, stride);
+    if (rc != GG_OK) return rc;
+    const int64_t total = ctx->w_total;
+    if (samples && total) GG_HIP(ctx, hipMemcpy(samples, ctx->w_samples.p, sizeof(int32_t) * total, hipMemcpyDeviceToHost));
+    if (path_len && total) GG_HIP(ctx, hipMemcpy(path_len, ctx->w_len.p, sizeof(int32_t) * total, hipMemcpyDeviceToHost));
+    if (paths && total) GG_HIP(ctx, hipMemcpy(paths, ctx->w_paths.p, sizeof(int32_t) * (size_t)total * stride, hipMemcpyDeviceToHost));
+    if (root_status && n_slots) GG_HIP(ctx, hipMemcpy(root_status, ctx->w_status.p, sizeof(int32_t) * n_slots, hipMemcpyDeviceToHost));
+    return GG_OK;
+}
+
+static int table_io(gg_ctx *ctx, int32_t which, float *out, const float *in, bool bias) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    GG_CHECK(ctx, which == 0 || which == 1, GG_EINVAL, "which must be 0 (gen) or 1 (dis)");
+    GG_CHECK(ctx, out || in, GG_EINVAL, "buffer is NULL");
+    GG_HIP(ctx, hipSetDevice(ctx->device));
+    GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    Model &M = ctx->model[which];
+    const int n = ctx->n_node, d = ctx->n_emb, ld = ctx->ld;
+    if (bias) {
+        if (out) GG_HIP(ctx, hipMemcpy(out, M.b, sizeof(float) * n, hipMemcpyDeviceToHost));
+        else GG_HIP(ctx, hipMemcpy(M.b, in, sizeof(float) * n, hipMemcpyHostToDevice));
+    } else if (out) {
+        GG_HIP(ctx, hipMemcpy2D(out, sizeof(float) * d, M.E, sizeof(float) * ld, sizeof(float) * d, n, hipMemcpyDeviceToHost));
+    } else {
+        return upload_table(ctx, M.E, in);
+    }
+    return GG_OK;
+}
+
+int gg_get_embeddings(gg_ctx *ctx, int32_t which, float *out) { return table_io(ctx, which, out, nullptr, false); }
+int gg_get_bias(gg_ctx *ctx, int32_t which, float *out) { return table_io(ctx, which, out, nullptr, true); }
+int gg_set_embeddings(gg_ctx *ctx, int32_t which, const float *emb) { return table_io(ctx, which, nullptr, emb, false); }
+int gg_set_bias(gg_ctx *ctx, int32_t which, const float *bias) { return table_io(ctx, which, nullptr, bias, true); }
+
+int gg_get_counters(gg_ctx *ctx, gg_counters *out) {
+    if (!ctx || !out) return fail(ctx, GG_EINVAL, "gg_get_counters: NULL argument");
+    *out = ctx->ctr;
+    return GG_OK;
+}
+
+}  // extern "C"
+
+// ---- tf.train.Saver replacement (graph_gan.py:55,124-127,137-138).  Flat binary:
+// header {magic "GGST", version, n_node, n_emb, ld, optimizer} then for gen, dis:
+// {t, beta1_power, beta2_power, E[n*ld], b[n], (mE, vE, mb, vb unless SGD)} -- fp32 little endian.
+namespace {
+struct StateHeader {
+    char magic[4];
+    int32_t version, n_node, n_emb, ld, optimizer;
+};
+
+int io_dev(gg_ctx *ctx, FILE *f, float *dev, size_t count, bool save, std::vector<float> &tmp) {
+    tmp.resize(count);
+    if (save) {
+        GG_HIP(ctx, hipMemcpy(tmp.data(), dev, sizeof(float) * count, hipMemcpyDeviceToHost));
+        if (fwrite(tmp.data(), sizeof(float), count, f) != count) return gg::fail(ctx, GG_EIO, "state: short write");
+    } else {
+        if (fread(tmp.data(), sizeof(float), count, f) != count) return gg::fail(ctx, GG_EIO, "state: short read");
+        GG_HIP(ctx, hipMemcpy(dev, tmp.data(), sizeof(float) * count, hipMemcpyHostToDevice));
+    }
+    return GG_OK;
+}
+
+int state_io(gg_ctx *ctx, const char *path, bool save) {
+    if (!ctx) return gg::fail(nullptr, GG_EINVAL, "ctx is NULL");
+    GG_CHECK(ctx, path, GG_EINVAL, "state: path is NULL");
+    GG_HIP(ctx, hipSetDevice(ctx->device));
+    GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FILE *f = fopen(path, save ? "wb" : "rb");
+    if (!f) return gg::fail(ctx, GG_EIO, "state: cannot open %s", path);
+    StateHeader h{{'G', 'G', 'S', 'T'}, 1, ctx->n_node, ctx->n_emb, ctx->ld, ctx->cfg.optimizer};
+    int rc = GG_OK;
+    if (save) {
+        if (fwrite(&h, sizeof(h), 1, f) != 1) rc = gg::fail(ctx, GG_EIO, "state: short write");
+    } else {
+        StateHeader g;
+        if (fread(&g, sizeof(g), 1, f) != 1 || memcmp(g.magic, "GGST", 4) != 0 || g.version != 1)
+            rc = gg::fail(ctx, GG_EIO, "state: %s is not a GGST v1 file", path);
+        else if (g.n_node != h.n_node || g.n_emb != h.n_emb || g.ld != h.ld || (g.optimizer == GG_OPT_SGD) != (h.optimizer == GG_OPT_SGD))
+            rc = gg::fail(ctx, GG_EINVAL, "state: shape/optimizer mismatch (file %dx%d opt %d)", g.n_node, g.n_emb, g.optimizer);
+    }
+    std::vector<float> tmp;
+    const size_t ne = (size_t)ctx->n_node * ctx->ld, nb = (size_t)ctx->n_node;
+    for (int m = 0; m < 2 && rc == GG_OK; ++m) {
+        gg::Model &M = ctx->model[m];
+        struct { int64_t t; float b1p, b2p; } sc{M.t, M.b1p, M.b2p};
+        if (save) {
+            if (fwrite(&sc, sizeof(sc), 1, f) != 1) rc = gg::fail(ctx, GG_EIO, "state: short write");
+        } else {
+            if (fread(&sc, sizeof(sc), 1, f) != 1) rc = gg::fail(ctx, GG_EIO, "state: short read");
+            else { M.t = sc.t; M.b1p = sc.b1p; M.b2p = sc.b2p; }
+        }
+        if (rc == GG_OK) rc = io_dev(ctx, f, M.E, ne, save, tmp);
+        if (rc == GG_OK) rc = io_dev(ctx, f, M.b, nb, save, tmp);
+        if (ctx->cfg.optimizer != GG_OPT_SGD) {
+            if (rc == GG_OK) rc = io_dev(ctx, f, M.mE, ne, save, tmp);
+            if (rc == GG_OK) rc = io_dev(ctx, f, M.vE, ne, save, tmp);
+            if (rc == GG_OK) rc = io_dev(ctx, f, M.mb, nb, save, tmp);
+            if (rc == GG_OK) rc = io_dev(ctx, f, M.vb, nb, save, tmp);
+        }
+    }
+    fclose(f);
+    return rc;
+}
+}  // namespace
+
+extern "C" int gg_save_state(gg_ctx *ctx, const char *path) { return state_io(ctx, path, true); }
+extern "C" int gg_load_state(gg_ctx *ctx, const char *path) { return state_io(ctx, path, false); }

@@ -1,0 +1,137 @@
+// gg_internal.h -- context layout and helpers shared by the translation units of
+// libgraphgan_hip.so.  Nothing here crosses the C ABI (include/graphgan_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/graphgan_hip.h"
+
+namespace gg {
+
+// One growable device allocation.
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipError_t reserve(size_t need) {
+        if (need <= bytes) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        size_t want = need + need / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) bytes = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+// One embedding model (generator or discriminator): table, bias, Adam slots.
+struct Model {
+    float *E = nullptr, *b = nullptr;      // [n_node * ld], [n_node]
+    float *mE = nullptr, *vE = nullptr;    // Adam first / second moments of E
+    float *mb = nullptr, *vb = nullptr;    // ... of b
+    float b1p = 0.9f, b2p = 0.999f;        // beta powers (TF keeps them as fp32 variables)
+    int64_t t = 0;                         // optimizer steps taken
+    float lr = 1e-3f, lambda = 1e-5f;
+};
+
+struct RcclApi;  // comm.hip
+
+}  // namespace gg
+
+struct gg_ctx {
+    int32_t n_node = 0, n_emb = 0, ld = 0;  // ld = n_emb rounded up to a multiple of 4 (zero padded)
+    gg_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    gg::Model model[2];  // 0 = generator, 1 = discriminator (config.modes order)
+
+    // dense gradient accumulators shared by D and G steps (zero between steps)
+    float *gradE = nullptr, *gradb = nullptr;
+    // touched-row bookkeeping for the lazy / sgd modes
+    int32_t *touched = nullptr;     // [n_node] flag
+    int32_t *touched_list = nullptr;  // [n_node]
+    int32_t *touched_cnt = nullptr;   // [1]
+
+    // graph CSR (utils.read_edges adjacency, list order)
+    int64_t *g_rowptr = nullptr;
+    int32_t *g_col = nullptr;
+    int64_t g_nnz = 0;
+    std::vector<int64_t> h_rowptr;  // host copies (tree builder, degrees)
+    std::vector<int32_t> h_col;
+
+    // tree CSR for n_tree_roots root slots
+    int32_t n_tree_roots = 0, tree_max_depth = 0, tree_max_list = 0;
+    int64_t tree_entries = 0;
+    int32_t *t_root = nullptr;   // [R] root node id of each slot
+    int32_t *t_off = nullptr;    // [R * (n_node+1)]
+    int32_t *t_nbr = nullptr;    // [entries]
+    int64_t *t_base = nullptr;   // [R+1]
+    std::vector<int32_t> h_troot;
+
+    // walk outputs (device resident)
+    gg::DevBuf w_slots, w_nwalks, w_ptr, w_samples, w_paths, w_len, w_status, w_first, w_abort, w_scratch;
+    int64_t w_total = 0;
+    int32_t w_stride = 0, w_nslots = 0;
+
+    // prepared data
+    gg::DevBuf d_center, d_neighbor, d_label, d_cnt, d_ptr;
+    int64_t d_rows = 0;
+    gg::DevBuf g_node1, g_node2, g_reward, g_cnt, g_ptr;
+    int64_t g_pairs = 0;
+    gg::DevBuf scan_tmp, step_u, step_v, step_x, starts_buf, misc;
+
+    // device-side counters: [0]=hops [1]=nbr_reads [2]=walks [3]=error flag
+    unsigned long long *dev_ctr = nullptr;
+    gg_counters ctr{};
+
+    // multi-GPU
+    void *comm = nullptr;  // ncclComm_t
+    int32_t rank = 0, world = 1;
+
+    std::string err;
+};
+
+namespace gg {
+
+extern thread_local std::string g_last_error;
+
+int fail(gg_ctx *ctx, int code, const char *fmt, ...);
+
+#define GG_HIP(ctx, call)                                                                      \
+    do {                                                                                       \
+        hipError_t e__ = (call);                                                               \
+        if (e__ != hipSuccess)                                                                 \
+            return gg::fail(ctx, GG_EHIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call,         \
+                            hipGetErrorString(e__));                                           \
+    } while (0)
+
+#define GG_CHECK(ctx, cond, code, ...)                        \
+    do {                                                      \
+        if (!(cond)) return gg::fail(ctx, code, __VA_ARGS__); \
+    } while (0)
+
+// exclusive scan of n int32 counts into n+1 int64 offsets (prepare.hip)
+int device_exclusive_scan(gg_ctx *ctx, const int32_t *cnt, int64_t *ptr, int64_t n);
+
+// launchers
+int walk_resident(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, int32_t uniform_walks, int32_t n_slots,
+                  int32_t for_d, uint64_t seed, uint32_t stream, int32_t stride);
+int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int for_d, uint64_t seed, uint32_t stream,
+                       int32_t stride);
+int run_step(gg_ctx *ctx, int which, const int32_t *d_u, const int32_t *d_v, const float *d_x, int32_t n);
+int comm_allreduce_grads(gg_ctx *ctx);
+void comm_destroy(gg_ctx *ctx);
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+}  // namespace gg

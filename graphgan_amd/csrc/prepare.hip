@@ -1,0 +1,337 @@
+// prepare.hip -- device-resident sample preparation:
+//   K6 paths -> window pairs   (reference src/GraphGAN/graph_gan.py:272-291, get_node_pairs_from_path)
+//   K2 pair_reward             (src/GraphGAN/discriminator.py:21-24,33-34 via graph_gan.py:220-222)
+//   D rows [pos..., neg...]    (graph_gan.py:193-201)
+// so that prepare_data_for_g / prepare_data_for_d (graph_gan.py:182-223) never round-trip
+// node lists through the host between the walk kernel and the update passes.
+#include "gg_internal.h"
+
+namespace gg {
+
+// ------------------------------------------------------------------ exclusive scan (int32 -> int64)
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+
+__device__ __forceinline__ int64_t block_excl_scan(int64_t v, int64_t *total, int64_t *sh /*[SCAN_THREADS/64]*/) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int64_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int64_t o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) sh[wv] = inc;
+    __syncthreads();
+    int64_t base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_THREADS / 64; ++i) {
+        if (i < wv) base += sh[i];
+        tot += sh[i];
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_tile_sums(const int32_t *cnt, int64_t n, int64_t *tile_sum) {
+    __shared__ int64_t sh[SCAN_THREADS / 64];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i)
+        if (base + i < n) s += cnt[base + i];
+    int64_t tot;
+    (void)block_excl_scan(s, &tot, sh);
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_tile_offsets(int64_t *tile_sum, int64_t n_tiles, int64_t *total_out) {
+    __shared__ int64_t sh[SCAN_THREADS / 64];
+    int64_t carry = 0;
+    for (int64_t t0 = 0; t0 < n_tiles; t0 += SCAN_THREADS) {
+        const int64_t i = t0 + threadIdx.x;
+        const int64_t v = i < n_tiles ? tile_sum[i] : 0;
+        int64_t tot;
+        const int64_t ex = block_excl_scan(v, &tot, sh);
+        if (i < n_tiles) tile_sum[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_apply(const int32_t *cnt, int64_t n, const int64_t *tile_off, int64_t *ptr) {
+    __shared__ int64_t sh[SCAN_THREADS / 64];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int64_t v[SCAN_ITEMS], s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        v[i] = base + i < n ? cnt[base + i] : 0;
+        s += v[i];
+    }
+    int64_t tot;
+    int64_t run = tile_off[blockIdx.x] + block_excl_scan(s, &tot, sh);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        if (base + i < n) ptr[base + i] = run;
+        run += v[i];
+    }
+}
+
+// ptr[0..n] <- exclusive prefix sums of cnt[0..n); ptr[n] = total.
+int device_exclusive_scan(gg_ctx *ctx, const int32_t *cnt, int64_t *ptr, int64_t n) {
+    const int64_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    GG_HIP(ctx, ctx->scan_tmp.reserve(sizeof(int64_t) * (tiles + 2)));
+    int64_t *ts = ctx->scan_tmp.as<int64_t>();
+    if (n == 0) {
+        GG_HIP(ctx, hipMemsetAsync(ptr, 0, sizeof(int64_t), ctx->stream));
+        return GG_OK;
+    }
+    hipLaunchKernelGGL(scan_tile_sums, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, ctx->stream, cnt, n, ts);
+    hipLaunchKernelGGL(scan_tile_offsets, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, ts, tiles, ptr + n);
+    hipLaunchKernelGGL(scan_apply, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, ctx->stream, cnt, n, ts, ptr);
+    GG_HIP(ctx, hipGetLastError());
+    return GG_OK;
+}
+
+// ------------------------------------------------------------------ K6 window pairs
+// pairs of path[:-1] with |i-j| <= window, i != j, in the reference's (i, then j) order.
+__global__ void pair_count_kernel(const int32_t *path_len, int64_t n_walks, int window, int32_t *cnt) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_walks) return;
+    const int L = path_len[w] - 1;  // the last element (back-step) is dropped (graph_gan.py:282)
+    int c = 0;
+    for (int i = 0; i < L; ++i) {
+        const int lo = max(i - window, 0), hi = min(i + window + 1, L);
+        c += hi - lo - 1;
+    }
+    cnt[w] = L > 0 ? c : 0;
+}
+
+__global__ void pair_fill_kernel(const int32_t *paths, const int32_t *path_len, int stride, int64_t n_walks, int window,
+                                 const int64_t *ptr, int32_t *node1, int32_t *node2) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_walks) return;
+    const int L = path_len[w] - 1;
+    const int32_t *p = paths + w * (int64_t)stride;
+    int64_t o = ptr[w];
+    for (int i = 0; i < L; ++i) {
+        const int lo = max(i - window, 0), hi = min(i + window + 1, L);
+        const int c = p[i];
+        for (int j = lo; j < hi; ++j) {
+            if (j == i) continue;
+            node1[o] = c;
+            node2[o] = p[j];
+            ++o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ K2 pair_reward
+// reward = log(1 + exp(clip(d_u . d_v + b[v], -10, 10))).  One 16-lane group per pair:
+// both rows streamed as float4 chunks, xor-butterfly reduce.  HBM-bound gather:
+// algorithmic bytes per pair = 8d + 4 + 8 + 4.
+__global__ __launch_bounds__(256) void pair_reward_kernel(const float *E, const float *bias, int ld, const int32_t *u,
+                                                          const int32_t *v, int64_t n, float *out) {
+    const int t = threadIdx.x & 15;
+    const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int64_t ng = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    const int nchunk = ld >> 2;
+    for (int64_t p = g0; p < n; p += ng) {
+        const int a = u[p], b = v[p];
+        const float4 *ra = (const float4 *)(E + (int64_t)a * ld);
+        const float4 *rb = (const float4 *)(E + (int64_t)b * ld);
+        float acc = 0.f;
+        for (int c = t; c < nchunk; c += 16) {
+            const float4 x = ra[c], y = rb[c];
+            acc = __builtin_fmaf(x.x, y.x, acc);
+            acc = __builtin_fmaf(x.y, y.y, acc);
+            acc = __builtin_fmaf(x.z, y.z, acc);
+            acc = __builtin_fmaf(x.w, y.w, acc);
+        }
+        acc += __shfl_xor(acc, 8, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 1, 64);
+        if (t == 0) {
+            float s = acc + bias[b];
+            s = fminf(fmaxf(s, -10.0f), 10.0f);
+            out[p] = logf(1.0f + expf(s));  // tf.log(1 + tf.exp(score)), fp32
+        }
+    }
+}
+
+int launch_pair_reward(gg_ctx *ctx, const int32_t *d_u, const int32_t *d_v, int64_t n, float *d_out) {
+    if (n == 0) return GG_OK;
+    const Model &D = ctx->model[1];
+    int64_t blocks = (n * 16 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(pair_reward_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, D.E, D.b, ctx->ld, d_u, d_v, n, d_out);
+    GG_HIP(ctx, hipGetLastError());
+    ctx->ctr.reward_pairs += n;
+    return GG_OK;
+}
+
+// ------------------------------------------------------------------ D rows
+__global__ void d_count_kernel(const int32_t *status, const int64_t *walk_ptr, int n_slots, int32_t *cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_slots) return;
+    const int64_t deg = walk_ptr[i + 1] - walk_ptr[i];
+    cnt[i] = (status[i] == GG_ROOT_OK && deg > 0) ? (int32_t)(2 * deg) : 0;
+}
+
+// one wavefront per root: [i]*deg + pos(graph[i]) + label 1, then [i]*deg + neg(samples) + label 0
+__global__ __launch_bounds__(256) void d_fill_kernel(const int32_t *slots, const int32_t *t_root, const int64_t *g_rowptr,
+                                                     const int32_t *g_col, const int32_t *samples, const int64_t *walk_ptr,
+                                                     const int64_t *row_ptr, int n_slots, int32_t *center, int32_t *neighbor,
+                                                     float *label) {
+    const int lane = threadIdx.x & 63;
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (i >= n_slots) return;
+    const int64_t o = row_ptr[i], rows = row_ptr[i + 1] - o;
+    if (rows == 0) return;
+    const int64_t deg = rows / 2;
+    const int root = t_root[slots[i]];
+    const int64_t e0 = g_rowptr[root], w0 = walk_ptr[i];
+    for (int64_t e = lane; e < deg; e += 64) {
+        center[o + e] = root;
+        neighbor[o + e] = g_col[e0 + e];
+        label[o + e] = 1.0f;
+        center[o + deg + e] = root;
+        neighbor[o + deg + e] = samples[w0 + e];
+        label[o + deg + e] = 0.0f;
+    }
+}
+
+}  // namespace gg
+
+using namespace gg;
+
+static int read_i64(gg_ctx *ctx, const int64_t *dptr, int64_t *out) {
+    GG_HIP(ctx, hipMemcpyAsync(out, dptr, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GG_OK;
+}
+
+extern "C" {
+
+int gg_prepare_d(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, uint64_t seed, uint32_t stream, int64_t *n_rows_out,
+                 int32_t *root_status) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    GG_CHECK(ctx, ctx->g_rowptr, GG_EINVAL, "gg_prepare_d: call gg_set_graph_csr first");
+    // a D path never exceeds tree depth + 2 entries
+    const int stride = ctx->tree_max_depth + 3;
+    int rc = walk_resident(ctx, slots, nullptr, -1, n_slots, 1, seed, stream, stride);
+    if (rc != GG_OK) return rc;
+    ctx->d_rows = 0;
+    if (n_slots > 0) {
+        GG_HIP(ctx, ctx->d_cnt.reserve(sizeof(int32_t) * n_slots));
+        GG_HIP(ctx, ctx->d_ptr.reserve(sizeof(int64_t) * (n_slots + 1)));
+        hipLaunchKernelGGL(d_count_kernel, dim3(cdiv(n_slots, 256)), dim3(256), 0, ctx->stream, ctx->w_status.as<int32_t>(),
+                           ctx->w_ptr.as<int64_t>(), n_slots, ctx->d_cnt.as<int32_t>());
+        rc = device_exclusive_scan(ctx, ctx->d_cnt.as<int32_t>(), ctx->d_ptr.as<int64_t>(), n_slots);
+        if (rc != GG_OK) return rc;
+        int64_t rows = 0;
+        rc = read_i64(ctx, ctx->d_ptr.as<int64_t>() + n_slots, &rows);
+        if (rc != GG_OK) return rc;
+        GG_HIP(ctx, ctx->d_center.reserve(sizeof(int32_t) * (rows + 1)));
+        GG_HIP(ctx, ctx->d_neighbor.reserve(sizeof(int32_t) * (rows + 1)));
+        GG_HIP(ctx, ctx->d_label.reserve(sizeof(float) * (rows + 1)));
+        if (rows) {
+            hipLaunchKernelGGL(d_fill_kernel, dim3(cdiv((int64_t)n_slots * 64, 256)), dim3(256), 0, ctx->stream,
+                               ctx->w_slots.as<int32_t>(), ctx->t_root, ctx->g_rowptr, ctx->g_col, ctx->w_samples.as<int32_t>(),
+                               ctx->w_ptr.as<int64_t>(), ctx->d_ptr.as<int64_t>(), n_slots, ctx->d_center.as<int32_t>(),
+                               ctx->d_neighbor.as<int32_t>(), ctx->d_label.as<float>());
+            GG_HIP(ctx, hipGetLastError());
+        }
+        GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->d_rows = rows;
+        if (root_status) GG_HIP(ctx, hipMemcpy(root_status, ctx->w_status.p, sizeof(int32_t) * n_slots, hipMemcpyDeviceToHost));
+    }
+    if (n_rows_out) *n_rows_out = ctx->d_rows;
+    return GG_OK;
+}
+
+int gg_get_d_data(gg_ctx *ctx, int32_t *center, int32_t *neighbor, float *label) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    const int64_t n = ctx->d_rows;
+    if (n == 0) return GG_OK;
+    GG_HIP(ctx, hipSetDevice(ctx->device));
+    GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (center) GG_HIP(ctx, hipMemcpy(center, ctx->d_center.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    if (neighbor) GG_HIP(ctx, hipMemcpy(neighbor, ctx->d_neighbor.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    if (label) GG_HIP(ctx, hipMemcpy(label, ctx->d_label.p, sizeof(float) * n, hipMemcpyDeviceToHost));
+    return GG_OK;
+}
+
+int gg_prepare_g(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, int32_t n_sample, uint64_t seed, uint32_t stream,
+                 int64_t *n_pairs_out, int32_t *root_status) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    GG_CHECK(ctx, n_sample >= 0, GG_EINVAL, "gg_prepare_g: n_sample < 0");
+    const int stride = ctx->tree_max_depth + 3;
+    int rc = walk_resident(ctx, slots, nullptr, n_sample, n_slots, 0, seed, stream, stride);
+    if (rc != GG_OK) return rc;
+    ctx->g_pairs = 0;
+    const int64_t nw = ctx->w_total;
+    if (nw > 0) {
+        const int window = ctx->cfg.window_size;
+        GG_HIP(ctx, ctx->g_cnt.reserve(sizeof(int32_t) * nw));
+        GG_HIP(ctx, ctx->g_ptr.reserve(sizeof(int64_t) * (nw + 1)));
+        hipLaunchKernelGGL(pair_count_kernel, dim3(cdiv(nw, 256)), dim3(256), 0, ctx->stream, ctx->w_len.as<int32_t>(), nw, window,
+                           ctx->g_cnt.as<int32_t>());
+        rc = device_exclusive_scan(ctx, ctx->g_cnt.as<int32_t>(), ctx->g_ptr.as<int64_t>(), nw);
+        if (rc != GG_OK) return rc;
+        int64_t P = 0;
+        rc = read_i64(ctx, ctx->g_ptr.as<int64_t>() + nw, &P);
+        if (rc != GG_OK) return rc;
+        GG_HIP(ctx, ctx->g_node1.reserve(sizeof(int32_t) * (P + 1)));
+        GG_HIP(ctx, ctx->g_node2.reserve(sizeof(int32_t) * (P + 1)));
+        GG_HIP(ctx, ctx->g_reward.reserve(sizeof(float) * (P + 1)));
+        if (P) {
+            hipLaunchKernelGGL(pair_fill_kernel, dim3(cdiv(nw, 256)), dim3(256), 0, ctx->stream, ctx->w_paths.as<int32_t>(),
+                               ctx->w_len.as<int32_t>(), ctx->w_stride, nw, window, ctx->g_ptr.as<int64_t>(),
+                               ctx->g_node1.as<int32_t>(), ctx->g_node2.as<int32_t>());
+            GG_HIP(ctx, hipGetLastError());
+            rc = launch_pair_reward(ctx, ctx->g_node1.as<int32_t>(), ctx->g_node2.as<int32_t>(), P, ctx->g_reward.as<float>());
+            if (rc != GG_OK) return rc;
+        }
+        GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->g_pairs = P;
+    }
+    if (root_status && n_slots) GG_HIP(ctx, hipMemcpy(root_status, ctx->w_status.p, sizeof(int32_t) * n_slots, hipMemcpyDeviceToHost));
+    if (n_pairs_out) *n_pairs_out = ctx->g_pairs;
+    return GG_OK;
+}
+
+int gg_get_g_data(gg_ctx *ctx, int32_t *node_1, int32_t *node_2, float *reward) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    const int64_t n = ctx->g_pairs;
+    if (n == 0) return GG_OK;
+    GG_HIP(ctx, hipSetDevice(ctx->device));
+    GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (node_1) GG_HIP(ctx, hipMemcpy(node_1, ctx->g_node1.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    if (node_2) GG_HIP(ctx, hipMemcpy(node_2, ctx->g_node2.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    if (reward) GG_HIP(ctx, hipMemcpy(reward, ctx->g_reward.p, sizeof(float) * n, hipMemcpyDeviceToHost));
+    return GG_OK;
+}
+
+int gg_pair_reward(gg_ctx *ctx, const int32_t *u, const int32_t *v, int64_t n, float *out) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    GG_CHECK(ctx, n >= 0 && (n == 0 || (u && v && out)), GG_EINVAL, "gg_pair_reward: bad argument");
+    if (n == 0) return GG_OK;
+    for (int64_t i = 0; i < n; ++i)
+        GG_CHECK(ctx, u[i] >= 0 && u[i] < ctx->n_node && v[i] >= 0 && v[i] < ctx->n_node, GG_EINVAL, "gg_pair_reward: id out of range at %lld", (long long)i);
+    GG_HIP(ctx, hipSetDevice(ctx->device));
+    GG_HIP(ctx, ctx->step_u.reserve(sizeof(int32_t) * n));
+    GG_HIP(ctx, ctx->step_v.reserve(sizeof(int32_t) * n));
+    GG_HIP(ctx, ctx->step_x.reserve(sizeof(float) * n));
+    GG_HIP(ctx, hipMemcpyAsync(ctx->step_u.p, u, sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    GG_HIP(ctx, hipMemcpyAsync(ctx->step_v.p, v, sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    int rc = launch_pair_reward(ctx, ctx->step_u.as<int32_t>(), ctx->step_v.as<int32_t>(), n, ctx->step_x.as<float>());
+    if (rc != GG_OK) return rc;
+    GG_HIP(ctx, hipMemcpyAsync(out, ctx->step_x.p, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
+    GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,314 @@
+// steps.hip -- K3 d_step, K4 g_step, K5 optimizers.
+//
+//   d_step  <- sess.run(discriminator.d_updates) (reference src/GraphGAN/graph_gan.py:154-157,
+//              src/GraphGAN/discriminator.py:21-32): L = sum_b sigmoid_CE(s_b, y_b)
+//              + lambda * 1/2 (|E_v|^2 + |E_u|^2 + b_v^2);  dL/ds_b = sigmoid(s_b) - y_b
+//   g_step  <- sess.run(generator.g_updates) (graph_gan.py:173-176, src/GraphGAN/generator.py:22-31):
+//              L = -mean_b(log(clip(sigmoid(s_b), 1e-5, 1)) * r_b) + lambda * 1/2 (|E_v|^2 + |E_u|^2);
+//              dL/ds_b = -(r_b / B) (1 - sigmoid(s_b)) inside the clip range, else 0
+//   Adam    <- tf.train.AdamOptimizer(lr).minimize (generator.py:30-31, discriminator.py:31-32),
+//              tensorflow==1.8.0 sparse-apply semantics: duplicate rows summed, m and v decayed
+//              over ALL rows, var moved over ALL rows, lr_t = lr*sqrt(1-b2^t)/(1-b1^t), eps outside.
+//
+// Two kernels per step: (A) one 16-lane group per pair accumulates the dense gradient with
+// fp32 atomics (rows of E_u, E_v and b_v); (B) the optimizer sweep.  GG_OPT_ADAM_DENSE sweeps
+// all N*(ld+1) elements (TF1 parity; 24 B/element, L2-resident on CA-GrQc); GG_OPT_ADAM_LAZY
+// and GG_OPT_SGD sweep only the rows a step touched (scale mode: 48d+24 / 16d+20 B per pair).
+// With gg_comm_init the gradient accumulators are all-reduced between (A) and (B).
+#include "gg_internal.h"
+
+namespace gg {
+
+struct StepArgs {
+    float *E, *b;          // variables
+    float *gE, *gb;        // dense gradient accumulators
+    int32_t *touched, *touched_list, *touched_cnt;
+    int ld, track;
+    const int32_t *u, *v;
+    const float *x;        // label (D) or reward (G)
+    int n;
+    float lambda, inv_n;
+    int is_d;
+};
+
+__global__ __launch_bounds__(256) void pair_grad_kernel(const StepArgs a) {
+    const int t = threadIdx.x & 15;
+    const int g0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int ng = (gridDim.x * blockDim.x) >> 4;
+    const int nchunk = a.ld >> 2;
+    for (int p = g0; p < a.n; p += ng) {
+        const int iu = a.u[p], iv = a.v[p];
+        const float4 *ru = (const float4 *)(a.E + (int64_t)iu * a.ld);
+        const float4 *rv = (const float4 *)(a.E + (int64_t)iv * a.ld);
+        float acc = 0.f;
+        for (int c = t; c < nchunk; c += 16) {
+            const float4 x = ru[c], y = rv[c];
+            acc = __builtin_fmaf(x.x, y.x, acc);
+            acc = __builtin_fmaf(x.y, y.y, acc);
+            acc = __builtin_fmaf(x.z, y.z, acc);
+            acc = __builtin_fmaf(x.w, y.w, acc);
+        }
+        acc += __shfl_xor(acc, 8, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 1, 64);
+        const float bv = a.b[iv];
+        const float s = acc + bv;
+        const float sg = 1.0f / (1.0f + expf(-s));
+        float ds;
+        if (a.is_d) {
+            ds = sg - a.x[p];
+        } else {
+            const bool inside = (sg >= 1e-5f) && (sg <= 1.0f);
+            ds = inside ? -(a.x[p] * a.inv_n) * (1.0f - sg) : 0.0f;
+        }
+        float *gu = a.gE + (int64_t)iu * a.ld, *gv = a.gE + (int64_t)iv * a.ld;
+        for (int c = t; c < nchunk; c += 16) {
+            const float4 x = ru[c], y = rv[c];
+            atomicAdd(gu + 4 * c + 0, ds * y.x + a.lambda * x.x);
+            atomicAdd(gu + 4 * c + 1, ds * y.y + a.lambda * x.y);
+            atomicAdd(gu + 4 * c + 2, ds * y.z + a.lambda * x.z);
+            atomicAdd(gu + 4 * c + 3, ds * y.w + a.lambda * x.w);
+            atomicAdd(gv + 4 * c + 0, ds * x.x + a.lambda * y.x);
+            atomicAdd(gv + 4 * c + 1, ds * x.y + a.lambda * y.y);
+            atomicAdd(gv + 4 * c + 2, ds * x.z + a.lambda * y.z);
+            atomicAdd(gv + 4 * c + 3, ds * x.w + a.lambda * y.w);
+        }
+        if (t == 0) {
+            atomicAdd(a.gb + iv, a.is_d ? ds + a.lambda * bv : ds);
+            if (a.track) {
+                if (atomicExch(a.touched + iu, 1) == 0) a.touched_list[atomicAdd(a.touched_cnt, 1)] = iu;
+                if (atomicExch(a.touched + iv, 1) == 0) a.touched_list[atomicAdd(a.touched_cnt, 1)] = iv;
+            }
+        }
+    }
+}
+
+struct OptArgs {
+    float *E, *b, *mE, *vE, *mb, *vb, *gE, *gb;
+    int64_t nE;   // n_node * ld
+    int n_node, ld;
+    float lr_t, b1, b2, eps, lr;
+    int32_t *touched, *touched_list, *touched_cnt;
+};
+
+__device__ __forceinline__ void adam_elem(float &var, float &m, float &v, float g, const OptArgs &a) {
+    m = m * a.b1;                          // m_t = assign(m, m * beta1)
+    m = m + (1.0f - a.b1) * g;             // scatter_add(m, idx, (1 - beta1) * grad)
+    v = v * a.b2;
+    v = v + (g * g) * (1.0f - a.b2);
+    var = var - (a.lr_t * m) / (sqrtf(v) + a.eps);
+}
+
+// Dense TF1 Adam over E (float4) and b; clears the gradient accumulators it consumed.
+__global__ __launch_bounds__(256) void adam_dense_kernel(const OptArgs a) {
+    const int64_t n4 = a.nE >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 var = ((float4 *)a.E)[i], m = ((float4 *)a.mE)[i], v = ((float4 *)a.vE)[i];
+        const float4 g = ((const float4 *)a.gE)[i];
+        adam_elem(var.x, m.x, v.x, g.x, a);
+        adam_elem(var.y, m.y, v.y, g.y, a);
+        adam_elem(var.z, m.z, v.z, g.z, a);
+        adam_elem(var.w, m.w, v.w, g.w, a);
+        ((float4 *)a.E)[i] = var;
+        ((float4 *)a.mE)[i] = m;
+        ((float4 *)a.vE)[i] = v;
+        if (g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f) ((float4 *)a.gE)[i] = z;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_node; i += stride) {
+        float var = a.b[i], m = a.mb[i], v = a.vb[i];
+        const float g = a.gb[i];
+        adam_elem(var, m, v, g, a);
+        a.b[i] = var;
+        a.mb[i] = m;
+        a.vb[i] = v;
+        if (g != 0.f) a.gb[i] = 0.f;
+    }
+}
+
+// Lazy Adam / SGD over the rows touched by this step: one 16-lane group per row.
+template <int SGD>
+__global__ __launch_bounds__(256) void sparse_opt_kernel(const OptArgs a) {
+    const int t = threadIdx.x & 15;
+    const int g0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int ng = (gridDim.x * blockDim.x) >> 4;
+    const int cnt = *a.touched_cnt;
+    const int nchunk = a.ld >> 2;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = g0; r < cnt; r += ng) {
+        const int row = a.touched_list[r];
+        const int64_t o = ((int64_t)row * a.ld) >> 2;
+        for (int c = t; c < nchunk; c += 16) {
+            float4 var = ((float4 *)a.E)[o + c];
+            const float4 g = ((const float4 *)a.gE)[o + c];
+            if (SGD) {
+                var.x -= a.lr * g.x; var.y -= a.lr * g.y; var.z -= a.lr * g.z; var.w -= a.lr * g.w;
+            } else {
+                float4 m = ((float4 *)a.mE)[o + c], v = ((float4 *)a.vE)[o + c];
+                adam_elem(var.x, m.x, v.x, g.x, a);
+                adam_elem(var.y, m.y, v.y, g.y, a);
+                adam_elem(var.z, m.z, v.z, g.z, a);
+                adam_elem(var.w, m.w, v.w, g.w, a);
+                ((float4 *)a.mE)[o + c] = m;
+                ((float4 *)a.vE)[o + c] = v;
+            }
+            ((float4 *)a.E)[o + c] = var;
+            ((float4 *)a.gE)[o + c] = z;
+        }
+        if (t == 0) {
+            float var = a.b[row];
+            const float g = a.gb[row];
+            if (SGD) {
+                var -= a.lr * g;
+            } else {
+                float m = a.mb[row], v = a.vb[row];
+                adam_elem(var, m, v, g, a);
+                a.mb[row] = m;
+                a.vb[row] = v;
+            }
+            a.b[row] = var;
+            a.gb[row] = 0.f;
+            a.touched[row] = 0;
+        }
+    }
+}
+
+__global__ void reset_touched_cnt_kernel(int32_t *cnt) { *cnt = 0; }
+
+// After an all-reduce the local touched list is incomplete: rebuild it from the summed gradient.
+__global__ __launch_bounds__(256) void rebuild_touched_kernel(const OptArgs a) {
+    const int t = threadIdx.x & 15;
+    const int g0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int ng = (gridDim.x * blockDim.x) >> 4;
+    const int nchunk = a.ld >> 2;
+    for (int row = g0; row < a.n_node; row += ng) {
+        bool nz = false;
+        const float4 *g = (const float4 *)(a.gE + (int64_t)row * a.ld);
+        for (int c = t; c < nchunk; c += 16) {
+            const float4 x = g[c];
+            nz |= (x.x != 0.f) | (x.y != 0.f) | (x.z != 0.f) | (x.w != 0.f);
+        }
+        nz |= (a.gb[row] != 0.f);
+        unsigned long long bal = __ballot(nz);
+        const int grp = (threadIdx.x & 63) >> 4;
+        const bool any = ((bal >> (grp * 16)) & 0xffffull) != 0;
+        if (t == 0 && any && a.touched[row] == 0) {
+            a.touched[row] = 1;
+            a.touched_list[atomicAdd(a.touched_cnt, 1)] = row;
+        }
+    }
+}
+
+// One optimizer step of model `which` on n device-resident rows.
+int run_step(gg_ctx *ctx, int which, const int32_t *d_u, const int32_t *d_v, const float *d_x, int32_t n) {
+    if (n <= 0) return GG_OK;
+    Model &M = ctx->model[which];
+    const int opt = ctx->cfg.optimizer;
+    StepArgs s{};
+    s.E = M.E; s.b = M.b; s.gE = ctx->gradE; s.gb = ctx->gradb;
+    s.touched = ctx->touched; s.touched_list = ctx->touched_list; s.touched_cnt = ctx->touched_cnt;
+    s.ld = ctx->ld;
+    s.track = (opt != GG_OPT_ADAM_DENSE) && ctx->world <= 1;
+    s.u = d_u; s.v = d_v; s.x = d_x; s.n = n;
+    s.lambda = M.lambda;
+    s.inv_n = 1.0f / (float)n;
+    s.is_d = which == 1;
+    int blocks = cdiv((int64_t)n * 16, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pair_grad_kernel, dim3(blocks), dim3(256), 0, ctx->stream, s);
+
+    int rc = comm_allreduce_grads(ctx);
+    if (rc != GG_OK) return rc;
+
+    OptArgs o{};
+    o.E = M.E; o.b = M.b; o.mE = M.mE; o.vE = M.vE; o.mb = M.mb; o.vb = M.vb; o.gE = ctx->gradE; o.gb = ctx->gradb;
+    o.nE = (int64_t)ctx->n_node * ctx->ld;
+    o.n_node = ctx->n_node; o.ld = ctx->ld;
+    o.b1 = ctx->cfg.adam_beta1; o.b2 = ctx->cfg.adam_beta2; o.eps = ctx->cfg.adam_eps;
+    o.lr = M.lr;
+    // lr_t = lr * sqrt(1 - beta2_power) / (1 - beta1_power), all fp32 (TF keeps the powers as fp32 variables)
+    o.lr_t = (M.lr * sqrtf(1.0f - M.b2p)) / (1.0f - M.b1p);
+    o.touched = ctx->touched; o.touched_list = ctx->touched_list; o.touched_cnt = ctx->touched_cnt;
+    if (opt == GG_OPT_ADAM_DENSE) {
+        int64_t nb = (o.nE / 4 + 255) / 256;
+        if (nb > 2048) nb = 2048;
+        if (nb < 1) nb = 1;
+        hipLaunchKernelGGL(adam_dense_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, o);
+    } else {
+        if (ctx->world > 1) {
+            int64_t nb = ((int64_t)ctx->n_node * 16 + 255) / 256;
+            if (nb > 4096) nb = 4096;
+            hipLaunchKernelGGL(rebuild_touched_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, o);
+        }
+        int nb = cdiv((int64_t)std::min<int64_t>(2ll * n * ctx->world, ctx->n_node) * 16, 256);
+        if (nb > 4096) nb = 4096;
+        if (opt == GG_OPT_SGD) hipLaunchKernelGGL(sparse_opt_kernel<1>, dim3(nb), dim3(256), 0, ctx->stream, o);
+        else hipLaunchKernelGGL(sparse_opt_kernel<0>, dim3(nb), dim3(256), 0, ctx->stream, o);
+        hipLaunchKernelGGL(reset_touched_cnt_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->touched_cnt);
+    }
+    GG_HIP(ctx, hipGetLastError());
+    M.t += 1;
+    M.b1p = M.b1p * ctx->cfg.adam_beta1;
+    M.b2p = M.b2p * ctx->cfg.adam_beta2;
+    if (which == 1) { ctx->ctr.d_pairs += n; ctx->ctr.d_steps += 1; }
+    else { ctx->ctr.g_pairs += n; ctx->ctr.g_steps += 1; }
+    return GG_OK;
+}
+
+}  // namespace gg
+
+using namespace gg;
+
+static int host_step(gg_ctx *ctx, int which, const int32_t *u, const int32_t *v, const float *x, int32_t n) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    GG_CHECK(ctx, n >= 0 && (n == 0 || (u && v && x)), GG_EINVAL, "step: bad argument");
+    if (n == 0) return GG_OK;
+    for (int i = 0; i < n; ++i)
+        GG_CHECK(ctx, u[i] >= 0 && u[i] < ctx->n_node && v[i] >= 0 && v[i] < ctx->n_node, GG_EINVAL, "step: id out of range at %d", i);
+    GG_HIP(ctx, hipSetDevice(ctx->device));
+    GG_HIP(ctx, ctx->step_u.reserve(sizeof(int32_t) * n));
+    GG_HIP(ctx, ctx->step_v.reserve(sizeof(int32_t) * n));
+    GG_HIP(ctx, ctx->step_x.reserve(sizeof(float) * n));
+    GG_HIP(ctx, hipMemcpyAsync(ctx->step_u.p, u, sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    GG_HIP(ctx, hipMemcpyAsync(ctx->step_v.p, v, sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    GG_HIP(ctx, hipMemcpyAsync(ctx->step_x.p, x, sizeof(float) * n, hipMemcpyHostToDevice, ctx->stream));
+    int rc = run_step(ctx, which, ctx->step_u.as<int32_t>(), ctx->step_v.as<int32_t>(), ctx->step_x.as<float>(), n);
+    if (rc != GG_OK) return rc;
+    GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GG_OK;
+}
+
+static int run_pass(gg_ctx *ctx, int which, const int64_t *starts, int64_t n_batches, int32_t batch_size) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    GG_CHECK(ctx, batch_size > 0 && n_batches >= 0 && (starts || n_batches == 0), GG_EINVAL, "pass: bad argument");
+    const int64_t rows = which == 1 ? ctx->d_rows : ctx->g_pairs;
+    const int32_t *u = which == 1 ? ctx->d_center.as<int32_t>() : ctx->g_node1.as<int32_t>();
+    const int32_t *v = which == 1 ? ctx->d_neighbor.as<int32_t>() : ctx->g_node2.as<int32_t>();
+    const float *x = which == 1 ? ctx->d_label.as<float>() : ctx->g_reward.as<float>();
+    GG_HIP(ctx, hipSetDevice(ctx->device));
+    GG_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for (int64_t k = 0; k < n_batches; ++k) {
+        const int64_t s = starts[k];
+        GG_CHECK(ctx, s >= 0 && s < rows, GG_EINVAL, "pass: start %lld outside the %lld prepared rows", (long long)s, (long long)rows);
+        const int32_t n = (int32_t)std::min<int64_t>(batch_size, rows - s);
+        int rc = run_step(ctx, which, u + s, v + s, x + s, n);
+        if (rc != GG_OK) return rc;
+    }
+    GG_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    GG_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    ctx->ctr.last_kernel_ms = ms;
+    return GG_OK;
+}
+
+extern "C" {
+
+int gg_d_step(gg_ctx *ctx, const int32_t *u, const int32_t *v, const float *label, int32_t n) { return host_step(ctx, 1, u, v, label, n); }
+int gg_g_step(gg_ctx *ctx, const int32_t *u, const int32_t *v, const float *reward, int32_t n) { return host_step(ctx, 0, u, v, reward, n); }
+int gg_d_pass(gg_ctx *ctx, const int64_t *starts, int64_t n_batches, int32_t batch_size) { return run_pass(ctx, 1, starts, n_batches, batch_size); }
+int gg_g_pass(gg_ctx *ctx, const int64_t *starts, int64_t n_batches, int32_t batch_size) { return run_pass(ctx, 0, starts, n_batches, batch_size); }
+
+}  // extern "C"

@@ -1,0 +1,260 @@
+"""numpy-facing wrapper of the C ABI (``include/graphgan_hip.h``).
+
+``Engine`` is what the ``graph_gan.py`` mirror drives in place of the reference's
+``tf.Session``: each method corresponds to one ``sess.run`` call site or host-side
+sampler of ``src/GraphGAN/graph_gan.py`` (cited per method).  All numerics run in
+``libgraphgan_hip.so``; nothing here computes scores, samples or updates.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import GGConfig, GGCounters, check, lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def graph_to_csr(n_node, graph):
+    """Adjacency dict of ``utils.read_edges`` -> (rowptr int64 [N+1], col int32), list order kept."""
+    deg = np.fromiter((len(graph.get(v, ())) for v in range(n_node)), dtype=np.int64, count=n_node)
+    rowptr = np.zeros(n_node + 1, dtype=np.int64)
+    np.cumsum(deg, out=rowptr[1:])
+    col = np.empty(int(rowptr[-1]), dtype=np.int32)
+    for v in range(n_node):
+        lst = graph.get(v)
+        if lst:
+            col[rowptr[v]:rowptr[v + 1]] = lst
+    return rowptr, col
+
+
+def edges_to_csr(n_node, edges):
+    """Vectorised ``read_edges`` adjacency for large synthetic graphs: for edge k = (a, b) the
+    reference appends b to graph[a] and then a to graph[b] (utils.py:36-37), in file order."""
+    edges = np.asarray(edges, dtype=np.int64).reshape(-1, 2)
+    src = np.empty(2 * len(edges), dtype=np.int64)
+    dst = np.empty(2 * len(edges), dtype=np.int32)
+    src[0::2], dst[0::2] = edges[:, 0], edges[:, 1]
+    src[1::2], dst[1::2] = edges[:, 1], edges[:, 0]
+    order = np.argsort(src, kind="stable")
+    rowptr = np.zeros(n_node + 1, dtype=np.int64)
+    np.cumsum(np.bincount(src, minlength=n_node), out=rowptr[1:])
+    return rowptr, np.ascontiguousarray(dst[order])
+
+
+def host_build_trees(n_node, rowptr, col, roots, n_threads=0):
+    """``construct_trees`` (graph_gan.py:84-108) on host threads; no GPU needed.
+    Returns (off int32 [R, N+1], nbr int32, nbr_base int64 [R+1], max_depth)."""
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+    col = _i32(col)
+    roots = _i32(roots)
+    R = len(roots)
+    base = np.zeros(R + 1, dtype=np.int64)
+    total = check(lib.gg_host_build_trees(n_node, _ptr(rowptr), _ptr(col), _ptr(roots), R, None, None, _ptr(base), 0,
+                                          n_threads, None))
+    off = np.zeros((R, n_node + 1), dtype=np.int32)
+    nbr = np.zeros(max(int(total), 1), dtype=np.int32)
+    dmax = np.zeros(1, dtype=np.int32)
+    check(lib.gg_host_build_trees(n_node, _ptr(rowptr), _ptr(col), _ptr(roots), R, _ptr(off), _ptr(nbr), _ptr(base),
+                                  int(total), n_threads, _ptr(dmax)))
+    return off, nbr[: int(total)], base, int(dmax[0])
+
+
+def synth_powerlaw(n_node, m, seed_graph=1, seed_perm=2):
+    """Barabasi-Albert edge list [E, 2] int32 (SURVEY.md section 8d recipe)."""
+    n = check(lib.gg_synth_powerlaw(n_node, m, seed_graph, seed_perm, None, 0))
+    edges = np.empty((int(n), 2), dtype=np.int32)
+    check(lib.gg_synth_powerlaw(n_node, m, seed_graph, seed_perm, _ptr(edges), int(n)))
+    return edges
+
+
+class Engine:
+    """One HIP context on one MI355X: both embedding models, graph, trees, sample buffers."""
+
+    def __init__(self, emb_gen, emb_dis, lr_gen=1e-3, lr_dis=1e-3, lambda_gen=1e-5, lambda_dis=1e-5, window_size=2,
+                 optimizer=_lib.GG_OPT_ADAM_DENSE, device=0, adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8):
+        eg = np.ascontiguousarray(emb_gen, dtype=np.float32)  # Q6: fp64 init rounded to fp32 once
+        ed = np.ascontiguousarray(emb_dis, dtype=np.float32)
+        assert eg.shape == ed.shape and eg.ndim == 2
+        self.n_node, self.n_emb = int(eg.shape[0]), int(eg.shape[1])
+        cfg = GGConfig(lr_gen, lr_dis, lambda_gen, lambda_dis, adam_beta1, adam_beta2, adam_eps, window_size, optimizer, device)
+        self._ctx = ctypes.c_void_p()
+        check(lib.gg_create(self.n_node, self.n_emb, _ptr(eg), _ptr(ed), ctypes.byref(cfg), ctypes.byref(self._ctx)))
+        self.tree_roots = np.zeros(0, dtype=np.int32)
+        self.max_depth = 0
+        self._rowptr = None
+
+    # ------------------------------------------------------------------ life cycle
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            lib.gg_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        return check(rc, self._ctx)
+
+    # ------------------------------------------------------------------ graph / trees
+    def set_graph_csr(self, rowptr, col):
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+        col = _i32(col)
+        self._ck(lib.gg_set_graph_csr(self._ctx, _ptr(rowptr), _ptr(col)))
+        self._rowptr = rowptr
+
+    def build_trees(self, roots, n_threads=0):
+        """graph_gan.py:31-46,84-108: BFS trees of ``roots`` -> device tree CSR (slot i = roots[i])."""
+        roots = _i32(roots)
+        self._ck(lib.gg_build_trees(self._ctx, _ptr(roots), len(roots), n_threads))
+        self._after_trees(roots)
+
+    def set_trees(self, roots, off, nbr, nbr_base, max_depth=0):
+        roots, off, nbr = _i32(roots), _i32(off), _i32(nbr)
+        nbr_base = np.ascontiguousarray(nbr_base, dtype=np.int64)
+        self._ck(lib.gg_set_trees(self._ctx, _ptr(roots), len(roots), _ptr(off), _ptr(nbr), _ptr(nbr_base), max_depth))
+        self._after_trees(roots)
+
+    def _after_trees(self, roots):
+        self.tree_roots = roots.copy()
+        nr, ne, md = ctypes.c_int32(), ctypes.c_int64(), ctypes.c_int32()
+        self._ck(lib.gg_tree_info(self._ctx, ctypes.byref(nr), ctypes.byref(ne), ctypes.byref(md)))
+        self.tree_entries, self.max_depth = ne.value, md.value
+
+    def get_trees(self):
+        R = len(self.tree_roots)
+        off = np.zeros((R, self.n_node + 1), dtype=np.int32)
+        nbr = np.zeros(max(self.tree_entries, 1), dtype=np.int32)
+        base = np.zeros(R + 1, dtype=np.int64)
+        self._ck(lib.gg_get_trees(self._ctx, _ptr(off), _ptr(nbr), _ptr(base)))
+        return off, nbr[: self.tree_entries], base
+
+    # ------------------------------------------------------------------ K1
+    def walk_sample(self, slots, n_walks, for_d, seed, stream, stride=None, fetch=True):
+        """GraphGAN.sample (graph_gan.py:225-270) for many roots at once."""
+        slots, n_walks = _i32(slots), _i32(n_walks)
+        stride = int(stride or (self.max_depth + 3))
+        total = int(n_walks.sum())
+        if not fetch:
+            self._ck(lib.gg_walk_sample(self._ctx, _ptr(slots), _ptr(n_walks), len(slots), int(bool(for_d)), seed, stream,
+                                        None, None, None, stride, None))
+            return None
+        samples = np.full(total, -1, dtype=np.int32)
+        paths = np.full((total, stride), -1, dtype=np.int32)
+        plen = np.zeros(total, dtype=np.int32)
+        status = np.zeros(len(slots), dtype=np.int32)
+        self._ck(lib.gg_walk_sample(self._ctx, _ptr(slots), _ptr(n_walks), len(slots), int(bool(for_d)), seed, stream,
+                                    _ptr(samples), _ptr(paths), _ptr(plen), stride, _ptr(status)))
+        return dict(samples=samples, paths=paths, path_len=plen, root_status=status)
+
+    # ------------------------------------------------------------------ prepared data
+    def prepare_d(self, slots, seed, stream, fetch=True):
+        """prepare_data_for_d (graph_gan.py:182-202) -> (center, neighbor, label, root_status)."""
+        slots = _i32(slots)
+        n = ctypes.c_int64()
+        status = np.zeros(len(slots), dtype=np.int32)
+        self._ck(lib.gg_prepare_d(self._ctx, _ptr(slots), len(slots), seed, stream, ctypes.byref(n), _ptr(status)))
+        self.d_rows = n.value
+        if not fetch:
+            return n.value
+        c, nb, lab = np.zeros(n.value, np.int32), np.zeros(n.value, np.int32), np.zeros(n.value, np.float32)
+        self._ck(lib.gg_get_d_data(self._ctx, _ptr(c), _ptr(nb), _ptr(lab)))
+        return c, nb, lab, status
+
+    def prepare_g(self, slots, n_sample, seed, stream, fetch=True):
+        """prepare_data_for_g (graph_gan.py:204-223) -> (node_1, node_2, reward, root_status)."""
+        slots = _i32(slots)
+        n = ctypes.c_int64()
+        status = np.zeros(len(slots), dtype=np.int32)
+        self._ck(lib.gg_prepare_g(self._ctx, _ptr(slots), len(slots), n_sample, seed, stream, ctypes.byref(n), _ptr(status)))
+        self.g_pairs = n.value
+        if not fetch:
+            return n.value
+        a, b, r = np.zeros(n.value, np.int32), np.zeros(n.value, np.int32), np.zeros(n.value, np.float32)
+        self._ck(lib.gg_get_g_data(self._ctx, _ptr(a), _ptr(b), _ptr(r)))
+        return a, b, r, status
+
+    def d_pass(self, starts, batch_size):
+        """One inner D epoch over the prepared rows (graph_gan.py:149-157)."""
+        starts = np.ascontiguousarray(starts, dtype=np.int64)
+        self._ck(lib.gg_d_pass(self._ctx, _ptr(starts), len(starts), batch_size))
+
+    def g_pass(self, starts, batch_size):
+        """One inner G epoch over the prepared pairs (graph_gan.py:168-176)."""
+        starts = np.ascontiguousarray(starts, dtype=np.int64)
+        self._ck(lib.gg_g_pass(self._ctx, _ptr(starts), len(starts), batch_size))
+
+    # ------------------------------------------------------------------ sess.run call sites with host buffers
+    def pair_reward(self, u, v):
+        """sess.run(discriminator.reward) (graph_gan.py:220-222)."""
+        u, v = _i32(u), _i32(v)
+        out = np.zeros(len(u), dtype=np.float32)
+        self._ck(lib.gg_pair_reward(self._ctx, _ptr(u), _ptr(v), len(u), _ptr(out)))
+        return out
+
+    def d_step(self, u, v, label):
+        """sess.run(discriminator.d_updates) (graph_gan.py:154-157)."""
+        u, v, label = _i32(u), _i32(v), np.ascontiguousarray(label, dtype=np.float32)
+        self._ck(lib.gg_d_step(self._ctx, _ptr(u), _ptr(v), _ptr(label), len(u)))
+
+    def g_step(self, u, v, reward):
+        """sess.run(generator.g_updates) (graph_gan.py:173-176)."""
+        u, v, reward = _i32(u), _i32(v), np.ascontiguousarray(reward, dtype=np.float32)
+        self._ck(lib.gg_g_step(self._ctx, _ptr(u), _ptr(v), _ptr(reward), len(u)))
+
+    def get_embeddings(self, which):
+        """sess.run(embedding_matrix) (graph_gan.py:298); which: 0 = gen, 1 = dis."""
+        out = np.zeros((self.n_node, self.n_emb), dtype=np.float32)
+        self._ck(lib.gg_get_embeddings(self._ctx, which, _ptr(out)))
+        return out
+
+    def get_bias(self, which):
+        out = np.zeros(self.n_node, dtype=np.float32)
+        self._ck(lib.gg_get_bias(self._ctx, which, _ptr(out)))
+        return out
+
+    def set_embeddings(self, which, emb):
+        emb = np.ascontiguousarray(emb, dtype=np.float32)
+        assert emb.shape == (self.n_node, self.n_emb)
+        self._ck(lib.gg_set_embeddings(self._ctx, which, _ptr(emb)))
+
+    def set_bias(self, which, bias):
+        bias = np.ascontiguousarray(bias, dtype=np.float32)
+        assert bias.shape == (self.n_node,)
+        self._ck(lib.gg_set_bias(self._ctx, which, _ptr(bias)))
+
+    def save_state(self, path):
+        self._ck(lib.gg_save_state(self._ctx, path.encode()))
+
+    def load_state(self, path):
+        self._ck(lib.gg_load_state(self._ctx, path.encode()))
+
+    def counters(self):
+        c = GGCounters()
+        self._ck(lib.gg_get_counters(self._ctx, ctypes.byref(c)))
+        return {k: getattr(c, k) for k, _ in GGCounters._fields_ if k != "reserved"}
+
+    # ------------------------------------------------------------------ multi-GPU
+    @staticmethod
+    def comm_unique_id():
+        buf = (ctypes.c_char * 128)()
+        check(lib.gg_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, world):
+        buf = (ctypes.c_char * 128).from_buffer_copy(unique_id)
+        self._ck(lib.gg_comm_init(self._ctx, buf, rank, world))
+
+    def comm_barrier(self):
+        self._ck(lib.gg_comm_barrier(self._ctx))

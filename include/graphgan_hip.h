@@ -1,0 +1,198 @@
+/*
+ * graphgan_hip.h -- C ABI of libgraphgan_hip.so, the MI355X (gfx950) engine for the
+ * GraphGAN hot path.  Plain C, no torch / numpy types: pointers, sizes, scalars.
+ *
+ * The reference (hwwang55/GraphGAN) has no FFI: its "operator API" is the five
+ * tf.Session.run call sites of src/GraphGAN/graph_gan.py plus the host-side sampler.
+ * Every entry point below names the reference interface it replaces (file:line under
+ * /root/reference).  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns int: 0 = GG_OK, negative = GG_E*; no exceptions / aborts cross
+ *     the ABI; gg_last_error() gives the message of the last failing call
+ *     (ctx == NULL: the last gg_create / host-only failure of the calling thread).
+ *   - the caller owns every host buffer it passes (C-contiguous; int32 node ids - the
+ *     reference's placeholders are tf.int32, generator.py:17-18; fp32 values; int64
+ *     offsets).  Inputs are copied; outputs are written before the call returns (every
+ *     call is synchronous: it returns after the context's HIP stream is idle).
+ *   - a gg_ctx owns all device memory (embedding tables, Adam slots, graph CSR, tree CSR,
+ *     prepared sample buffers, scratch) and one HIP stream on one device; it is not
+ *     re-entrant.  Multi-GPU = one process and one context per GPU (gg_comm_*).
+ *   - per-root outcomes (the reference's ``return None, None``) are DATA (root_status),
+ *     not errors.
+ *   - there is no CPU fallback: without a gfx950 device gg_create fails with GG_EHIP.
+ */
+#ifndef GRAPHGAN_HIP_H
+#define GRAPHGAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GG_ABI_VERSION 1
+
+enum {
+    GG_OK = 0,
+    GG_EINVAL = -1,    /* bad argument / call order */
+    GG_ECAPACITY = -2, /* caller capacity too small (e.g. path stride) */
+    GG_EHIP = -3,      /* HIP runtime error, or no usable device */
+    GG_ECOMM = -4,     /* RCCL error / librccl not loadable */
+    GG_ENOMEM = -5,
+    GG_EIO = -6
+};
+
+/* optimizer modes (a12) */
+enum {
+    GG_OPT_ADAM_DENSE = 0, /* TF1.8 sparse-apply semantics: m, v and var move over ALL rows each step */
+    GG_OPT_ADAM_LAZY = 1,  /* only touched rows decay/move (scale mode) */
+    GG_OPT_SGD = 2         /* var -= lr * grad on touched rows (north-star SGD variant) */
+};
+
+/* root_status values written by gg_walk_sample / gg_prepare_* */
+enum {
+    GG_ROOT_OK = 0,
+    GG_ROOT_ABORTED = 1, /* reference: sample() returned (None, None), graph_gan.py:252-257 */
+    GG_ROOT_EMPTY = 2    /* zero walks requested (D-mode, deg == 0): reference returns ([], []) */
+};
+
+/* hyper-parameters, names as in src/GraphGAN/config.py:4-25 */
+typedef struct gg_config {
+    float lr_gen;      /* config.py:9  */
+    float lr_dis;      /* config.py:10 */
+    float lambda_gen;  /* config.py:6  */
+    float lambda_dis;  /* config.py:7  */
+    float adam_beta1;  /* tf.train.AdamOptimizer default 0.9   */
+    float adam_beta2;  /* 0.999 */
+    float adam_eps;    /* 1e-8  */
+    int32_t window_size; /* config.py:25 */
+    int32_t optimizer;   /* GG_OPT_* */
+    int32_t device;      /* HIP device ordinal */
+    int32_t reserved[6];
+} gg_config;
+
+typedef struct gg_counters {
+    int64_t walks;          /* walks completed since creation */
+    int64_t hops;           /* sampled edges: one softmax-sample each (graph_gan.py:262-263) */
+    int64_t nbr_reads;      /* sum over hops of k = tree neighbours scored */
+    int64_t reward_pairs;   /* rows through gg_pair_reward / prepare_g */
+    int64_t d_pairs;        /* rows through d steps */
+    int64_t g_pairs;        /* rows through g steps */
+    int64_t d_steps;
+    int64_t g_steps;
+    double last_kernel_ms;  /* HIP-event time of the last timed kernel region (walk / pass) */
+    double walk_kernel_ms;  /* cumulative HIP-event time of walk_sample kernels */
+    int64_t walk_launches;
+    int64_t reserved[5];
+} gg_counters;
+
+typedef struct gg_ctx gg_ctx;
+
+int gg_abi_version(void);
+const char *gg_last_error(const gg_ctx *ctx);
+
+/* ---- life cycle.  Replaces build_generator/build_discriminator + tf.Session init
+ * (graph_gan.py:48-61, generator.py:11-15, discriminator.py:11-15): two [n_node, n_emb]
+ * fp32 tables from the caller's init matrices, zero bias vectors, zero Adam slots. */
+int gg_create(int32_t n_node, int32_t n_emb, const float *emb_gen, const float *emb_dis,
+              const gg_config *cfg, gg_ctx **out);
+int gg_destroy(gg_ctx *ctx);
+
+/* ---- graph + BFS trees.
+ * gg_set_graph_csr: the adjacency dict of utils.read_edges (utils.py:12-47) as CSR,
+ * neighbour order = list order (it decides BFS child order and D-step positives). */
+int gg_set_graph_csr(gg_ctx *ctx, const int64_t *rowptr /*[n_node+1]*/, const int32_t *col);
+
+/* gg_host_build_trees: construct_trees (graph_gan.py:84-108) on host threads, no GPU, no ctx.
+ * Tree CSR of root slot r: node v's list [father, child_0, ...] (root: [root, child...]) is
+ * nbr[nbr_base[r] + off[r*(n_node+1)+v] .. off[r*(n_node+1)+v+1]), lists in node-id order.
+ * nbr == NULL sizes only.  Returns total entries (>= 0) or GG_E*. */
+int64_t gg_host_build_trees(int32_t n_node, const int64_t *rowptr, const int32_t *col,
+                            const int32_t *roots, int32_t n_roots,
+                            int32_t *off /*[n_roots*(n_node+1)]*/, int32_t *nbr, int64_t *nbr_base /*[n_roots+1]*/,
+                            int64_t cap, int32_t n_threads, int32_t *max_depth_out);
+
+/* gg_build_trees: same, built in batches and uploaded into the context (replaces the pickle
+ * cache load/construct branch, graph_gan.py:31-46).  Root slot i holds the tree of roots[i]. */
+int gg_build_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, int32_t n_threads);
+/* gg_set_trees / gg_get_trees: upload / download a tree CSR (cache files, tests; download
+ * includes the in-place D-mode mutations, graph_gan.py:258-259). */
+int gg_set_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int32_t *off,
+                 const int32_t *nbr, const int64_t *nbr_base, int32_t max_depth);
+int gg_tree_info(const gg_ctx *ctx, int32_t *n_roots, int64_t *n_entries, int32_t *max_depth);
+int gg_get_trees(gg_ctx *ctx, int32_t *off, int32_t *nbr, int64_t *nbr_base);
+
+/* ---- K1 walk_sample.  Replaces GraphGAN.sample (graph_gan.py:225-270) including the
+ * all_score fetch (:238, generator.py:21), utils.softmax (utils.py:131-133) and
+ * np.random.choice (:262).  For each i: n_walks[i] walks on the tree in slot slots[i]
+ * (D-mode: for_d = 1, n_walks = len(graph[root]), :190-191; G-mode: n_sample_gen, :210).
+ * Walk w = walk_ptr[i] + j writes samples[w] (end node, -1 if the root aborted),
+ * paths[w*stride ..] = [root, ..., end, prev-of-end], path_len[w] (0 if aborted).
+ * Host output pointers may be NULL (results stay resident for gg_prepare_*).
+ * Uniforms: Philox4x32-10(key = seed; counter = hop, j, root id, stream) -> results do not
+ * depend on slot order, batching or GPU count.  Arithmetic: DESIGN.md section 3. */
+int gg_walk_sample(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, int32_t n_slots,
+                   int32_t for_d, uint64_t seed, uint32_t stream,
+                   int32_t *samples, int32_t *paths, int32_t *path_len, int32_t stride,
+                   int32_t *root_status);
+
+/* ---- prepared sample buffers (device resident).
+ * gg_prepare_d: prepare_data_for_d (graph_gan.py:182-202) for the given root slots: D-mode
+ * walks (n_walks = CSR degree), then rows [pos..., neg...] per non-aborted root, in slot order.
+ * gg_prepare_g: prepare_data_for_g (:204-223): n_sample walks per root, window pairs
+ * (get_node_pairs_from_path, :272-291) and reward (discriminator.py:33-34) for all pairs. */
+int gg_prepare_d(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, uint64_t seed, uint32_t stream,
+                 int64_t *n_rows_out, int32_t *root_status /*[n_slots] or NULL*/);
+int gg_get_d_data(gg_ctx *ctx, int32_t *center, int32_t *neighbor, float *label);
+int gg_prepare_g(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, int32_t n_sample, uint64_t seed,
+                 uint32_t stream, int64_t *n_pairs_out, int32_t *root_status);
+int gg_get_g_data(gg_ctx *ctx, int32_t *node_1, int32_t *node_2, float *reward);
+
+/* gg_d_pass / gg_g_pass: one inner epoch over the prepared rows = the minibatch loops
+ * graph_gan.py:149-157 / :168-176: for each s in starts (the caller's shuffled start_list),
+ * one optimizer step on rows [s, min(s+batch, n)). */
+int gg_d_pass(gg_ctx *ctx, const int64_t *starts, int64_t n_batches, int32_t batch_size);
+int gg_g_pass(gg_ctx *ctx, const int64_t *starts, int64_t n_batches, int32_t batch_size);
+
+/* ---- the sess.run call sites with host buffers.
+ * gg_pair_reward: sess.run(discriminator.reward) (graph_gan.py:220-222, discriminator.py:21-24,33-34)
+ * gg_d_step:      sess.run(discriminator.d_updates) (graph_gan.py:154-157, discriminator.py:26-32)
+ * gg_g_step:      sess.run(generator.g_updates)     (graph_gan.py:173-176, generator.py:22-31) */
+int gg_pair_reward(gg_ctx *ctx, const int32_t *u, const int32_t *v, int64_t n, float *out);
+int gg_d_step(gg_ctx *ctx, const int32_t *u, const int32_t *v, const float *label, int32_t n);
+int gg_g_step(gg_ctx *ctx, const int32_t *u, const int32_t *v, const float *reward, int32_t n);
+
+/* sess.run(embedding_matrix) (graph_gan.py:298); which: 0 = generator, 1 = discriminator
+ * (config.modes order, config.py:1).  out is [n_node, n_emb] fp32, unpadded. */
+int gg_get_embeddings(gg_ctx *ctx, int32_t which, float *out);
+int gg_get_bias(gg_ctx *ctx, int32_t which, float *out);
+int gg_set_embeddings(gg_ctx *ctx, int32_t which, const float *emb);
+int gg_set_bias(gg_ctx *ctx, int32_t which, const float *bias);
+
+/* tf.train.Saver save/restore (graph_gan.py:55,124-127,137-138): all variables + Adam
+ * slots + step counts, as one flat binary file (format: DESIGN.md). */
+int gg_save_state(gg_ctx *ctx, const char *path);
+int gg_load_state(gg_ctx *ctx, const char *path);
+
+int gg_get_counters(gg_ctx *ctx, gg_counters *out);
+
+/* ---- multi-GPU (no reference counterpart: single tf.Session, graph_gan.py:57-61).
+ * One process per GPU.  Rank 0 calls gg_comm_unique_id, the 128 bytes travel by any side
+ * channel, every rank calls gg_comm_init.  Afterwards each optimizer step sums the
+ * gradients of all ranks (RCCL all-reduce on the context's stream) before the update,
+ * so replicas stay identical. */
+int gg_comm_unique_id(void *id128);
+int gg_comm_init(gg_ctx *ctx, const void *id128, int32_t rank, int32_t world);
+int gg_comm_barrier(gg_ctx *ctx);
+
+/* ---- synthetic power-law graphs for the benchmark configs (BASELINE.json configs[2..4];
+ * recipe in SURVEY.md section 8d): Barabasi-Albert, m edges per new node, node ids permuted.
+ * edges_out: [n_edges_cap][2] int32; returns the number of edges written or GG_E*. */
+int64_t gg_synth_powerlaw(int32_t n_node, int32_t m, uint64_t seed_graph, uint64_t seed_perm,
+                          int32_t *edges_out, int64_t n_edges_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAPHGAN_HIP_H */

@@ -1,0 +1,133 @@
+"""GPU parity: the HIP walk sampler (K1, through the C ABI) against the spec-arithmetic CPU
+oracle (oracle/walk_oracle.c) on the same seeded inputs -- BIT-EXACT on samples, paths, path
+lengths, root status and the in-place tree mutations (integer work: no tolerance)."""
+import numpy as np
+import pytest
+
+from oracle import graphgan_oracle as orc
+from tests.helpers import load_ca_grqc, load_small, star_graph_edges, ca_grqc_init_embeddings
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ga():
+    import graphgan_amd
+    return graphgan_amd
+
+
+def run_both(ga, n, rowptr, col, roots, E, b, rounds, seed, n_sample=20, stride=None):
+    """D, G, D, G ... on engine and oracle; returns nothing, asserts equality."""
+    roots = np.asarray(roots, dtype=np.int32)
+    deg = (rowptr[1:] - rowptr[:-1]).astype(np.int32)
+    eng = ga.Engine(E, E)
+    eng.set_bias(0, b)
+    eng.set_graph_csr(rowptr, col)
+    eng.build_trees(roots)
+    off, nbr, base, dmax = orc.c_build_trees(n, rowptr, col, roots)
+    toff, tnbr, tbase = eng.get_trees()
+    assert np.array_equal(toff, off) and np.array_equal(tnbr, nbr) and np.array_equal(tbase, base)
+    assert eng.max_depth == dmax
+    stride = stride or dmax + 3
+    Ep = orc.pad_rows(E)
+    slots = np.arange(len(roots), dtype=np.int32)
+    nbr = nbr.copy()
+    hops = 0
+    for r in range(rounds):
+        for_d = r % 2 == 0
+        nw = deg[roots] if for_d else np.full(len(roots), n_sample, dtype=np.int32)
+        want = orc.c_walk_sample(Ep, b, off, nbr, base, roots, slots, nw, for_d, seed, r, stride)
+        got = eng.walk_sample(slots, nw, for_d, seed, r, stride=stride)
+        assert np.array_equal(got["root_status"], want["root_status"]), "round %d status" % r
+        assert np.array_equal(got["path_len"], want["path_len"]), "round %d path_len" % r
+        assert np.array_equal(got["samples"], want["samples"]), "round %d samples" % r
+        m = np.arange(stride)[None, :] < want["path_len"][:, None]
+        assert np.array_equal(got["paths"][m], want["paths"][m]), "round %d paths" % r
+        _, tnbr, _ = eng.get_trees()
+        assert np.array_equal(tnbr, nbr), "round %d tree mutation state (Q3)" % r
+        hops += want["hops"]
+        c = eng.counters()
+        assert c["hops"] == hops
+    eng.close()
+    return hops
+
+
+@pytest.mark.parametrize("gi", [0, 1, 2, 3])
+def test_small_graphs_bit_exact(ga, gi):
+    g, n, graph = load_small(gi)
+    rowptr, col = ga.graph_to_csr(n, graph)
+    hops = run_both(ga, n, rowptr, col, np.arange(n), g["E"], g["b"], rounds=4, seed=1234 + gi)
+    assert hops > 100
+
+
+@pytest.mark.parametrize("d", [4, 50, 128, 200, 256])
+def test_embedding_widths(ga, d):
+    g, n, graph = load_small(1)
+    rs = np.random.RandomState(d)
+    E = (rs.randn(n, d) * (1.5 / np.sqrt(d))).astype(np.float32)
+    b = (rs.randn(n) * 0.2).astype(np.float32)
+    rowptr, col = ga.graph_to_csr(n, graph)
+    run_both(ga, n, rowptr, col, np.arange(n), E, b, rounds=2, seed=99)
+
+
+def test_ca_grqc_all_roots_bit_exact(ga):
+    """BASELINE.json configs[1]: CA-GrQc, n_emb = 50, every root, D then G then D then G."""
+    d, n, graph = load_ca_grqc()
+    E = ca_grqc_init_embeddings(d, n).astype(np.float32)
+    b = (np.random.RandomState(1).randn(n) * 0.05).astype(np.float32)
+    rowptr, col = ga.graph_to_csr(n, graph)
+    hops = run_both(ga, n, rowptr, col, np.arange(n), E, b, rounds=4, seed=2026)
+    assert hops > 500000
+
+
+@pytest.mark.parametrize("leaves", [70, 300, 1500])
+def test_hub_lists_longer_than_one_pass(ga, leaves):
+    """k > 64 (multi-block scan) and k > 1024 (scores in HBM scratch instead of LDS)."""
+    edges, n = star_graph_edges(leaves)
+    rowptr, col = ga.edges_to_csr(n, edges)
+    rs = np.random.RandomState(leaves)
+    E = (rs.randn(n, 32) * 0.4).astype(np.float32)
+    b = (rs.randn(n) * 0.5).astype(np.float32)
+    roots = np.array([0, 1, 2, n - 1, n - 2], dtype=np.int32)
+    run_both(ga, n, rowptr, col, roots, E, b, rounds=4, seed=5, n_sample=200)
+
+
+def test_slot_order_and_batching_do_not_change_walks(ga):
+    """Counter RNG keyed by (root id, walk, hop, stream): any slot order / batch split gives the same walks."""
+    g, n, graph = load_small(3)
+    rowptr, col = ga.graph_to_csr(n, graph)
+    eng = ga.Engine(g["E"], g["E"])
+    eng.set_bias(0, g["b"])
+    eng.set_graph_csr(rowptr, col)
+    roots = np.arange(n, dtype=np.int32)
+    eng.build_trees(roots)
+    nw = np.full(n, 20, dtype=np.int32)
+    full = eng.walk_sample(np.arange(n), nw, False, 7, 3)
+    perm = np.random.RandomState(0).permutation(n).astype(np.int32)
+    a = eng.walk_sample(perm[: n // 2], nw[: n // 2], False, 7, 3, stride=full["paths"].shape[1])
+    bb = eng.walk_sample(perm[n // 2:], nw[n // 2:], False, 7, 3, stride=full["paths"].shape[1])
+    got_paths = np.concatenate([a["paths"], bb["paths"]]).reshape(n, 20, -1)
+    want_paths = full["paths"].reshape(n, 20, -1)[perm]
+    assert np.array_equal(got_paths, want_paths)
+    eng.close()
+
+
+def test_errors_are_codes_not_crashes(ga):
+    g, n, graph = load_small(0)
+    rowptr, col = ga.graph_to_csr(n, graph)
+    eng = ga.Engine(g["E"], g["E"])
+    with pytest.raises(ga.GraphGANHipError) as ei:  # no trees yet
+        eng.walk_sample([0], [1], False, 0, 0, stride=8)
+    assert ei.value.code == -1
+    eng.set_graph_csr(rowptr, col)
+    eng.build_trees(np.arange(n))
+    with pytest.raises(ga.GraphGANHipError) as ei:  # slot out of range
+        eng.walk_sample([n + 3], [1], False, 0, 0)
+    assert ei.value.code == -1
+    with pytest.raises(ga.GraphGANHipError) as ei:  # stride too small -> GG_ECAPACITY, not memory corruption
+        eng.walk_sample(np.arange(n), np.full(n, 20), False, 0, 0, stride=2)
+    assert ei.value.code == -2
+    # empty launch is fine
+    out = eng.walk_sample(np.zeros(0, np.int32), np.zeros(0, np.int32), False, 0, 0)
+    assert len(out["samples"]) == 0
+    eng.close()
