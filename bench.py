@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- the GraphGAN hot path on MI355X, one JSON line.
+
+Metric (BASELINE.json): sampled-edges/sec of the graph-softmax walk sampler, with the D-step /
+G-step pairs/sec beside it.  One *step* = one epoch body of the reference's ``train()``
+(src/GraphGAN/graph_gan.py:144-176 with one inner pass each) over this rank's R root slots:
+
+    prepare_data_for_d (D-mode walks, deg(root) each)  ->  one D optimizer pass over those rows
+    prepare_data_for_g (G-mode walks, n_sample_gen=20, window pairs, rewards) -> one G pass
+
+``value`` = sampled edges (hops of both walk launches, all ranks) / wall time of the K timed
+steps, inputs resident in HBM.  Workload at N=1: synthetic power-law graph, 1M nodes / 10M
+edges, n_emb = 128 (the configuration the north-star target is quoted on), R roots per step.
+Weak scaling: every rank walks its own R roots; replicas exchange gradients through RCCL.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--workload", default="powerlaw", choices=["powerlaw", "ca_grqc"])
+    p.add_argument("--nodes", type=int, default=1_000_000)
+    p.add_argument("--m", type=int, default=10)
+    p.add_argument("--emb", type=int, default=128)
+    p.add_argument("--roots", type=int, default=2048, help="root slots per rank per step")
+    p.add_argument("--n-sample-gen", type=int, default=20)
+    p.add_argument("--optimizer", default="adam_lazy", choices=["adam_dense", "adam_lazy", "sgd"])
+    p.add_argument("--threads", type=int, default=0, help="host BFS threads (0 = min(64, cores))")
+    p.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--seed", type=int, default=6)
+    return p.parse_args()
+
+
+def make_workload(args, ga):
+    if args.workload == "ca_grqc":
+        g = np.load(os.path.join(ROOT, "tests", "golden", "ca_grqc.npz"))
+        n = int(g["n_node"])
+        rowptr, col = ga.edges_to_csr(n, g["train"])
+        emb = np.random.RandomState(5).rand(n, g["emb_rows"].shape[1])
+        emb[g["emb_ids"]] = g["emb_rows"]
+        name = "CA-GrQc (5242 nodes, 13046 train edges), n_emb=50, shipped pre-trained embeddings"
+        return n, rowptr, col, emb.astype(np.float32), name
+    n, d = args.nodes, args.emb
+    edges = ga.synth_powerlaw(n, args.m, 1, 2)  # BA m=10, graph seed 1, permutation seed 2
+    rowptr, col = ga.edges_to_csr(n, edges)
+    sigma = 0.6 * np.sqrt(50.0 / d)  # matches the dot-product scale of the shipped CA-GrQc pre-training
+    rs = np.random.default_rng(5)
+    emb = rs.standard_normal((n, d), dtype=np.float32) * np.float32(sigma)
+    name = "synthetic power-law (Barabasi-Albert m=%d): %d nodes / %d edges, n_emb=%d" % (args.m, n, len(edges), d)
+    return n, rowptr, col, emb, name
+
+
+def cpu_baseline(args, n, rowptr, col, emb, bias, roots, seconds):
+    """The C oracle ('port' of graph_gan.py:225-270 with scores computed on demand, i.e. the
+    'hoisted' fair baseline of BASELINE.md section 3) on ONE host core, G-mode walks over a bounded
+    sample of this workload's roots; returns (edges/s, sample description)."""
+    from oracle import graphgan_oracle as orc
+    Ep = orc.pad_rows(emb)
+    rts = np.ascontiguousarray(roots[:48])
+    # trees are a cached precompute in the reference too (graph_gan.py:31-46): not timed
+    off, nbr, base, dmax = orc.c_build_trees(n, rowptr, col, rts)
+    slots = np.arange(len(rts), dtype=np.int32)
+    nw = np.full(len(rts), args.n_sample_gen, dtype=np.int32)
+    hops, t, stream = 0, 0.0, 1
+    while t < seconds:
+        t0 = time.perf_counter()
+        res = orc.c_walk_sample(Ep, bias, off, nbr, base, rts, slots, nw, False, args.seed, stream, dmax + 3)
+        t += time.perf_counter() - t0
+        hops += int(res["hops"])
+        stream += 2
+    return hops / t, "G-mode walks (%d per root) from %d roots of the same graph, repeated over %d RNG streams: %d hops in %.1f s, scores computed on demand (hoisted flavour)" % (
+        args.n_sample_gen, len(rts), stream // 2, hops, t)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import graphgan_amd as ga  # loads libgraphgan_hip.so (and with it the HIP runtime) before anything else
+    from graphgan_amd import _lib
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # control plane only (gloo on CPU): barrier, max, id broadcast
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    t_setup = time.time()
+    n, rowptr, col, emb, wl_name = make_workload(args, ga)
+    opt = {"adam_dense": _lib.GG_OPT_ADAM_DENSE, "adam_lazy": _lib.GG_OPT_ADAM_LAZY, "sgd": _lib.GG_OPT_SGD}[args.optimizer]
+    eng = ga.Engine(emb, emb, optimizer=opt, device=local_rank)
+    eng.set_graph_csr(rowptr, col)
+    R = min(args.roots, n // world)
+    deg = rowptr[1:] - rowptr[:-1]
+    cand = np.flatnonzero(deg > 0)
+    all_roots = np.random.RandomState(args.seed).permutation(cand)[: R * world].astype(np.int32)
+    roots = np.ascontiguousarray(all_roots[rank * R:(rank + 1) * R])
+    threads = args.threads or min(64, os.cpu_count() or 1)
+    eng.build_trees(roots, n_threads=max(1, threads // max(1, min(world, 8))))
+    slots = np.arange(len(roots), dtype=np.int32)
+    if world > 1:
+        import torch
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(ga.Engine.comm_unique_id()), dtype=torch.uint8).clone()
+        dist.broadcast(uid, 0)
+        eng.comm_init(bytes(uid.numpy().tobytes()), rank, world)
+    setup_s = time.time() - t_setup
+
+    def step(i):
+        rows = eng.prepare_d(slots, args.seed, 2 * i, fetch=False)
+        if rows:
+            eng.d_pass(np.zeros(1, np.int64), int(rows))
+        pairs = eng.prepare_g(slots, args.n_sample_gen, args.seed, 2 * i + 1, fetch=False)
+        if pairs:
+            eng.g_pass(np.zeros(1, np.int64), int(pairs))
+
+    def barrier():
+        eng.comm_barrier()
+        if dist is not None:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    c0 = eng.counters()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    c1 = eng.counters()
+
+    hops = c1["hops"] - c0["hops"]
+    reads = c1["nbr_reads"] - c0["nbr_reads"]
+    walk_ms = c1["walk_kernel_ms"] - c0["walk_kernel_ms"]
+    launches = c1["walk_launches"] - c0["walk_launches"]
+    dpairs = c1["d_pairs"] - c0["d_pairs"]
+    gpairs = c1["g_pairs"] - c0["g_pairs"]
+    tot = np.array([hops, dpairs, gpairs, dt], dtype=np.float64)
+    if dist is not None:
+        import torch
+        tsum = torch.tensor(tot[:3])
+        dist.all_reduce(tsum)
+        tmax = torch.tensor([dt])
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tot = np.array([tsum[0].item(), tsum[1].item(), tsum[2].item(), tmax.item()])
+    if rank != 0:
+        eng.close()
+        return
+
+    d = eng.n_emb
+    # algorithmic bytes of the walk kernel (SURVEY.md section 8d / DESIGN.md section 5): per hop with k tree
+    # neighbours 4k(d+2) (ids, rows, biases) + 4d (current row) + 12 (offset pair + output id)
+    alg_bytes = 4.0 * (d + 2) * reads + (4.0 * d + 12.0) * hops
+    per_launch_bytes = alg_bytes / max(launches, 1)
+    per_launch_ms = walk_ms / max(launches, 1)
+    achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+    out = {
+        "metric": "sampled_edges_per_sec",
+        "value": tot[0] / tot[3],
+        "unit": "edges/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * tot[3] / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": wl_name, "roots_per_gpu_per_step": int(R), "n_sample_gen": args.n_sample_gen,
+                   "optimizer": args.optimizer, "step": "prepare_d + d_pass + prepare_g + g_pass (graph_gan.py:144-176, one inner pass each)",
+                   "parallelism": "roots sharded x%d, replicated tables, RCCL grad all-reduce" % world if world > 1 else "single GPU"},
+        "d_step_pairs_per_sec": tot[1] / tot[3],
+        "g_step_pairs_per_sec": tot[2] / tot[3],
+        "walk_kernel_edges_per_sec": hops / (walk_ms * 1e-3) if walk_ms > 0 else None,
+        "hops_per_step_rank0": hops / args.steps,
+        "mean_k": reads / max(hops, 1),
+        "setup_s": setup_s,
+        "roofline": {"kernel": "walk_sample_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": per_launch_ms, "launches": int(launches)},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        bias = eng.get_bias(0)
+        embg = eng.get_embeddings(0)
+        v, sample = cpu_baseline(args, n, rowptr, col, embg, bias, roots, args.cpu_baseline_seconds)
+        out["cpu_baseline"] = {"value": v, "unit": "edges/s", "cores": 1, "kind": "port", "sample": sample}
+        out["walk_kernel_vs_cpu"] = out["walk_kernel_edges_per_sec"] / v if v > 0 and out["walk_kernel_edges_per_sec"] else None
+    eng.close()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -284,8 +284,8 @@ int gg_build_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, int32_t n
     host_tree_sizes(n, ctx->h_rowptr.data(), ctx->h_col.data(), roots, n_roots, base.data());
     int rc = alloc_trees(ctx, roots, n_roots, base.data());
     if (rc != GG_OK) return rc;
-    // batches of roots bounded by ~256 MiB of host staging
-    const int64_t budget = 64ll << 20;  // int32 entries
+    // batches of roots bounded by ~2 GiB of host staging
+    const int64_t budget = 512ll << 20;  // int32 entries (2 GiB)
     int32_t md = 0, ml = 0;
     std::vector<int32_t> off_h, nbr_h;
     for (int r0 = 0; r0 < n_roots;) {

@@ -33,6 +33,7 @@ def run_both(ga, n, rowptr, col, roots, E, b, rounds, seed, n_sample=20, stride=
     slots = np.arange(len(roots), dtype=np.int32)
     nbr = nbr.copy()
     hops = 0
+    prev_ctr = 0
     for r in range(rounds):
         for_d = r % 2 == 0
         nw = deg[roots] if for_d else np.full(len(roots), n_sample, dtype=np.int32)
@@ -47,7 +48,11 @@ def run_both(ga, n, rowptr, col, roots, E, b, rounds, seed, n_sample=20, stride=
         assert np.array_equal(tnbr, nbr), "round %d tree mutation state (Q3)" % r
         hops += want["hops"]
         c = eng.counters()
-        assert c["hops"] == hops
+        # G-mode: hop counters agree exactly.  D-mode: the reference stops a root at its first
+        # aborting walk; the kernel runs all walks of a root concurrently and discards them.
+        delta = c["hops"] - prev_ctr
+        assert (delta == want["hops"]) if not for_d else (delta >= want["hops"])
+        prev_ctr = c["hops"]
     eng.close()
     return hops
 
@@ -106,9 +111,17 @@ def test_slot_order_and_batching_do_not_change_walks(ga):
     perm = np.random.RandomState(0).permutation(n).astype(np.int32)
     a = eng.walk_sample(perm[: n // 2], nw[: n // 2], False, 7, 3, stride=full["paths"].shape[1])
     bb = eng.walk_sample(perm[n // 2:], nw[n // 2:], False, 7, 3, stride=full["paths"].shape[1])
-    got_paths = np.concatenate([a["paths"], bb["paths"]]).reshape(n, 20, -1)
-    want_paths = full["paths"].reshape(n, 20, -1)[perm]
-    assert np.array_equal(got_paths, want_paths)
+    stride = full["paths"].shape[1]
+
+    def masked(res):
+        m = np.arange(stride)[None, :] < res["path_len"][:, None]
+        return np.where(m, res["paths"], -1).reshape(-1, 20, stride), res["path_len"].reshape(-1, 20)
+
+    pa, la = masked(a)
+    pb, lb = masked(bb)
+    pf, lf = masked(full)
+    assert np.array_equal(np.concatenate([pa, pb]), pf[perm])
+    assert np.array_equal(np.concatenate([la, lb]), lf[perm])
     eng.close()
 
 
