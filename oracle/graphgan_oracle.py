@@ -380,7 +380,8 @@ class TF1Adam:
 # ----------------------------------------------------------------------------- models
 
 def _sigmoid(x):
-    return (1.0 / (1.0 + np.exp(-x.astype(np.float64)))).astype(np.float32)
+    with np.errstate(over="ignore"):
+        return (1.0 / (1.0 + np.exp(-x.astype(np.float64)))).astype(np.float32)
 
 
 class PairModel:

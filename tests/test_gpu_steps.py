@@ -1,0 +1,235 @@
+"""GPU parity of the float kernels (through the C ABI) against the numpy oracle:
+K2 pair_reward (abs 1e-5), K3/K4 d_step / g_step with TF1-Adam (rows to 1e-6 relative,
+atol 1e-7: fp32 atomics sum duplicates in a different order than np.add.at), lazy-Adam and
+SGD variants, prepared-data pipelines (integer arrays bit-exact), state save / restore."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import graphgan_oracle as orc
+from tests.helpers import load_ca_grqc, load_small, ca_grqc_init_embeddings
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-6, 2e-7
+
+
+@pytest.fixture(scope="module")
+def ga():
+    import graphgan_amd
+    return graphgan_amd
+
+
+def make_models(n, d, seed):
+    rs = np.random.RandomState(seed)
+    Eg = (rs.randn(n, d) * 0.5).astype(np.float32)
+    Ed = (rs.randn(n, d) * 0.5).astype(np.float32)
+    bg = (rs.randn(n) * 0.1).astype(np.float32)
+    bd = (rs.randn(n) * 0.1).astype(np.float32)
+    return Eg, Ed, bg, bd
+
+
+def engine_with(ga, Eg, Ed, bg, bd, **kw):
+    eng = ga.Engine(Eg, Ed, **kw)
+    eng.set_bias(0, bg)
+    eng.set_bias(1, bd)
+    return eng
+
+
+@pytest.mark.parametrize("d", [8, 50, 128])
+def test_pair_reward(ga, d):
+    n = 500
+    Eg, Ed, bg, bd = make_models(n, d, d)
+    Ed *= np.float32(np.sqrt(5.0 / np.sqrt(d)) / 0.5)  # dot std ~5: some scores beyond the +-10 clip
+    eng = engine_with(ga, Eg, Ed, bg, bd)
+    rs = np.random.RandomState(0)
+    u, v = rs.randint(0, n, 10000), rs.randint(0, n, 10000)
+    dis = orc.Discriminator(Ed, 1e-3)
+    dis.b[:] = bd
+    want = dis.reward(u, v)
+    got = eng.pair_reward(u, v)
+    # 1e-5 absolute (summation order of the fp32 dot differs from numpy's)
+    assert np.max(np.abs(got - want)) <= 1e-5
+    assert (np.abs(want - np.log1p(np.exp(10.0))) < 1e-5).any()  # the clip was exercised
+    assert len(eng.pair_reward(np.zeros(0, np.int32), np.zeros(0, np.int32))) == 0
+    with pytest.raises(ga.GraphGANHipError):
+        eng.pair_reward([0], [n])
+    eng.close()
+
+
+@pytest.mark.parametrize("d,steps", [(50, 12), (128, 6)])
+def test_dense_adam_steps_match_tf1_semantics(ga, d, steps):
+    """B = 64 batches with duplicate rows, both models, several consecutive steps
+    (m, v, beta powers carried on both sides)."""
+    n = 300
+    Eg, Ed, bg, bd = make_models(n, d, 7)
+    eng = engine_with(ga, Eg, Ed, bg, bd)
+    gen, dis = orc.Generator(Eg, 1e-3), orc.Discriminator(Ed, 1e-3)
+    gen.b[:] = bg
+    dis.b[:] = bd
+    rs = np.random.RandomState(3)
+    for t in range(steps):
+        B = 64 if t != steps - 1 else 37  # ragged last chunk (graph_gan.py:153)
+        u = rs.randint(0, n, B)
+        v = rs.randint(0, n, B)
+        u[: B // 2] = u[0]  # contiguous chunks of one root's rows: heavy duplication (a13)
+        lab = (rs.rand(B) < 0.5).astype(np.float32)
+        rew = (rs.rand(B) * 2).astype(np.float32)
+        dis.d_step(u, v, lab, 1e-5)
+        eng.d_step(u, v, lab)
+        gen.g_step(u, v, rew, 1e-5)
+        eng.g_step(u, v, rew)
+        # one step: 1e-6 relative.  Later steps: Adam's m/sqrt(v) normalisation turns the
+        # relative rounding noise of near-cancelling duplicate sums into absolute noise of order lr * 1e-3.
+        rtol, atol = (RTOL, ATOL) if t == 0 else (1e-5, 3e-6)
+        for which, m in ((0, gen), (1, dis)):
+            dE = np.abs(eng.get_embeddings(which) - m.E)
+            assert np.all(dE <= atol + rtol * np.abs(m.E)), (t, which, float(dE.max()))
+            db = np.abs(eng.get_bias(which) - m.b)
+            assert np.all(db <= atol + rtol * np.abs(m.b)), (t, which, float(db.max()))
+    # rows never touched did not move (their m, v are exactly zero)
+    c = eng.counters()
+    assert c["d_steps"] == steps and c["g_steps"] == steps
+    eng.close()
+
+
+@pytest.mark.parametrize("mode", ["lazy", "sgd"])
+def test_scale_mode_optimizers(ga, mode):
+    n, d = 400, 64
+    Eg, Ed, bg, bd = make_models(n, d, 11)
+    opt = ga.GG_OPT_ADAM_LAZY if mode == "lazy" else ga.GG_OPT_SGD
+    eng = engine_with(ga, Eg, Ed, bg, bd, optimizer=opt)
+    dis = orc.Discriminator(Ed, 1e-3, lazy=True)
+    dis.b[:] = bd
+    rs = np.random.RandomState(5)
+    for t in range(5):
+        B = 3000
+        u, v = rs.randint(0, n // 2, B), rs.randint(0, n // 2, B)  # rows >= n/2 stay untouched
+        lab = (rs.rand(B) < 0.5).astype(np.float32)
+        if mode == "lazy":
+            dis.d_step(u, v, lab, 1e-5)
+        else:
+            _, gu, gv, gb = dis.loss_and_grads(u, v, lab, 1e-5)
+            GE, Gb = np.zeros_like(dis.E, dtype=np.float64), np.zeros(n)
+            np.add.at(GE, u, gu)
+            np.add.at(GE, v, gv)
+            np.add.at(Gb, v, gb)
+            dis.E -= (1e-3 * GE).astype(np.float32)
+            dis.b -= (1e-3 * Gb).astype(np.float32)
+        eng.d_step(u, v, lab)
+        assert np.allclose(eng.get_embeddings(1), dis.E, rtol=2e-5, atol=1e-6), t
+        assert np.allclose(eng.get_bias(1), dis.b, rtol=2e-5, atol=1e-6), t
+    assert np.array_equal(eng.get_embeddings(1)[n // 2:], Ed[n // 2:])
+    eng.close()
+
+
+def _setup_graph_engine(ga, gi=3, **kw):
+    g, n, graph = load_small(gi)
+    rs = np.random.RandomState(0)
+    Ed = (rs.randn(n, g["E"].shape[1]) * 0.8).astype(np.float32)
+    eng = ga.Engine(g["E"], Ed, **kw)
+    eng.set_bias(0, g["b"])
+    rowptr, col = ga.graph_to_csr(n, graph)
+    eng.set_graph_csr(rowptr, col)
+    eng.build_trees(np.arange(n))
+    return g, n, graph, rowptr, col, Ed, eng
+
+
+def test_prepare_d_and_g_match_oracle(ga):
+    """prepare_data_for_d / prepare_data_for_g (graph_gan.py:182-223) device pipelines:
+    integer arrays bit-exact against the spec oracle walks + the reference's row layout."""
+    g, n, graph, rowptr, col, Ed, eng = _setup_graph_engine(ga)
+    roots = np.arange(n, dtype=np.int32)
+    off, nbr, base, dmax = orc.c_build_trees(n, rowptr, col, roots)
+    Ep = orc.pad_rows(g["E"])
+    deg = (rowptr[1:] - rowptr[:-1]).astype(np.int32)
+    slots = np.arange(n, dtype=np.int32)
+    dis = orc.Discriminator(Ed, 1e-3)
+    for rnd in range(2):
+        # D
+        want = orc.c_walk_sample(Ep, g["b"], off, nbr, base, roots, slots, deg, True, 9, 2 * rnd, dmax + 3)
+        c, nb, lab = [], [], []
+        w = 0
+        for i in range(n):
+            k = int(deg[i])
+            if want["root_status"][i] == 0 and k > 0:
+                c += [i] * k + [i] * k
+                nb += list(col[rowptr[i]:rowptr[i + 1]]) + list(want["samples"][w:w + k])
+                lab += [1] * k + [0] * k
+            w += k
+        gc, gn, gl, st = eng.prepare_d(slots, 9, 2 * rnd)
+        assert np.array_equal(st, want["root_status"])
+        assert np.array_equal(gc, np.array(c, np.int32)) and np.array_equal(gn, np.array(nb, np.int32))
+        assert np.array_equal(gl, np.array(lab, np.float32))
+        assert len(gc) > 0 and (st == 1).any()
+        # G
+        nw = np.full(n, 20, np.int32)
+        want = orc.c_walk_sample(Ep, g["b"], off, nbr, base, roots, slots, nw, False, 9, 2 * rnd + 1, dmax + 3)
+        n1, n2 = [], []
+        for wlk in range(len(nw) * 20):
+            L = want["path_len"][wlk]
+            if L > 0:
+                for a, b in orc.pairs_from_path(list(want["paths"][wlk, :L]), 2):
+                    n1.append(a)
+                    n2.append(b)
+        g1, g2, rew, st = eng.prepare_g(slots, 20, 9, 2 * rnd + 1)
+        assert np.array_equal(st, want["root_status"])
+        assert np.array_equal(g1, np.array(n1, np.int32)) and np.array_equal(g2, np.array(n2, np.int32))
+        assert np.max(np.abs(rew - dis.reward(g1.astype(np.int64), g2.astype(np.int64)))) <= 1e-5
+    eng.close()
+
+
+def test_passes_equal_sequences_of_steps(ga):
+    """gg_d_pass / gg_g_pass over resident rows == the reference's minibatch loops
+    (graph_gan.py:149-157, 168-176) issued one sess.run-equivalent at a time."""
+    g, n, graph, rowptr, col, Ed, eng = _setup_graph_engine(ga)
+    _, _, _, _, _, _, eng2 = _setup_graph_engine(ga)
+    slots = np.arange(n, dtype=np.int32)
+    c, nb, lab, _ = eng.prepare_d(slots, 4, 0)
+    eng2.prepare_d(slots, 4, 0, fetch=False)
+    starts = np.arange(0, len(c), 64)
+    np.random.RandomState(0).shuffle(starts)
+    eng.d_pass(starts, 64)
+    for s in starts:
+        eng2.d_step(c[s:s + 64], nb[s:s + 64], lab[s:s + 64])
+    assert np.allclose(eng.get_embeddings(1), eng2.get_embeddings(1), rtol=1e-6, atol=1e-7)
+    n1, n2, rew, _ = eng.prepare_g(slots, 20, 4, 1)
+    r2 = eng2.pair_reward(n1, n2)
+    assert np.allclose(rew, r2, rtol=1e-6, atol=1e-7)
+    starts = np.arange(0, len(n1), 64)[:200]
+    eng.g_pass(starts, 64)
+    for s in starts:
+        eng2.g_step(n1[s:s + 64], n2[s:s + 64], rew[s:s + 64])
+    assert np.allclose(eng.get_embeddings(0), eng2.get_embeddings(0), rtol=1e-6, atol=1e-7)
+    with pytest.raises(ga.GraphGANHipError):
+        eng.g_pass(np.array([len(n1) + 5]), 64)
+    eng.close()
+    eng2.close()
+
+
+def test_state_save_restore(ga, tmp_path):
+    n, d = 100, 50
+    Eg, Ed, bg, bd = make_models(n, d, 1)
+    eng = engine_with(ga, Eg, Ed, bg, bd)
+    rs = np.random.RandomState(0)
+    u, v = rs.randint(0, n, 64), rs.randint(0, n, 64)
+    lab = (rs.rand(64) < 0.5).astype(np.float32)
+    eng.d_step(u, v, lab)
+    eng.g_step(u, v, lab)
+    path = str(tmp_path / "model.ggst")
+    eng.save_state(path)
+    eng.d_step(u, v, lab)
+    eng.g_step(v, u, lab)
+    want = [eng.get_embeddings(0), eng.get_embeddings(1), eng.get_bias(0), eng.get_bias(1)]
+    eng2 = engine_with(ga, Eg * 0, Ed * 0, bg * 0, bd * 0)
+    eng2.load_state(path)
+    eng2.d_step(u, v, lab)
+    eng2.g_step(v, u, lab)
+    got = [eng2.get_embeddings(0), eng2.get_embeddings(1), eng2.get_bias(0), eng2.get_bias(1)]
+    for a, b in zip(want, got):
+        assert np.allclose(a, b, rtol=1e-6, atol=1e-7)
+    with pytest.raises(ga.GraphGANHipError):
+        eng2.load_state(str(tmp_path / "missing"))
+    eng.close()
+    eng2.close()

@@ -1,0 +1,119 @@
+"""Self-checks of the oracle's floating-point restatement (TF1 graphs cannot run here:
+parity unpinned): gradients against torch-CPU autograd of the reference's
+loss formulas, TF1 sparse-Adam against a hand-computed example with duplicate indices."""
+import numpy as np
+import pytest
+
+from oracle import graphgan_oracle as orc
+
+torch = pytest.importorskip("torch")
+
+
+def _dense_grads(n, d, u, v, gu, gv, gb):
+    GE = np.zeros((n, d), dtype=np.float64)
+    Gb = np.zeros(n, dtype=np.float64)
+    np.add.at(GE, u, gu.astype(np.float64))
+    np.add.at(GE, v, gv.astype(np.float64))
+    np.add.at(Gb, v, gb.astype(np.float64))
+    return GE, Gb
+
+
+def test_discriminator_gradients_match_autograd():
+    rs = np.random.RandomState(0)
+    n, d, B = 30, 7, 64
+    E0 = (rs.randn(n, d) * 0.7).astype(np.float32)
+    dis = orc.Discriminator(E0, 1e-3)
+    dis.b[:] = rs.randn(n) * 0.2
+    u, v = rs.randint(0, n, B), rs.randint(0, n, B)
+    y = (rs.rand(B) < 0.5).astype(np.float32)
+    lam = 1e-2
+    loss, gu, gv, gb = dis.loss_and_grads(u, v, y, lam)
+    E = torch.tensor(dis.E, dtype=torch.float64, requires_grad=True)
+    b = torch.tensor(dis.b, dtype=torch.float64, requires_grad=True)
+    eu, ev, bv = E[torch.tensor(u)], E[torch.tensor(v)], b[torch.tensor(v)]
+    s = (eu * ev).sum(1) + bv
+    # discriminator.py:26-30: reduce_sum(sigmoid_cross_entropy_with_logits) + lambda*(l2_loss(ev)+l2_loss(eu)+l2_loss(bias))
+    L = torch.nn.functional.binary_cross_entropy_with_logits(s, torch.tensor(y, dtype=torch.float64), reduction="sum") \
+        + lam * 0.5 * ((ev ** 2).sum() + (eu ** 2).sum() + (bv ** 2).sum())
+    L.backward()
+    GE, Gb = _dense_grads(n, d, u, v, gu, gv, gb)
+    assert abs(loss - L.item()) < 1e-3
+    assert np.allclose(GE, E.grad.numpy(), rtol=1e-4, atol=1e-5)
+    assert np.allclose(Gb, b.grad.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_generator_gradients_match_autograd():
+    rs = np.random.RandomState(1)
+    n, d, B = 30, 7, 64
+    E0 = (rs.randn(n, d) * 0.7).astype(np.float32)
+    gen = orc.Generator(E0, 1e-3)
+    gen.b[:] = rs.randn(n) * 0.2
+    gen.E[3] *= 40  # drive one score far enough that sigmoid clips at 1e-5 (zero-gradient branch)
+    u, v = rs.randint(0, n, B), rs.randint(0, n, B)
+    u[0], v[0] = 3, 3
+    gen.E[4] = -gen.E[3]
+    u[1], v[1] = 3, 4
+    r = (rs.rand(B) * 3).astype(np.float32)
+    lam = 1e-2
+    loss, gu, gv, gb = gen.loss_and_grads(u, v, r, lam)
+    E = torch.tensor(gen.E, dtype=torch.float64, requires_grad=True)
+    b = torch.tensor(gen.b, dtype=torch.float64, requires_grad=True)
+    eu, ev, bv = E[torch.tensor(u)], E[torch.tensor(v)], b[torch.tensor(v)]
+    s = (eu * ev).sum(1) + bv
+    # generator.py:26-29
+    p = torch.clamp(torch.sigmoid(s), 1e-5, 1)
+    L = -(torch.log(p) * torch.tensor(r, dtype=torch.float64)).mean() + lam * 0.5 * ((ev ** 2).sum() + (eu ** 2).sum())
+    L.backward()
+    GE, Gb = _dense_grads(n, d, u, v, gu, gv, gb)
+    assert abs(loss - L.item()) < 1e-3 * max(1, abs(L.item()))
+    assert np.allclose(GE, E.grad.numpy(), rtol=1e-3, atol=1e-5)
+    assert np.allclose(Gb, b.grad.numpy(), rtol=1e-3, atol=1e-5)
+    assert gb[1] == 0.0  # clipped pair contributes nothing
+
+
+def test_reward_formula():
+    rs = np.random.RandomState(2)
+    E0 = (rs.randn(20, 5) * 2).astype(np.float32)
+    dis = orc.Discriminator(E0, 1e-3)
+    dis.b[:] = rs.randn(20)
+    u, v = rs.randint(0, 20, 100), rs.randint(0, 20, 100)
+    s = np.clip((dis.E[u].astype(np.float64) * dis.E[v]).sum(1) + dis.b[v], -10, 10)
+    # fp32 log(1 + exp(s)) as the reference computes it: absolute error ~1 ulp of 1.0 near s = -10
+    assert np.allclose(dis.reward(u, v), np.log1p(np.exp(s)), rtol=1e-5, atol=1e-6)
+
+
+def test_tf1_adam_hand_computed_with_duplicates():
+    """3 steps on a [4, 1] variable, row 1 duplicated in step 1.  Never-touched rows have
+    m = v = 0 and stay put; a row touched ONCE keeps moving on later steps because m and v are
+    decayed and applied over all rows -- the TF1.8 sparse-apply behaviour."""
+    lr, b1, b2, eps = 0.1, 0.9, 0.999, 1e-8
+    var = np.array([[1.0], [2.0], [3.0], [4.0]], dtype=np.float32)
+    opt = orc.TF1Adam([var.shape], lr, b1, b2, eps)
+    ref = var.astype(np.float64).copy()
+    m = np.zeros_like(ref)
+    v = np.zeros_like(ref)
+    steps = [(np.array([1, 1, 0]), np.array([[0.5], [0.25], [-1.0]])),
+             (np.array([2]), np.array([[2.0]])),
+             (np.array([0, 2]), np.array([[1.0], [-2.0]]))]
+    for t, (idx, g) in enumerate(steps, 1):
+        opt.step([var], [(idx, g.astype(np.float32))])
+        G = np.zeros_like(ref)
+        np.add.at(G, idx, g)
+        m = b1 * m + (1 - b1) * G
+        v = b2 * v + (1 - b2) * G * G
+        lr_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+        ref = ref - lr_t * m / (np.sqrt(v) + eps)
+        assert np.allclose(var, ref, rtol=2e-6, atol=1e-7), t
+    assert var[3, 0] == 4.0            # never touched: never moves
+    # row 1 was touched only in step 1 but moved again in steps 2 and 3 (dense m decay)
+    one_step = 2.0 - 0.1 * 1.0  # first step of Adam moves by ~lr
+    assert var[1, 0] < one_step - 0.05
+
+
+def test_lazy_adam_only_moves_touched_rows():
+    var = np.ones((4, 2), dtype=np.float32)
+    opt = orc.TF1Adam([var.shape], 0.1, lazy=True)
+    opt.step([var], [(np.array([1]), np.ones((1, 2), np.float32))])
+    after1 = var.copy()
+    opt.step([var], [(np.array([2]), np.ones((1, 2), np.float32))])
+    assert np.array_equal(var[1], after1[1]) and var[2, 0] < 1.0 and var[0, 0] == 1.0
