@@ -1,0 +1,26 @@
+"""Link-prediction evaluator with the reference's semantics
+(``src/evaluation/link_prediction.py:10-38``): re-read the ``.emb`` text, score every test and
+negative edge by a dot product, predict "edge" when the score is at or above the median, report
+the accuracy against (first half = positives, second half = negatives)."""
+import numpy as np
+
+from .. import utils
+
+
+class LinkPredictEval(object):
+    def __init__(self, embed_filename, test_filename, test_neg_filename, n_node, n_embed):
+        self.embed_filename = embed_filename
+        self.test_filename = test_filename
+        self.test_neg_filename = test_neg_filename
+        self.n_node = n_node
+        self.n_embed = n_embed
+        self.emd = utils.read_embeddings(embed_filename, n_node=n_node, n_embed=n_embed)
+
+    def eval_link_prediction(self):
+        edges = np.array(utils.read_edges_from_file(self.test_filename) +
+                         utils.read_edges_from_file(self.test_neg_filename), dtype=np.int64)
+        # per-edge np.dot like the reference (link_prediction.py:26-27): identical fp64 rounding
+        score = np.array([np.dot(self.emd[a], self.emd[b]) for a, b in edges])
+        predicted = score >= np.median(score)
+        truth = np.arange(len(edges)) < len(edges) // 2
+        return float(np.mean(predicted == truth))

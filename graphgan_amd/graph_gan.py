@@ -1,0 +1,268 @@
+"""GraphGAN trainer: the reference's entry point (``src/GraphGAN/graph_gan.py``) on the MI355X engine.
+
+Same class, method names, return shapes, schedule, file formats and ``config`` names as the
+reference; every ``tf.Session.run`` call site and the interpreted walk sampler are replaced by
+calls into ``libgraphgan_hip.so`` (``graphgan_amd.engine.Engine``):
+
+    reference                                             here
+    ----------------------------------------------------  -------------------------------------------
+    construct_trees (:84-108) + pickle cache (:31-46)     Engine.build_trees (threaded C++ BFS -> HBM)
+    sample (:225-270) incl. sess.run(all_score) (:238)    Engine.walk_sample / prepare_d / prepare_g (K1)
+    get_node_pairs_from_path (:272-291)                   device kernel inside prepare_g (K6)
+    sess.run(discriminator.reward) (:220-222)             device kernel inside prepare_g (K2)
+    sess.run(d_updates) loop (:149-157)                   Engine.d_pass (K3 + K5)
+    sess.run(g_updates) loop (:168-176)                   Engine.g_pass (K4 + K5)
+    sess.run(embedding_matrix) (:298)                     Engine.get_embeddings
+    tf.train.Saver (:55,124-127,137-138)                  Engine.save_state / load_state
+
+Run exactly like the reference: ``cd src/GraphGAN && python <this file>`` -- a ``config.py`` in
+the working directory (the reference's own) is honoured; otherwise ``graphgan_amd/config.py``.
+Randomness: the reference draws from the unseeded global numpy RNG (Q5); here the walk sampler
+uses Philox keyed by ``config.engine_seed`` and the host decisions (root selection, batch order)
+use ``numpy.random.RandomState(engine_seed)``, so runs are reproducible.
+"""
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+if __package__ in (None, ""):  # executed as a script: make the package importable
+    sys.path.insert(0, os.path.dirname(_HERE))
+
+try:  # the user's flag module in the working directory wins, as with the reference (graph_gan.py:8)
+    if os.path.isfile(os.path.join(os.getcwd(), "config.py")) and os.getcwd() != _HERE:
+        sys.path.insert(0, os.getcwd())
+        import config  # noqa: E402
+    else:
+        raise ImportError
+except ImportError:
+    from graphgan_amd import config  # noqa: E402
+
+from graphgan_amd import _lib, engine as _engine, utils  # noqa: E402
+from graphgan_amd.evaluation import link_prediction as lp  # noqa: E402
+
+_OPTIMIZERS = {"adam_dense": _lib.GG_OPT_ADAM_DENSE, "adam_lazy": _lib.GG_OPT_ADAM_LAZY, "sgd": _lib.GG_OPT_SGD}
+
+
+def _cfg(cfg, name, default):
+    return getattr(cfg, name, default)
+
+
+class GraphGAN(object):
+    def __init__(self, cfg=None):
+        self.config = cfg if cfg is not None else config
+        cfg = self.config
+        print("reading graphs...")
+        self.n_node, self.graph = utils.read_edges(cfg.train_filename, cfg.test_filename)
+        self.root_nodes = [i for i in range(self.n_node)]
+
+        print("reading initial embeddings...")
+        self.node_embed_init_d = utils.read_embeddings(filename=cfg.pretrain_emb_filename_d, n_node=self.n_node,
+                                                       n_embed=cfg.n_emb)
+        self.node_embed_init_g = utils.read_embeddings(filename=cfg.pretrain_emb_filename_g, n_node=self.n_node,
+                                                       n_embed=cfg.n_emb)
+
+        self.seed = int(_cfg(cfg, "engine_seed", 0))
+        self.host_rng = np.random.RandomState(self.seed)
+
+        print("building GAN model...")
+        self.engine = None
+        self.generator = None
+        self.discriminator = None
+        self.build_generator()
+        self.build_discriminator()
+
+        # BFS trees live in HBM as a tree CSR; with update_ratio >= 1 every root is resident for the
+        # whole run (like the reference's self.trees), otherwise they are rebuilt per sampled root set.
+        print("constructing BFS-trees...")
+        self.trees = None
+        self._slot_of_root = None
+        if cfg.update_ratio >= 1:
+            self.trees = self.construct_trees(self.root_nodes)
+
+        self.latest_checkpoint = os.path.join(cfg.model_log, "model.checkpoint.ggst")
+
+    # ------------------------------------------------------------------ model construction
+    def _ensure_engine(self):
+        if self.engine is None:
+            cfg = self.config
+            self.engine = _engine.Engine(
+                self.node_embed_init_g, self.node_embed_init_d, lr_gen=cfg.lr_gen, lr_dis=cfg.lr_dis,
+                lambda_gen=cfg.lambda_gen, lambda_dis=cfg.lambda_dis, window_size=cfg.window_size,
+                optimizer=_OPTIMIZERS[_cfg(cfg, "engine_optimizer", "adam_dense")], device=int(_cfg(cfg, "engine_device", 0)))
+            rowptr, col = _engine.graph_to_csr(self.n_node, self.graph)
+            self.engine.set_graph_csr(rowptr, col)
+        return self.engine
+
+    def build_generator(self):
+        """initializing the generator (table [n_node, n_emb] from the pre-trained rows, zero bias)"""
+        self._ensure_engine()
+        self.generator = _ModelView(self.engine, 0)
+
+    def build_discriminator(self):
+        """initializing the discriminator"""
+        self._ensure_engine()
+        self.discriminator = _ModelView(self.engine, 1)
+
+    def construct_trees(self, nodes):
+        """BFS trees of ``nodes`` (reference :84-108) -> resident tree CSR; returns the slot map
+        root -> slot (the reference returns the dict of dicts itself)."""
+        nodes = np.asarray(list(nodes), dtype=np.int32)
+        self.engine.build_trees(nodes, n_threads=int(_cfg(self.config, "engine_tree_threads", 0)))
+        self._slot_of_root = {int(r): i for i, r in enumerate(nodes)}
+        return self._slot_of_root
+
+    def construct_trees_with_mp(self, nodes):
+        """kept for API compatibility (reference :63-82): the C++ builder is always multi-threaded"""
+        self.trees = self.construct_trees(nodes)
+
+    # ------------------------------------------------------------------ training
+    @staticmethod
+    def stream_id(epoch, inner_epoch, n_inner, for_d):
+        """Philox stream of a prepare call: distinct per (outer epoch, inner epoch, phase)."""
+        return 2 * (epoch * max(n_inner, 1) + inner_epoch) + (0 if for_d else 1)
+
+    def train(self):
+        cfg = self.config
+        if os.path.isfile(self.latest_checkpoint) and cfg.load_model:
+            print("loading the checkpoint: %s" % self.latest_checkpoint)
+            self.engine.load_state(self.latest_checkpoint)
+
+        self.write_embeddings_to_file()
+        self.evaluation(self)
+
+        print("start training...")
+        for epoch in range(cfg.n_epochs):
+            print("epoch %d" % epoch)
+
+            if epoch > 0 and epoch % cfg.save_steps == 0:
+                os.makedirs(cfg.model_log, exist_ok=True)
+                self.engine.save_state(self.latest_checkpoint)
+
+            # D-steps
+            train_size = 0
+            for d_epoch in range(cfg.n_epochs_dis):
+                if d_epoch % cfg.dis_interval == 0:
+                    self._stream = self.stream_id(epoch, d_epoch, cfg.n_epochs_dis, True)
+                    train_size = self._prepare_d_resident()
+                start_list = list(range(0, train_size, cfg.batch_size_dis))
+                self.host_rng.shuffle(start_list)
+                self.engine.d_pass(start_list, cfg.batch_size_dis)
+
+            # G-steps
+            train_size = 0
+            for g_epoch in range(cfg.n_epochs_gen):
+                if g_epoch % cfg.gen_interval == 0:
+                    self._stream = self.stream_id(epoch, g_epoch, cfg.n_epochs_gen, False)
+                    train_size = self._prepare_g_resident()
+                start_list = list(range(0, train_size, cfg.batch_size_gen))
+                self.host_rng.shuffle(start_list)
+                self.engine.g_pass(start_list, cfg.batch_size_gen)
+
+            self.write_embeddings_to_file()
+            self.evaluation(self)
+        print("training completes")
+
+    # ------------------------------------------------------------------ sample preparation
+    def _select_slots(self):
+        """``np.random.rand() < update_ratio`` per root (reference :189, :209)."""
+        cfg = self.config
+        if cfg.update_ratio >= 1:
+            return np.arange(len(self.root_nodes), dtype=np.int32)
+        take = [r for r in self.root_nodes if self.host_rng.rand() < cfg.update_ratio]
+        self.trees = self.construct_trees(take)
+        return np.arange(len(take), dtype=np.int32)
+
+    def _prepare_d_resident(self):
+        return self.engine.prepare_d(self._select_slots(), self.seed, self._stream, fetch=False)
+
+    def _prepare_g_resident(self):
+        return self.engine.prepare_g(self._select_slots(), self.config.n_sample_gen, self.seed, self._stream, fetch=False)
+
+    def prepare_data_for_d(self):
+        """generate positive and negative samples for the discriminator (reference :182-202);
+        returns (center_nodes, neighbor_nodes, labels) and leaves them resident for d_pass"""
+        if not hasattr(self, "_stream"):
+            self._stream = 0
+        center, neighbor, label, _ = self.engine.prepare_d(self._select_slots(), self.seed, self._stream)
+        return center.tolist(), neighbor.tolist(), label.astype(np.int64).tolist()
+
+    def prepare_data_for_g(self):
+        """sample nodes for the generator (reference :204-223); returns (node_1, node_2, reward)"""
+        if not hasattr(self, "_stream"):
+            self._stream = 1
+        n1, n2, reward, _ = self.engine.prepare_g(self._select_slots(), self.config.n_sample_gen, self.seed, self._stream)
+        return n1.tolist(), n2.tolist(), reward
+
+    def sample(self, root, tree, sample_num, for_d):
+        """sample nodes from the BFS-tree of ``root`` (reference :225-270).  ``tree`` is accepted
+        for signature compatibility; the resident tree of ``root`` is used.
+        Returns (samples, paths), or (None, None) when the reference would."""
+        slot = self._slot_of_root[int(root)]
+        stream = getattr(self, "_stream", 0)
+        res = self.engine.walk_sample([slot], [sample_num], for_d, self.seed, stream)
+        if res["root_status"][0] == _lib.GG_ROOT_ABORTED:
+            return None, None
+        paths = [res["paths"][j, : res["path_len"][j]].tolist() for j in range(sample_num)]
+        return res["samples"].tolist(), paths
+
+    @staticmethod
+    def get_node_pairs_from_path(path):
+        """window pairs of a path whose last element (the back-step) is dropped (reference :272-291);
+        host twin of the device kernel, kept for API compatibility"""
+        window = config.window_size
+        nodes = path[:-1]
+        pairs = []
+        for i, center in enumerate(nodes):
+            lo, hi = max(i - window, 0), min(i + window + 1, len(nodes))
+            pairs.extend([center, nodes[j]] for j in range(lo, hi) if j != i)
+        return pairs
+
+    # ------------------------------------------------------------------ outputs
+    def write_embeddings_to_file(self):
+        """write embeddings of the generator and the discriminator to files (reference :293-306):
+        header ``N<TAB>d``, then ``id<TAB>v0<TAB>...``; values are the fp32 numbers widened to
+        fp64 and printed with ``str`` (what ``np.hstack([index, matrix]).tolist()`` gives)"""
+        cfg = self.config
+        for i in range(2):
+            matrix = self.engine.get_embeddings(i).astype(np.float64)
+            os.makedirs(os.path.dirname(cfg.emb_filenames[i]) or ".", exist_ok=True)
+            with open(cfg.emb_filenames[i], "w+") as f:
+                f.write(str(self.n_node) + "\t" + str(cfg.n_emb) + "\n")
+                f.writelines(str(idx) + "\t" + "\t".join(map(str, row)) + "\n" for idx, row in enumerate(matrix.tolist()))
+
+    @staticmethod
+    def evaluation(self):
+        cfg = self.config
+        results = []
+        if cfg.app == "link_prediction":
+            for i in range(2):
+                lpe = lp.LinkPredictEval(cfg.emb_filenames[i], cfg.test_filename, cfg.test_neg_filename, self.n_node, cfg.n_emb)
+                result = lpe.eval_link_prediction()
+                results.append(cfg.modes[i] + ":" + str(result) + "\n")
+        os.makedirs(os.path.dirname(cfg.result_filename) or ".", exist_ok=True)
+        with open(cfg.result_filename, mode="a+") as f:
+            f.writelines(results)
+        return results
+
+
+class _ModelView(object):
+    """Stand-in for the reference's Generator / Discriminator objects: exposes the variables the
+    driver fetches (``embedding_matrix``, ``bias_vector``) as numpy arrays read from the engine."""
+
+    def __init__(self, eng, which):
+        self._eng, self._which = eng, which
+
+    @property
+    def embedding_matrix(self):
+        return self._eng.get_embeddings(self._which)
+
+    @property
+    def bias_vector(self):
+        return self._eng.get_bias(self._which)
+
+
+if __name__ == "__main__":
+    graph_gan = GraphGAN()
+    graph_gan.train()

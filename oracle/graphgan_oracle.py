@@ -488,7 +488,12 @@ class GraphGANOracle:
         self.all_score_fn = all_score_fn  # optional override of generator.py:21 (golden pin uses an fp64 product)
         self.generator = Generator(emb_init_g, self.cfg.lr_gen, lazy=lazy_adam)
         self.discriminator = Discriminator(emb_init_d, self.cfg.lr_dis, lazy=lazy_adam)
-        self.trees = trees if trees is not None else construct_trees(graph, self.root_nodes)
+        self.csr = None
+        if arith == "spec":
+            assert rng == "counter", "spec arithmetic is defined on the counter RNG"
+            self.trees = None  # tree CSR is built lazily for self.root_nodes (C oracle)
+        else:
+            self.trees = trees if trees is not None else construct_trees(graph, self.root_nodes)
         self.stream = 0
         self.host_rng = np.random.RandomState(seed)  # batch-order shuffles in counter mode
         self.counters = dict(hops=0, nbr_reads=0)
@@ -546,7 +551,38 @@ class GraphGANOracle:
         return True if self.cfg.update_ratio >= 1 else self.host_rng.rand() < self.cfg.update_ratio
 
     # -- graph_gan.py:182-202
+    def _spec_setup(self):
+        if self.csr is None:
+            self._rowptr, self._col = graph_to_csr(self.n_node, self.graph)
+            roots = np.asarray(self.root_nodes, dtype=np.int32)
+            off, nbr, base, dmax = c_build_trees(self.n_node, self._rowptr, self._col, roots)
+            self.csr = dict(off=off, nbr=nbr.copy(), base=base, roots=roots, stride=dmax + 3)
+        return self.csr
+
+    def _spec_walks(self, n_walks, for_d):
+        t = self._spec_setup()
+        slots = np.arange(len(t["roots"]), dtype=np.int32)
+        res = c_walk_sample(pad_rows(self.generator.E), self.generator.b, t["off"], t["nbr"], t["base"], t["roots"], slots,
+                            n_walks, for_d, self.seed, self.stream, t["stride"])
+        self.counters["hops"] += res["hops"]
+        self.counters["nbr_reads"] += res["nbr_reads"]
+        return res
+
     def prepare_data_for_d(self):
+        if self.arith == "spec":
+            assert self.cfg.update_ratio >= 1
+            t = self._spec_setup()
+            deg = (self._rowptr[1:] - self._rowptr[:-1]).astype(np.int32)[t["roots"]]
+            res = self._spec_walks(deg, True)
+            centers, neighbors, labels, w = [], [], [], 0
+            for i, r in enumerate(t["roots"]):
+                k = int(deg[i])
+                if k and res["root_status"][i] == 0:
+                    centers += [int(r)] * (2 * k)
+                    neighbors += self.graph[int(r)] + res["samples"][w:w + k].tolist()
+                    labels += [1] * k + [0] * k
+                w += k
+            return centers, neighbors, labels
         centers, neighbors, labels = [], [], []
         for i in self.root_nodes:
             if self._take_root():
@@ -563,6 +599,19 @@ class GraphGANOracle:
 
     # -- graph_gan.py:204-223
     def prepare_data_for_g(self):
+        if self.arith == "spec":
+            assert self.cfg.update_ratio >= 1
+            t = self._spec_setup()
+            res = self._spec_walks(np.full(len(t["roots"]), self.cfg.n_sample_gen, dtype=np.int32), False)
+            node_1, node_2 = [], []
+            for w in range(len(res["path_len"])):
+                L = int(res["path_len"][w])
+                if L:
+                    for a, b in pairs_from_path(res["paths"][w, :L].tolist(), self.cfg.window_size):
+                        node_1.append(a)
+                        node_2.append(b)
+            reward = self.discriminator.reward(np.array(node_1, dtype=np.int64), np.array(node_2, dtype=np.int64))
+            return node_1, node_2, reward
         paths = []
         for i in self.root_nodes:
             if self._take_root():

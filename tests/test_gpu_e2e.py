@@ -1,0 +1,143 @@
+"""End-to-end on CA-GrQc (BASELINE.json configs[1]): the ``graph_gan.py`` mirror on the HIP
+engine against the oracle trainer with the same seed, schedule and optimizer mode.
+Gates: epoch-0 line == 0.7598343685300207; integer sample data identical;
+final gen/dis accuracy within +-0.5 % absolute; output file formats as the reference writes them."""
+import os
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+
+from oracle import graphgan_oracle as orc
+from tests.helpers import load_ca_grqc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def write_reference_layout(base):
+    """materialise the CA-GrQc fixture in the reference's directory layout under ``base``"""
+    d, n, graph = load_ca_grqc()
+    os.makedirs(os.path.join(base, "data", "link_prediction"))
+    os.makedirs(os.path.join(base, "pre_train", "link_prediction"))
+    for name, key in (("train", "train"), ("test", "test"), ("test_neg", "test_neg")):
+        with open(os.path.join(base, "data", "link_prediction", "CA-GrQc_%s.txt" % name), "w") as f:
+            f.writelines("%d\t%d\n" % (a, b) for a, b in d[key].tolist())
+    with open(os.path.join(base, "pre_train", "link_prediction", "CA-GrQc_pre_train.emb"), "w") as f:
+        f.write("%d %d\n" % (len(d["emb_ids"]), d["emb_rows"].shape[1]))
+        for i, row in zip(d["emb_ids"].tolist(), d["emb_rows"].astype(np.float64).tolist()):
+            f.write(str(i) + " " + " ".join(repr(x) for x in row) + "\n")
+    return d, n, graph
+
+
+def make_cfg(base, **over):
+    from graphgan_amd import config as base_cfg
+    cfg = types.SimpleNamespace(**{k: getattr(base_cfg, k) for k in dir(base_cfg) if not k.startswith("_")})
+    app, ds = cfg.app, cfg.dataset
+    cfg.train_filename = "%s/data/%s/%s_train.txt" % (base, app, ds)
+    cfg.test_filename = "%s/data/%s/%s_test.txt" % (base, app, ds)
+    cfg.test_neg_filename = "%s/data/%s/%s_test_neg.txt" % (base, app, ds)
+    cfg.pretrain_emb_filename_d = cfg.pretrain_emb_filename_g = "%s/pre_train/%s/%s_pre_train.emb" % (base, app, ds)
+    cfg.emb_filenames = ["%s/results/%s/%s_gen_.emb" % (base, app, ds), "%s/results/%s/%s_dis_.emb" % (base, app, ds)]
+    cfg.result_filename = "%s/results/%s/%s.txt" % (base, app, ds)
+    cfg.model_log = "%s/log/" % base
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def test_reduced_schedule_matches_oracle(tmp_path):
+    base = str(tmp_path)
+    d, n, graph = write_reference_layout(base)
+    cfg = make_cfg(base, n_epochs=1, n_epochs_dis=2, n_epochs_gen=2, dis_interval=2, gen_interval=2, engine_seed=17)
+    from graphgan_amd.graph_gan import GraphGAN
+    np.random.seed(123)
+    g = GraphGAN(cfg)
+    assert g.n_node == 5242
+    subset = list(range(0, n, 7))
+    g.root_nodes = subset
+    g.trees = g.construct_trees(subset)
+    g.train()
+
+    # ---- the oracle, same init, same schedule, same seed, dense TF1-Adam
+    ocfg = orc.Config()
+    ocfg.n_epochs_dis = ocfg.n_epochs_gen = ocfg.dis_interval = ocfg.gen_interval = 2
+    o = orc.GraphGANOracle(n, graph, g.node_embed_init_g, g.node_embed_init_d, cfg=ocfg, rng="counter", arith="spec", seed=17)
+    o.root_nodes = subset
+    o.train_epoch(0)
+
+    eg, ed = g.generator.embedding_matrix, g.discriminator.embedding_matrix
+    # trajectories agree closely (different fp32 summation orders inside 1.5k Adam steps)
+    for got, want in ((eg, o.generator.E), (ed, o.discriminator.E)):
+        diff = np.abs(got - want)
+        print("abs diff: mean %.3g p99 %.3g p99.99 %.3g max %.3g" % (diff.mean(), np.quantile(diff, 0.99), np.quantile(diff, 0.9999), diff.max()))
+        assert diff.mean() < 5e-5 and np.quantile(diff, 0.99) < 5e-4
+    assert np.abs(eg - g.node_embed_init_g.astype(np.float32)).max() > 1e-2  # training moved the tables
+
+    lines = open(cfg.result_filename).read().split()
+    assert lines[0] == "gen:0.7598343685300207" and lines[1] == "dis:0.7598343685300207"
+    assert len(lines) == 4 and lines[2].startswith("gen:") and lines[3].startswith("dis:")
+    acc_g, acc_d = float(lines[2][4:]), float(lines[3][4:])
+    oacc_g = orc.eval_link_prediction(o.generator.E.astype(np.float64), d["test"].tolist(), d["test_neg"].tolist())
+    oacc_d = orc.eval_link_prediction(o.discriminator.E.astype(np.float64), d["test"].tolist(), d["test_neg"].tolist())
+    assert abs(acc_g - oacc_g) <= 0.005 and abs(acc_d - oacc_d) <= 0.005
+
+    # ---- file format (graph_gan.py:293-306): header, tab separated, str(float64(fp32))
+    with open(cfg.emb_filenames[0]) as f:
+        assert f.readline() == "5242\t50\n"
+        row0 = f.readline().rstrip("\n").split("\t")
+    assert row0[0] == "0" and len(row0) == 51
+    assert [float(x) for x in row0[1:]] == eg[0].astype(np.float64).tolist()
+    assert row0[1] == str(float(eg[0, 0]))
+
+
+def test_user_facing_api_shapes(tmp_path):
+    """prepare_data_for_d / prepare_data_for_g / sample / get_node_pairs_from_path keep the reference's
+    return shapes (graph_gan.py:182-291)."""
+    base = str(tmp_path)
+    d, n, graph = write_reference_layout(base)
+    cfg = make_cfg(base)
+    from graphgan_amd.graph_gan import GraphGAN
+    np.random.seed(1)
+    g = GraphGAN(cfg)
+    g.root_nodes = list(range(0, n, 11))
+    g.trees = g.construct_trees(g.root_nodes)
+    c, nb, lab = g.prepare_data_for_d()
+    assert len(c) == len(nb) == len(lab) > 0 and set(lab) == {0, 1}
+    r0 = c[0]
+    k = len(graph[r0])
+    assert nb[:k] == graph[r0] and lab[:k] == [1] * k and lab[k:2 * k] == [0] * k  # positives first per root
+    n1, n2, rew = g.prepare_data_for_g()
+    assert len(n1) == len(n2) == len(rew) > 0 and rew.dtype == np.float32 and rew.min() > 0
+    root = g.root_nodes[3]
+    samples, paths = g.sample(root, None, 20, for_d=False)
+    if samples is not None:
+        assert len(samples) == len(paths) == 20 and all(p[0] == root and p[-1] == p[-3] for p in paths if len(p) > 2)
+    isolated = [v for v in range(n) if len(graph[v]) == 0][0]
+    g.trees = g.construct_trees([isolated])
+    assert g.sample(isolated, None, 20, for_d=False) == (None, None)
+    assert g.get_node_pairs_from_path([1, 0, 2, 4, 2]) == [[1, 0], [1, 2], [0, 1], [0, 2], [0, 4], [2, 1], [2, 0], [2, 4], [4, 0], [4, 2]]
+
+
+def test_script_entry_point_with_user_config(tmp_path):
+    """``cd <dir with config.py> && python graph_gan.py`` -- the reference's way of running (README.md:43-45)."""
+    base = str(tmp_path)
+    write_reference_layout(base)
+    work = os.path.join(base, "src", "GraphGAN")
+    os.makedirs(work)
+    src = open(os.path.join(ROOT, "graphgan_amd", "config.py")).read()
+    src = src.replace("n_epochs = 20", "n_epochs = 1").replace("n_epochs_gen = 30", "n_epochs_gen = 1").replace("n_epochs_dis = 30", "n_epochs_dis = 1")
+    with open(os.path.join(work, "config.py"), "w") as f:
+        f.write(src)
+    env = dict(os.environ)
+    env.pop("GRAPHGAN_ROOT", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "graphgan_amd", "graph_gan.py")], cwd=work, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "training completes" in p.stdout
+    res = open(os.path.join(base, "results", "link_prediction", "CA-GrQc.txt")).read().split()
+    assert res[0] == "gen:0.7598343685300207" and len(res) == 4
+    for name in ("CA-GrQc_gen_.emb", "CA-GrQc_dis_.emb"):
+        assert os.path.getsize(os.path.join(base, "results", "link_prediction", name)) > 1e6
