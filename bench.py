@@ -103,10 +103,8 @@ def main():
     import graphgan_amd as ga  # loads libgraphgan_hip.so (and with it the HIP runtime) before anything else
     from graphgan_amd import _lib
 
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # control plane only (gloo on CPU): barrier, max, id broadcast
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from graphgan_amd import parallel
+    ctl = parallel.Control(rank, world)  # control plane only (gloo on CPU): barrier, max, RCCL id broadcast
 
     t_setup = time.time()
     n, rowptr, col, emb, wl_name = make_workload(args, ga)
@@ -121,13 +119,7 @@ def main():
     threads = args.threads or min(64, os.cpu_count() or 1)
     eng.build_trees(roots, n_threads=max(1, threads // max(1, min(world, 8))))
     slots = np.arange(len(roots), dtype=np.int32)
-    if world > 1:
-        import torch
-        uid = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            uid = torch.frombuffer(bytearray(ga.Engine.comm_unique_id()), dtype=torch.uint8).clone()
-        dist.broadcast(uid, 0)
-        eng.comm_init(bytes(uid.numpy().tobytes()), rank, world)
+    ctl.connect_engine(eng)
     setup_s = time.time() - t_setup
 
     def step(i):
@@ -140,8 +132,7 @@ def main():
 
     def barrier():
         eng.comm_barrier()
-        if dist is not None:
-            dist.barrier()
+        ctl.barrier()
 
     for i in range(args.warmup):
         step(i)
@@ -160,14 +151,8 @@ def main():
     launches = c1["walk_launches"] - c0["walk_launches"]
     dpairs = c1["d_pairs"] - c0["d_pairs"]
     gpairs = c1["g_pairs"] - c0["g_pairs"]
-    tot = np.array([hops, dpairs, gpairs, dt], dtype=np.float64)
-    if dist is not None:
-        import torch
-        tsum = torch.tensor(tot[:3])
-        dist.all_reduce(tsum)
-        tmax = torch.tensor([dt])
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tot = np.array([tsum[0].item(), tsum[1].item(), tsum[2].item(), tmax.item()])
+    sums = ctl.sum([hops, dpairs, gpairs])
+    tot = np.array([sums[0], sums[1], sums[2], ctl.max(dt)])
     if rank != 0:
         eng.close()
         return
