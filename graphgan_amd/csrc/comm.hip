@@ -8,6 +8,7 @@
 //
 // librccl is dlopen'ed on first use: a single-GPU run never loads it.
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "gg_internal.h"
@@ -63,7 +64,7 @@ static int load_rccl(gg_ctx *ctx) {
     } while (0)
 
 int comm_allreduce_grads(gg_ctx *ctx) {
-    if (ctx->world <= 1 || !ctx->comm) return GG_OK;
+    if (!ctx->comm) return GG_OK;
     const size_t ne = (size_t)ctx->n_node * ctx->ld;
     GG_NCCL(ctx, g_rccl.AllReduce(ctx->gradE, ctx->gradE, ne, NCCL_FLOAT32, NCCL_SUM, ctx->comm, ctx->stream));
     GG_NCCL(ctx, g_rccl.AllReduce(ctx->gradb, ctx->gradb, (size_t)ctx->n_node, NCCL_FLOAT32, NCCL_SUM, ctx->comm, ctx->stream));
@@ -97,7 +98,9 @@ int gg_comm_init(gg_ctx *ctx, const void *id128, int32_t rank, int32_t world) {
     if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
     GG_CHECK(ctx, id128 && world >= 1 && rank >= 0 && rank < world, GG_EINVAL, "gg_comm_init: bad argument");
     GG_CHECK(ctx, !ctx->comm, GG_EINVAL, "gg_comm_init: already initialised");
-    if (world == 1) return GG_OK;
+    // world == 1 needs no communicator; GG_COMM_FORCE=1 creates a 1-rank one anyway so that the
+    // RCCL plumbing (dlopen, enums, stream) can be exercised on a single-GPU box (tests).
+    if (world == 1 && !getenv("GG_COMM_FORCE")) return GG_OK;
     int rc = load_rccl(ctx);
     if (rc != GG_OK) return rc;
     GG_HIP(ctx, hipSetDevice(ctx->device));
@@ -114,7 +117,7 @@ int gg_comm_init(gg_ctx *ctx, const void *id128, int32_t rank, int32_t world) {
 int gg_comm_barrier(gg_ctx *ctx) {
     if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
     GG_HIP(ctx, hipSetDevice(ctx->device));
-    if (ctx->world > 1 && ctx->comm) {
+    if (ctx->comm) {
         // a 4-byte all-reduce on the (idle) touched_cnt scratch word [3]
         float *w = (float *)(ctx->touched_cnt + 3);
         GG_NCCL(ctx, g_rccl.AllReduce(w, w, 1, NCCL_FLOAT32, NCCL_SUM, ctx->comm, ctx->stream));

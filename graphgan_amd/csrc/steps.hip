@@ -210,7 +210,7 @@ int run_step(gg_ctx *ctx, int which, const int32_t *d_u, const int32_t *d_v, con
     s.E = M.E; s.b = M.b; s.gE = ctx->gradE; s.gb = ctx->gradb;
     s.touched = ctx->touched; s.touched_list = ctx->touched_list; s.touched_cnt = ctx->touched_cnt;
     s.ld = ctx->ld;
-    s.track = (opt != GG_OPT_ADAM_DENSE) && ctx->world <= 1;
+    s.track = (opt != GG_OPT_ADAM_DENSE) && !ctx->comm;
     s.u = d_u; s.v = d_v; s.x = d_x; s.n = n;
     s.lambda = M.lambda;
     s.inv_n = 1.0f / (float)n;
@@ -237,7 +237,7 @@ int run_step(gg_ctx *ctx, int which, const int32_t *d_u, const int32_t *d_v, con
         if (nb < 1) nb = 1;
         hipLaunchKernelGGL(adam_dense_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, o);
     } else {
-        if (ctx->world > 1) {
+        if (ctx->comm) {
             int64_t nb = ((int64_t)ctx->n_node * 16 + 255) / 256;
             if (nb > 4096) nb = 4096;
             hipLaunchKernelGGL(rebuild_touched_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, o);

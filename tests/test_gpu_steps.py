@@ -233,3 +233,31 @@ def test_state_save_restore(ga, tmp_path):
         eng2.load_state(str(tmp_path / "missing"))
     eng.close()
     eng2.close()
+
+
+@pytest.mark.parametrize("mode", ["dense", "lazy"])
+def test_rccl_plumbing_with_one_rank_communicator(ga, mode, monkeypatch):
+    """gpurun boxes have ONE GPU: a 1-rank RCCL communicator (GG_COMM_FORCE=1) still exercises
+    dlopen(librccl), the enum values, the all-reduce on the engine's stream and, in lazy mode, the
+    rebuild of the touched-row list from the reduced gradient.  Results must equal the no-comm run."""
+    monkeypatch.setenv("GG_COMM_FORCE", "1")
+    n, d = 300, 50
+    Eg, Ed, bg, bd = make_models(n, d, 2)
+    opt = ga.GG_OPT_ADAM_DENSE if mode == "dense" else ga.GG_OPT_ADAM_LAZY
+    a = engine_with(ga, Eg, Ed, bg, bd, optimizer=opt)
+    b = engine_with(ga, Eg, Ed, bg, bd, optimizer=opt)
+    b.comm_init(ga.Engine.comm_unique_id(), 0, 1)
+    rs = np.random.RandomState(0)
+    for t in range(3):
+        u, v = rs.randint(0, n, 500), rs.randint(0, n, 500)
+        lab = (rs.rand(500) < 0.5).astype(np.float32)
+        a.d_step(u, v, lab)
+        b.d_step(u, v, lab)
+        a.g_step(v, u, lab)
+        b.g_step(v, u, lab)
+    b.comm_barrier()
+    for which in (0, 1):
+        assert np.allclose(a.get_embeddings(which), b.get_embeddings(which), rtol=1e-5, atol=1e-6)
+        assert np.allclose(a.get_bias(which), b.get_bias(which), rtol=1e-5, atol=1e-6)
+    a.close()
+    b.close()
