@@ -116,6 +116,7 @@ def main():
     cand = np.flatnonzero(deg > 0)
     all_roots = np.random.RandomState(args.seed).permutation(cand)[: R * world].astype(np.int32)
     roots = np.ascontiguousarray(all_roots[rank * R:(rank + 1) * R])
+    roots = roots[np.argsort(-deg[roots], kind="stable")]  # longest (hub) roots first: LPT order for the walk scheduler
     threads = args.threads or min(64, os.cpu_count() or 1)
     eng.build_trees(roots, n_threads=max(1, threads // max(1, min(world, 8))))
     slots = np.arange(len(roots), dtype=np.int32)
@@ -147,6 +148,7 @@ def main():
 
     hops = c1["hops"] - c0["hops"]
     reads = c1["nbr_reads"] - c0["nbr_reads"]
+    rows_scored = c1["rows_scored"] - c0["rows_scored"]
     walk_ms = c1["walk_kernel_ms"] - c0["walk_kernel_ms"]
     launches = c1["walk_launches"] - c0["walk_launches"]
     dpairs = c1["d_pairs"] - c0["d_pairs"]
@@ -185,6 +187,8 @@ def main():
         "walk_kernel_edges_per_sec": hops / (walk_ms * 1e-3) if walk_ms > 0 else None,
         "hops_per_step_rank0": hops / args.steps,
         "mean_k": reads / max(hops, 1),
+        "rows_scored_per_step_rank0": rows_scored / args.steps,
+        "nbr_reads_per_step_rank0": reads / args.steps,
         "setup_s": setup_s,
         "roofline": {"kernel": "walk_sample_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,

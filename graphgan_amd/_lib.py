@@ -33,7 +33,7 @@ class GGCounters(ctypes.Structure):
                 ("reward_pairs", ctypes.c_int64), ("d_pairs", ctypes.c_int64), ("g_pairs", ctypes.c_int64),
                 ("d_steps", ctypes.c_int64), ("g_steps", ctypes.c_int64),
                 ("last_kernel_ms", ctypes.c_double), ("walk_kernel_ms", ctypes.c_double),
-                ("walk_launches", ctypes.c_int64), ("reserved", ctypes.c_int64 * 5)]
+                ("walk_launches", ctypes.c_int64), ("rows_scored", ctypes.c_int64), ("reserved", ctypes.c_int64 * 4)]
 
 
 class GraphGANHipError(RuntimeError):

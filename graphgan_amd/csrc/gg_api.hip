@@ -2,6 +2,7 @@
 // variable fetch / restore.  The C ABI is include/graphgan_hip.h; each function there cites
 // the reference interface it replaces.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -115,10 +116,11 @@ int gg::walk_resident(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks,
     int rc = launch_walk_sample(ctx, n_slots, total, for_d, seed, stream, stride);
     if (rc != GG_OK) return rc;
     GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    unsigned long long c[4];
+    unsigned long long c[6];
     GG_HIP(ctx, hipMemcpy(c, ctx->dev_ctr, sizeof(c), hipMemcpyDeviceToHost));
     ctx->ctr.hops = (int64_t)c[0];
     ctx->ctr.nbr_reads = (int64_t)c[1];
+    ctx->ctr.rows_scored = (int64_t)c[5];
     ctx->ctr.walks += total;
     if (total) {
         float ms = 0.f;
@@ -166,6 +168,7 @@ int gg_create(int32_t n_node, int32_t n_emb, const float *emb_gen, const float *
     ctx->ld = (n_emb + 3) / 4 * 4;
     ctx->cfg = *cfg;
     ctx->device = cfg->device;
+    if (const char *lv = getenv("GG_WALK_LEVELS")) ctx->walk_levels = atoi(lv);
 #define GG_TRY(call)                        \
     do {                                    \
         int rc__ = (call);                  \
@@ -240,7 +243,8 @@ int gg_destroy(gg_ctx *ctx) {
     DevBuf *bufs[] = {&ctx->w_slots, &ctx->w_nwalks, &ctx->w_ptr, &ctx->w_samples, &ctx->w_paths, &ctx->w_len, &ctx->w_status,
                       &ctx->w_first, &ctx->w_abort, &ctx->w_scratch, &ctx->d_center, &ctx->d_neighbor, &ctx->d_label, &ctx->d_cnt,
                       &ctx->d_ptr, &ctx->g_node1, &ctx->g_node2, &ctx->g_reward, &ctx->g_cnt, &ctx->g_ptr, &ctx->scan_tmp,
-                      &ctx->step_u, &ctx->step_v, &ctx->step_x, &ctx->starts_buf, &ctx->misc};
+                      &ctx->step_u, &ctx->step_v, &ctx->step_x, &ctx->starts_buf, &ctx->misc, &ctx->st_cur, &ctx->st_prev, &ctx->st_len,
+                      &ctx->st_alive, &ctx->lv_beg, &ctx->lv_k, &ctx->lv_owner, &ctx->lv_chunks, &ctx->lv_coff, &ctx->lv_scores, &ctx->lv_chunk_owner, &ctx->lv_prefix};
     for (DevBuf *b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

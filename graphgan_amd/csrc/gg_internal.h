@@ -80,6 +80,9 @@ struct gg_ctx {
 
     // walk outputs (device resident)
     gg::DevBuf w_slots, w_nwalks, w_ptr, w_samples, w_paths, w_len, w_status, w_first, w_abort, w_scratch;
+    // level-synchronous front end of the walk sampler (walk_sample.hip): per-walk state + per-level tasks
+    gg::DevBuf st_cur, st_prev, st_len, st_alive, lv_beg, lv_k, lv_owner, lv_chunks, lv_coff, lv_scores, lv_chunk_owner, lv_prefix;
+    int32_t walk_levels = 0;  // hops handled by the streaming level kernels before the per-walk finisher (GG_WALK_LEVELS)
     int64_t w_total = 0;
     int32_t w_stride = 0, w_nslots = 0;
 
@@ -90,7 +93,7 @@ struct gg_ctx {
     int64_t g_pairs = 0;
     gg::DevBuf scan_tmp, step_u, step_v, step_x, starts_buf, misc;
 
-    // device-side counters: [0]=hops [1]=nbr_reads [2]=walks [3]=error flag
+    // device-side counters: [0]=hops [1]=nbr_reads [2]=alive walks [3]=error flag [4]=ticket [5]=rows scored
     unsigned long long *dev_ctr = nullptr;
     gg_counters ctr{};
 

@@ -31,13 +31,38 @@ struct StepArgs {
     int is_d;
 };
 
+// One 16-lane group per run of PAIRS_PER_GROUP consecutive pairs.  The reference's batches are
+// contiguous slices of the prepare-order lists (a13): a D slice is one root's rows (same u for
+// deg(root) rows), a G slice is the pairs of consecutive path positions (same u for 2-4 rows).
+// The u-side gradient is therefore accumulated in registers while u stays the same and flushed
+// with one row of atomics per run; the v side goes out per pair.  Lane t owns floats t, t+16, ...
+// so that one atomic instruction of the group covers one contiguous 64-byte line.
+constexpr int PAIRS_PER_GROUP = 16;
+
+template <int NF>  // NF = ceil(ld / 16) floats per lane
 __global__ __launch_bounds__(256) void pair_grad_kernel(const StepArgs a) {
     const int t = threadIdx.x & 15;
-    const int g0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const int ng = (gridDim.x * blockDim.x) >> 4;
+    const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int p0 = g * PAIRS_PER_GROUP;
+    if (p0 >= a.n) return;
+    const int p1 = min(p0 + PAIRS_PER_GROUP, a.n);
     const int nchunk = a.ld >> 2;
-    for (int p = g0; p < a.n; p += ng) {
+    float accu[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) accu[i] = 0.f;
+    int run_u = a.u[p0];
+    for (int p = p0; p < p1; ++p) {
         const int iu = a.u[p], iv = a.v[p];
+        if (iu != run_u) {  // flush the finished run of u
+            float *gu = a.gE + (int64_t)run_u * a.ld;
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const int f = t + 16 * i;
+                if (f < a.ld) atomicAdd(gu + f, accu[i]);
+                accu[i] = 0.f;
+            }
+            run_u = iu;
+        }
         const float4 *ru = (const float4 *)(a.E + (int64_t)iu * a.ld);
         const float4 *rv = (const float4 *)(a.E + (int64_t)iv * a.ld);
         float acc = 0.f;
@@ -62,17 +87,16 @@ __global__ __launch_bounds__(256) void pair_grad_kernel(const StepArgs a) {
             const bool inside = (sg >= 1e-5f) && (sg <= 1.0f);
             ds = inside ? -(a.x[p] * a.inv_n) * (1.0f - sg) : 0.0f;
         }
-        float *gu = a.gE + (int64_t)iu * a.ld, *gv = a.gE + (int64_t)iv * a.ld;
-        for (int c = t; c < nchunk; c += 16) {
-            const float4 x = ru[c], y = rv[c];
-            atomicAdd(gu + 4 * c + 0, ds * y.x + a.lambda * x.x);
-            atomicAdd(gu + 4 * c + 1, ds * y.y + a.lambda * x.y);
-            atomicAdd(gu + 4 * c + 2, ds * y.z + a.lambda * x.z);
-            atomicAdd(gu + 4 * c + 3, ds * y.w + a.lambda * x.w);
-            atomicAdd(gv + 4 * c + 0, ds * x.x + a.lambda * y.x);
-            atomicAdd(gv + 4 * c + 1, ds * x.y + a.lambda * y.y);
-            atomicAdd(gv + 4 * c + 2, ds * x.z + a.lambda * y.z);
-            atomicAdd(gv + 4 * c + 3, ds * x.w + a.lambda * y.w);
+        float *gv = a.gE + (int64_t)iv * a.ld;
+        const float *fu = (const float *)ru, *fv = (const float *)rv;  // rows were just read: L1/L2 hits
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int f = t + 16 * i;
+            if (f < a.ld) {
+                const float x = fu[f], y = fv[f];
+                accu[i] += ds * y + a.lambda * x;
+                atomicAdd(gv + f, ds * x + a.lambda * y);
+            }
         }
         if (t == 0) {
             atomicAdd(a.gb + iv, a.is_d ? ds + a.lambda * bv : ds);
@@ -81,6 +105,12 @@ __global__ __launch_bounds__(256) void pair_grad_kernel(const StepArgs a) {
                 if (atomicExch(a.touched + iv, 1) == 0) a.touched_list[atomicAdd(a.touched_cnt, 1)] = iv;
             }
         }
+    }
+    float *gu = a.gE + (int64_t)run_u * a.ld;
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        const int f = t + 16 * i;
+        if (f < a.ld) atomicAdd(gu + f, accu[i]);
     }
 }
 
@@ -215,9 +245,13 @@ int run_step(gg_ctx *ctx, int which, const int32_t *d_u, const int32_t *d_v, con
     s.lambda = M.lambda;
     s.inv_n = 1.0f / (float)n;
     s.is_d = which == 1;
-    int blocks = cdiv((int64_t)n * 16, 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(pair_grad_kernel, dim3(blocks), dim3(256), 0, ctx->stream, s);
+    const int groups = cdiv(n, PAIRS_PER_GROUP);
+    const int blocks = cdiv((int64_t)groups * 16, 256);
+    const int nf = (ctx->ld + 15) / 16;
+    if (nf <= 4) hipLaunchKernelGGL(pair_grad_kernel<4>, dim3(blocks), dim3(256), 0, ctx->stream, s);
+    else if (nf <= 8) hipLaunchKernelGGL(pair_grad_kernel<8>, dim3(blocks), dim3(256), 0, ctx->stream, s);
+    else if (nf <= 16) hipLaunchKernelGGL(pair_grad_kernel<16>, dim3(blocks), dim3(256), 0, ctx->stream, s);
+    else hipLaunchKernelGGL(pair_grad_kernel<32>, dim3(blocks), dim3(256), 0, ctx->stream, s);
 
     int rc = comm_allreduce_grads(ctx);
     if (rc != GG_OK) return rc;

@@ -4,23 +4,39 @@
 // all_score fetch it performs per call (:238; generator.py:21, score = g_cur . g_j + b[j]),
 // utils.softmax (src/utils.py:131-133) and np.random.choice (:262).
 //
-// Mapping: one 64-lane wavefront per walk, persistent grid, walks of a root
-// kept on one XCD.  Per hop the wave
-//   1. reads the tree list of (root, cur) from the tree CSR (scalar loads),
-//   2. scores the k tree neighbours: four 16-lane groups, each streaming one neighbour row as
-//      float4 chunks (256 B contiguous per group per load), fmaf chain per lane, xor-butterfly
-//      over the 16 lanes (spec S1), + bias; scores parked in LDS (4 KiB per wave; a per-wave
-//      HBM scratch row when k > 1024),
-//   3. turns scores into exact fixed-point weights (S2, S3), wave-scans them (uint64) and
-//      picks the first neighbour whose inclusive prefix exceeds floor(m * W / 2^53) (S4, S5).
-// The kernel is HBM/L2-latency bound: algorithmic bytes per hop = 4k(d+2) + 4d + 12.
+// Structure.  On power-law graphs the bytes of a launch are dominated by the
+// first hops (hop 1 lands on hubs with thousands of tree children) while later hops are
+// short latency chains.  So the launch is split:
+//
+//   levels 0 .. L-1  ("streaming front end", L = GG_WALK_LEVELS, default 2), per level:
+//     level_setup_kernel   one thread per walk: tree list of (root, cur), the reference's
+//                          hop rules (root-only-children, Q2 abort, Q3 father removal), and an
+//                          in-wave dedup: walks of one root standing on the same node need the
+//                          SAME distribution (the reference recomputes it per walk) -> one owner
+//     exclusive scan       of 64-neighbour chunk counts of the owners
+//     level_score_kernel   one wavefront per chunk: four 16-lane groups stream neighbour rows
+//                          as float4 (256 B contiguous per group per load), fmaf chain per lane,
+//                          xor butterfly (spec S1), + bias -> score buffer.  Uniform work
+//                          items: no hub tail, no dependent chains beyond ids -> rows.
+//     level_sample_kernel  one wavefront per walk: max, exact fixed-point weights, uint64 scan,
+//                          Philox uniform, inverse-CDF pick (spec S2..S5); path append;
+//                          termination (next == previous)
+//   remaining hops   walk_sample_kernel: one wavefront per walk runs its walk to the end
+//                          (scores parked in LDS, 4 KiB per wave; HBM scratch when k > 1024),
+//                          walks pulled from a ticket counter (longest roots first).
+//
+// Every (cur, j) score and every weight is computed by the same specified arithmetic in both
+// parts, and the sampling is exact integer arithmetic, so the split point does not change a
+// single sampled node.  Bound: HBM / L2 bandwidth for the score kernel, latency for the rest.
+// Algorithmic bytes per hop with k tree neighbours: 4k(d+2) + 4d + 12.
 #include "gg_arith.h"
 #include "gg_internal.h"
 
 namespace gg {
 
 constexpr int WAVES_PER_BLOCK = 4;
-constexpr int SCORE_CAP = 1024;  // fp32 scores per wave kept in LDS
+constexpr int SCORE_CAP = 1024;  // fp32 scores per wave kept in LDS (finisher)
+constexpr int CHUNK = 16;        // neighbours per score work item (= one 16-lane group pass: little divergence between the 4 groups of a wave)
 
 struct WalkArgs {
     const float *E;
@@ -42,9 +58,21 @@ struct WalkArgs {
     int32_t *status;       // [n_slots]
     int32_t *first_child;  // [total_walks]  D-mode: depth-1 child whose father entry this walk removes
     int32_t *abort_walk;   // [n_slots]      D-mode: smallest walk index that hit a leaf child
-    float *scratch;        // per-wave score rows for k > SCORE_CAP
+    float *scratch;        // per-wave score rows for k > SCORE_CAP (finisher)
     int64_t scratch_stride;
-    unsigned long long *ctr;  // [0] hops [1] nbr_reads [2] walks [3] error flag
+    unsigned long long *ctr;  // [0] hops [1] nbr_reads [2] alive walks [3] error flag [4] ticket [5] rows scored
+    // walk state carried between levels / into the finisher
+    int32_t *st_cur, *st_prev, *st_len, *st_alive;
+    int32_t level;         // hop index handled by this launch (level kernels) / first hop (finisher)
+    // per-level tasks
+    int64_t *lv_beg;       // absolute offset of the candidate list in t_nbr
+    int32_t *lv_k;         // candidates
+    int32_t *lv_owner;     // walk whose score region this walk reads
+    int32_t *lv_chunks;    // 64-neighbour chunks this walk owns (0 for non-owners / dead walks)
+    const int64_t *lv_coff;  // exclusive scan of lv_chunks, [total_walks + 1]
+    float *lv_scores;      // [64 * total chunks]
+    int4 *lv_chunk_desc;   // [total chunks] {cur node, rows in this chunk, list offset lo, hi} of chunk c
+    uint64_t *lv_prefix;   // [64 * total chunks] inclusive prefix sums of the fixed-point weights
 };
 
 __device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, int lane) {
@@ -62,15 +90,356 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     return v;
 }
 
+__device__ __forceinline__ int find_item(const int64_t *walk_ptr, int n_slots, int64_t w) {
+    int lo = 0, hi = n_slots;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (walk_ptr[mid] <= w) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// Scores of up to 64 candidates ids[0..nblock) against the row of `cur` (spec S1), handed to
+// store(j, score).  The whole wave participates; group q = lane >> 4 handles candidates q, q+4, ...
+template <int NCH, class Store>
+__device__ __forceinline__ float score_block(const WalkArgs &a, const float4 (&gc)[NCH], const int32_t *ids, int nblock,
+                                             int lane, Store store) {
+    const int t = lane & 15, q = lane >> 4;
+    const int myid = (lane < nblock) ? ids[lane] : 0;
+    float mx = -INFINITY;
+    for (int s = 0; s < nblock; s += 16) {
+        float4 y[4][NCH];
+        int id[4];
+        bool valid[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int jj = s + u * 4 + q;
+            valid[u] = jj < nblock;
+            id[u] = __shfl(myid, jj & 63, 64);
+            const float4 *const row = (const float4 *)(a.E + (int64_t)id[u] * a.ld);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int ch = t + 16 * c;
+                y[u][c] = (valid[u] && ch < a.nchunk) ? row[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                acc = __builtin_fmaf(gc[c].x, y[u][c].x, acc);
+                acc = __builtin_fmaf(gc[c].y, y[u][c].y, acc);
+                acc = __builtin_fmaf(gc[c].z, y[u][c].z, acc);
+                acc = __builtin_fmaf(gc[c].w, y[u][c].w, acc);
+            }
+            acc = acc + __shfl_xor(acc, 8, 64);
+            acc = acc + __shfl_xor(acc, 4, 64);
+            acc = acc + __shfl_xor(acc, 2, 64);
+            acc = acc + __shfl_xor(acc, 1, 64);
+            if (valid[u]) {
+                const float sc = acc + a.bias[id[u]];
+                mx = fmaxf(mx, sc);
+                if (t == 0) store(s + u * 4 + q, sc);
+            }
+        }
+    }
+    return mx;
+}
+
+template <int NCH>
+__device__ __forceinline__ void load_cur_row(const WalkArgs &a, int cur, int lane, float4 (&gc)[NCH]) {
+    const int t = lane & 15;
+    const float4 *const crow = (const float4 *)(a.E + (int64_t)cur * a.ld);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int ch = t + 16 * c;
+        gc[c] = (ch < a.nchunk) ? crow[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// Exact inverse-CDF pick among k scores sbuf(0..k) (spec S2, S3, S5); all lanes return idx.
+template <class Load>
+__device__ __forceinline__ int sample_index(Load sbuf, int k, float mx, uint64_t m53, int lane) {
+    int idx = 0;
+    if (k <= 64) {
+        const uint64_t wgt = (lane < k) ? weight_fix40(exp_spec(sbuf(lane) - mx)) : 0ull;
+        const uint64_t C = wave_incl_scan_u64(wgt, lane);
+        const uint64_t W = __shfl(C, 63, 64);
+        const uint64_t thr = threshold(m53, W);
+        const unsigned long long bal = __ballot(C > thr);
+        idx = __ffsll((long long)bal) - 1;
+    } else {
+        uint64_t part = 0;
+        for (int jj = lane; jj < k; jj += 64) part += weight_fix40(exp_spec(sbuf(jj) - mx));
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+        const uint64_t thr = threshold(m53, part);
+        uint64_t carry = 0;
+        for (int j0 = 0; j0 < k; j0 += 64) {
+            const int jj = j0 + lane;
+            const uint64_t wgt = (jj < k) ? weight_fix40(exp_spec(sbuf(jj) - mx)) : 0ull;
+            const uint64_t C = carry + wave_incl_scan_u64(wgt, lane);
+            const unsigned long long bal = __ballot(C > thr);
+            if (bal) { idx = j0 + __ffsll((long long)bal) - 1; break; }
+            carry = __shfl(C, 63, 64);
+        }
+    }
+    return idx;
+}
+
+// ------------------------------------------------------------------------------------------
+// Level kernels
+// ------------------------------------------------------------------------------------------
+
+// One thread per walk (a wave = 64 consecutive walks).  Level 0 also initialises the walk.
+__global__ __launch_bounds__(256) void level_setup_kernel(const WalkArgs a) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool in_range = w < a.total_walks;
+    bool alive = false;
+    int item = 0, cur = -1, k = 0;
+    int64_t beg_abs = 0;
+    if (in_range) {
+        item = find_item(a.walk_ptr, a.n_slots, w);
+        const int slot = a.slots[item];
+        const int root = a.t_root[slot];
+        if (a.level == 0) {
+            alive = true;
+            cur = root;
+            a.st_prev[w] = -1;
+            a.st_len[w] = 1;
+            a.paths[w * (int64_t)a.stride] = root;
+            if (a.for_d) a.first_child[w] = -1;
+        } else {
+            alive = a.st_alive[w] != 0;
+            cur = a.st_cur[w];
+        }
+        if (alive) {
+            const int32_t *const o = a.t_off + (int64_t)slot * (a.n_node + 1);
+            const int32_t *const nb = a.t_nbr + a.t_base[slot];
+            int beg = o[cur];
+            const int end = o[cur + 1];
+            if (a.level == 0) beg += 1;           // tree[root][1:]  (graph_gan.py:250)
+            else if (nb[beg] < 0) beg += 1;       // father entry removed earlier (Q3)
+            k = end - beg;
+            const int j = (int)(w - a.walk_ptr[item]);
+            bool aborted = false;
+            if (k == 0) {                          // "the tree only has a root" (:252-253)
+                aborted = true;
+                if (a.for_d) atomicMin(&a.abort_walk[item], 0);
+                else a.status[item] = GG_ROOT_ABORTED;
+            } else if (a.for_d && a.level == 1 && nb[beg] == root) {
+                if (k == 1) {                      // node_neighbor == [root] (:255-257)
+                    atomicMin(&a.abort_walk[item], j);
+                    aborted = true;
+                } else {                           // node_neighbor.remove(root) (:258-259), applied by the post-pass
+                    a.first_child[w] = cur;
+                    beg += 1;
+                    k -= 1;
+                }
+            }
+            if (aborted) {
+                alive = false;
+                k = 0;
+                a.path_len[w] = 0;
+                a.samples[w] = -1;
+            }
+            beg_abs = a.t_base[slot] + beg;
+        }
+        a.st_cur[w] = cur;
+        a.st_alive[w] = alive ? 1 : 0;
+    }
+    // in-wave dedup: the first lane with the same (item, cur) owns the distribution
+    const long long key = alive ? (((long long)item << 32) | (unsigned)cur) : (-1ll - lane);
+    int owner = -1;
+    for (int l = 0; l < 64; ++l) {
+        const long long kl = __shfl(key, l, 64);
+        if (owner < 0 && kl == key) owner = l;
+    }
+    if (in_range) {
+        const bool owns = alive && owner == lane;
+        a.lv_beg[w] = beg_abs;
+        a.lv_k[w] = k;
+        a.lv_owner[w] = (int32_t)((w & ~63ll) + owner);
+        a.lv_chunks[w] = owns ? (k + CHUNK - 1) / CHUNK : 0;
+    }
+    const unsigned long long bal = __ballot(alive);
+    if (lane == 0 && bal) atomicAdd(&a.ctr[2], (unsigned long long)__popcll(bal));
+}
+
+// chunk descriptors (one thread per walk; owners describe their chunks): everything the score
+// kernel needs arrives with ONE 16-byte load per chunk instead of a chain of dependent loads
+__global__ void level_expand_kernel(const WalkArgs a) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= a.total_walks) return;
+    const int n = a.lv_chunks[w];
+    if (n == 0) return;
+    const int64_t c0 = a.lv_coff[w];
+    const int k = a.lv_k[w], cur = a.st_cur[w];
+    const int64_t beg = a.lv_beg[w];
+    for (int i = 0; i < n; ++i) {
+        const int64_t o = beg + (int64_t)i * CHUNK;
+        a.lv_chunk_desc[c0 + i] = make_int4(cur, min(CHUNK, k - i * CHUNK), (int)(o & 0xffffffffll), (int)(o >> 32));
+    }
+}
+
+// One 16-lane group per 64-candidate chunk (grid-stride): four independent chunks in flight per
+// wavefront, so the short dependent chain (descriptor -> ids + current row -> neighbour rows) of
+// the many small tasks is overlapped four-fold; rows are streamed UNROLL at a time per group
+// (float4 per lane, 256 B contiguous per row per load), fmaf chain + xor butterfly (spec S1).
+template <int NCH>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const WalkArgs a, const int64_t total_chunks) {
+    constexpr int UNROLL = 4;
+    __shared__ unsigned long long blk_rows;
+    if (threadIdx.x == 0) blk_rows = 0;
+    __syncthreads();
+    const int t = threadIdx.x & 15;
+    const int nblk = gridDim.x;
+    // consecutive chunks (same task / same root) -> consecutive logical blocks -> one XCD's L2
+    const int lblock = (nblk % 8 == 0) ? (int)((blockIdx.x % 8) * (nblk / 8) + blockIdx.x / 8) : (int)blockIdx.x;
+    const int64_t n_groups = (int64_t)nblk * (WAVES_PER_BLOCK * 4);
+    unsigned long long rows = 0;
+    for (int64_t c = (int64_t)lblock * (WAVES_PER_BLOCK * 4) + (threadIdx.x >> 4); c < total_chunks; c += n_groups) {
+        const int4 d = a.lv_chunk_desc[c];
+        const int cur = d.x, nblock = d.y;
+        const int32_t *const ids = a.t_nbr + (((int64_t)d.w << 32) | (unsigned)d.z);
+        float *const out = a.lv_scores + c * CHUNK;
+        float4 gc[NCH];
+        const float4 *const crow = (const float4 *)(a.E + (int64_t)cur * a.ld);
+#pragma unroll
+        for (int cc = 0; cc < NCH; ++cc) {
+            const int ch = t + 16 * cc;
+            gc[cc] = (ch < a.nchunk) ? crow[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (int jb = 0; jb < nblock; jb += 16) {
+            const int myid = (jb + t < nblock) ? ids[jb + t] : -1;  // 16 ids per group with one coalesced load
+            const int nb16 = min(16, nblock - jb);
+            for (int j0 = 0; j0 < nb16; j0 += UNROLL) {
+                float4 y[UNROLL][NCH];
+                int id[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    id[u] = __shfl(myid, j0 + u, 16);
+                    const bool valid = id[u] >= 0;
+                    const float4 *const row = (const float4 *)(a.E + (int64_t)(valid ? id[u] : 0) * a.ld);
+#pragma unroll
+                    for (int cc = 0; cc < NCH; ++cc) {
+                        const int ch = t + 16 * cc;
+                        y[u][cc] = (valid && ch < a.nchunk) ? row[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int cc = 0; cc < NCH; ++cc) {
+                        acc = __builtin_fmaf(gc[cc].x, y[u][cc].x, acc);
+                        acc = __builtin_fmaf(gc[cc].y, y[u][cc].y, acc);
+                        acc = __builtin_fmaf(gc[cc].z, y[u][cc].z, acc);
+                        acc = __builtin_fmaf(gc[cc].w, y[u][cc].w, acc);
+                    }
+                    acc = acc + __shfl_xor(acc, 8, 64);
+                    acc = acc + __shfl_xor(acc, 4, 64);
+                    acc = acc + __shfl_xor(acc, 2, 64);
+                    acc = acc + __shfl_xor(acc, 1, 64);
+                    if (id[u] >= 0 && t == 0) out[jb + j0 + u] = acc + a.bias[id[u]];
+                }
+            }
+        }
+        rows += (unsigned long long)nblock;
+    }
+    // one counter update per block (same-address atomics serialise at ~12 ns each)
+    if (t == 0 && rows) atomicAdd(&blk_rows, rows);
+    __syncthreads();
+    if (threadIdx.x == 0 && blk_rows) atomicAdd(&a.ctr[5], blk_rows);
+}
+
+// One wavefront per owner task: max, exact fixed-point weights (spec S2, S3) and their inclusive
+// prefix sums, computed once and shared by every walk that stands on this (root, node).
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_weights_kernel(const WalkArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t w = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wib;
+    if (w >= a.total_walks || a.lv_chunks[w] == 0) return;
+    const int k = a.lv_k[w];
+    const int64_t base = a.lv_coff[w] * CHUNK;
+    const float *const sc = a.lv_scores + base;
+    uint64_t *const pf = a.lv_prefix + base;
+    float mx = -INFINITY;
+    for (int jj = lane; jj < k; jj += 64) mx = fmaxf(mx, sc[jj]);
+    mx = wave_max_f32(mx);
+    uint64_t carry = 0;
+    for (int j0 = 0; j0 < k; j0 += 64) {
+        const int jj = j0 + lane;
+        const uint64_t wgt = (jj < k) ? weight_fix40(exp_spec(sc[jj] - mx)) : 0ull;
+        const uint64_t C = carry + wave_incl_scan_u64(wgt, lane);
+        if (jj < k) pf[jj] = C;
+        carry = __shfl(C, 63, 64);
+    }
+}
+
+// One thread per walk: Philox uniform, threshold, binary search in the owner's prefix sums
+// (first j with C_j > floor(m W / 2^53), spec S4, S5), path append, termination.
+__global__ __launch_bounds__(256) void level_sample_kernel(const WalkArgs a) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    unsigned long long my_k = 0;
+    bool did = false;
+    if (w < a.total_walks && a.st_alive[w]) {
+        did = true;
+        const int item = find_item(a.walk_ptr, a.n_slots, w);
+        const uint32_t j = (uint32_t)(w - a.walk_ptr[item]);
+        const int root = a.t_root[a.slots[item]];
+        const int k = a.lv_k[w];
+        my_k = (unsigned long long)k;
+        const uint64_t *const pf = a.lv_prefix + a.lv_coff[a.lv_owner[w]] * CHUNK;
+        const uint64_t thr = threshold(uniform53(a.seed, a.stream, (uint32_t)root, j, (uint32_t)a.level), pf[k - 1]);
+        int lo = 0, hi = k - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (pf[mid] > thr) hi = mid; else lo = mid + 1;
+        }
+        const int nxt = a.t_nbr[a.lv_beg[w] + lo];
+        const int len = a.st_len[w];
+        const int cur = a.st_cur[w], prev = a.st_prev[w];
+        if (len >= a.stride) {
+            a.ctr[3] = 1ull;
+            a.path_len[w] = 0;
+            a.samples[w] = -1;
+            a.st_alive[w] = 0;
+        } else {
+            a.paths[w * (int64_t)a.stride + len] = nxt;
+            if (nxt == prev) {              // terminating condition (:264-266): sample = cur
+                a.path_len[w] = len + 1;
+                a.samples[w] = cur;
+                a.st_alive[w] = 0;
+            } else {
+                a.st_len[w] = len + 1;
+                a.st_prev[w] = cur;
+                a.st_cur[w] = nxt;
+            }
+        }
+    }
+    const unsigned long long bal = __ballot(did);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) my_k += __shfl_xor(my_k, off, 64);
+    if (lane == 0 && bal) {
+        atomicAdd(&a.ctr[0], (unsigned long long)__popcll(bal));
+        atomicAdd(&a.ctr[1], my_k);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Finisher: one wavefront per walk, from hop a.level to the end of the walk.
+// ------------------------------------------------------------------------------------------
 template <int NCH>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void walk_sample_kernel(const WalkArgs a) {
     __shared__ float lds_scores[WAVES_PER_BLOCK][SCORE_CAP];
     __shared__ unsigned long long blk_ctr[2];
 
     const int lane = threadIdx.x & 63;
-    const int wib = threadIdx.x >> 6;
-    const int t = lane & 15;  // virtual lane of spec S1
-    const int q = lane >> 4;  // 16-lane group
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (threadIdx.x < 2) blk_ctr[threadIdx.x] = 0;
     __syncthreads();
 
@@ -81,161 +450,102 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void walk_sample_kernel(const
     const int64_t n_waves = (int64_t)nblk * WAVES_PER_BLOCK;
     float *const sbuf_lds = lds_scores[wib];
     float *const sbuf_glb = a.scratch + ((int64_t)blockIdx.x * WAVES_PER_BLOCK + wib) * a.scratch_stride;
+    const bool resume = a.level > 0;
 
     unsigned long long my_hops = 0, my_reads = 0;
 
-    for (int64_t w = (int64_t)lblock * WAVES_PER_BLOCK + wib; w < a.total_walks; w += n_waves) {
-        // walk -> (item i, walk-in-root j): upper_bound on walk_ptr
-        int lo = 0, hi = a.n_slots;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (a.walk_ptr[mid] <= w) lo = mid; else hi = mid;
-        }
-        const int item = lo;
-        const uint32_t j = (uint32_t)(w - a.walk_ptr[item]);
-        const int slot = a.slots[item];
-        const int root = a.t_root[slot];
-        const int32_t *const o = a.t_off + (int64_t)slot * (a.n_node + 1);
-        int32_t *const nb = a.t_nbr + a.t_base[slot];
-        int32_t *const path = a.paths + w * (int64_t)a.stride;
+    // dynamic work distribution: waves pull the next walk from one ticket counter, so a wave that
+    // drew a hub hop does not hold back a fixed share of the remaining walks (the first n_waves
+    // walks keep the XCD-contiguous static assignment)
+    for (int64_t w = (int64_t)lblock * WAVES_PER_BLOCK + wib; w < a.total_walks;) {
+        if (!resume || a.st_alive[w]) {
+            const int item = find_item(a.walk_ptr, a.n_slots, w);
+            const uint32_t j = (uint32_t)(w - a.walk_ptr[item]);
+            const int slot = a.slots[item];
+            const int root = a.t_root[slot];
+            const int32_t *const o = a.t_off + (int64_t)slot * (a.n_node + 1);
+            int32_t *const nb = a.t_nbr + a.t_base[slot];
+            int32_t *const path = a.paths + w * (int64_t)a.stride;
 
-        int cur = root, prev = -1, len = 1;
-        uint32_t hop = 0;
-        bool aborted = false, overflow = false;
-        if (lane == 0) path[0] = root;
-        if (a.for_d && lane == 0) a.first_child[w] = -1;
-
-        for (;;) {
-            int beg = o[cur];
-            const int end = o[cur + 1];
-            if (hop == 0) beg += 1;                 // tree[root][1:]  (graph_gan.py:250)
-            else if (nb[beg] < 0) beg += 1;         // father entry removed earlier (Q3)
-            int k = end - beg;
-            if (k == 0) { aborted = true; break; }  // "the tree only has a root" (:252-253)
-            if (a.for_d && hop == 1 && nb[beg] == root) {
-                if (k == 1) {                       // node_neighbor == [root] (:255-257)
-                    if (lane == 0) atomicMin(&a.abort_walk[item], (int)j);
-                    aborted = true;
-                    break;
-                }
-                if (lane == 0) a.first_child[w] = cur;  // node_neighbor.remove(root) (:258-259), applied by the post-pass
-                beg += 1;
-                k -= 1;
-            }
-            const int32_t *const ids = nb + beg;
-            float *const sbuf = (k <= SCORE_CAP) ? sbuf_lds : sbuf_glb;
-
-            // ---- current-node row, chunks t, t+16, ... (spec S1)
-            float4 gc[NCH];
-            const float4 *const crow = (const float4 *)(a.E + (int64_t)cur * a.ld);
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const int ch = t + 16 * c;
-                gc[c] = (ch < a.nchunk) ? crow[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-
-            // ---- pass 1: scores
-            float mx = -INFINITY;
-            for (int j0 = 0; j0 < k; j0 += 64) {
-                const int nblock = min(64, k - j0);
-                const int myid = (lane < nblock) ? ids[j0 + lane] : 0;
-                for (int s = 0; s < nblock; s += 16) {
-                    float4 y[4][NCH];
-                    int id[4];
-                    bool valid[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int jj = s + u * 4 + q;
-                        valid[u] = jj < nblock;
-                        id[u] = __shfl(myid, jj & 63, 64);
-                        const float4 *const row = (const float4 *)(a.E + (int64_t)id[u] * a.ld);
-#pragma unroll
-                        for (int c = 0; c < NCH; ++c) {
-                            const int ch = t + 16 * c;
-                            y[u][c] = (valid[u] && ch < a.nchunk) ? row[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        float acc = 0.0f;
-#pragma unroll
-                        for (int c = 0; c < NCH; ++c) {
-                            acc = __builtin_fmaf(gc[c].x, y[u][c].x, acc);
-                            acc = __builtin_fmaf(gc[c].y, y[u][c].y, acc);
-                            acc = __builtin_fmaf(gc[c].z, y[u][c].z, acc);
-                            acc = __builtin_fmaf(gc[c].w, y[u][c].w, acc);
-                        }
-                        acc = acc + __shfl_xor(acc, 8, 64);
-                        acc = acc + __shfl_xor(acc, 4, 64);
-                        acc = acc + __shfl_xor(acc, 2, 64);
-                        acc = acc + __shfl_xor(acc, 1, 64);
-                        if (valid[u]) {
-                            const float sc = acc + a.bias[id[u]];
-                            mx = fmaxf(mx, sc);
-                            if (t == 0) sbuf[j0 + s + u * 4 + q] = sc;
-                        }
-                    }
-                }
-            }
-            mx = wave_max_f32(mx);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-            // ---- passes 2/3: exact fixed-point inverse-CDF sample
-            const uint64_t m53 = uniform53(a.seed, a.stream, (uint32_t)root, j, hop);
-            int idx = 0;
-            if (k <= 64) {
-                const uint64_t wgt = (lane < k) ? weight_fix40(exp_spec(sbuf[lane] - mx)) : 0ull;
-                const uint64_t C = wave_incl_scan_u64(wgt, lane);
-                const uint64_t W = __shfl(C, 63, 64);
-                const uint64_t thr = threshold(m53, W);
-                const unsigned long long bal = __ballot(C > thr);
-                idx = __ffsll((long long)bal) - 1;
+            int cur = root, prev = -1, len = 1;
+            uint32_t hop = 0;
+            if (resume) {
+                cur = a.st_cur[w];
+                prev = a.st_prev[w];
+                len = a.st_len[w];
+                hop = (uint32_t)a.level;
             } else {
-                uint64_t part = 0;
-                for (int jj = lane; jj < k; jj += 64) part += weight_fix40(exp_spec(sbuf[jj] - mx));
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
-                const uint64_t thr = threshold(m53, part);
-                uint64_t carry = 0;
+                if (lane == 0) path[0] = root;
+                if (a.for_d && lane == 0) a.first_child[w] = -1;
+            }
+            bool aborted = false, overflow = false;
+
+            for (;;) {
+                int beg = o[cur];
+                const int end = o[cur + 1];
+                if (hop == 0) beg += 1;                 // tree[root][1:]  (graph_gan.py:250)
+                else if (nb[beg] < 0) beg += 1;         // father entry removed earlier (Q3)
+                int k = end - beg;
+                if (k == 0) { aborted = true; break; }  // "the tree only has a root" (:252-253)
+                if (a.for_d && hop == 1 && nb[beg] == root) {
+                    if (k == 1) {                       // node_neighbor == [root] (:255-257)
+                        if (lane == 0) atomicMin(&a.abort_walk[item], (int)j);
+                        aborted = true;
+                        break;
+                    }
+                    if (lane == 0) a.first_child[w] = cur;  // node_neighbor.remove(root) (:258-259), applied by the post-pass
+                    beg += 1;
+                    k -= 1;
+                }
+                const int32_t *const ids = nb + beg;
+                float *const sbuf = (k <= SCORE_CAP) ? sbuf_lds : sbuf_glb;
+
+                float4 gc[NCH];
+                load_cur_row<NCH>(a, cur, lane, gc);
+                float mx = -INFINITY;
                 for (int j0 = 0; j0 < k; j0 += 64) {
-                    const int jj = j0 + lane;
-                    const uint64_t wgt = (jj < k) ? weight_fix40(exp_spec(sbuf[jj] - mx)) : 0ull;
-                    const uint64_t C = carry + wave_incl_scan_u64(wgt, lane);
-                    const unsigned long long bal = __ballot(C > thr);
-                    if (bal) { idx = j0 + __ffsll((long long)bal) - 1; break; }
-                    carry = __shfl(C, 63, 64);
+                    const int nblock = min(64, k - j0);
+                    mx = fmaxf(mx, score_block<NCH>(a, gc, ids + j0, nblock, lane, [&](int jj, float sc) { sbuf[j0 + jj] = sc; }));
+                }
+                mx = wave_max_f32(mx);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+                const uint64_t m53 = uniform53(a.seed, a.stream, (uint32_t)root, j, hop);
+                const int idx = sample_index([&](int jj) { return sbuf[jj]; }, k, mx, m53, lane);
+                __builtin_amdgcn_wave_barrier();
+                const int nxt = ids[idx];
+                my_hops += 1;
+                my_reads += (unsigned long long)k;
+                if (len >= a.stride) { overflow = true; break; }
+                if (lane == 0) path[len] = nxt;
+                len += 1;
+                hop += 1;
+                if (nxt == prev) break;  // terminating condition (:264-266): sample = cur
+                prev = cur;
+                cur = nxt;
+            }
+
+            if (lane == 0) {
+                if (overflow) {
+                    a.ctr[3] = 1ull;
+                    a.path_len[w] = 0;
+                    a.samples[w] = -1;
+                } else if (aborted) {
+                    a.path_len[w] = 0;
+                    a.samples[w] = -1;
+                    if (!a.for_d) a.status[item] = GG_ROOT_ABORTED;
+                    else if (hop == 0) atomicMin(&a.abort_walk[item], 0);
+                } else {
+                    a.path_len[w] = len;
+                    a.samples[w] = cur;
                 }
             }
-            __builtin_amdgcn_wave_barrier();
-            const int nxt = ids[idx];
-            my_hops += 1;
-            my_reads += (unsigned long long)k;
-            if (len >= a.stride) { overflow = true; break; }
-            if (lane == 0) path[len] = nxt;
-            len += 1;
-            hop += 1;
-            if (nxt == prev) break;  // terminating condition (:264-266): sample = cur
-            prev = cur;
-            cur = nxt;
         }
-
-        if (lane == 0) {
-            if (overflow) {
-                a.ctr[3] = 1ull;
-                a.path_len[w] = 0;
-                a.samples[w] = -1;
-            } else if (aborted) {
-                a.path_len[w] = 0;
-                a.samples[w] = -1;
-                if (!a.for_d) a.status[item] = GG_ROOT_ABORTED;
-                else if (hop == 0) atomicMin(&a.abort_walk[item], 0);
-            } else {
-                a.path_len[w] = len;
-                a.samples[w] = cur;
-            }
-        }
+        unsigned long long nw = 0;
+        if (lane == 0) nw = atomicAdd(&a.ctr[4], 1ull);
+        w = n_waves + (int64_t)__shfl(nw, 0, 64);
     }
 
     if (lane == 0) {
@@ -245,7 +555,10 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void walk_sample_kernel(const
     __syncthreads();
     if (threadIdx.x == 0) {
         if (blk_ctr[0]) atomicAdd(&a.ctr[0], blk_ctr[0]);
-        if (blk_ctr[1]) atomicAdd(&a.ctr[1], blk_ctr[1]);
+        if (blk_ctr[1]) {
+            atomicAdd(&a.ctr[1], blk_ctr[1]);
+            atomicAdd(&a.ctr[5], blk_ctr[1]);  // the finisher scores every hop's rows itself
+        }
     }
 }
 
@@ -254,12 +567,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void walk_sample_kernel(const
 __global__ void walk_d_postpass_kernel(const WalkArgs a) {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= a.total_walks) return;
-    int lo = 0, hi = a.n_slots;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (a.walk_ptr[mid] <= w) lo = mid; else hi = mid;
-    }
-    const int item = lo;
+    const int item = find_item(a.walk_ptr, a.n_slots, w);
     const int j = (int)(w - a.walk_ptr[item]);
     const int ab = a.abort_walk[item];
     const int slot = a.slots[item];
@@ -282,6 +590,75 @@ __global__ void walk_init_status_kernel(const WalkArgs a) {
     if (i >= a.n_slots) return;
     a.status[i] = (a.walk_ptr[i + 1] == a.walk_ptr[i]) ? GG_ROOT_EMPTY : GG_ROOT_OK;
     a.abort_walk[i] = 0x7fffffff;
+}
+
+template <int NCH>
+static int run_levels_and_finish(gg_ctx *ctx, WalkArgs &a, int64_t total_walks) {
+    const dim3 blk(WAVES_PER_BLOCK * 64);
+    int level = 0;
+    const int n_levels = ctx->walk_levels < 0 ? 0 : ctx->walk_levels;
+    if (n_levels > 0) {
+        GG_HIP(ctx, ctx->st_cur.reserve(sizeof(int32_t) * total_walks));
+        GG_HIP(ctx, ctx->st_prev.reserve(sizeof(int32_t) * total_walks));
+        GG_HIP(ctx, ctx->st_len.reserve(sizeof(int32_t) * total_walks));
+        GG_HIP(ctx, ctx->st_alive.reserve(sizeof(int32_t) * total_walks));
+        GG_HIP(ctx, ctx->lv_beg.reserve(sizeof(int64_t) * total_walks));
+        GG_HIP(ctx, ctx->lv_k.reserve(sizeof(int32_t) * total_walks));
+        GG_HIP(ctx, ctx->lv_owner.reserve(sizeof(int32_t) * total_walks));
+        GG_HIP(ctx, ctx->lv_chunks.reserve(sizeof(int32_t) * total_walks));
+        GG_HIP(ctx, ctx->lv_coff.reserve(sizeof(int64_t) * (total_walks + 1)));
+        a.st_cur = ctx->st_cur.as<int32_t>();
+        a.st_prev = ctx->st_prev.as<int32_t>();
+        a.st_len = ctx->st_len.as<int32_t>();
+        a.st_alive = ctx->st_alive.as<int32_t>();
+        a.lv_beg = ctx->lv_beg.as<int64_t>();
+        a.lv_k = ctx->lv_k.as<int32_t>();
+        a.lv_owner = ctx->lv_owner.as<int32_t>();
+        a.lv_chunks = ctx->lv_chunks.as<int32_t>();
+        a.lv_coff = ctx->lv_coff.as<int64_t>();
+    }
+    bool any_alive = true;
+    for (; level < n_levels; ++level) {
+        a.level = level;
+        GG_HIP(ctx, hipMemsetAsync(ctx->dev_ctr + 2, 0, sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(level_setup_kernel, dim3(cdiv(total_walks, 256)), dim3(256), 0, ctx->stream, a);
+        int rc = device_exclusive_scan(ctx, a.lv_chunks, ctx->lv_coff.as<int64_t>(), total_walks);
+        if (rc != GG_OK) return rc;
+        // one 16-byte read per level: chunks to score (sizes the score buffer) and walks still alive
+        int64_t total_chunks = 0;
+        unsigned long long alive = 0;
+        GG_HIP(ctx, hipMemcpyAsync(&total_chunks, ctx->lv_coff.as<int64_t>() + total_walks, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        GG_HIP(ctx, hipMemcpyAsync(&alive, ctx->dev_ctr + 2, sizeof(alive), hipMemcpyDeviceToHost, ctx->stream));
+        GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (alive == 0) { any_alive = false; break; }
+        GG_HIP(ctx, ctx->lv_scores.reserve(sizeof(float) * CHUNK * (size_t)total_chunks + 256));
+        GG_HIP(ctx, ctx->lv_chunk_owner.reserve(sizeof(int4) * (size_t)total_chunks + 256));
+        GG_HIP(ctx, ctx->lv_prefix.reserve(sizeof(uint64_t) * CHUNK * (size_t)total_chunks + 256));
+        a.lv_prefix = ctx->lv_prefix.as<uint64_t>();
+        a.lv_scores = ctx->lv_scores.as<float>();
+        a.lv_chunk_desc = ctx->lv_chunk_owner.as<int4>();
+        hipLaunchKernelGGL(level_expand_kernel, dim3(cdiv(total_walks, 256)), dim3(256), 0, ctx->stream, a);
+        int64_t blocks = (total_chunks + WAVES_PER_BLOCK * 4 - 1) / (WAVES_PER_BLOCK * 4);
+        if (blocks > 256 * 8) blocks = 256 * 8;
+        if (blocks >= 8) blocks -= blocks % 8;
+        hipLaunchKernelGGL(level_score_kernel<NCH>, dim3((unsigned)blocks), blk, 0, ctx->stream, a, total_chunks);
+        hipLaunchKernelGGL(level_weights_kernel, dim3(cdiv(total_walks, WAVES_PER_BLOCK)), blk, 0, ctx->stream, a);
+        hipLaunchKernelGGL(level_sample_kernel, dim3(cdiv(total_walks, 256)), dim3(256), 0, ctx->stream, a);
+    }
+    if (any_alive) {
+        a.level = level;
+        int64_t blocks = (total_walks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+        const int64_t max_blocks = 256 * 8;
+        if (blocks > max_blocks) blocks = max_blocks;
+        if (blocks >= 8) blocks -= blocks % 8;
+        const int64_t need_stride = ctx->tree_max_list > SCORE_CAP ? ((ctx->tree_max_list + 63) / 64 * 64) : 0;
+        GG_HIP(ctx, ctx->w_scratch.reserve((size_t)need_stride * blocks * WAVES_PER_BLOCK * sizeof(float) + 16));
+        a.scratch = ctx->w_scratch.as<float>();
+        a.scratch_stride = need_stride;
+        hipLaunchKernelGGL(walk_sample_kernel<NCH>, dim3((unsigned)blocks), blk, 0, ctx->stream, a);
+    }
+    GG_HIP(ctx, hipGetLastError());
+    return GG_OK;
 }
 
 int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int for_d, uint64_t seed, uint32_t stream,
@@ -312,26 +689,19 @@ int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int fo
     a.abort_walk = ctx->w_abort.as<int32_t>();
     a.ctr = ctx->dev_ctr;
 
+    GG_HIP(ctx, hipMemsetAsync(ctx->dev_ctr + 4, 0, sizeof(unsigned long long), ctx->stream));
     hipLaunchKernelGGL(walk_init_status_kernel, dim3(cdiv(n_slots, 256)), dim3(256), 0, ctx->stream, a);
     if (total_walks == 0) return GG_OK;
 
-    // persistent grid: <= 8 blocks of 4 waves per CU, multiple of 8 for the XCD mapping
-    int64_t blocks = (total_walks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-    const int64_t max_blocks = 256 * 8;
-    if (blocks > max_blocks) blocks = max_blocks;
-    if (blocks >= 8) blocks -= blocks % 8;
-    const int64_t need_stride = ctx->tree_max_list > SCORE_CAP ? ((ctx->tree_max_list + 63) / 64 * 64) : 0;
-    GG_HIP(ctx, ctx->w_scratch.reserve((size_t)need_stride * blocks * WAVES_PER_BLOCK * sizeof(float) + 16));
-    a.scratch = ctx->w_scratch.as<float>();
-    a.scratch_stride = need_stride;
-
     const int nch = (a.nchunk + 15) / 16;
     GG_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    if (nch <= 1) hipLaunchKernelGGL(walk_sample_kernel<1>, dim3((unsigned)blocks), dim3(WAVES_PER_BLOCK * 64), 0, ctx->stream, a);
-    else if (nch == 2) hipLaunchKernelGGL(walk_sample_kernel<2>, dim3((unsigned)blocks), dim3(WAVES_PER_BLOCK * 64), 0, ctx->stream, a);
-    else if (nch <= 4) hipLaunchKernelGGL(walk_sample_kernel<4>, dim3((unsigned)blocks), dim3(WAVES_PER_BLOCK * 64), 0, ctx->stream, a);
-    else if (nch <= 8) hipLaunchKernelGGL(walk_sample_kernel<8>, dim3((unsigned)blocks), dim3(WAVES_PER_BLOCK * 64), 0, ctx->stream, a);
+    int rc;
+    if (nch <= 1) rc = run_levels_and_finish<1>(ctx, a, total_walks);
+    else if (nch == 2) rc = run_levels_and_finish<2>(ctx, a, total_walks);
+    else if (nch <= 4) rc = run_levels_and_finish<4>(ctx, a, total_walks);
+    else if (nch <= 8) rc = run_levels_and_finish<8>(ctx, a, total_walks);
     else return fail(ctx, GG_EINVAL, "n_emb %d not supported (max 512)", ctx->n_emb);
+    if (rc != GG_OK) return rc;
     GG_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     if (for_d)
         hipLaunchKernelGGL(walk_d_postpass_kernel, dim3(cdiv(total_walks, 256)), dim3(256), 0, ctx->stream, a);

@@ -84,7 +84,9 @@ typedef struct gg_counters {
     double last_kernel_ms;  /* HIP-event time of the last timed kernel region (walk / pass) */
     double walk_kernel_ms;  /* cumulative HIP-event time of walk_sample kernels */
     int64_t walk_launches;
-    int64_t reserved[5];
+    int64_t rows_scored;    /* neighbour rows actually streamed: identical (root, node) distributions of one
+                               launch are evaluated once and shared by the walks that need them */
+    int64_t reserved[4];
 } gg_counters;
 
 typedef struct gg_ctx gg_ctx;
