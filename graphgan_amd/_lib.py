@@ -33,7 +33,8 @@ class GGCounters(ctypes.Structure):
                 ("reward_pairs", ctypes.c_int64), ("d_pairs", ctypes.c_int64), ("g_pairs", ctypes.c_int64),
                 ("d_steps", ctypes.c_int64), ("g_steps", ctypes.c_int64),
                 ("last_kernel_ms", ctypes.c_double), ("walk_kernel_ms", ctypes.c_double),
-                ("walk_launches", ctypes.c_int64), ("rows_scored", ctypes.c_int64), ("reserved", ctypes.c_int64 * 4)]
+                ("walk_launches", ctypes.c_int64), ("rows_scored", ctypes.c_int64), ("score_kernel_ms", ctypes.c_double),
+                ("score_launches", ctypes.c_int64), ("score_chunks", ctypes.c_int64), ("reserved", ctypes.c_int64 * 1)]
 
 
 class GraphGANHipError(RuntimeError):

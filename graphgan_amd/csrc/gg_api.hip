@@ -113,11 +113,25 @@ int gg::walk_resident(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks,
     ctx->w_stride = stride;
     ctx->w_nslots = n_slots;
     if (n_slots == 0) return GG_OK;
+    // cumulative device counters as of the previous launch (to restore them if this launch is rerun)
+    unsigned long long c0[6] = {(unsigned long long)ctx->ctr.hops, (unsigned long long)ctx->ctr.nbr_reads, 0, 0, 0,
+                                (unsigned long long)ctx->ctr.rows_scored}, c[6];
     int rc = launch_walk_sample(ctx, n_slots, total, for_d, seed, stream, stride);
     if (rc != GG_OK) return rc;
     GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    unsigned long long c[6];
     GG_HIP(ctx, hipMemcpy(c, ctx->dev_ctr, sizeof(c), hipMemcpyDeviceToHost));
+    if (c[3] == 2ull) {
+        // the sync-free launch ran out of its learned buffer capacity at some level: nothing it wrote
+        // is final (the D-mode post-pass is gated by the same flag), rerun with per-level sizing
+        c0[3] = 0;
+        GG_HIP(ctx, hipMemcpy(ctx->dev_ctr, c0, sizeof(c0), hipMemcpyHostToDevice));
+        ctx->walk_force_sized = true;
+        rc = launch_walk_sample(ctx, n_slots, total, for_d, seed, stream, stride);
+        ctx->walk_force_sized = false;
+        if (rc != GG_OK) return rc;
+        GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        GG_HIP(ctx, hipMemcpy(c, ctx->dev_ctr, sizeof(c), hipMemcpyDeviceToHost));
+    }
     ctx->ctr.hops = (int64_t)c[0];
     ctx->ctr.nbr_reads = (int64_t)c[1];
     ctx->ctr.rows_scored = (int64_t)c[5];
@@ -128,6 +142,15 @@ int gg::walk_resident(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks,
         ctx->ctr.last_kernel_ms = ms;
         ctx->ctr.walk_kernel_ms += ms;
         ctx->ctr.walk_launches += 1;
+        for (int i = 0; i < ctx->lv_ev_used; ++i) {
+            float lms = 0.f;
+            GG_HIP(ctx, hipEventElapsedTime(&lms, ctx->lv_ev[2 * i], ctx->lv_ev[2 * i + 1]));
+            ctx->ctr.score_kernel_ms += lms;
+            ctx->ctr.score_launches += 1;
+        }
+        unsigned long long chunks[64];
+        GG_HIP(ctx, hipMemcpy(chunks, ctx->dev_ctr + 136, sizeof(chunks), hipMemcpyDeviceToHost));
+        for (int i = 0; i < ctx->lv_ev_used; ++i) ctx->ctr.score_chunks += (int64_t)chunks[i];
     }
     if (c[3]) {
         unsigned long long z = 0;
@@ -214,8 +237,8 @@ int gg_create(int32_t n_node, int32_t n_emb, const float *emb_gen, const float *
         GG_HIP(ctx, hipMalloc((void **)&ctx->touched_cnt, sizeof(int32_t) * 4));
         GG_HIP(ctx, hipMemset(ctx->touched, 0, sizeof(int32_t) * n_node));
         GG_HIP(ctx, hipMemset(ctx->touched_cnt, 0, sizeof(int32_t) * 4));
-        GG_HIP(ctx, hipMalloc((void **)&ctx->dev_ctr, sizeof(unsigned long long) * 8));
-        GG_HIP(ctx, hipMemset(ctx->dev_ctr, 0, sizeof(unsigned long long) * 8));
+        GG_HIP(ctx, hipMalloc((void **)&ctx->dev_ctr, sizeof(unsigned long long) * 256));
+        GG_HIP(ctx, hipMemset(ctx->dev_ctr, 0, sizeof(unsigned long long) * 256));
         GG_HIP(ctx, hipDeviceSynchronize());
         return GG_OK;
     };
@@ -243,9 +266,11 @@ int gg_destroy(gg_ctx *ctx) {
     DevBuf *bufs[] = {&ctx->w_slots, &ctx->w_nwalks, &ctx->w_ptr, &ctx->w_samples, &ctx->w_paths, &ctx->w_len, &ctx->w_status,
                       &ctx->w_first, &ctx->w_abort, &ctx->w_scratch, &ctx->d_center, &ctx->d_neighbor, &ctx->d_label, &ctx->d_cnt,
                       &ctx->d_ptr, &ctx->g_node1, &ctx->g_node2, &ctx->g_reward, &ctx->g_cnt, &ctx->g_ptr, &ctx->scan_tmp,
-                      &ctx->step_u, &ctx->step_v, &ctx->step_x, &ctx->starts_buf, &ctx->misc, &ctx->st_cur, &ctx->st_prev, &ctx->st_len,
-                      &ctx->st_alive, &ctx->lv_beg, &ctx->lv_k, &ctx->lv_owner, &ctx->lv_chunks, &ctx->lv_coff, &ctx->lv_scores, &ctx->lv_chunk_owner, &ctx->lv_prefix};
+                      &ctx->step_u, &ctx->step_v, &ctx->step_x, &ctx->starts_buf, &ctx->misc, &ctx->st_item, &ctx->st_cur, &ctx->st_prev, &ctx->st_len,
+                      &ctx->st_alive, &ctx->lv_beg, &ctx->lv_k, &ctx->lv_owner, &ctx->lv_chunks, &ctx->lv_coff, &ctx->lv_scores, &ctx->lv_chunk_owner, &ctx->lv_prefix, &ctx->lv_big};
     for (DevBuf *b : bufs) b->release();
+    for (hipEvent_t e : ctx->lv_ev)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -53,6 +53,8 @@ struct gg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t lv_ev[128] = {};  // per-level event pairs around level_score_kernel
+    int lv_ev_used = 0;
     gg::Model model[2];  // 0 = generator, 1 = discriminator (config.modes order)
 
     // dense gradient accumulators shared by D and G steps (zero between steps)
@@ -81,8 +83,11 @@ struct gg_ctx {
     // walk outputs (device resident)
     gg::DevBuf w_slots, w_nwalks, w_ptr, w_samples, w_paths, w_len, w_status, w_first, w_abort, w_scratch;
     // level-synchronous front end of the walk sampler (walk_sample.hip): per-walk state + per-level tasks
-    gg::DevBuf st_cur, st_prev, st_len, st_alive, lv_beg, lv_k, lv_owner, lv_chunks, lv_coff, lv_scores, lv_chunk_owner, lv_prefix;
-    int32_t walk_levels = 0;  // hops handled by the streaming level kernels before the per-walk finisher (GG_WALK_LEVELS)
+    gg::DevBuf st_cur, st_prev, st_len, st_alive, st_item, lv_beg, lv_k, lv_owner, lv_chunks, lv_coff, lv_scores, lv_chunk_owner, lv_prefix, lv_big;
+    int64_t lv_cap_chunks = 0;         // learned capacity (chunks per level) for the sync-free launches
+    bool walk_force_sized = false;     // retry path after a speculative overflow
+    bool walk_used_speculation = false;
+    int32_t walk_levels = 64;  // hops handled by the streaming level kernels before the per-walk finisher (GG_WALK_LEVELS)
     int64_t w_total = 0;
     int32_t w_stride = 0, w_nslots = 0;
 

