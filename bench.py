@@ -90,6 +90,21 @@ def cpu_baseline(args, n, rowptr, col, emb, bias, roots, seconds):
         args.n_sample_gen, len(rts), stream // 2, hops, t)
 
 
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
+    (profiles/summarize.py; FETCH_SIZE / WRITE_SIZE collected in separate passes of this same
+    command, gfx950 correction applied).  PMC counters cannot be read from inside the bench."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
+    if not files:
+        return None, None
+    data = json.load(open(files[-1]))
+    for name, v in data.items():
+        if kernel_substr in name:
+            return v["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+    return None, None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -171,6 +186,7 @@ def main():
     # The reference evaluates every hop's distribution from scratch (4k(d+2) + 4d + 12 per hop);
     # the engine evaluates each distinct (root, node) distribution of a launch once.
     ref_bytes = 4.0 * (d + 2) * reads + (4.0 * d + 12.0) * hops
+    traffic, traffic_src = pmc_traffic("level_score_kernel") if args.workload == "powerlaw" and args.nodes == 1_000_000 else (None, None)
     out = {
         "metric": "sampled_edges_per_sec",
         "value": tot[0] / tot[3],
@@ -196,7 +212,7 @@ def main():
         "nbr_reads_per_step_rank0": reads / args.steps,
         "setup_s": setup_s,
         "roofline": {"kernel": "level_score_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": sc_bytes / max(sc_launches, 1), "avg_launch_ms": sc_ms / max(sc_launches, 1),
                      "launches": int(sc_launches), "rows_per_launch": rows_scored / max(sc_launches, 1),
                      "gather_microbench_ceiling_GBs": 5600.0},

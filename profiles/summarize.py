@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 outputs (gpurun_out/, scratch) into the committed per-round summaries.
+
+    python profiles/summarize.py <round-tag> <kernel_trace_dir> <fetch_dir> <write_dir>
+
+Commands that produced the inputs (on the MI355X box, `cd /tmp && export TMPDIR=/tmp` first):
+    rocprofv3 --kernel-trace --stats --output-format csv -d <kernel_trace_dir> -o b -- python bench.py --no-cpu-baseline
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d <fetch_dir> -o f -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d <write_dir> -o w -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline
+PMC passes are separate runs (FETCH_SIZE and WRITE_SIZE do not fit one pass).  gfx950 correction
+(MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 64 B per 128 B request of wide coalesced reads,
+so read bytes = 2 * FETCH_SIZE KiB; WRITE_SIZE is taken as reported.
+"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+
+def pmc(path, counter):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+
+def main():
+    tag, kt, fd, wd = sys.argv[1:5]
+    here = os.path.dirname(os.path.abspath(__file__))
+    shutil.copy(os.path.join(kt, "b_kernel_stats.csv"), os.path.join(here, "%s_kernel_stats.csv" % tag))
+    fetch = pmc(os.path.join(fd, "f_counter_collection.csv"), "FETCH_SIZE")
+    write = pmc(os.path.join(wd, "w_counter_collection.csv"), "WRITE_SIZE")
+    out = {}
+    for name in sorted(set(fetch) | set(write)):
+        f, w = fetch.get(name, []), write.get(name, [])
+        if not f:
+            continue
+        fm = sum(f) / len(f)
+        wm = sum(w) / len(w) if w else 0.0
+        out[name] = {"launches_sampled": len(f), "FETCH_SIZE_KiB_mean": fm, "WRITE_SIZE_KiB_mean": wm,
+                     "hbm_bytes_per_launch": (2.0 * fm + wm) * 1024.0}
+    with open(os.path.join(here, "%s_pmc_hbm_traffic.json" % tag), "w") as fjs:
+        json.dump(out, fjs, indent=1, sort_keys=True)
+    for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_sampled"])[:6]:
+        print("%-60s %4d launches  %.1f MB/launch" % (k[:60], v["launches_sampled"], v["hbm_bytes_per_launch"] / 1e6))
+
+
+if __name__ == "__main__":
+    main()
