@@ -4,31 +4,22 @@
 // all_score fetch it performs per call (:238; generator.py:21, score = g_cur . g_j + b[j]),
 // utils.softmax (src/utils.py:131-133) and np.random.choice (:262).
 //
-// Structure.  On power-law graphs the bytes of a launch are dominated by the
-// first hops (hop 1 lands on hubs with thousands of tree children) while later hops are
-// short latency chains.  So the launch is split:
-//
-//   levels 0 .. L-1  ("streaming front end", L = GG_WALK_LEVELS, default 2), per level:
-//     level_setup_kernel   one thread per walk: tree list of (root, cur), the reference's
-//                          hop rules (root-only-children, Q2 abort, Q3 father removal), and an
-//                          in-wave dedup: walks of one root standing on the same node need the
-//                          SAME distribution (the reference recomputes it per walk) -> one owner
-//     exclusive scan       of 64-neighbour chunk counts of the owners
-//     level_score_kernel   one wavefront per chunk: four 16-lane groups stream neighbour rows
-//                          as float4 (256 B contiguous per group per load), fmaf chain per lane,
-//                          xor butterfly (spec S1), + bias -> score buffer.  Uniform work
-//                          items: no hub tail, no dependent chains beyond ids -> rows.
-//     level_sample_kernel  one wavefront per walk: max, exact fixed-point weights, uint64 scan,
-//                          Philox uniform, inverse-CDF pick (spec S2..S5); path append;
-//                          termination (next == previous)
-//   remaining hops   walk_sample_kernel: one wavefront per walk runs its walk to the end
-//                          (scores parked in LDS, 4 KiB per wave; HBM scratch when k > 1024),
-//                          walks pulled from a ticket counter (longest roots first).
-//
-// Every (cur, j) score and every weight is computed by the same specified arithmetic in both
-// parts, and the sampling is exact integer arithmetic, so the split point does not change a
-// single sampled node.  Bound: HBM / L2 bandwidth for the score kernel, latency for the rest.
-// Algorithmic bytes per hop with k tree neighbours: 4k(d+2) + 4d + 12.
+// Structure: all walks of a launch advance one hop at a time.
+//   level_advance_kernel        one thread per walk: finish hop h-1 (Philox uniform, threshold,
+//                               binary search in the shared prefix sums, path append,
+//                               termination), prepare hop h (tree list + the reference's hop
+//                               rules, in-wave dedup of identical (root, node) distributions,
+//                               chunk offsets, chunk descriptors)
+//   level_score_kernel          one 16-lane group per <= 16-candidate chunk: neighbour rows as
+//                               float4 (256 B contiguous per row per load), fmaf chain, xor
+//                               butterfly (spec S1), + bias -> score buffer.  Dominant, HBM-bound.
+//   level_weights_small / big   max, exact fixed-point weights, uint64 prefix sums (S2, S3),
+//                               once per distribution
+//   walk_sample_kernel          "finisher": one wavefront per walk runs the remaining hops
+//                               (GG_WALK_LEVELS < tree depth + 2; = 0: the whole walk)
+// Scores follow S1 and everything after them is exact integer arithmetic, so the decomposition
+// cannot change a sampled node.  Algorithmic bytes of the score kernel: 4(d+3) per candidate row
+// + 4d+16 per chunk.
 #include "gg_arith.h"
 #include "gg_internal.h"
 
