@@ -75,14 +75,15 @@ static int upload_table(gg_ctx *ctx, float *dst, const float *src) {
 
 using namespace gg;
 
-// Shared by gg_walk_sample and gg_prepare_*: stage the launch on device, run, leave the
-// results resident.  n_walks == NULL: CSR degree of each slot's root (D-mode, graph_gan.py:190-191).
-int gg::walk_resident(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, int32_t uniform_walks, int32_t n_slots,
-                  int32_t for_d, uint64_t seed, uint32_t stream, int32_t stride) {
+// Shared by gg_walk_sample and gg_prepare_*: stage the launch on device and enqueue it (no host
+// synchronisation).  n_walks == NULL: CSR degree of each slot's root (D-mode, graph_gan.py:190-191).
+int gg::walk_launch_async(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, int32_t uniform_walks, int32_t n_slots,
+                          int32_t for_d, uint64_t seed, uint32_t stream, int32_t stride) {
     GG_CHECK(ctx, ctx->n_tree_roots > 0, GG_EINVAL, "walk: no trees loaded (gg_build_trees / gg_set_trees)");
     GG_CHECK(ctx, n_slots >= 0 && (slots || n_slots == 0), GG_EINVAL, "walk: bad slots");
     GG_CHECK(ctx, stride >= 2, GG_ECAPACITY, "walk: stride %d < 2", stride);
-    std::vector<int64_t> ptr(n_slots + 1, 0);
+    std::vector<int64_t> &ptr = ctx->h_walk_ptr;
+    ptr.assign(n_slots + 1, 0);
     for (int i = 0; i < n_slots; ++i) {
         GG_CHECK(ctx, slots[i] >= 0 && slots[i] < ctx->n_tree_roots, GG_EINVAL, "walk: slot %d out of range", slots[i]);
         int64_t nw;
@@ -106,31 +107,42 @@ int gg::walk_resident(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks,
     GG_HIP(ctx, ctx->w_len.reserve(sizeof(int32_t) * (total + 1)));
     GG_HIP(ctx, ctx->w_first.reserve(sizeof(int32_t) * (total + 1)));
     GG_HIP(ctx, ctx->w_paths.reserve(sizeof(int32_t) * ((size_t)total * stride + 1)));
+    // h_walk_ptr and the caller's slots outlive the enqueued copies: every public call ends with a stream sync
     if (n_slots) GG_HIP(ctx, hipMemcpyAsync(ctx->w_slots.p, slots, sizeof(int32_t) * n_slots, hipMemcpyHostToDevice, ctx->stream));
     GG_HIP(ctx, hipMemcpyAsync(ctx->w_ptr.p, ptr.data(), sizeof(int64_t) * (n_slots + 1), hipMemcpyHostToDevice, ctx->stream));
-    GG_HIP(ctx, hipStreamSynchronize(ctx->stream));  // ptr is a local
     ctx->w_total = total;
     ctx->w_stride = stride;
     ctx->w_nslots = n_slots;
+    ctx->w_args = {for_d, seed, stream};
     if (n_slots == 0) return GG_OK;
+    return launch_walk_sample(ctx, n_slots, total, for_d, seed, stream, stride);
+}
+
+// Wait for the enqueued launch (and whatever the caller enqueued behind it), collect counters,
+// rerun once in sized mode if the sync-free launch overflowed its learned buffer capacity.
+int gg::walk_finalize(gg_ctx *ctx, bool *retried) {
+    if (retried) *retried = false;
+    if (ctx->w_nslots == 0) {
+        GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return GG_OK;
+    }
+    const int64_t total = ctx->w_total;
     // cumulative device counters as of the previous launch (to restore them if this launch is rerun)
     unsigned long long c0[6] = {(unsigned long long)ctx->ctr.hops, (unsigned long long)ctx->ctr.nbr_reads, 0, 0, 0,
-                                (unsigned long long)ctx->ctr.rows_scored}, c[6];
-    int rc = launch_walk_sample(ctx, n_slots, total, for_d, seed, stream, stride);
-    if (rc != GG_OK) return rc;
+                                (unsigned long long)ctx->ctr.rows_scored};
+    unsigned long long *c = ctx->h_ctr;  // 200 words, one read-back
+    GG_HIP(ctx, hipMemcpyAsync(c, ctx->dev_ctr, sizeof(unsigned long long) * 200, hipMemcpyDeviceToHost, ctx->stream));
     GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    GG_HIP(ctx, hipMemcpy(c, ctx->dev_ctr, sizeof(c), hipMemcpyDeviceToHost));
     if (c[3] == 2ull) {
-        // the sync-free launch ran out of its learned buffer capacity at some level: nothing it wrote
-        // is final (the D-mode post-pass is gated by the same flag), rerun with per-level sizing
-        c0[3] = 0;
+        // nothing the overflowed launch wrote is final (the D-mode post-pass is gated by the same flag)
         GG_HIP(ctx, hipMemcpy(ctx->dev_ctr, c0, sizeof(c0), hipMemcpyHostToDevice));
         ctx->walk_force_sized = true;
-        rc = launch_walk_sample(ctx, n_slots, total, for_d, seed, stream, stride);
+        int rc = launch_walk_sample(ctx, ctx->w_nslots, total, ctx->w_args.for_d, ctx->w_args.seed, ctx->w_args.stream, ctx->w_stride);
         ctx->walk_force_sized = false;
         if (rc != GG_OK) return rc;
+        GG_HIP(ctx, hipMemcpyAsync(c, ctx->dev_ctr, sizeof(unsigned long long) * 200, hipMemcpyDeviceToHost, ctx->stream));
         GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        GG_HIP(ctx, hipMemcpy(c, ctx->dev_ctr, sizeof(c), hipMemcpyDeviceToHost));
+        if (retried) *retried = true;
     }
     ctx->ctr.hops = (int64_t)c[0];
     ctx->ctr.nbr_reads = (int64_t)c[1];
@@ -147,19 +159,23 @@ int gg::walk_resident(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks,
             GG_HIP(ctx, hipEventElapsedTime(&lms, ctx->lv_ev[2 * i], ctx->lv_ev[2 * i + 1]));
             ctx->ctr.score_kernel_ms += lms;
             ctx->ctr.score_launches += 1;
+            ctx->ctr.score_chunks += (int64_t)c[136 + i];
         }
-        unsigned long long chunks[64];
-        GG_HIP(ctx, hipMemcpy(chunks, ctx->dev_ctr + 136, sizeof(chunks), hipMemcpyDeviceToHost));
-        for (int i = 0; i < ctx->lv_ev_used; ++i) ctx->ctr.score_chunks += (int64_t)chunks[i];
     }
     if (c[3]) {
         unsigned long long z = 0;
         (void)hipMemcpy(ctx->dev_ctr + 3, &z, sizeof(z), hipMemcpyHostToDevice);
-        return fail(ctx, GG_ECAPACITY, "walk: a path needed more than stride=%d entries", stride);
+        return fail(ctx, GG_ECAPACITY, "walk: a path needed more than stride=%d entries", ctx->w_stride);
     }
     return GG_OK;
 }
 
+int gg::walk_resident(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, int32_t uniform_walks, int32_t n_slots,
+                      int32_t for_d, uint64_t seed, uint32_t stream, int32_t stride) {
+    int rc = walk_launch_async(ctx, slots, n_walks, uniform_walks, n_slots, for_d, seed, stream, stride);
+    if (rc != GG_OK) return rc;
+    return walk_finalize(ctx, nullptr);
+}
 
 extern "C" {
 

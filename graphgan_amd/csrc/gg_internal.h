@@ -90,6 +90,10 @@ struct gg_ctx {
     int32_t walk_levels = 64;  // hops handled by the streaming level kernels before the per-walk finisher (GG_WALK_LEVELS)
     int64_t w_total = 0;
     int32_t w_stride = 0, w_nslots = 0;
+    struct { int32_t for_d; uint64_t seed; uint32_t stream; } w_args{};
+    std::vector<int64_t> h_walk_ptr;
+    unsigned long long h_ctr[256] = {};
+    int64_t h_total = 0;  // row / pair count read back at the end of a prepare call
 
     // prepared data
     gg::DevBuf d_center, d_neighbor, d_label, d_cnt, d_ptr;
@@ -132,6 +136,9 @@ int fail(gg_ctx *ctx, int code, const char *fmt, ...);
 int device_exclusive_scan(gg_ctx *ctx, const int32_t *cnt, int64_t *ptr, int64_t n);
 
 // launchers
+int walk_launch_async(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, int32_t uniform_walks, int32_t n_slots,
+                      int32_t for_d, uint64_t seed, uint32_t stream, int32_t stride);
+int walk_finalize(gg_ctx *ctx, bool *retried);
 int walk_resident(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, int32_t uniform_walks, int32_t n_slots,
                   int32_t for_d, uint64_t seed, uint32_t stream, int32_t stride);
 int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int for_d, uint64_t seed, uint32_t stream,

@@ -96,9 +96,12 @@ int device_exclusive_scan(gg_ctx *ctx, const int32_t *cnt, int64_t *ptr, int64_t
 
 // ------------------------------------------------------------------ K6 window pairs
 // pairs of path[:-1] with |i-j| <= window, i != j, in the reference's (i, then j) order.
-__global__ void pair_count_kernel(const int32_t *path_len, int64_t n_walks, int window, int32_t *cnt) {
+// `flag` = the walk launch's status word: 2 means the launch is being rerun (its outputs are not
+// final, path_len may be garbage) -> produce nothing.
+__global__ void pair_count_kernel(const int32_t *path_len, int64_t n_walks, int window, int32_t *cnt, const unsigned long long *flag) {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n_walks) return;
+    if (*flag == 2ull) { cnt[w] = 0; return; }
     const int L = path_len[w] - 1;  // the last element (back-step) is dropped (graph_gan.py:282)
     int c = 0;
     for (int i = 0; i < L; ++i) {
@@ -109,9 +112,9 @@ __global__ void pair_count_kernel(const int32_t *path_len, int64_t n_walks, int 
 }
 
 __global__ void pair_fill_kernel(const int32_t *paths, const int32_t *path_len, int stride, int64_t n_walks, int window,
-                                 const int64_t *ptr, int32_t *node1, int32_t *node2) {
+                                 const int64_t *ptr, int32_t *node1, int32_t *node2, const unsigned long long *flag) {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= n_walks) return;
+    if (w >= n_walks || *flag == 2ull) return;
     const int L = path_len[w] - 1;
     const int32_t *p = paths + w * (int64_t)stride;
     int64_t o = ptr[w];
@@ -132,7 +135,8 @@ __global__ void pair_fill_kernel(const int32_t *paths, const int32_t *path_len, 
 // both rows streamed as float4 chunks, xor-butterfly reduce.  HBM-bound gather:
 // algorithmic bytes per pair = 8d + 4 + 8 + 4.
 __global__ __launch_bounds__(256) void pair_reward_kernel(const float *E, const float *bias, int ld, const int32_t *u,
-                                                          const int32_t *v, int64_t n, float *out) {
+                                                          const int32_t *v, int64_t n_host, const int64_t *n_dev, float *out) {
+    const int64_t n = n_dev ? *n_dev : n_host;  // device-side count: no host round trip between pair expansion and rewards
     const int t = threadIdx.x & 15;
     const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int64_t ng = ((int64_t)gridDim.x * blockDim.x) >> 4;
@@ -166,16 +170,18 @@ int launch_pair_reward(gg_ctx *ctx, const int32_t *d_u, const int32_t *d_v, int6
     const Model &D = ctx->model[1];
     int64_t blocks = (n * 16 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(pair_reward_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, D.E, D.b, ctx->ld, d_u, d_v, n, d_out);
+    hipLaunchKernelGGL(pair_reward_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, D.E, D.b, ctx->ld, d_u, d_v, n,
+                       (const int64_t *)nullptr, d_out);
     GG_HIP(ctx, hipGetLastError());
     ctx->ctr.reward_pairs += n;
     return GG_OK;
 }
 
 // ------------------------------------------------------------------ D rows
-__global__ void d_count_kernel(const int32_t *status, const int64_t *walk_ptr, int n_slots, int32_t *cnt) {
+__global__ void d_count_kernel(const int32_t *status, const int64_t *walk_ptr, int n_slots, int32_t *cnt, const unsigned long long *flag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_slots) return;
+    if (*flag == 2ull) { cnt[i] = 0; return; }
     const int64_t deg = walk_ptr[i + 1] - walk_ptr[i];
     cnt[i] = (status[i] == GG_ROOT_OK && deg > 0) ? (int32_t)(2 * deg) : 0;
 }
@@ -184,10 +190,10 @@ __global__ void d_count_kernel(const int32_t *status, const int64_t *walk_ptr, i
 __global__ __launch_bounds__(256) void d_fill_kernel(const int32_t *slots, const int32_t *t_root, const int64_t *g_rowptr,
                                                      const int32_t *g_col, const int32_t *samples, const int64_t *walk_ptr,
                                                      const int64_t *row_ptr, int n_slots, int32_t *center, int32_t *neighbor,
-                                                     float *label) {
+                                                     float *label, const unsigned long long *flag) {
     const int lane = threadIdx.x & 63;
     const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (i >= n_slots) return;
+    if (i >= n_slots || *flag == 2ull) return;
     const int64_t o = row_ptr[i], rows = row_ptr[i + 1] - o;
     if (rows == 0) return;
     const int64_t deg = rows / 2;
@@ -207,13 +213,22 @@ __global__ __launch_bounds__(256) void d_fill_kernel(const int32_t *slots, const
 
 using namespace gg;
 
-static int read_i64(gg_ctx *ctx, const int64_t *dptr, int64_t *out) {
-    GG_HIP(ctx, hipMemcpyAsync(out, dptr, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-    GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+extern "C" {
+
+// rows of gg_prepare_d behind the walk on the same stream; capacity = 2 * (walks launched) >= rows
+static int enqueue_d_rows(gg_ctx *ctx, int32_t n_slots) {
+    hipLaunchKernelGGL(d_count_kernel, dim3(cdiv(n_slots, 256)), dim3(256), 0, ctx->stream, ctx->w_status.as<int32_t>(),
+                       ctx->w_ptr.as<int64_t>(), n_slots, ctx->d_cnt.as<int32_t>(), ctx->dev_ctr + 3);
+    int rc = device_exclusive_scan(ctx, ctx->d_cnt.as<int32_t>(), ctx->d_ptr.as<int64_t>(), n_slots);
+    if (rc != GG_OK) return rc;
+    hipLaunchKernelGGL(d_fill_kernel, dim3(cdiv((int64_t)n_slots * 64, 256)), dim3(256), 0, ctx->stream,
+                       ctx->w_slots.as<int32_t>(), ctx->t_root, ctx->g_rowptr, ctx->g_col, ctx->w_samples.as<int32_t>(),
+                       ctx->w_ptr.as<int64_t>(), ctx->d_ptr.as<int64_t>(), n_slots, ctx->d_center.as<int32_t>(),
+                       ctx->d_neighbor.as<int32_t>(), ctx->d_label.as<float>(), ctx->dev_ctr + 3);
+    GG_HIP(ctx, hipMemcpyAsync(&ctx->h_total, ctx->d_ptr.as<int64_t>() + n_slots, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    GG_HIP(ctx, hipGetLastError());
     return GG_OK;
 }
-
-extern "C" {
 
 int gg_prepare_d(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, uint64_t seed, uint32_t stream, int64_t *n_rows_out,
                  int32_t *root_status) {
@@ -221,31 +236,29 @@ int gg_prepare_d(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, uint64_t se
     GG_CHECK(ctx, ctx->g_rowptr, GG_EINVAL, "gg_prepare_d: call gg_set_graph_csr first");
     // a D path never exceeds tree depth + 2 entries
     const int stride = ctx->tree_max_depth + 3;
-    int rc = walk_resident(ctx, slots, nullptr, -1, n_slots, 1, seed, stream, stride);
-    if (rc != GG_OK) return rc;
     ctx->d_rows = 0;
+    int rc = walk_launch_async(ctx, slots, nullptr, -1, n_slots, 1, seed, stream, stride);
+    if (rc != GG_OK) return rc;
     if (n_slots > 0) {
+        const int64_t cap = 2 * ctx->w_total;  // every root contributes at most 2 * deg rows
         GG_HIP(ctx, ctx->d_cnt.reserve(sizeof(int32_t) * n_slots));
         GG_HIP(ctx, ctx->d_ptr.reserve(sizeof(int64_t) * (n_slots + 1)));
-        hipLaunchKernelGGL(d_count_kernel, dim3(cdiv(n_slots, 256)), dim3(256), 0, ctx->stream, ctx->w_status.as<int32_t>(),
-                           ctx->w_ptr.as<int64_t>(), n_slots, ctx->d_cnt.as<int32_t>());
-        rc = device_exclusive_scan(ctx, ctx->d_cnt.as<int32_t>(), ctx->d_ptr.as<int64_t>(), n_slots);
+        GG_HIP(ctx, ctx->d_center.reserve(sizeof(int32_t) * (cap + 1)));
+        GG_HIP(ctx, ctx->d_neighbor.reserve(sizeof(int32_t) * (cap + 1)));
+        GG_HIP(ctx, ctx->d_label.reserve(sizeof(float) * (cap + 1)));
+        rc = enqueue_d_rows(ctx, n_slots);
         if (rc != GG_OK) return rc;
-        int64_t rows = 0;
-        rc = read_i64(ctx, ctx->d_ptr.as<int64_t>() + n_slots, &rows);
-        if (rc != GG_OK) return rc;
-        GG_HIP(ctx, ctx->d_center.reserve(sizeof(int32_t) * (rows + 1)));
-        GG_HIP(ctx, ctx->d_neighbor.reserve(sizeof(int32_t) * (rows + 1)));
-        GG_HIP(ctx, ctx->d_label.reserve(sizeof(float) * (rows + 1)));
-        if (rows) {
-            hipLaunchKernelGGL(d_fill_kernel, dim3(cdiv((int64_t)n_slots * 64, 256)), dim3(256), 0, ctx->stream,
-                               ctx->w_slots.as<int32_t>(), ctx->t_root, ctx->g_rowptr, ctx->g_col, ctx->w_samples.as<int32_t>(),
-                               ctx->w_ptr.as<int64_t>(), ctx->d_ptr.as<int64_t>(), n_slots, ctx->d_center.as<int32_t>(),
-                               ctx->d_neighbor.as<int32_t>(), ctx->d_label.as<float>());
-            GG_HIP(ctx, hipGetLastError());
+    }
+    bool retried = false;
+    rc = walk_finalize(ctx, &retried);  // the only host synchronisation of the call
+    if (rc != GG_OK) return rc;
+    if (n_slots > 0) {
+        if (retried) {
+            rc = enqueue_d_rows(ctx, n_slots);
+            if (rc != GG_OK) return rc;
+            GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
-        GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->d_rows = rows;
+        ctx->d_rows = ctx->h_total;
         if (root_status) GG_HIP(ctx, hipMemcpy(root_status, ctx->w_status.p, sizeof(int32_t) * n_slots, hipMemcpyDeviceToHost));
     }
     if (n_rows_out) *n_rows_out = ctx->d_rows;
@@ -264,39 +277,57 @@ int gg_get_d_data(gg_ctx *ctx, int32_t *center, int32_t *neighbor, float *label)
     return GG_OK;
 }
 
+// pairs + rewards of gg_prepare_g behind the walk on the same stream; capacity = bound on pairs
+static int enqueue_g_pairs(gg_ctx *ctx, int64_t nw, int64_t cap) {
+    const int window = ctx->cfg.window_size;
+    hipLaunchKernelGGL(pair_count_kernel, dim3(cdiv(nw, 256)), dim3(256), 0, ctx->stream, ctx->w_len.as<int32_t>(), nw, window,
+                       ctx->g_cnt.as<int32_t>(), ctx->dev_ctr + 3);
+    int rc = device_exclusive_scan(ctx, ctx->g_cnt.as<int32_t>(), ctx->g_ptr.as<int64_t>(), nw);
+    if (rc != GG_OK) return rc;
+    hipLaunchKernelGGL(pair_fill_kernel, dim3(cdiv(nw, 256)), dim3(256), 0, ctx->stream, ctx->w_paths.as<int32_t>(),
+                       ctx->w_len.as<int32_t>(), ctx->w_stride, nw, window, ctx->g_ptr.as<int64_t>(),
+                       ctx->g_node1.as<int32_t>(), ctx->g_node2.as<int32_t>(), ctx->dev_ctr + 3);
+    // rewards for the device-side pair count (the host does not know it yet)
+    const Model &D = ctx->model[1];
+    hipLaunchKernelGGL(pair_reward_kernel, dim3(256 * 16), dim3(256), 0, ctx->stream, D.E, D.b, ctx->ld, ctx->g_node1.as<int32_t>(),
+                       ctx->g_node2.as<int32_t>(), (int64_t)-1, ctx->g_ptr.as<int64_t>() + nw, ctx->g_reward.as<float>());
+    GG_HIP(ctx, hipMemcpyAsync(&ctx->h_total, ctx->g_ptr.as<int64_t>() + nw, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    GG_HIP(ctx, hipGetLastError());
+    (void)cap;
+    return GG_OK;
+}
+
 int gg_prepare_g(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, int32_t n_sample, uint64_t seed, uint32_t stream,
                  int64_t *n_pairs_out, int32_t *root_status) {
     if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
     GG_CHECK(ctx, n_sample >= 0, GG_EINVAL, "gg_prepare_g: n_sample < 0");
     const int stride = ctx->tree_max_depth + 3;
-    int rc = walk_resident(ctx, slots, nullptr, n_sample, n_slots, 0, seed, stream, stride);
-    if (rc != GG_OK) return rc;
     ctx->g_pairs = 0;
+    int rc = walk_launch_async(ctx, slots, nullptr, n_sample, n_slots, 0, seed, stream, stride);
+    if (rc != GG_OK) return rc;
     const int64_t nw = ctx->w_total;
+    // a path of L = len - 1 <= stride - 1 nodes gives at most 2 * window * L pairs
+    const int64_t cap = nw * 2 * ctx->cfg.window_size * (stride - 1);
     if (nw > 0) {
-        const int window = ctx->cfg.window_size;
         GG_HIP(ctx, ctx->g_cnt.reserve(sizeof(int32_t) * nw));
         GG_HIP(ctx, ctx->g_ptr.reserve(sizeof(int64_t) * (nw + 1)));
-        hipLaunchKernelGGL(pair_count_kernel, dim3(cdiv(nw, 256)), dim3(256), 0, ctx->stream, ctx->w_len.as<int32_t>(), nw, window,
-                           ctx->g_cnt.as<int32_t>());
-        rc = device_exclusive_scan(ctx, ctx->g_cnt.as<int32_t>(), ctx->g_ptr.as<int64_t>(), nw);
+        GG_HIP(ctx, ctx->g_node1.reserve(sizeof(int32_t) * (cap + 1)));
+        GG_HIP(ctx, ctx->g_node2.reserve(sizeof(int32_t) * (cap + 1)));
+        GG_HIP(ctx, ctx->g_reward.reserve(sizeof(float) * (cap + 1)));
+        rc = enqueue_g_pairs(ctx, nw, cap);
         if (rc != GG_OK) return rc;
-        int64_t P = 0;
-        rc = read_i64(ctx, ctx->g_ptr.as<int64_t>() + nw, &P);
-        if (rc != GG_OK) return rc;
-        GG_HIP(ctx, ctx->g_node1.reserve(sizeof(int32_t) * (P + 1)));
-        GG_HIP(ctx, ctx->g_node2.reserve(sizeof(int32_t) * (P + 1)));
-        GG_HIP(ctx, ctx->g_reward.reserve(sizeof(float) * (P + 1)));
-        if (P) {
-            hipLaunchKernelGGL(pair_fill_kernel, dim3(cdiv(nw, 256)), dim3(256), 0, ctx->stream, ctx->w_paths.as<int32_t>(),
-                               ctx->w_len.as<int32_t>(), ctx->w_stride, nw, window, ctx->g_ptr.as<int64_t>(),
-                               ctx->g_node1.as<int32_t>(), ctx->g_node2.as<int32_t>());
-            GG_HIP(ctx, hipGetLastError());
-            rc = launch_pair_reward(ctx, ctx->g_node1.as<int32_t>(), ctx->g_node2.as<int32_t>(), P, ctx->g_reward.as<float>());
+    }
+    bool retried = false;
+    rc = walk_finalize(ctx, &retried);  // the only host synchronisation of the call
+    if (rc != GG_OK) return rc;
+    if (nw > 0) {
+        if (retried) {
+            rc = enqueue_g_pairs(ctx, nw, cap);
             if (rc != GG_OK) return rc;
+            GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
-        GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->g_pairs = P;
+        ctx->g_pairs = ctx->h_total;
+        ctx->ctr.reward_pairs += ctx->g_pairs;
     }
     if (root_status && n_slots) GG_HIP(ctx, hipMemcpy(root_status, ctx->w_status.p, sizeof(int32_t) * n_slots, hipMemcpyDeviceToHost));
     if (n_pairs_out) *n_pairs_out = ctx->g_pairs;
