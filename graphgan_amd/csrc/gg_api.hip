@@ -114,6 +114,7 @@ int gg::walk_launch_async(gg_ctx *ctx, const int32_t *slots, const int32_t *n_wa
     ctx->w_stride = stride;
     ctx->w_nslots = n_slots;
     ctx->w_args = {for_d, seed, stream};
+    ctx->g_paths_valid = false;
     if (n_slots == 0) return GG_OK;
     return launch_walk_sample(ctx, n_slots, total, for_d, seed, stream, stride);
 }

@@ -328,6 +328,7 @@ int gg_prepare_g(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, int32_t n_s
         }
         ctx->g_pairs = ctx->h_total;
         ctx->ctr.reward_pairs += ctx->g_pairs;
+        ctx->g_paths_valid = true;
     }
     if (root_status && n_slots) GG_HIP(ctx, hipMemcpy(root_status, ctx->w_status.p, sizeof(int32_t) * n_slots, hipMemcpyDeviceToHost));
     if (n_pairs_out) *n_pairs_out = ctx->g_pairs;

@@ -15,6 +15,8 @@
 // all N*(ld+1) elements (TF1 parity; 24 B/element, L2-resident on CA-GrQc); GG_OPT_ADAM_LAZY
 // and GG_OPT_SGD sweep only the rows a step touched (scale mode: 48d+24 / 16d+20 B per pair).
 // With gg_comm_init the gradient accumulators are all-reduced between (A) and (B).
+#include <stdlib.h>
+
 #include "gg_internal.h"
 
 namespace gg {
@@ -112,6 +114,108 @@ __global__ __launch_bounds__(256) void pair_grad_kernel(const StepArgs a) {
         const int f = t + 16 * i;
         if (f < a.ld) atomicAdd(gu + f, accu[i]);
     }
+}
+
+// G pass over whole walks (fast mode: one fused batch = every prepared pair, graph_gan.py:168-176 with
+// batch_size >= train_size).  The pairs of a walk are the window-2 pairs of its path
+// (graph_gan.py:272-291), i.e. every node row is needed by up to 8 pairs.  One 16-lane group per
+// walk slides a 5-row window over the path: each row is read ONCE, each node's gradient is
+// accumulated in registers and flushed ONCE (instead of 8 row reads + 8 rows of atomics).
+struct PathArgs {
+    float *E, *b, *gE, *gb;
+    int32_t *touched, *touched_list, *touched_cnt;
+    int ld, track, window;
+    const int32_t *paths, *path_len;
+    int stride;
+    const int64_t *pair_ptr;  // [n_walks + 1] first pair of each walk
+    const float *reward;
+    int64_t n_walks;
+    float lambda, inv_n;
+};
+
+template <int NF>
+__global__ __launch_bounds__(256) void path_grad_kernel(const PathArgs a) {
+    const int t = threadIdx.x & 15;
+    const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (w >= a.n_walks) return;
+    const int L = a.path_len[w] - 1;  // the back-step is dropped (graph_gan.py:282)
+    if (L <= 1) return;               // no pairs
+    const int32_t *p = a.paths + w * (int64_t)a.stride;
+    int64_t pi = a.pair_ptr[w];
+    // window slots 0..4 hold path positions c-2 .. c+2 of the current centre c
+    float R[5][NF], A[5][NF], bv[5], gb[5];
+    int node[5];
+#pragma unroll
+    for (int sl = 0; sl < 5; ++sl) {
+        node[sl] = -1; bv[sl] = 0.f; gb[sl] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NF; ++i) { R[sl][i] = 0.f; A[sl][i] = 0.f; }
+    }
+    auto load = [&](int sl, int pos) {
+        const int nd = (pos >= 0 && pos < L) ? p[pos] : -1;
+        node[sl] = nd;
+        gb[sl] = 0.f;
+        bv[sl] = nd >= 0 ? a.b[nd] : 0.f;
+        const float *row = a.E + (int64_t)(nd >= 0 ? nd : 0) * a.ld;
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int f = t + 16 * i;
+            R[sl][i] = (nd >= 0 && f < a.ld) ? row[f] : 0.f;
+            A[sl][i] = 0.f;
+        }
+    };
+    auto flush = [&](int sl) {
+        const int nd = node[sl];
+        if (nd < 0) return;
+        float *g = a.gE + (int64_t)nd * a.ld;
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int f = t + 16 * i;
+            if (f < a.ld) atomicAdd(g + f, A[sl][i]);
+        }
+        if (t == 0) {
+            if (gb[sl] != 0.f) atomicAdd(a.gb + nd, gb[sl]);
+            if (a.track && atomicExch(a.touched + nd, 1) == 0) a.touched_list[atomicAdd(a.touched_cnt, 1)] = nd;
+        }
+    };
+    load(2, 0);
+    load(3, 1);
+    load(4, 2);
+    for (int c = 0; c < L; ++c) {
+#pragma unroll
+        for (int sl = 0; sl < 5; ++sl) {
+            if (sl == 2 || node[sl] < 0) continue;
+            if (sl < 2 - a.window || sl > 2 + a.window) continue;
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < NF; ++i) acc = __builtin_fmaf(R[2][i], R[sl][i], acc);
+            acc += __shfl_xor(acc, 8, 64);
+            acc += __shfl_xor(acc, 4, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            acc += __shfl_xor(acc, 1, 64);
+            const float s = acc + bv[sl];
+            const float sg = 1.0f / (1.0f + expf(-s));
+            const bool inside = (sg >= 1e-5f) && (sg <= 1.0f);
+            const float ds = inside ? -(a.reward[pi] * a.inv_n) * (1.0f - sg) : 0.0f;
+            ++pi;
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                A[2][i] += ds * R[sl][i] + a.lambda * R[2][i];
+                A[sl][i] += ds * R[2][i] + a.lambda * R[sl][i];
+            }
+            gb[sl] += ds;
+        }
+        flush(0);  // node c-2 has received its last contribution
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            node[sl] = node[sl + 1]; bv[sl] = bv[sl + 1]; gb[sl] = gb[sl + 1];
+#pragma unroll
+            for (int i = 0; i < NF; ++i) { R[sl][i] = R[sl + 1][i]; A[sl][i] = A[sl + 1][i]; }
+        }
+        load(4, c + 3);
+    }
+    flush(0);
+    flush(1);
 }
 
 struct OptArgs {
@@ -231,6 +335,9 @@ __global__ __launch_bounds__(256) void rebuild_touched_kernel(const OptArgs a) {
     }
 }
 
+int apply_optimizer(gg_ctx *ctx, int which, int64_t n);
+int run_path_step(gg_ctx *ctx);
+
 // One optimizer step of model `which` on n device-resident rows.
 int run_step(gg_ctx *ctx, int which, const int32_t *d_u, const int32_t *d_v, const float *d_x, int32_t n) {
     if (n <= 0) return GG_OK;
@@ -253,6 +360,39 @@ int run_step(gg_ctx *ctx, int which, const int32_t *d_u, const int32_t *d_v, con
     else if (nf <= 16) hipLaunchKernelGGL(pair_grad_kernel<16>, dim3(blocks), dim3(256), 0, ctx->stream, s);
     else hipLaunchKernelGGL(pair_grad_kernel<32>, dim3(blocks), dim3(256), 0, ctx->stream, s);
 
+    return apply_optimizer(ctx, which, n);
+}
+
+// G step over whole walks of the resident prepare_g data (see path_grad_kernel).
+int run_path_step(gg_ctx *ctx) {
+    Model &M = ctx->model[0];
+    const int64_t n = ctx->g_pairs;
+    PathArgs p{};
+    p.E = M.E; p.b = M.b; p.gE = ctx->gradE; p.gb = ctx->gradb;
+    p.touched = ctx->touched; p.touched_list = ctx->touched_list; p.touched_cnt = ctx->touched_cnt;
+    p.ld = ctx->ld;
+    p.track = (ctx->cfg.optimizer != GG_OPT_ADAM_DENSE) && !ctx->comm;
+    p.window = ctx->cfg.window_size;
+    p.paths = ctx->w_paths.as<int32_t>();
+    p.path_len = ctx->w_len.as<int32_t>();
+    p.stride = ctx->w_stride;
+    p.pair_ptr = ctx->g_ptr.as<int64_t>();
+    p.reward = ctx->g_reward.as<float>();
+    p.n_walks = ctx->w_total;
+    p.lambda = M.lambda;
+    p.inv_n = 1.0f / (float)n;
+    const int blocks = cdiv(p.n_walks * 16, 256);
+    const int nf = (ctx->ld + 15) / 16;
+    if (nf <= 4) hipLaunchKernelGGL(path_grad_kernel<4>, dim3(blocks), dim3(256), 0, ctx->stream, p);
+    else if (nf <= 8) hipLaunchKernelGGL(path_grad_kernel<8>, dim3(blocks), dim3(256), 0, ctx->stream, p);
+    else hipLaunchKernelGGL(path_grad_kernel<16>, dim3(blocks), dim3(256), 0, ctx->stream, p);
+    return apply_optimizer(ctx, 0, n);
+}
+
+// all-reduce (multi-GPU) + optimizer kernel + step bookkeeping, after a gradient kernel
+int apply_optimizer(gg_ctx *ctx, int which, int64_t n) {
+    Model &M = ctx->model[which];
+    const int opt = ctx->cfg.optimizer;
     int rc = comm_allreduce_grads(ctx);
     if (rc != GG_OK) return rc;
 
@@ -323,12 +463,18 @@ static int run_pass(gg_ctx *ctx, int which, const int64_t *starts, int64_t n_bat
     const float *x = which == 1 ? ctx->d_label.as<float>() : ctx->g_reward.as<float>();
     GG_HIP(ctx, hipSetDevice(ctx->device));
     GG_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    for (int64_t k = 0; k < n_batches; ++k) {
-        const int64_t s = starts[k];
-        GG_CHECK(ctx, s >= 0 && s < rows, GG_EINVAL, "pass: start %lld outside the %lld prepared rows", (long long)s, (long long)rows);
-        const int32_t n = (int32_t)std::min<int64_t>(batch_size, rows - s);
-        int rc = run_step(ctx, which, u + s, v + s, x + s, n);
+    const bool whole = n_batches == 1 && starts[0] == 0 && batch_size >= rows && rows > 0;
+    if (which == 0 && whole && ctx->g_paths_valid && ctx->cfg.window_size <= 2 && ctx->ld <= 256 && !getenv("GG_NO_PATH_GRAD")) {
+        int rc = run_path_step(ctx);
         if (rc != GG_OK) return rc;
+    } else {
+        for (int64_t k = 0; k < n_batches; ++k) {
+            const int64_t s = starts[k];
+            GG_CHECK(ctx, s >= 0 && s < rows, GG_EINVAL, "pass: start %lld outside the %lld prepared rows", (long long)s, (long long)rows);
+            const int32_t n = (int32_t)std::min<int64_t>(batch_size, rows - s);
+            int rc = run_step(ctx, which, u + s, v + s, x + s, n);
+            if (rc != GG_OK) return rc;
+        }
     }
     GG_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     GG_HIP(ctx, hipStreamSynchronize(ctx->stream));

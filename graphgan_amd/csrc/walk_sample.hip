@@ -200,6 +200,7 @@ constexpr int MAX_LEVELS = 64;
 __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, const int do_sample, const int do_setup, const int write_desc,
                                                             const int64_t cap_chunks) {
     if (a.ctr[3] == 2ull) return;  // a previous level overflowed its speculative buffers: the host reruns in sized mode
+    if (a.level > 0 && a.ctr[CTR_ALIVE + a.level - 1] == 0ull) return;  // every walk has finished: empty level
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool in_range = w < a.total_walks;
@@ -444,7 +445,7 @@ __device__ __forceinline__ uint64_t group16_incl_scan_u64(uint64_t v, int t) {
 // Small owner tasks (k <= BIG_TASK): one 16-lane group per walk -- max, exact fixed-point weights
 // (spec S2, S3) and their inclusive prefix sums, computed once per (root, node).
 __global__ __launch_bounds__(256) void level_weights_small_kernel(const WalkArgs a, const int64_t cap_chunks) {
-    if ((int64_t)a.ctr[CTR_CHUNKS + a.level] > cap_chunks) return;
+    if ((int64_t)a.ctr[CTR_CHUNKS + a.level] > cap_chunks || a.ctr[CTR_CHUNKS + a.level] == 0ull) return;
     const int t = threadIdx.x & 15;
     const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     if (w >= a.total_walks || a.lv_chunks[w] == 0) return;

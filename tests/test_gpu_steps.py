@@ -261,3 +261,30 @@ def test_rccl_plumbing_with_one_rank_communicator(ga, mode, monkeypatch):
         assert np.allclose(a.get_bias(which), b.get_bias(which), rtol=1e-5, atol=1e-6)
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("opt", ["lazy", "dense"])
+def test_whole_walk_g_pass_equals_generic_pair_kernel(ga, opt, monkeypatch):
+    """A fused G pass over all prepared pairs takes the path-structured kernel (one row read and
+    one gradient flush per path node); it must equal the generic per-pair kernel and the oracle's
+    g_step on the same pair list."""
+    optimizer = ga.GG_OPT_ADAM_LAZY if opt == "lazy" else ga.GG_OPT_ADAM_DENSE
+    g, n, graph, rowptr, col, Ed, eng = _setup_graph_engine(ga, optimizer=optimizer)
+    _, _, _, _, _, _, eng2 = _setup_graph_engine(ga, optimizer=optimizer)
+    slots = np.arange(n, dtype=np.int32)
+    n1, n2, rew, _ = eng.prepare_g(slots, 20, 4, 1)
+    eng2.prepare_g(slots, 20, 4, 1, fetch=False)
+    eng.g_pass([0], len(n1))                      # path-structured kernel
+    monkeypatch.setenv("GG_NO_PATH_GRAD", "1")
+    eng2.g_pass([0], len(n1))                     # generic pair kernel
+    monkeypatch.delenv("GG_NO_PATH_GRAD")
+    gen = orc.Generator(g["E"], 1e-3, lazy=(opt == "lazy"))
+    gen.b[:] = g["b"]
+    gen.g_step(n1.astype(np.int64), n2.astype(np.int64), rew, 1e-5)
+    for e in (eng, eng2):
+        assert np.allclose(e.get_embeddings(0), gen.E, rtol=2e-5, atol=2e-6)
+        assert np.allclose(e.get_bias(0), gen.b, rtol=2e-5, atol=2e-6)
+    c = eng.counters()
+    assert c["g_pairs"] == len(n1) and c["g_steps"] == 1
+    eng.close()
+    eng2.close()
