@@ -101,6 +101,7 @@ struct gg_ctx {
     gg::DevBuf g_node1, g_node2, g_reward, g_cnt, g_ptr;
     int64_t g_pairs = 0;
     bool g_paths_valid = false;  // w_paths / g_ptr still describe the resident prepare_g data
+    gg::DevBuf touched_ptr;
     gg::DevBuf scan_tmp, step_u, step_v, step_x, starts_buf, misc;
 
     // device-side counters: [0]=hops [1]=nbr_reads [2]=alive walks [3]=error flag [4]=ticket [5]=rows scored

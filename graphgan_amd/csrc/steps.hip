@@ -102,9 +102,9 @@ __global__ __launch_bounds__(256) void pair_grad_kernel(const StepArgs a) {
         }
         if (t == 0) {
             atomicAdd(a.gb + iv, a.is_d ? ds + a.lambda * bv : ds);
-            if (a.track) {
-                if (atomicExch(a.touched + iu, 1) == 0) a.touched_list[atomicAdd(a.touched_cnt, 1)] = iu;
-                if (atomicExch(a.touched + iv, 1) == 0) a.touched_list[atomicAdd(a.touched_cnt, 1)] = iv;
+            if (a.track) {  // plain flag stores; the row list is built by a scan (no contended atomics)
+                a.touched[iu] = 1;
+                a.touched[iv] = 1;
             }
         }
     }
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void path_grad_kernel(const PathArgs a) {
         }
         if (t == 0) {
             if (gb[sl] != 0.f) atomicAdd(a.gb + nd, gb[sl]);
-            if (a.track && atomicExch(a.touched + nd, 1) == 0) a.touched_list[atomicAdd(a.touched_cnt, 1)] = nd;
+            if (a.track) a.touched[nd] = 1;
         }
     };
     load(2, 0);
@@ -220,6 +220,8 @@ __global__ __launch_bounds__(256) void path_grad_kernel(const PathArgs a) {
 
 struct OptArgs {
     float *E, *b, *mE, *vE, *mb, *vb, *gE, *gb;
+    const int64_t *touched_ptr;    // exclusive scan of the touched flags, [n_node + 1]
+    const int64_t *touched_total;  // = touched_ptr + n_node
     int64_t nE;   // n_node * ld
     int n_node, ld;
     float lr_t, b1, b2, eps, lr;
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(256) void sparse_opt_kernel(const OptArgs a) {
     const int t = threadIdx.x & 15;
     const int g0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int ng = (gridDim.x * blockDim.x) >> 4;
-    const int cnt = *a.touched_cnt;
+    const int cnt = (int)*a.touched_total;
     const int nchunk = a.ld >> 2;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int r = g0; r < cnt; r += ng) {
@@ -309,30 +311,15 @@ __global__ __launch_bounds__(256) void sparse_opt_kernel(const OptArgs a) {
     }
 }
 
-__global__ void reset_touched_cnt_kernel(int32_t *cnt) { *cnt = 0; }
+__global__ void normalize_flags_kernel(int32_t *f, int n) {  // after the cross-rank sum: counts -> 0/1
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && f[i] > 1) f[i] = 1;
+}
 
-// After an all-reduce the local touched list is incomplete: rebuild it from the summed gradient.
-__global__ __launch_bounds__(256) void rebuild_touched_kernel(const OptArgs a) {
-    const int t = threadIdx.x & 15;
-    const int g0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const int ng = (gridDim.x * blockDim.x) >> 4;
-    const int nchunk = a.ld >> 2;
-    for (int row = g0; row < a.n_node; row += ng) {
-        bool nz = false;
-        const float4 *g = (const float4 *)(a.gE + (int64_t)row * a.ld);
-        for (int c = t; c < nchunk; c += 16) {
-            const float4 x = g[c];
-            nz |= (x.x != 0.f) | (x.y != 0.f) | (x.z != 0.f) | (x.w != 0.f);
-        }
-        nz |= (a.gb[row] != 0.f);
-        unsigned long long bal = __ballot(nz);
-        const int grp = (threadIdx.x & 63) >> 4;
-        const bool any = ((bal >> (grp * 16)) & 0xffffull) != 0;
-        if (t == 0 && any && a.touched[row] == 0) {
-            a.touched[row] = 1;
-            a.touched_list[atomicAdd(a.touched_cnt, 1)] = row;
-        }
-    }
+// touched flags -> row list in row order (deterministic), via the exclusive scan of the flags
+__global__ void compact_touched_kernel(const OptArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.n_node && a.touched[i] > 0) a.touched_list[a.touched_ptr[i]] = i;
 }
 
 int apply_optimizer(gg_ctx *ctx, int which, int64_t n);
@@ -347,7 +334,7 @@ int run_step(gg_ctx *ctx, int which, const int32_t *d_u, const int32_t *d_v, con
     s.E = M.E; s.b = M.b; s.gE = ctx->gradE; s.gb = ctx->gradb;
     s.touched = ctx->touched; s.touched_list = ctx->touched_list; s.touched_cnt = ctx->touched_cnt;
     s.ld = ctx->ld;
-    s.track = (opt != GG_OPT_ADAM_DENSE) && !ctx->comm;
+    s.track = opt != GG_OPT_ADAM_DENSE;
     s.u = d_u; s.v = d_v; s.x = d_x; s.n = n;
     s.lambda = M.lambda;
     s.inv_n = 1.0f / (float)n;
@@ -371,7 +358,7 @@ int run_path_step(gg_ctx *ctx) {
     p.E = M.E; p.b = M.b; p.gE = ctx->gradE; p.gb = ctx->gradb;
     p.touched = ctx->touched; p.touched_list = ctx->touched_list; p.touched_cnt = ctx->touched_cnt;
     p.ld = ctx->ld;
-    p.track = (ctx->cfg.optimizer != GG_OPT_ADAM_DENSE) && !ctx->comm;
+    p.track = ctx->cfg.optimizer != GG_OPT_ADAM_DENSE;
     p.window = ctx->cfg.window_size;
     p.paths = ctx->w_paths.as<int32_t>();
     p.path_len = ctx->w_len.as<int32_t>();
@@ -411,16 +398,19 @@ int apply_optimizer(gg_ctx *ctx, int which, int64_t n) {
         if (nb < 1) nb = 1;
         hipLaunchKernelGGL(adam_dense_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, o);
     } else {
-        if (ctx->comm) {
-            int64_t nb = ((int64_t)ctx->n_node * 16 + 255) / 256;
-            if (nb > 4096) nb = 4096;
-            hipLaunchKernelGGL(rebuild_touched_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, o);
-        }
+        // rows to update = rows flagged by the gradient kernel (all ranks' flags were summed with the gradients)
+        GG_HIP(ctx, ctx->touched_ptr.reserve(sizeof(int64_t) * ((size_t)ctx->n_node + 1)));
+        o.touched_ptr = ctx->touched_ptr.as<int64_t>();
+        o.touched_total = o.touched_ptr + ctx->n_node;
+        if (ctx->comm) hipLaunchKernelGGL(normalize_flags_kernel, dim3(cdiv(ctx->n_node, 256)), dim3(256), 0, ctx->stream, ctx->touched, ctx->n_node);
+        rc = device_exclusive_scan(ctx, ctx->touched, ctx->touched_ptr.as<int64_t>(), ctx->n_node);
+        if (rc != GG_OK) return rc;
+        hipLaunchKernelGGL(compact_touched_kernel, dim3(cdiv(ctx->n_node, 256)), dim3(256), 0, ctx->stream, o);
         int nb = cdiv((int64_t)std::min<int64_t>(2ll * n * ctx->world, ctx->n_node) * 16, 256);
         if (nb > 4096) nb = 4096;
+        if (nb < 1) nb = 1;
         if (opt == GG_OPT_SGD) hipLaunchKernelGGL(sparse_opt_kernel<1>, dim3(nb), dim3(256), 0, ctx->stream, o);
         else hipLaunchKernelGGL(sparse_opt_kernel<0>, dim3(nb), dim3(256), 0, ctx->stream, o);
-        hipLaunchKernelGGL(reset_touched_cnt_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->touched_cnt);
     }
     GG_HIP(ctx, hipGetLastError());
     M.t += 1;
