@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Run the graph_gan.py mirror on the HIP engine for a few outer epochs of the reference schedule
+on the CA-GrQc fixture (same seed / init as tools/run_oracle_epochs.py) and record the gen/dis
+accuracy after each epoch and the wall time per epoch.
+    python tools/run_engine_epochs.py <n_epochs> <out.json>"""
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tests.helpers import ca_grqc_init_embeddings, load_ca_grqc  # noqa: E402
+from tests.test_gpu_e2e import make_cfg, write_reference_layout  # noqa: E402
+
+
+def main():
+    n_epochs, out = int(sys.argv[1]), sys.argv[2]
+    base = tempfile.mkdtemp()
+    d, n, graph = write_reference_layout(base)
+    cfg = make_cfg(base, n_epochs=n_epochs, engine_seed=0)
+    from graphgan_amd.graph_gan import GraphGAN
+    np.random.seed(0)
+    t0 = time.time()
+    g = GraphGAN(cfg)
+    init = ca_grqc_init_embeddings(d, n, seed=0).astype(np.float32)
+    g.engine.set_embeddings(0, init)
+    g.engine.set_embeddings(1, init)
+    t_init = time.time() - t0
+    t0 = time.time()
+    g.train()
+    t_train = time.time() - t0
+    lines = open(cfg.result_filename).read().split()
+    acc = [[float(lines[2 * i][4:]), float(lines[2 * i + 1][4:])] for i in range(len(lines) // 2)]
+    c = g.engine.counters()
+    res = {"epochs": acc, "init_seconds": t_init, "train_seconds": t_train, "seconds_per_epoch": t_train / max(n_epochs, 1),
+           "d_steps": c["d_steps"], "g_steps": c["g_steps"], "hops": c["hops"]}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Run the CPU oracle trainer (reference schedule, dense TF1-Adam, spec-arithmetic walks) on the
+CA-GrQc fixture for a few outer epochs and record the gen/dis link-prediction accuracy after each
+-- the curve the HIP engine's run with the same seed is compared against.
+    python tools/run_oracle_epochs.py <n_epochs> <out.json>"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import graphgan_oracle as orc  # noqa: E402
+from tests.helpers import ca_grqc_init_embeddings, load_ca_grqc  # noqa: E402
+
+
+def main():
+    n_epochs, out = int(sys.argv[1]), sys.argv[2]
+    d, n, graph = load_ca_grqc()
+    init = ca_grqc_init_embeddings(d, n, seed=0)
+    o = orc.GraphGANOracle(n, graph, init, init, rng="counter", arith="spec", seed=0)
+    test, neg = d["test"].tolist(), d["test_neg"].tolist()
+    res = {"epochs": [], "seconds": []}
+    res["epochs"].append([orc.eval_link_prediction(o.generator.E.astype(np.float64), test, neg),
+                          orc.eval_link_prediction(o.discriminator.E.astype(np.float64), test, neg)])
+    for ep in range(n_epochs):
+        t = time.time()
+        o.train_epoch(ep)
+        res["seconds"].append(time.time() - t)
+        res["epochs"].append([orc.eval_link_prediction(o.generator.E.astype(np.float64), test, neg),
+                              orc.eval_link_prediction(o.discriminator.E.astype(np.float64), test, neg)])
+        json.dump(res, open(out, "w"))
+        print(ep, res["epochs"][-1], res["seconds"][-1], flush=True)
+
+
+if __name__ == "__main__":
+    main()
