@@ -132,7 +132,7 @@ int gg::walk_finalize(gg_ctx *ctx, bool *retried) {
     unsigned long long c0[6] = {(unsigned long long)ctx->ctr.hops, (unsigned long long)ctx->ctr.nbr_reads, 0, 0, 0,
                                 (unsigned long long)ctx->ctr.rows_scored};
     unsigned long long *c = ctx->h_ctr;  // 200 words, one read-back
-    GG_HIP(ctx, hipMemcpyAsync(c, ctx->dev_ctr, sizeof(unsigned long long) * 200, hipMemcpyDeviceToHost, ctx->stream));
+    GG_HIP(ctx, hipMemcpyAsync(c, ctx->dev_ctr, sizeof(unsigned long long) * 264, hipMemcpyDeviceToHost, ctx->stream));
     GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (c[3] == 2ull) {
         // nothing the overflowed launch wrote is final (the D-mode post-pass is gated by the same flag)
@@ -141,7 +141,7 @@ int gg::walk_finalize(gg_ctx *ctx, bool *retried) {
         int rc = launch_walk_sample(ctx, ctx->w_nslots, total, ctx->w_args.for_d, ctx->w_args.seed, ctx->w_args.stream, ctx->w_stride);
         ctx->walk_force_sized = false;
         if (rc != GG_OK) return rc;
-        GG_HIP(ctx, hipMemcpyAsync(c, ctx->dev_ctr, sizeof(unsigned long long) * 200, hipMemcpyDeviceToHost, ctx->stream));
+        GG_HIP(ctx, hipMemcpyAsync(c, ctx->dev_ctr, sizeof(unsigned long long) * 264, hipMemcpyDeviceToHost, ctx->stream));
         GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (retried) *retried = true;
     }
@@ -161,6 +161,9 @@ int gg::walk_finalize(gg_ctx *ctx, bool *retried) {
             ctx->ctr.score_kernel_ms += lms;
             ctx->ctr.score_launches += 1;
             ctx->ctr.score_chunks += (int64_t)c[136 + i];
+            if (getenv("GG_WALK_DEBUG"))
+                fprintf(stderr, "[walk] for_d=%d level %d alive %llu chunks %llu rows %llu big %llu score %.1f us\n", ctx->w_args.for_d, i,
+                        c[8 + i], c[136 + i], c[200 + i], c[72 + i], lms * 1e3);
         }
     }
     if (c[3]) {
@@ -254,8 +257,8 @@ int gg_create(int32_t n_node, int32_t n_emb, const float *emb_gen, const float *
         GG_HIP(ctx, hipMalloc((void **)&ctx->touched_cnt, sizeof(int32_t) * 4));
         GG_HIP(ctx, hipMemset(ctx->touched, 0, sizeof(int32_t) * n_node));
         GG_HIP(ctx, hipMemset(ctx->touched_cnt, 0, sizeof(int32_t) * 4));
-        GG_HIP(ctx, hipMalloc((void **)&ctx->dev_ctr, sizeof(unsigned long long) * 256));
-        GG_HIP(ctx, hipMemset(ctx->dev_ctr, 0, sizeof(unsigned long long) * 256));
+        GG_HIP(ctx, hipMalloc((void **)&ctx->dev_ctr, sizeof(unsigned long long) * 512));
+        GG_HIP(ctx, hipMemset(ctx->dev_ctr, 0, sizeof(unsigned long long) * 512));
         GG_HIP(ctx, hipDeviceSynchronize());
         return GG_OK;
     };

@@ -92,7 +92,7 @@ struct gg_ctx {
     int32_t w_stride = 0, w_nslots = 0;
     struct { int32_t for_d; uint64_t seed; uint32_t stream; } w_args{};
     std::vector<int64_t> h_walk_ptr;
-    unsigned long long h_ctr[256] = {};
+    unsigned long long h_ctr[512] = {};
     int64_t h_total = 0;  // row / pair count read back at the end of a prepare call
 
     // prepared data

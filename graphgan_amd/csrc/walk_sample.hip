@@ -187,7 +187,8 @@ constexpr int BIG_TASK = 256;   // owner tasks with more candidates get a whole 
 constexpr int CTR_ALIVE = 8;    // ctr[CTR_ALIVE + level]: walks alive when hop `level` was set up
 constexpr int CTR_BIG = 72;     // ctr[CTR_BIG + level]:   big owner tasks of hop `level`
 constexpr int CTR_CHUNKS = 136; // ctr[CTR_CHUNKS + level]: chunks of hop `level` (chunk offsets are handed out per wave)
-constexpr int CTR_WORDS = 200;
+constexpr int CTR_ROWS = 200;   // ctr[CTR_ROWS + level]: candidate rows scored at hop `level`
+constexpr int CTR_WORDS = 264;
 constexpr int MAX_LEVELS = 64;
 
 // One thread per walk (a wave = 64 consecutive walks), fused per hop boundary:
@@ -430,7 +431,10 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const
     // one counter update per block (same-address atomics serialise at ~12 ns each)
     if (t == 0 && rows) atomicAdd(&blk_rows, rows);
     __syncthreads();
-    if (threadIdx.x == 0 && blk_rows) atomicAdd(&a.ctr[5], blk_rows);
+    if (threadIdx.x == 0 && blk_rows) {
+        atomicAdd(&a.ctr[5], blk_rows);
+        atomicAdd(&a.ctr[CTR_ROWS + a.level], blk_rows);
+    }
 }
 
 __device__ __forceinline__ uint64_t group16_incl_scan_u64(uint64_t v, int t) {

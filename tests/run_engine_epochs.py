@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Run the graph_gan.py mirror on the HIP engine for a few outer epochs of the reference schedule
-on the CA-GrQc fixture (same seed / init as tools/run_oracle_epochs.py) and record the gen/dis
+on the CA-GrQc fixture (same seed / init as tests/run_oracle_epochs.py) and record the gen/dis
 accuracy after each epoch and the wall time per epoch.
-    python tools/run_engine_epochs.py <n_epochs> <out.json>"""
+    python tests/run_engine_epochs.py <n_epochs> <out.json>"""
 import json
 import os
 import sys

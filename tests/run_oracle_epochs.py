@@ -2,7 +2,7 @@
 """Run the CPU oracle trainer (reference schedule, dense TF1-Adam, spec-arithmetic walks) on the
 CA-GrQc fixture for a few outer epochs and record the gen/dis link-prediction accuracy after each
 -- the curve the HIP engine's run with the same seed is compared against.
-    python tools/run_oracle_epochs.py <n_epochs> <out.json>"""
+    python tests/run_oracle_epochs.py <n_epochs> <out.json>"""
 import json
 import os
 import sys

@@ -1,0 +1,117 @@
+"""Parity at the benchmark scales.
+  * BASELINE.json configs[2] (power-law, 100k nodes / 1M edges, n_emb = 128): a sample of roots,
+    HIP walks BIT-EXACT against the spec oracle, D and G mode, hub lists included.
+  * BASELINE.json configs[3] size (1M nodes / 10M edges, n_emb = 128): the oracle cannot cover it in
+    seconds, so size-independent properties are checked instead -- every step of every path is a
+    tree edge of that root, a walk ends exactly when it steps back to its previous node, the
+    sample is the node before the back-step, hop counters equal the path lengths, D rows have the
+    reference's [pos..., neg...] layout, walks do not depend on how the roots are batched."""
+import numpy as np
+import pytest
+
+from oracle import graphgan_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ga():
+    import graphgan_amd
+    return graphgan_amd
+
+
+def make(ga, n, d, seed):
+    edges = ga.synth_powerlaw(n, 10, 1, 2)
+    rowptr, col = ga.edges_to_csr(n, edges)
+    rs = np.random.default_rng(seed)
+    E = rs.standard_normal((n, d), dtype=np.float32) * np.float32(0.6 * np.sqrt(50.0 / d))
+    b = (rs.standard_normal(n, dtype=np.float32) * np.float32(0.05))
+    return rowptr, col, E, b
+
+
+def test_powerlaw_100k_sampled_roots_bit_exact(ga):
+    n, d = 100_000, 128
+    rowptr, col, E, b = make(ga, n, d, 5)
+    deg = (rowptr[1:] - rowptr[:-1]).astype(np.int32)
+    rs = np.random.RandomState(0)
+    roots = np.unique(np.concatenate([np.argsort(-deg)[:6], rs.choice(n, 90, replace=False)])).astype(np.int32)
+    eng = ga.Engine(E, E)
+    eng.set_bias(0, b)
+    eng.set_graph_csr(rowptr, col)
+    eng.build_trees(roots)
+    off, nbr, base, dmax = orc.c_build_trees(n, rowptr, col, roots)
+    assert eng.max_depth == dmax
+    Ep = orc.pad_rows(E)
+    slots = np.arange(len(roots), dtype=np.int32)
+    stride = dmax + 3
+    nbr = nbr.copy()
+    for rnd, for_d in enumerate((True, False, True, False)):
+        nw = deg[roots] if for_d else np.full(len(roots), 20, np.int32)
+        want = orc.c_walk_sample(Ep, b, off, nbr, base, roots, slots, nw, for_d, 6, rnd, stride)
+        got = eng.walk_sample(slots, nw, for_d, 6, rnd, stride=stride)
+        assert np.array_equal(got["root_status"], want["root_status"])
+        assert np.array_equal(got["path_len"], want["path_len"])
+        assert np.array_equal(got["samples"], want["samples"])
+        m = np.arange(stride)[None, :] < want["path_len"][:, None]
+        assert np.array_equal(got["paths"][m], want["paths"][m])
+        assert want["nbr_reads"] > 10 * want["hops"]  # hub lists were exercised
+    _, tnbr, _ = eng.get_trees()
+    assert np.array_equal(tnbr, nbr)
+    eng.close()
+
+
+def test_powerlaw_1m_walk_invariants(ga):
+    n, d = 1_000_000, 128
+    rowptr, col, E, b = make(ga, n, d, 5)
+    deg = (rowptr[1:] - rowptr[:-1]).astype(np.int64)
+    roots = np.random.RandomState(6).permutation(n)[:192].astype(np.int32)
+    eng = ga.Engine(E, E, optimizer=ga.GG_OPT_ADAM_LAZY)
+    eng.set_bias(0, b)
+    eng.set_graph_csr(rowptr, col)
+    eng.build_trees(roots, n_threads=32)
+    toff, tnbr, tbase = eng.get_trees()
+    slots = np.arange(len(roots), dtype=np.int32)
+    nw = np.full(len(roots), 20, np.int32)
+    c0 = eng.counters()
+    res = eng.walk_sample(slots, nw, False, 9, 1)
+    c1 = eng.counters()
+    L = res["path_len"]
+    assert (res["root_status"] == 0).all() and (L >= 3).all()
+    assert c1["hops"] - c0["hops"] == int((L - 1).sum())
+    P = res["paths"]
+    item = np.repeat(np.arange(len(roots)), 20)
+    assert np.array_equal(P[:, 0], roots[item])
+    rows = np.arange(len(L))
+    # ends: last == third-last (the back-step), sample == second-last
+    assert np.array_equal(P[rows, L - 1], P[rows, L - 3])
+    assert np.array_equal(res["samples"], P[rows, L - 2])
+    # every step is a tree edge of that root: next is in the tree list of cur
+    for w in range(0, len(L), 7):
+        i = item[w]
+        for h in range(L[w] - 1):
+            cur, nxt = P[w, h], P[w, h + 1]
+            lst = tnbr[tbase[i] + toff[i, cur]: tbase[i] + toff[i, cur + 1]]
+            assert nxt in (lst[1:] if h == 0 else lst)
+        # before the end the walk never steps back
+        assert all(P[w, h + 2] != P[w, h] for h in range(L[w] - 3))
+    # batching independence at scale
+    a = eng.walk_sample(slots[:50], nw[:50], False, 9, 1, stride=P.shape[1])
+    assert np.array_equal(a["path_len"], L[:1000]) and np.array_equal(a["samples"], res["samples"][:1000])
+    # D rows layout (graph_gan.py:193-201)
+    c, nb, lab, st = eng.prepare_d(slots, 9, 2)
+    o = 0
+    for i, r in enumerate(roots):
+        k = int(deg[r])
+        if st[i] == 0 and k:
+            assert (c[o:o + 2 * k] == r).all()
+            assert np.array_equal(nb[o:o + k], col[rowptr[r]:rowptr[r + 1]])
+            assert (lab[o:o + k] == 1).all() and (lab[o + k:o + 2 * k] == 0).all()
+            o += 2 * k
+    assert o == len(c)
+    # one fused D and G step keep the tables finite and move only touched rows
+    before = eng.get_embeddings(1)
+    eng.d_pass([0], len(c))
+    after = eng.get_embeddings(1)
+    moved = np.flatnonzero(np.abs(after - before).max(1) > 0)
+    assert np.isfinite(after).all() and set(moved.tolist()) <= set(np.concatenate([c, nb]).tolist())
+    eng.close()
