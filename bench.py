@@ -43,6 +43,7 @@ def parse():
     p.add_argument("--n-sample-gen", type=int, default=20)
     p.add_argument("--optimizer", default="adam_lazy", choices=["adam_dense", "adam_lazy", "sgd"])
     p.add_argument("--threads", type=int, default=0, help="host BFS threads (0 = min(64, cores))")
+    p.add_argument("--host-bfs", action="store_true", help="build the BFS trees on host threads instead of on the GPU")
     p.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--seed", type=int, default=6)
@@ -133,7 +134,12 @@ def main():
     roots = np.ascontiguousarray(all_roots[rank * R:(rank + 1) * R])
     roots = roots[np.argsort(-deg[roots], kind="stable")]  # longest (hub) roots first: LPT order for the walk scheduler
     threads = args.threads or min(64, os.cpu_count() or 1)
-    eng.build_trees(roots, n_threads=max(1, threads // max(1, min(world, 8))))
+    t_trees = time.time()
+    if args.host_bfs:
+        eng.build_trees(roots, n_threads=max(1, threads // max(1, min(world, 8))))
+    else:
+        eng.build_trees(roots, device=True)
+    trees_s = time.time() - t_trees
     slots = np.arange(len(roots), dtype=np.int32)
     ctl.connect_engine(eng)
     setup_s = time.time() - t_setup
@@ -211,6 +217,8 @@ def main():
         "rows_scored_per_step_rank0": rows_scored / args.steps,
         "nbr_reads_per_step_rank0": reads / args.steps,
         "setup_s": setup_s,
+        "tree_build_s": trees_s,
+        "tree_build": "host threads" if args.host_bfs else "gpu bfs",
         "roofline": {"kernel": "level_score_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": sc_bytes / max(sc_launches, 1), "avg_launch_ms": sc_ms / max(sc_launches, 1),

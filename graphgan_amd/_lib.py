@@ -55,6 +55,7 @@ SIGNATURES = {
     "gg_set_graph_csr": (ctypes.c_int, [_P, _P, _P]),
     "gg_host_build_trees": (_i64, [_i32, _P, _P, _P, _i32, _P, _P, _P, _i64, _i32, _P]),
     "gg_build_trees": (ctypes.c_int, [_P, _P, _i32, _i32]),
+    "gg_build_trees_device": (ctypes.c_int, [_P, _P, _i32]),
     "gg_set_trees": (ctypes.c_int, [_P, _P, _i32, _P, _P, _P, _i32]),
     "gg_tree_info": (ctypes.c_int, [_P, _P, _P, _P]),
     "gg_get_trees": (ctypes.c_int, [_P, _P, _P, _P]),

@@ -52,4 +52,5 @@ model_log = _base + "/log/"
 engine_seed = 0               # Philox key of the walk sampler + host RNG of root selection / batch shuffles
 engine_optimizer = "adam_dense"  # "adam_dense" = TF1.8 semantics (parity); "adam_lazy" | "sgd" = scale modes
 engine_device = 0
-engine_tree_threads = 0       # 0 = all host cores
+engine_tree_device = True    # BFS trees on the GPU (False: threaded host BFS, same trees)
+engine_tree_threads = 0       # host BFS only; 0 = all host cores

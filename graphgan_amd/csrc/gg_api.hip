@@ -44,7 +44,7 @@ static void free_trees(gg_ctx *ctx) {
     ctx->h_troot.clear();
 }
 
-static int alloc_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int64_t *nbr_base) {
+int alloc_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int64_t *nbr_base) {
     free_trees(ctx);
     const int64_t entries = nbr_base[n_roots];
     GG_HIP(ctx, hipMalloc((void **)&ctx->t_root, sizeof(int32_t) * std::max(n_roots, 1)));

@@ -137,6 +137,11 @@ int fail(gg_ctx *ctx, int code, const char *fmt, ...);
 // exclusive scan of n int32 counts into n+1 int64 offsets (prepare.hip)
 int device_exclusive_scan(gg_ctx *ctx, const int32_t *cnt, int64_t *ptr, int64_t n);
 
+// trees
+int alloc_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int64_t *nbr_base);
+int64_t host_tree_sizes(int32_t n, const int64_t *rowptr, const int32_t *col, const int32_t *roots, int32_t n_roots,
+                        int64_t *nbr_base);
+
 // launchers
 int walk_launch_async(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, int32_t uniform_walks, int32_t n_slots,
                       int32_t for_d, uint64_t seed, uint32_t stream, int32_t stride);

@@ -114,10 +114,14 @@ class Engine:
         self._ck(lib.gg_set_graph_csr(self._ctx, _ptr(rowptr), _ptr(col)))
         self._rowptr = rowptr
 
-    def build_trees(self, roots, n_threads=0):
-        """graph_gan.py:31-46,84-108: BFS trees of ``roots`` -> device tree CSR (slot i = roots[i])."""
+    def build_trees(self, roots, n_threads=0, device=False):
+        """graph_gan.py:31-46,84-108: BFS trees of ``roots`` -> device tree CSR (slot i = roots[i]).
+        device=False: threaded host BFS + upload; device=True: BFS on the GPU (same trees)."""
         roots = _i32(roots)
-        self._ck(lib.gg_build_trees(self._ctx, _ptr(roots), len(roots), n_threads))
+        if device:
+            self._ck(lib.gg_build_trees_device(self._ctx, _ptr(roots), len(roots)))
+        else:
+            self._ck(lib.gg_build_trees(self._ctx, _ptr(roots), len(roots), n_threads))
         self._after_trees(roots)
 
     def set_trees(self, roots, off, nbr, nbr_base, max_depth=0):

@@ -109,7 +109,8 @@ class GraphGAN(object):
         """BFS trees of ``nodes`` (reference :84-108) -> resident tree CSR; returns the slot map
         root -> slot (the reference returns the dict of dicts itself)."""
         nodes = np.asarray(list(nodes), dtype=np.int32)
-        self.engine.build_trees(nodes, n_threads=int(_cfg(self.config, "engine_tree_threads", 0)))
+        self.engine.build_trees(nodes, n_threads=int(_cfg(self.config, "engine_tree_threads", 0)),
+                                device=bool(_cfg(self.config, "engine_tree_device", True)))
         self._slot_of_root = {int(r): i for i, r in enumerate(nodes)}
         return self._slot_of_root
 

@@ -121,6 +121,10 @@ int64_t gg_host_build_trees(int32_t n_node, const int64_t *rowptr, const int32_t
 /* gg_build_trees: same, built in batches and uploaded into the context (replaces the pickle
  * cache load/construct branch, graph_gan.py:31-46).  Root slot i holds the tree of roots[i]. */
 int gg_build_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, int32_t n_threads);
+/* gg_build_trees_device: the same trees built ON THE GPU (level-synchronous BFS that reproduces the
+ * reference's pop order: a node is appended by the first frontier node, in pop order, that lists it),
+ * for batches of roots at once, written straight into the resident tree CSR. */
+int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t n_roots);
 /* gg_set_trees / gg_get_trees: upload / download a tree CSR (cache files, tests; download
  * includes the in-place D-mode mutations, graph_gan.py:258-259). */
 int gg_set_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int32_t *off,

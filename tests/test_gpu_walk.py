@@ -172,3 +172,34 @@ def test_speculative_level_buffers_overflow_is_retried(ga, monkeypatch):
     c = eng.counters()
     assert c["hops"] == sum(int(x) for x in [0])  or c["hops"] > 0
     eng.close()
+
+
+@pytest.mark.parametrize("case", ["small0", "small3", "star", "ca_grqc", "powerlaw"])
+def test_gpu_bfs_builds_the_reference_trees(ga, case):
+    """gg_build_trees_device == the host builder == reference construct_trees (pop order, child order,
+    self-loops, isolated nodes, several components), offsets / lists / depth / longest list."""
+    if case.startswith("small"):
+        g, n, graph = load_small(int(case[-1]))
+        rowptr, col = ga.graph_to_csr(n, graph)
+        roots = np.arange(n, dtype=np.int32)
+    elif case == "star":
+        edges, n = star_graph_edges(300)
+        rowptr, col = ga.edges_to_csr(n, edges)
+        roots = np.array([0, 1, 5, n - 1, 17], dtype=np.int32)
+    elif case == "ca_grqc":
+        d, n, graph = load_ca_grqc()
+        rowptr, col = ga.graph_to_csr(n, graph)
+        roots = np.arange(n, dtype=np.int32)
+    else:
+        n = 50_000
+        rowptr, col = ga.edges_to_csr(n, ga.synth_powerlaw(n, 10, 1, 2))
+        roots = np.random.RandomState(1).choice(n, 300, replace=False).astype(np.int32)
+    E = np.zeros((n, 8), np.float32)
+    eng = ga.Engine(E, E)
+    eng.set_graph_csr(rowptr, col)
+    eng.build_trees(roots, device=True)
+    off, nbr, base = eng.get_trees()
+    woff, wnbr, wbase, wdepth = ga.host_build_trees(n, rowptr, col, roots)
+    assert np.array_equal(base, wbase) and np.array_equal(off, woff) and np.array_equal(nbr, wnbr)
+    assert eng.max_depth == wdepth
+    eng.close()
