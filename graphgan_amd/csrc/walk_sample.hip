@@ -20,6 +20,8 @@
 // Scores follow S1 and everything after them is exact integer arithmetic, so the decomposition
 // cannot change a sampled node.  Algorithmic bytes of the score kernel: 4(d+3) per candidate row
 // + 4d+16 per chunk.
+#include <algorithm>
+
 #include "gg_arith.h"
 #include "gg_internal.h"
 
@@ -294,6 +296,9 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         }
         if (alive) a.st_cur[w] = cur;
         a.st_alive[w] = alive ? 1 : 0;
+        // the sync-free launch ran only as many levels as earlier launches needed: a walk that is
+        // still going after the last one sends the launch to the sized rerun
+        if (alive && !do_setup && write_desc == 2) a.ctr[3] = 2ull;
     }
     if (do_sample) {
         const unsigned long long bal = __ballot(sampled);
@@ -699,6 +704,8 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
         if (rc != GG_OK) return rc;
     }
     const unsigned wblocks = (unsigned)cdiv(total_walks, 256);
+    const bool all_levels = n_levels >= ctx->tree_max_depth + 2;
+    if (!sized && all_levels && ctx->lv_levels_learned > 0) n_levels = std::min(n_levels, ctx->lv_levels_learned + 1);
     *any_alive = true;
     ctx->lv_ev_used = 0;
     int level = 0;
@@ -711,6 +718,7 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
             GG_HIP(ctx, hipMemcpyAsync(&alive, ctx->dev_ctr + CTR_ALIVE + level, sizeof(alive), hipMemcpyDeviceToHost, ctx->stream));
             GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
             if (alive == 0) { *any_alive = false; return GG_OK; }
+            if (level + 1 > ctx->lv_levels_learned) ctx->lv_levels_learned = level + 1;
             cap = (int64_t)total_chunks;
             if (cap + cap / 4 + 4096 > ctx->lv_cap_chunks) ctx->lv_cap_chunks = cap + cap / 4 + 4096;
             int rc = reserve_level_buffers(ctx, a, cap);
@@ -734,7 +742,7 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
     }
     // finish the last prepared hop
     a.level = level;
-    hipLaunchKernelGGL(level_advance_kernel, dim3(wblocks), dim3(256), 0, ctx->stream, a, 1, 0, 0, 0);
+    hipLaunchKernelGGL(level_advance_kernel, dim3(wblocks), dim3(256), 0, ctx->stream, a, 1, 0, (!sized && all_levels) ? 2 : 0, 0);
     GG_HIP(ctx, hipGetLastError());
     return GG_OK;
 }
