@@ -69,6 +69,7 @@ SIGNATURES = {
     "gg_pair_reward": (ctypes.c_int, [_P, _P, _P, _i64, _P]),
     "gg_d_step": (ctypes.c_int, [_P, _P, _P, _P, _i32]),
     "gg_g_step": (ctypes.c_int, [_P, _P, _P, _P, _i32]),
+    "gg_all_score": (ctypes.c_int, [_P, _P, _i32, _P]),
     "gg_get_embeddings": (ctypes.c_int, [_P, _i32, _P]),
     "gg_get_bias": (ctypes.c_int, [_P, _i32, _P]),
     "gg_set_embeddings": (ctypes.c_int, [_P, _i32, _P]),

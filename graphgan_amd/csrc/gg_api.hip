@@ -283,10 +283,10 @@ int gg_destroy(gg_ctx *ctx) {
     for (void *p : ps)
         if (p) (void)hipFree(p);
     free_trees(ctx);
-    DevBuf *bufs[] = {&ctx->w_slots, &ctx->w_nwalks, &ctx->w_ptr, &ctx->w_samples, &ctx->w_paths, &ctx->w_len, &ctx->w_status,
+    DevBuf *bufs[] = {&ctx->w_slots, &ctx->w_ptr, &ctx->w_samples, &ctx->w_paths, &ctx->w_len, &ctx->w_status,
                       &ctx->w_first, &ctx->w_abort, &ctx->w_scratch, &ctx->d_center, &ctx->d_neighbor, &ctx->d_label, &ctx->d_cnt,
                       &ctx->d_ptr, &ctx->g_node1, &ctx->g_node2, &ctx->g_reward, &ctx->g_cnt, &ctx->g_ptr, &ctx->scan_tmp,
-                      &ctx->step_u, &ctx->step_v, &ctx->step_x, &ctx->starts_buf, &ctx->misc, &ctx->touched_ptr, &ctx->st_item, &ctx->st_cur, &ctx->st_prev, &ctx->st_len,
+                      &ctx->step_u, &ctx->step_v, &ctx->step_x, &ctx->touched_ptr, &ctx->st_item, &ctx->st_cur, &ctx->st_prev, &ctx->st_len,
                       &ctx->st_alive, &ctx->lv_beg, &ctx->lv_k, &ctx->lv_owner, &ctx->lv_chunks, &ctx->lv_coff, &ctx->lv_scores, &ctx->lv_chunk_owner, &ctx->lv_prefix, &ctx->lv_big};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : ctx->lv_ev)

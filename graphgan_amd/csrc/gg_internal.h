@@ -43,8 +43,6 @@ struct Model {
     float lr = 1e-3f, lambda = 1e-5f;
 };
 
-struct RcclApi;  // comm.hip
-
 }  // namespace gg
 
 struct gg_ctx {
@@ -81,7 +79,7 @@ struct gg_ctx {
     std::vector<int32_t> h_troot;
 
     // walk outputs (device resident)
-    gg::DevBuf w_slots, w_nwalks, w_ptr, w_samples, w_paths, w_len, w_status, w_first, w_abort, w_scratch;
+    gg::DevBuf w_slots, w_ptr, w_samples, w_paths, w_len, w_status, w_first, w_abort, w_scratch;
     // level-synchronous front end of the walk sampler (walk_sample.hip): per-walk state + per-level tasks
     gg::DevBuf st_cur, st_prev, st_len, st_alive, st_item, lv_beg, lv_k, lv_owner, lv_chunks, lv_coff, lv_scores, lv_chunk_owner, lv_prefix, lv_big;
     int32_t lv_levels_learned = 0;     // hops earlier (sized) launches needed until every walk had finished
@@ -103,7 +101,7 @@ struct gg_ctx {
     int64_t g_pairs = 0;
     bool g_paths_valid = false;  // w_paths / g_ptr still describe the resident prepare_g data
     gg::DevBuf touched_ptr;
-    gg::DevBuf scan_tmp, step_u, step_v, step_x, starts_buf, misc;
+    gg::DevBuf scan_tmp, step_u, step_v, step_x;
 
     // device-side counters: [0]=hops [1]=nbr_reads [2]=alive walks [3]=error flag [4]=ticket [5]=rows scored
     unsigned long long *dev_ctr = nullptr;

@@ -217,6 +217,17 @@ class Engine:
         u, v, reward = _i32(u), _i32(v), np.ascontiguousarray(reward, dtype=np.float32)
         self._ck(lib.gg_g_step(self._ctx, _ptr(u), _ptr(v), _ptr(reward), len(u)))
 
+    def all_score(self, rows=None):
+        """sess.run(generator.all_score) (graph_gan.py:238) for ``rows`` (None: all) -> fp32 [len(rows), n_node]."""
+        if rows is None:
+            out = np.zeros((self.n_node, self.n_node), dtype=np.float32)
+            self._ck(lib.gg_all_score(self._ctx, None, 0, _ptr(out)))
+            return out
+        rows = _i32(rows)
+        out = np.zeros((len(rows), self.n_node), dtype=np.float32)
+        self._ck(lib.gg_all_score(self._ctx, _ptr(rows), len(rows), _ptr(out)))
+        return out
+
     def get_embeddings(self, which):
         """sess.run(embedding_matrix) (graph_gan.py:298); which: 0 = gen, 1 = dis."""
         out = np.zeros((self.n_node, self.n_emb), dtype=np.float32)

@@ -172,6 +172,13 @@ int gg_pair_reward(gg_ctx *ctx, const int32_t *u, const int32_t *v, int64_t n, f
 int gg_d_step(gg_ctx *ctx, const int32_t *u, const int32_t *v, const float *label, int32_t n);
 int gg_g_step(gg_ctx *ctx, const int32_t *u, const int32_t *v, const float *reward, int32_t n);
 
+/* gg_all_score: sess.run(generator.all_score) (graph_gan.py:238, generator.py:21) for the given rows:
+ * out[i * n_node + j] = g_rows[i] . g_j + b_g[j]; rows == NULL -> every row (n_rows ignored, out is
+ * [n_node, n_node]).  Exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32, k-ordered fmaf chain).
+ * The engine itself never needs it (gg_walk_sample scores tree neighbours on demand); it is here for
+ * callers that still want score rows. */
+int gg_all_score(gg_ctx *ctx, const int32_t *rows, int32_t n_rows, float *out);
+
 /* sess.run(embedding_matrix) (graph_gan.py:298); which: 0 = generator, 1 = discriminator
  * (config.modes order, config.py:1).  out is [n_node, n_emb] fp32, unpadded. */
 int gg_get_embeddings(gg_ctx *ctx, int32_t which, float *out);

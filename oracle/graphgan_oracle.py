@@ -223,6 +223,8 @@ def c_oracle():
     lib.orc_walk_sample.restype = ctypes.c_int
     lib.orc_pairs_from_path.argtypes = [P, ctypes.c_int, ctypes.c_int, P, P]
     lib.orc_pairs_from_path.restype = ctypes.c_int
+    lib.orc_all_score_rows.argtypes = [P, P, ctypes.c_int, ctypes.c_int, P, ctypes.c_int, P]
+    lib.orc_all_score_rows.restype = None
     _C = lib
     return lib
 
@@ -256,6 +258,17 @@ def c_build_trees(n_node, rowptr, col, roots):
     got = lib.orc_build_trees(n_node, _p(rowptr), _p(col), _p(roots), R, _p(off), _p(nbr), _p(base), int(total), _p(dmax))
     assert got == total
     return off, nbr[: int(total)], base, int(dmax[0])
+
+
+def c_all_score_rows(emb_pad, bias, rows):
+    """generator.py:21 for selected rows, k-ordered fp32 fmaf chain + bias (the MFMA kernel's arithmetic)."""
+    lib = c_oracle()
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    bias = np.ascontiguousarray(bias, dtype=np.float32)
+    n = emb_pad.shape[0]
+    out = np.zeros((len(rows), n), dtype=np.float32)
+    lib.orc_all_score_rows(_p(emb_pad), _p(bias), n, emb_pad.shape[1], _p(rows), len(rows), _p(out))
+    return out
 
 
 def c_walk_sample(emb_pad, bias, off, nbr, base, tree_root, slots, n_walks, for_d, seed, stream, stride):

@@ -314,3 +314,19 @@ int orc_pairs_from_path(const int32_t *path, int len, int window, int32_t *a, in
     }
     return np;
 }
+
+/* --------------------------------------------------------- generator.py:21 */
+/* Rows of all_score = E.E^T + b (bias per column).  Arithmetic restated for the MFMA kernel
+ * (v_mfma_f32_32x32x2_f32 is a k-ordered fp32 fmaf chain from 0): acc = fmaf(a_k, b_k, acc) for
+ * k = 0..ld-1 in order, then one fp32 add of the bias. */
+void orc_all_score_rows(const float *E, const float *bias, int n, int ld, const int32_t *rows, int n_rows, float *out) {
+    for (int i = 0; i < n_rows; ++i) {
+        const float *a = E + (int64_t)(rows ? rows[i] : i) * ld;
+        for (int j = 0; j < n; ++j) {
+            const float *b = E + (int64_t)j * ld;
+            float acc = 0.0f;
+            for (int k = 0; k < ld; ++k) acc = fmaf(a[k], b[k], acc);
+            out[(int64_t)i * n + j] = acc + bias[j];
+        }
+    }
+}

@@ -288,3 +288,26 @@ def test_whole_walk_g_pass_equals_generic_pair_kernel(ga, opt, monkeypatch):
     assert c["g_pairs"] == len(n1) and c["g_steps"] == 1
     eng.close()
     eng2.close()
+
+
+@pytest.mark.parametrize("n,d", [(300, 50), (1000, 128), (77, 6), (4100, 256)])
+def test_all_score_rows_on_mfma(ga, n, d):
+    """K7: rows of generator.all_score (generator.py:21) from the fp32 MFMA kernel: BIT-EXACT against
+    the k-ordered fmaf chain of the oracle (the instruction's documented arithmetic), and within
+    1e-5 of a float64 product; bias is added per column."""
+    Eg, Ed, bg, bd = make_models(n, d, n)
+    eng = engine_with(ga, Eg, Ed, bg, bd)
+    rs = np.random.RandomState(1)
+    rows = rs.choice(n, min(n, 70), replace=False).astype(np.int32)
+    got = eng.all_score(rows)
+    want = orc.c_all_score_rows(orc.pad_rows(Eg), bg, rows)
+    assert np.array_equal(got, want)
+    ref = Eg[rows].astype(np.float64) @ Eg.T.astype(np.float64) + bg.astype(np.float64)
+    assert np.max(np.abs(got - ref)) < 1e-5 * max(1.0, np.abs(ref).max())
+    if n <= 300:
+        full = eng.all_score()
+        assert full.shape == (n, n) and np.array_equal(full[rows], got)
+        assert not np.allclose(full, full.T)  # column bias makes S asymmetric
+    with pytest.raises(ga.GraphGANHipError):
+        eng.all_score([n])
+    eng.close()

@@ -169,8 +169,6 @@ def test_speculative_level_buffers_overflow_is_retried(ga, monkeypatch):
         assert np.array_equal(got["path_len"], want["path_len"]) and np.array_equal(got["samples"], want["samples"])
         m = np.arange(stride)[None, :] < want["path_len"][:, None]
         assert np.array_equal(got["paths"][m], want["paths"][m])
-    c = eng.counters()
-    assert c["hops"] == sum(int(x) for x in [0])  or c["hops"] > 0
     eng.close()
 
 
