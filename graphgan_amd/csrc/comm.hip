@@ -20,6 +20,7 @@ typedef int (*fn_GetUniqueId)(RcclUniqueId *);
 typedef int (*fn_CommInitRank)(void **, int, RcclUniqueId, int);
 typedef int (*fn_CommDestroy)(void *);
 typedef int (*fn_AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t);
+typedef int (*fn_AllGather)(const void *, void *, size_t, int, void *, hipStream_t);
 typedef const char *(*fn_GetErrorString)(int);
 
 struct RcclApi {
@@ -28,13 +29,14 @@ struct RcclApi {
     fn_CommInitRank CommInitRank = nullptr;
     fn_CommDestroy CommDestroy = nullptr;
     fn_AllReduce AllReduce = nullptr;
+    fn_AllGather AllGather = nullptr;
     fn_GetErrorString GetErrorString = nullptr;
 };
 
 static RcclApi g_rccl;
 constexpr int NCCL_FLOAT32 = 7;  // ncclFloat32
 constexpr int NCCL_SUM = 0;      // ncclSum
-constexpr int NCCL_INT32 = 2;    // ncclInt32
+constexpr int NCCL_INT64 = 4;    // ncclInt64
 
 static int load_rccl(gg_ctx *ctx) {
     if (g_rccl.handle) return GG_OK;
@@ -51,8 +53,9 @@ static int load_rccl(gg_ctx *ctx) {
     api.CommInitRank = (fn_CommInitRank)dlsym(h, "ncclCommInitRank");
     api.CommDestroy = (fn_CommDestroy)dlsym(h, "ncclCommDestroy");
     api.AllReduce = (fn_AllReduce)dlsym(h, "ncclAllReduce");
+    api.AllGather = (fn_AllGather)dlsym(h, "ncclAllGather");
     api.GetErrorString = (fn_GetErrorString)dlsym(h, "ncclGetErrorString");
-    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.GetErrorString)
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.AllGather || !api.GetErrorString)
         return fail(ctx, GG_ECOMM, "librccl is missing a required symbol");
     g_rccl = api;
     return GG_OK;
@@ -64,13 +67,25 @@ static int load_rccl(gg_ctx *ctx) {
         if (r__ != 0) return fail(ctx, GG_ECOMM, "%s -> %s", #call, g_rccl.GetErrorString(r__));        \
     } while (0)
 
+// dense exchange (GG_OPT_ADAM_DENSE): sum the whole accumulators
 int comm_allreduce_grads(gg_ctx *ctx) {
     if (!ctx->comm) return GG_OK;
     const size_t ne = (size_t)ctx->n_node * ctx->ld;
     GG_NCCL(ctx, g_rccl.AllReduce(ctx->gradE, ctx->gradE, ne, NCCL_FLOAT32, NCCL_SUM, ctx->comm, ctx->stream));
     GG_NCCL(ctx, g_rccl.AllReduce(ctx->gradb, ctx->gradb, (size_t)ctx->n_node, NCCL_FLOAT32, NCCL_SUM, ctx->comm, ctx->stream));
-    if (ctx->cfg.optimizer != GG_OPT_ADAM_DENSE)  // row flags of the lazy / sgd modes: union over ranks
-        GG_NCCL(ctx, g_rccl.AllReduce(ctx->touched, ctx->touched, (size_t)ctx->n_node, NCCL_INT32, NCCL_SUM, ctx->comm, ctx->stream));
+    return GG_OK;
+}
+
+// all-gather of `count` elements per rank (bytes = count * elem); with GG_COMM_FAKE_WORLD (tests on one
+// GPU) every "rank" is a copy of the local buffer
+int comm_allgather(gg_ctx *ctx, const void *send, void *recv, size_t count, int elem_bytes) {
+    if (ctx->comm) {
+        const int dt = elem_bytes == 8 ? NCCL_INT64 : NCCL_FLOAT32;  // 4-byte payloads travel as fp32 words
+        GG_NCCL(ctx, g_rccl.AllGather(send, recv, count, dt, ctx->comm, ctx->stream));
+        return GG_OK;
+    }
+    for (int r = 0; r < ctx->fake_world; ++r)
+        GG_HIP(ctx, hipMemcpyAsync((char *)recv + (size_t)r * count * elem_bytes, send, count * elem_bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return GG_OK;
 }
 

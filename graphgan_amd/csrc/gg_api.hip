@@ -212,6 +212,7 @@ int gg_create(int32_t n_node, int32_t n_emb, const float *emb_gen, const float *
     ctx->cfg = *cfg;
     ctx->device = cfg->device;
     if (const char *lv = getenv("GG_WALK_LEVELS")) ctx->walk_levels = atoi(lv);
+    if (const char *fw = getenv("GG_COMM_FAKE_WORLD")) ctx->fake_world = atoi(fw);
 #define GG_TRY(call)                        \
     do {                                    \
         int rc__ = (call);                  \
@@ -286,7 +287,8 @@ int gg_destroy(gg_ctx *ctx) {
     DevBuf *bufs[] = {&ctx->w_slots, &ctx->w_ptr, &ctx->w_samples, &ctx->w_paths, &ctx->w_len, &ctx->w_status,
                       &ctx->w_first, &ctx->w_abort, &ctx->w_scratch, &ctx->d_center, &ctx->d_neighbor, &ctx->d_label, &ctx->d_cnt,
                       &ctx->d_ptr, &ctx->g_node1, &ctx->g_node2, &ctx->g_reward, &ctx->g_cnt, &ctx->g_ptr, &ctx->scan_tmp,
-                      &ctx->step_u, &ctx->step_v, &ctx->step_x, &ctx->touched_ptr, &ctx->st_item, &ctx->st_cur, &ctx->st_prev, &ctx->st_len,
+                      &ctx->step_u, &ctx->step_v, &ctx->step_x, &ctx->touched_ptr, &ctx->x_cnt, &ctx->x_send_ids, &ctx->x_send_rows,
+                      &ctx->x_recv_ids, &ctx->x_recv_rows, &ctx->st_item, &ctx->st_cur, &ctx->st_prev, &ctx->st_len,
                       &ctx->st_alive, &ctx->lv_beg, &ctx->lv_k, &ctx->lv_owner, &ctx->lv_chunks, &ctx->lv_coff, &ctx->lv_scores, &ctx->lv_chunk_owner, &ctx->lv_prefix, &ctx->lv_big};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : ctx->lv_ev)

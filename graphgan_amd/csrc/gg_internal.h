@@ -110,6 +110,8 @@ struct gg_ctx {
     // multi-GPU
     void *comm = nullptr;  // ncclComm_t
     int32_t rank = 0, world = 1;
+    int32_t fake_world = 0;  // GG_COMM_FAKE_WORLD=k: exercise the k-rank exchange code on one GPU (every rank = this one)
+    gg::DevBuf x_cnt, x_send_ids, x_send_rows, x_recv_ids, x_recv_rows;  // sparse gradient exchange
 
     std::string err;
 };
@@ -151,6 +153,7 @@ int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int fo
                        int32_t stride);
 int run_step(gg_ctx *ctx, int which, const int32_t *d_u, const int32_t *d_v, const float *d_x, int32_t n);
 int comm_allreduce_grads(gg_ctx *ctx);
+int comm_allgather(gg_ctx *ctx, const void *send, void *recv, size_t count, int elem_bytes);
 void comm_destroy(gg_ctx *ctx);
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -17,6 +17,9 @@
 // With gg_comm_init the gradient accumulators are all-reduced between (A) and (B).
 #include <stdlib.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "gg_internal.h"
 
 namespace gg {
@@ -311,9 +314,35 @@ __global__ __launch_bounds__(256) void sparse_opt_kernel(const OptArgs a) {
     }
 }
 
-__global__ void normalize_flags_kernel(int32_t *f, int n) {  // after the cross-rank sum: counts -> 0/1
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && f[i] > 1) f[i] = 1;
+// ---- sparse gradient exchange between replicas (lazy / sgd modes).  A step touches a small part of
+// the tables, so instead of all-reducing N*(ld+1) floats each rank packs its touched rows
+// {row id, gradient row, bias gradient}, the packs are all-gathered, and every rank adds the packs
+// in RANK ORDER with one launch per source rank (ids are unique inside a pack -> plain adds, no
+// atomics): all replicas compute bit-identical sums, so they stay bit-identical.
+__global__ __launch_bounds__(256) void pack_rows_kernel(float *gE, float *gb, int32_t *touched, const int32_t *list, const int64_t *cnt_ptr,
+                                                        int ld, int32_t *out_ids, float *out_rows) {
+    const int t = threadIdx.x & 15;
+    const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4, ng = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    const int64_t cnt = *cnt_ptr;
+    for (int64_t r = g0; r < cnt; r += ng) {
+        const int row = list[r];
+        float *src = gE + (int64_t)row * ld, *dst = out_rows + r * (ld + 1);
+        for (int f = t; f < ld; f += 16) { dst[f] = src[f]; src[f] = 0.f; }
+        if (t == 0) { dst[ld] = gb[row]; gb[row] = 0.f; out_ids[r] = row; touched[row] = 0; }
+    }
+}
+
+__global__ __launch_bounds__(256) void add_rows_kernel(float *gE, float *gb, int32_t *touched, const int32_t *ids, const float *rows, int64_t cnt,
+                                                       int ld) {
+    const int t = threadIdx.x & 15;
+    const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4, ng = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    for (int64_t r = g0; r < cnt; r += ng) {
+        const int row = ids[r];
+        float *dst = gE + (int64_t)row * ld;
+        const float *src = rows + r * (ld + 1);
+        for (int f = t; f < ld; f += 16) dst[f] += src[f];
+        if (t == 0) { gb[row] += src[ld]; touched[row] = 1; }
+    }
 }
 
 // touched flags -> row list in row order (deterministic), via the exclusive scan of the flags
@@ -376,11 +405,52 @@ int run_path_step(gg_ctx *ctx) {
     return apply_optimizer(ctx, 0, n);
 }
 
-// all-reduce (multi-GPU) + optimizer kernel + step bookkeeping, after a gradient kernel
+// Sparse exchange: see pack_rows_kernel.  One host read-back (the per-rank row counts) per step.
+static int exchange_sparse(gg_ctx *ctx, OptArgs &o, int world) {
+    const int n = ctx->n_node, ld = ctx->ld;
+    int rc = device_exclusive_scan(ctx, ctx->touched, ctx->touched_ptr.as<int64_t>(), n);
+    if (rc != GG_OK) return rc;
+    hipLaunchKernelGGL(compact_touched_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, o);
+    GG_HIP(ctx, ctx->x_cnt.reserve(sizeof(int64_t) * (world + 1)));
+    rc = comm_allgather(ctx, o.touched_total, ctx->x_cnt.as<int64_t>(), 1, 8);
+    if (rc != GG_OK) return rc;
+    std::vector<int64_t> cnt(world);
+    GG_HIP(ctx, hipMemcpyAsync(cnt.data(), ctx->x_cnt.p, sizeof(int64_t) * world, hipMemcpyDeviceToHost, ctx->stream));
+    GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int64_t maxc = 0;
+    for (int r = 0; r < world; ++r) {
+        GG_CHECK(ctx, cnt[r] >= 0 && cnt[r] <= n, GG_ECOMM, "sparse exchange: rank %d reports %lld rows", r, (long long)cnt[r]);
+        maxc = std::max(maxc, cnt[r]);
+    }
+    if (maxc == 0) return GG_OK;
+    const size_t row_f = (size_t)ld + 1;
+    GG_HIP(ctx, ctx->x_send_ids.reserve(sizeof(int32_t) * maxc));
+    GG_HIP(ctx, ctx->x_send_rows.reserve(sizeof(float) * maxc * row_f));
+    GG_HIP(ctx, ctx->x_recv_ids.reserve(sizeof(int32_t) * maxc * world));
+    GG_HIP(ctx, ctx->x_recv_rows.reserve(sizeof(float) * maxc * row_f * world));
+    int nb = cdiv(maxc * 16, 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(nb), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, ctx->touched, ctx->touched_list,
+                       o.touched_total, ld, ctx->x_send_ids.as<int32_t>(), ctx->x_send_rows.as<float>());
+    rc = comm_allgather(ctx, ctx->x_send_ids.p, ctx->x_recv_ids.p, (size_t)maxc, 4);
+    if (rc != GG_OK) return rc;
+    rc = comm_allgather(ctx, ctx->x_send_rows.p, ctx->x_recv_rows.p, (size_t)maxc * row_f, 4);
+    if (rc != GG_OK) return rc;
+    for (int r = 0; r < world; ++r) {
+        if (cnt[r] == 0) continue;
+        hipLaunchKernelGGL(add_rows_kernel, dim3(nb), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, ctx->touched,
+                           ctx->x_recv_ids.as<int32_t>() + (size_t)r * maxc, ctx->x_recv_rows.as<float>() + (size_t)r * maxc * row_f, cnt[r], ld);
+    }
+    GG_HIP(ctx, hipGetLastError());
+    return GG_OK;
+}
+
+// gradient exchange (multi-GPU) + optimizer kernel + step bookkeeping, after a gradient kernel
 int apply_optimizer(gg_ctx *ctx, int which, int64_t n) {
     Model &M = ctx->model[which];
     const int opt = ctx->cfg.optimizer;
-    int rc = comm_allreduce_grads(ctx);
+    int rc = GG_OK;
+    if (opt == GG_OPT_ADAM_DENSE) rc = comm_allreduce_grads(ctx);
     if (rc != GG_OK) return rc;
 
     OptArgs o{};
@@ -402,7 +472,11 @@ int apply_optimizer(gg_ctx *ctx, int which, int64_t n) {
         GG_HIP(ctx, ctx->touched_ptr.reserve(sizeof(int64_t) * ((size_t)ctx->n_node + 1)));
         o.touched_ptr = ctx->touched_ptr.as<int64_t>();
         o.touched_total = o.touched_ptr + ctx->n_node;
-        if (ctx->comm) hipLaunchKernelGGL(normalize_flags_kernel, dim3(cdiv(ctx->n_node, 256)), dim3(256), 0, ctx->stream, ctx->touched, ctx->n_node);
+        const int world = ctx->comm ? ctx->world : ctx->fake_world;
+        if (world > 1 || (ctx->comm && ctx->world == 1)) {
+            rc = exchange_sparse(ctx, o, world < 1 ? 1 : world);
+            if (rc != GG_OK) return rc;
+        }
         rc = device_exclusive_scan(ctx, ctx->touched, ctx->touched_ptr.as<int64_t>(), ctx->n_node);
         if (rc != GG_OK) return rc;
         hipLaunchKernelGGL(compact_touched_kernel, dim3(cdiv(ctx->n_node, 256)), dim3(256), 0, ctx->stream, o);

@@ -311,3 +311,41 @@ def test_all_score_rows_on_mfma(ga, n, d):
     with pytest.raises(ga.GraphGANHipError):
         eng.all_score([n])
     eng.close()
+
+
+@pytest.mark.parametrize("mode", ["sgd", "lazy"])
+def test_sparse_exchange_with_simulated_ranks(ga, mode, monkeypatch):
+    """The replica gradient exchange of the lazy / sgd modes packs touched rows, all-gathers the
+    packs and adds them in rank order.  gpurun has one GPU, so GG_COMM_FAKE_WORLD=3 feeds the
+    3-rank code path with three copies of the local pack: the applied gradient must be exactly
+    3x the local one (offsets, counts, per-rank launches, flag union all exercised)."""
+    monkeypatch.setenv("GG_COMM_FAKE_WORLD", "3")
+    n, d = 400, 64
+    Eg, Ed, bg, bd = make_models(n, d, 21)
+    opt = ga.GG_OPT_SGD if mode == "sgd" else ga.GG_OPT_ADAM_LAZY
+    eng = engine_with(ga, Eg, Ed, bg, bd, optimizer=opt)
+    monkeypatch.delenv("GG_COMM_FAKE_WORLD")
+    dis = orc.Discriminator(Ed, 1e-3, lazy=True)
+    dis.b[:] = bd
+    rs = np.random.RandomState(8)
+    for t in range(3):
+        B = 2000
+        u, v = rs.randint(0, n // 2, B), rs.randint(0, n // 2, B)
+        lab = (rs.rand(B) < 0.5).astype(np.float32)
+        _, gu, gv, gb = dis.loss_and_grads(u, v, lab, 1e-5)
+        GE, Gb = np.zeros((n, d), np.float64), np.zeros(n)
+        np.add.at(GE, u, gu)
+        np.add.at(GE, v, gv)
+        np.add.at(Gb, v, gb)
+        GE, Gb = (3 * GE).astype(np.float32), (3 * Gb).astype(np.float32)
+        rows = np.flatnonzero((np.abs(GE).sum(1) > 0) | (Gb != 0))
+        if mode == "sgd":
+            dis.E -= np.float32(1e-3) * GE
+            dis.b -= np.float32(1e-3) * Gb
+        else:
+            dis.opt.step([dis.E, dis.b], [(rows, GE[rows]), (rows, Gb[rows])])
+        eng.d_step(u, v, lab)
+        assert np.allclose(eng.get_embeddings(1), dis.E, rtol=3e-5, atol=2e-6), t
+        assert np.allclose(eng.get_bias(1), dis.b, rtol=3e-5, atol=2e-6), t
+    assert np.array_equal(eng.get_embeddings(1)[n // 2:], Ed[n // 2:])
+    eng.close()
