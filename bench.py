@@ -145,12 +145,11 @@ def main():
     setup_s = time.time() - t_setup
 
     def step(i):
+        # every rank issues both passes (they contain the replicas' gradient exchange), even with no rows
         rows = eng.prepare_d(slots, args.seed, 2 * i, fetch=False)
-        if rows:
-            eng.d_pass(np.zeros(1, np.int64), int(rows))
+        eng.d_pass(np.zeros(1, np.int64), max(int(rows), 1))
         pairs = eng.prepare_g(slots, args.n_sample_gen, args.seed, 2 * i + 1, fetch=False)
-        if pairs:
-            eng.g_pass(np.zeros(1, np.int64), int(pairs))
+        eng.g_pass(np.zeros(1, np.int64), max(int(pairs), 1))
 
     def barrier():
         eng.comm_barrier()
@@ -208,7 +207,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": wl_name, "roots_per_gpu_per_step": int(R), "n_sample_gen": args.n_sample_gen,
                    "optimizer": args.optimizer, "step": "prepare_d + d_pass + prepare_g + g_pass (graph_gan.py:144-176, one inner pass each)",
-                   "parallelism": "roots sharded x%d, replicated tables, RCCL grad all-reduce" % world if world > 1 else "single GPU"},
+                   "parallelism": "roots sharded x%d, replicated tables, RCCL sparse gradient all-gather per pass" % world if world > 1 else "single GPU"},
         "d_step_pairs_per_sec": tot[1] / tot[3],
         "g_step_pairs_per_sec": tot[2] / tot[3],
         "walk_kernel_edges_per_sec": hops / (walk_ms * 1e-3) if walk_ms > 0 else None,

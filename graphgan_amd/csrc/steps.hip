@@ -526,6 +526,16 @@ static int run_pass(gg_ctx *ctx, int which, const int64_t *starts, int64_t n_bat
     const int32_t *v = which == 1 ? ctx->d_neighbor.as<int32_t>() : ctx->g_node2.as<int32_t>();
     const float *x = which == 1 ? ctx->d_label.as<float>() : ctx->g_reward.as<float>();
     GG_HIP(ctx, hipSetDevice(ctx->device));
+    if (rows == 0) {
+        // nothing prepared on this rank; with replicas it still has to take part in the step's
+        // gradient exchange (the other ranks are waiting in the collective)
+        if (ctx->comm && n_batches > 0) {
+            int rc = apply_optimizer(ctx, which, 0);
+            if (rc != GG_OK) return rc;
+            GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        return GG_OK;
+    }
     GG_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     const bool whole = n_batches == 1 && starts[0] == 0 && batch_size >= rows && rows > 0;
     if (which == 0 && whole && ctx->g_paths_valid && ctx->cfg.window_size <= 2 && ctx->ld <= 256 && !getenv("GG_NO_PATH_GRAD")) {
