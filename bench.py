@@ -111,6 +111,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    share_gpu = os.environ.get("GG_BENCH_SHARE_GPU") == "1"  # plumbing test on a 1-GPU box: all ranks on device 0, no RCCL
+    if share_gpu:
+        local_rank = 0
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
@@ -141,7 +144,8 @@ def main():
         eng.build_trees(roots, device=True)
     trees_s = time.time() - t_trees
     slots = np.arange(len(roots), dtype=np.int32)
-    ctl.connect_engine(eng)
+    if not share_gpu:
+        ctl.connect_engine(eng)
     setup_s = time.time() - t_setup
 
     def step(i):
