@@ -34,6 +34,7 @@ struct StepArgs {
     int n;
     float lambda, inv_n;
     int is_d;
+    int ppg;               // consecutive pairs handled by one 16-lane group
 };
 
 // One 16-lane group per run of PAIRS_PER_GROUP consecutive pairs.  The reference's batches are
@@ -42,15 +43,15 @@ struct StepArgs {
 // The u-side gradient is therefore accumulated in registers while u stays the same and flushed
 // with one row of atomics per run; the v side goes out per pair.  Lane t owns floats t, t+16, ...
 // so that one atomic instruction of the group covers one contiguous 64-byte line.
-constexpr int PAIRS_PER_GROUP = 16;
+constexpr int PAIRS_PER_GROUP = 16;  // large fused batches; small (B = 64) batches use 1 pair per group: latency, not contention, rules there
 
 template <int NF>  // NF = ceil(ld / 16) floats per lane
 __global__ __launch_bounds__(256) void pair_grad_kernel(const StepArgs a) {
     const int t = threadIdx.x & 15;
     const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const int p0 = g * PAIRS_PER_GROUP;
+    const int p0 = g * a.ppg;
     if (p0 >= a.n) return;
-    const int p1 = min(p0 + PAIRS_PER_GROUP, a.n);
+    const int p1 = min(p0 + a.ppg, a.n);
     const int nchunk = a.ld >> 2;
     float accu[NF];
 #pragma unroll
@@ -368,7 +369,8 @@ int run_step(gg_ctx *ctx, int which, const int32_t *d_u, const int32_t *d_v, con
     s.lambda = M.lambda;
     s.inv_n = 1.0f / (float)n;
     s.is_d = which == 1;
-    const int groups = cdiv(n, PAIRS_PER_GROUP);
+    s.ppg = n >= 16384 ? PAIRS_PER_GROUP : (n >= 2048 ? 4 : 1);
+    const int groups = cdiv(n, s.ppg);
     const int blocks = cdiv((int64_t)groups * 16, 256);
     const int nf = (ctx->ld + 15) / 16;
     if (nf <= 4) hipLaunchKernelGGL(pair_grad_kernel<4>, dim3(blocks), dim3(256), 0, ctx->stream, s);
