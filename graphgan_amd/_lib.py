@@ -72,6 +72,8 @@ SIGNATURES = {
     "gg_all_score": (ctypes.c_int, [_P, _P, _i32, _P]),
     "gg_get_embeddings": (ctypes.c_int, [_P, _i32, _P]),
     "gg_get_bias": (ctypes.c_int, [_P, _i32, _P]),
+    "gg_write_embeddings": (ctypes.c_int, [_P, _i32, ctypes.c_char_p, _i32]),
+    "gg_host_write_embeddings": (ctypes.c_int, [_P, _i64, _i32, ctypes.c_char_p, _i32]),
     "gg_set_embeddings": (ctypes.c_int, [_P, _i32, _P]),
     "gg_set_bias": (ctypes.c_int, [_P, _i32, _P]),
     "gg_save_state": (ctypes.c_int, [_P, ctypes.c_char_p]),

@@ -68,6 +68,12 @@ def host_build_trees(n_node, rowptr, col, roots, n_threads=0):
     return off, nbr[: int(total)], base, int(dmax[0])
 
 
+def host_write_embeddings(path, emb, n_threads=0):
+    """The reference's ``.emb`` text (graph_gan.py:293-306), byte-identical, from host threads."""
+    emb = np.ascontiguousarray(emb, dtype=np.float32)
+    check(lib.gg_host_write_embeddings(_ptr(emb), emb.shape[0], emb.shape[1], str(path).encode(), n_threads))
+
+
 def synth_powerlaw(n_node, m, seed_graph=1, seed_perm=2):
     """Barabasi-Albert edge list [E, 2] int32 (SURVEY.md section 8d recipe)."""
     n = check(lib.gg_synth_powerlaw(n_node, m, seed_graph, seed_perm, None, 0))
@@ -233,6 +239,10 @@ class Engine:
         out = np.zeros((self.n_node, self.n_emb), dtype=np.float32)
         self._ck(lib.gg_get_embeddings(self._ctx, which, _ptr(out)))
         return out
+
+    def write_embeddings(self, which, path, n_threads=0):
+        """write_embeddings_to_file (graph_gan.py:293-306) for one model, natively."""
+        self._ck(lib.gg_write_embeddings(self._ctx, which, str(path).encode(), n_threads))
 
     def get_bias(self, which):
         out = np.zeros(self.n_node, dtype=np.float32)

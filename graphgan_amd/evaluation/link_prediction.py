@@ -8,13 +8,15 @@ from .. import utils
 
 
 class LinkPredictEval(object):
-    def __init__(self, embed_filename, test_filename, test_neg_filename, n_node, n_embed):
+    def __init__(self, embed_filename, test_filename, test_neg_filename, n_node, n_embed, emd=None):
         self.embed_filename = embed_filename
         self.test_filename = test_filename
         self.test_neg_filename = test_neg_filename
         self.n_node = n_node
         self.n_embed = n_embed
-        self.emd = utils.read_embeddings(embed_filename, n_node=n_node, n_embed=n_embed)
+        # ``emd`` (float64 [n_node, n_embed]) skips re-parsing the text that was just written: the file holds
+        # repr(float64(fp32)) of exactly these numbers, so parsing it back gives the same matrix
+        self.emd = emd if emd is not None else utils.read_embeddings(embed_filename, n_node=n_node, n_embed=n_embed)
 
     def eval_link_prediction(self):
         edges = np.array(utils.read_edges_from_file(self.test_filename) +

@@ -12,7 +12,7 @@ calls into ``libgraphgan_hip.so`` (``graphgan_amd.engine.Engine``):
     sess.run(discriminator.reward) (:220-222)             device kernel inside prepare_g (K2)
     sess.run(d_updates) loop (:149-157)                   Engine.d_pass (K3 + K5)
     sess.run(g_updates) loop (:168-176)                   Engine.g_pass (K4 + K5)
-    sess.run(embedding_matrix) (:298)                     Engine.get_embeddings
+    sess.run(embedding_matrix) (:298) + text formatting   Engine.get_embeddings / write_embeddings (native, same bytes)
     tf.train.Saver (:55,124-127,137-138)                  Engine.save_state / load_state
 
 Run exactly like the reference: ``cd src/GraphGAN && python <this file>`` -- a ``config.py`` in
@@ -227,11 +227,8 @@ class GraphGAN(object):
         fp64 and printed with ``str`` (what ``np.hstack([index, matrix]).tolist()`` gives)"""
         cfg = self.config
         for i in range(2):
-            matrix = self.engine.get_embeddings(i).astype(np.float64)
             os.makedirs(os.path.dirname(cfg.emb_filenames[i]) or ".", exist_ok=True)
-            with open(cfg.emb_filenames[i], "w+") as f:
-                f.write(str(self.n_node) + "\t" + str(cfg.n_emb) + "\n")
-                f.writelines(str(idx) + "\t" + "\t".join(map(str, row)) + "\n" for idx, row in enumerate(matrix.tolist()))
+            self.engine.write_embeddings(i, cfg.emb_filenames[i])  # native formatter, byte-identical text
 
     @staticmethod
     def evaluation(self):
@@ -239,7 +236,8 @@ class GraphGAN(object):
         results = []
         if cfg.app == "link_prediction":
             for i in range(2):
-                lpe = lp.LinkPredictEval(cfg.emb_filenames[i], cfg.test_filename, cfg.test_neg_filename, self.n_node, cfg.n_emb)
+                lpe = lp.LinkPredictEval(cfg.emb_filenames[i], cfg.test_filename, cfg.test_neg_filename, self.n_node, cfg.n_emb,
+                                         emd=self.engine.get_embeddings(i).astype(np.float64))
                 result = lpe.eval_link_prediction()
                 results.append(cfg.modes[i] + ":" + str(result) + "\n")
         os.makedirs(os.path.dirname(cfg.result_filename) or ".", exist_ok=True)

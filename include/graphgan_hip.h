@@ -183,6 +183,11 @@ int gg_all_score(gg_ctx *ctx, const int32_t *rows, int32_t n_rows, float *out);
  * (config.modes order, config.py:1).  out is [n_node, n_emb] fp32, unpadded. */
 int gg_get_embeddings(gg_ctx *ctx, int32_t which, float *out);
 int gg_get_bias(gg_ctx *ctx, int32_t which, float *out);
+/* gg_write_embeddings: write_embeddings_to_file (graph_gan.py:293-306) for one model, byte-identical to
+ * the reference's text (header "N\td\n"; rows "id\tv0\t...\n"; str(float64(fp32)) per value), formatted by
+ * host threads.  gg_host_write_embeddings: the same for a caller-supplied [n_node, n_emb] fp32 matrix. */
+int gg_write_embeddings(gg_ctx *ctx, int32_t which, const char *path, int32_t n_threads);
+int gg_host_write_embeddings(const float *emb, int64_t n_node, int32_t n_emb, const char *path, int32_t n_threads);
 int gg_set_embeddings(gg_ctx *ctx, int32_t which, const float *emb);
 int gg_set_bias(gg_ctx *ctx, int32_t which, const float *bias);
 

@@ -89,3 +89,21 @@ def test_synth_powerlaw(ga):
     assert not np.any(e[:, 0] == e[:, 1])
     u = np.unique(np.sort(e, 1), axis=0)
     assert len(u) == len(e)  # simple graph
+
+
+def test_native_embedding_writer_is_byte_identical(ga, tmp_path):
+    """gg_host_write_embeddings == the reference's write_embeddings_to_file text (graph_gan.py:293-306:
+    hstack promotes fp32 -> fp64, str(x) per value), including the notation switches of repr()."""
+    rs = np.random.RandomState(0)
+    special = np.array([0.0, -0.0, 1.0, -1.0, 123.0, 1e-4, 9.999e-5, 1e-5, 1.5e-5, 1e15, 1e16, 1.2345e20, 3.4e38, 1e-38, 1.4e-45,
+                        0.1, 0.5, 2.5, 100000.0, 16777216.0, 0.22650299966335297, -0.016766, 65504.0, 1e-7, 123456.789], dtype=np.float32)
+    emb = np.concatenate([special, (rs.randn(2975) * 10.0 ** rs.randint(-8, 8, 2975)).astype(np.float32)]).reshape(-1, 50)
+    emb = np.concatenate([emb, rs.randn(5000, 50).astype(np.float32)])
+    n, d = emb.shape
+    want = [str(n) + "\t" + str(d) + "\n"]
+    mat = np.hstack([np.array(range(n)).reshape(-1, 1), emb]).tolist()
+    want += [str(int(r[0])) + "\t" + "\t".join(str(x) for x in r[1:]) + "\n" for r in mat]
+    for threads in (1, 5):
+        path = tmp_path / ("emb%d.txt" % threads)
+        ga.host_write_embeddings(path, emb, n_threads=threads)
+        assert open(path).read() == "".join(want)
