@@ -393,8 +393,11 @@ class TF1Adam:
 # ----------------------------------------------------------------------------- models
 
 def _sigmoid(x):
+    """tf.nn.sigmoid on fp32 tensors: evaluated in fp32 (saturates to exactly 1.0 for x > ~16.6, like
+    TF's fp32 kernel), not in fp64."""
+    x = x.astype(np.float32)
     with np.errstate(over="ignore"):
-        return (1.0 / (1.0 + np.exp(-x.astype(np.float64)))).astype(np.float32)
+        return (np.float32(1) / (np.float32(1) + np.exp(-x))).astype(np.float32)
 
 
 class PairModel:
