@@ -39,7 +39,7 @@ def parse():
     p.add_argument("--nodes", type=int, default=1_000_000)
     p.add_argument("--m", type=int, default=10)
     p.add_argument("--emb", type=int, default=128)
-    p.add_argument("--roots", type=int, default=2048, help="root slots per rank per step")
+    p.add_argument("--roots", type=int, default=8192, help="root slots per rank per step (8192 trees of the 1M-node graph = 96 GB of the 288 GB HBM)")
     p.add_argument("--n-sample-gen", type=int, default=20)
     p.add_argument("--optimizer", default="adam_lazy", choices=["adam_dense", "adam_lazy", "sgd"])
     p.add_argument("--threads", type=int, default=0, help="host BFS threads (0 = min(64, cores))")
