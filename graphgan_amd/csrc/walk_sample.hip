@@ -400,6 +400,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const
             gc[cc] = (ch < a.nchunk) ? crow[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         const int myid = (t < nblock) ? ids[t] : -1;  // the chunk's ids with one coalesced load
+        const float mybias = (t < nblock) ? a.bias[myid] : 0.f;  // ... and its biases with one 16-lane gather
         for (int j0 = 0; j0 < nblock; j0 += UNROLL) {
             float4 y[UNROLL][NCH];
             int id[UNROLL];
@@ -428,7 +429,8 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const
                 acc = acc + __shfl_xor(acc, 4, 64);
                 acc = acc + __shfl_xor(acc, 2, 64);
                 acc = acc + __shfl_xor(acc, 1, 64);
-                if (id[u] >= 0 && t == 0) out[j0 + u] = acc + a.bias[id[u]];
+                const float bj = __shfl(mybias, j0 + u, 16);
+                if (id[u] >= 0 && t == 0) out[j0 + u] = acc + bj;
             }
         }
         rows += (unsigned long long)nblock;
