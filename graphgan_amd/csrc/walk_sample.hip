@@ -401,6 +401,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const
         }
         const int myid = (t < nblock) ? ids[t] : -1;  // the chunk's ids with one coalesced load
         const float mybias = (t < nblock) ? a.bias[myid] : 0.f;  // ... and its biases with one 16-lane gather
+        float mysc = 0.f;
         for (int j0 = 0; j0 < nblock; j0 += UNROLL) {
             float4 y[UNROLL][NCH];
             int id[UNROLL];
@@ -429,10 +430,10 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const
                 acc = acc + __shfl_xor(acc, 4, 64);
                 acc = acc + __shfl_xor(acc, 2, 64);
                 acc = acc + __shfl_xor(acc, 1, 64);
-                const float bj = __shfl(mybias, j0 + u, 16);
-                if (id[u] >= 0 && t == 0) out[j0 + u] = acc + bj;
+                if (t == j0 + u) mysc = acc + mybias;  // lane j keeps the score of candidate j
             }
         }
+        if (t < nblock) out[t] = mysc;  // one coalesced 64-byte store per chunk
         rows += (unsigned long long)nblock;
     }
     // one counter update per block (same-address atomics serialise at ~12 ns each)
