@@ -132,7 +132,7 @@ int gg::walk_finalize(gg_ctx *ctx, bool *retried) {
     unsigned long long c0[6] = {(unsigned long long)ctx->ctr.hops, (unsigned long long)ctx->ctr.nbr_reads, 0, 0, 0,
                                 (unsigned long long)ctx->ctr.rows_scored};
     unsigned long long *c = ctx->h_ctr;  // 200 words, one read-back
-    GG_HIP(ctx, hipMemcpyAsync(c, ctx->dev_ctr, sizeof(unsigned long long) * 264, hipMemcpyDeviceToHost, ctx->stream));
+    GG_HIP(ctx, hipMemcpyAsync(c, ctx->dev_ctr, sizeof(unsigned long long) * 392, hipMemcpyDeviceToHost, ctx->stream));
     GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (c[3] == 2ull) {
         // nothing the overflowed launch wrote is final (the D-mode post-pass is gated by the same flag)
@@ -141,9 +141,18 @@ int gg::walk_finalize(gg_ctx *ctx, bool *retried) {
         int rc = launch_walk_sample(ctx, ctx->w_nslots, total, ctx->w_args.for_d, ctx->w_args.seed, ctx->w_args.stream, ctx->w_stride);
         ctx->walk_force_sized = false;
         if (rc != GG_OK) return rc;
-        GG_HIP(ctx, hipMemcpyAsync(c, ctx->dev_ctr, sizeof(unsigned long long) * 264, hipMemcpyDeviceToHost, ctx->stream));
+        GG_HIP(ctx, hipMemcpyAsync(c, ctx->dev_ctr, sizeof(unsigned long long) * 392, hipMemcpyDeviceToHost, ctx->stream));
         GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (retried) *retried = true;
+    }
+    // ctr[0], ctr[1]: cumulative counts of the per-walk finisher; the level pipeline's counts of THIS launch
+    // sit in 64 spread words each -> fold them into the cumulative device words
+    unsigned long long lv_hops = 0, lv_reads = 0;
+    for (int i = 0; i < 64; ++i) { lv_hops += c[264 + i]; lv_reads += c[328 + i]; }
+    if (lv_hops || lv_reads) {
+        c[0] += lv_hops;
+        c[1] += lv_reads;
+        GG_HIP(ctx, hipMemcpy(ctx->dev_ctr, c, sizeof(unsigned long long) * 2, hipMemcpyHostToDevice));
     }
     ctx->ctr.hops = (int64_t)c[0];
     ctx->ctr.nbr_reads = (int64_t)c[1];

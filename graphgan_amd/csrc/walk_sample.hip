@@ -190,7 +190,9 @@ constexpr int CTR_ALIVE = 8;    // ctr[CTR_ALIVE + level]: walks alive when hop 
 constexpr int CTR_BIG = 72;     // ctr[CTR_BIG + level]:   big owner tasks of hop `level`
 constexpr int CTR_CHUNKS = 136; // ctr[CTR_CHUNKS + level]: chunks of hop `level` (chunk offsets are handed out per wave)
 constexpr int CTR_ROWS = 200;   // ctr[CTR_ROWS + level]: candidate rows scored at hop `level`
-constexpr int CTR_WORDS = 264;
+constexpr int CTR_HOPS_V = 264;  // ctr[CTR_HOPS_V + (block & 63)]: hop counts of the level pipeline, spread over 64 words
+constexpr int CTR_READS_V = 328; // (same-address atomics serialise at ~12 ns each); summed by the host
+constexpr int CTR_WORDS = 392;
 constexpr int MAX_LEVELS = 64;
 
 // One thread per walk (a wave = 64 consecutive walks), fused per hop boundary:
@@ -305,8 +307,8 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) my_k += __shfl_xor(my_k, off, 64);
         if (lane == 0 && bal) {
-            atomicAdd(&a.ctr[0], (unsigned long long)__popcll(bal));
-            atomicAdd(&a.ctr[1], my_k);
+            atomicAdd(&a.ctr[CTR_HOPS_V + (blockIdx.x & 63)], (unsigned long long)__popcll(bal));
+            atomicAdd(&a.ctr[CTR_READS_V + (blockIdx.x & 63)], my_k);
         }
     }
     if (!do_setup) return;
@@ -319,37 +321,62 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     }
     const bool owns = in_range && alive && owner == lane;
     const int chunks = owns ? (k + CHUNK - 1) / CHUNK : 0;
-    // chunk offsets: in-wave exclusive scan + ONE atomic per wave on the level's chunk counter (the
-    // order of the waves' regions in the score buffer is irrelevant), no separate scan kernel
+    const bool big = owns && k > BIG_TASK;
+    // chunk offsets and big-task slots: in-wave exclusive scans, per-block totals through LDS, and ONE
+    // returning atomic per block and counter (a single word serves only ~88 returning atomics per us);
+    // the order of the blocks' regions in the score buffer is irrelevant
+    __shared__ int wv_chunks[4], wv_big[4];
+    __shared__ unsigned long long blk_base[2];
     int inc = chunks;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const int o = __shfl_up(inc, off, 64);
         if (lane >= off) inc += o;
     }
-    const int wave_total = __shfl(inc, 63, 64);
-    unsigned long long base = 0;
-    if (lane == 0 && wave_total) base = atomicAdd(&a.ctr[CTR_CHUNKS + a.level], (unsigned long long)wave_total);
-    base = __shfl(base, 0, 64);
-    const int64_t coff = (int64_t)base + inc - chunks;
-    const bool fits = (int64_t)base + wave_total <= cap_chunks;
-    if (write_desc && !fits && lane == 0) a.ctr[3] = 2ull;  // speculative capacity exceeded: the host reruns in sized mode
+    const unsigned long long big_bal = __ballot(big);
+    const int wv = threadIdx.x >> 6;
+    if (lane == 63) wv_chunks[wv] = inc;
+    if (lane == 0) wv_big[wv] = __popcll(big_bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tc = wv_chunks[0] + wv_chunks[1] + wv_chunks[2] + wv_chunks[3];
+        const int tb = wv_big[0] + wv_big[1] + wv_big[2] + wv_big[3];
+        blk_base[0] = tc ? atomicAdd(&a.ctr[CTR_CHUNKS + a.level], (unsigned long long)tc) : 0ull;
+        blk_base[1] = tb ? atomicAdd(&a.ctr[CTR_BIG + a.level], (unsigned long long)tb) : 0ull;
+    }
+    __syncthreads();
+    int chunks_before = 0, big_before = 0, blk_chunks = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < wv) { chunks_before += wv_chunks[i]; big_before += wv_big[i]; }
+        blk_chunks += wv_chunks[i];
+    }
+    const int64_t coff = (int64_t)blk_base[0] + chunks_before + inc - chunks;
+    const bool fits = (int64_t)blk_base[0] + blk_chunks <= cap_chunks;
+    if (write_desc == 1 && !fits && threadIdx.x == 0) a.ctr[3] = 2ull;  // speculative capacity exceeded: the host reruns in sized mode
     if (in_range) {
         a.lv_beg[w] = beg_abs;
         a.lv_k[w] = k;
         a.lv_owner[w] = (int32_t)((w & ~63ll) + owner);
         a.lv_chunks[w] = chunks;
         a.lv_coff[w] = coff;
-        if (owns && k > BIG_TASK) a.lv_big[atomicAdd(&a.ctr[CTR_BIG + a.level], 1ull)] = (int32_t)w;
-        if (write_desc && fits) {
+        if (big) a.lv_big[blk_base[1] + big_before + __popcll(big_bal & ((1ull << lane) - 1ull))] = (int32_t)w;
+        if (write_desc == 1 && fits) {
             for (int i = 0; i < chunks; ++i) {
                 const int64_t o = beg_abs + (int64_t)i * CHUNK;
                 a.lv_chunk_desc[coff + i] = make_int4(cur, min(CHUNK, k - i * CHUNK), (int)(o & 0xffffffffll), (int)(o >> 32));
             }
         }
     }
+    // walks still alive at this hop: one atomic per block
+    __shared__ int wv_alive[4];
     const unsigned long long bal = __ballot(alive);
-    if (lane == 0 && bal) atomicAdd(&a.ctr[CTR_ALIVE + a.level], (unsigned long long)__popcll(bal));
+    if (lane == 0) wv_alive[wv] = __popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int ta = wv_alive[0] + wv_alive[1] + wv_alive[2] + wv_alive[3];
+        if (ta) atomicAdd(&a.ctr[CTR_ALIVE + a.level], (unsigned long long)ta);
+    }
 }
 
 // chunk descriptors (one thread per walk; owners describe their chunks): everything the score
@@ -741,7 +768,7 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
         GG_HIP(ctx, hipEventRecord(ctx->lv_ev[2 * level + 1], ctx->stream));
         ctx->lv_ev_used = level + 1;
         hipLaunchKernelGGL(level_weights_small_kernel, dim3((unsigned)cdiv(total_walks * 16, 256)), dim3(256), 0, ctx->stream, a, cap);
-        hipLaunchKernelGGL(level_weights_big_kernel, dim3(512), dim3(256), 0, ctx->stream, a, cap);
+        hipLaunchKernelGGL(level_weights_big_kernel, dim3(2048), dim3(256), 0, ctx->stream, a, cap);
     }
     // finish the last prepared hop
     a.level = level;
