@@ -209,6 +209,20 @@ __global__ __launch_bounds__(256) void path_grad_kernel(const PathArgs a) {
             }
             gb[sl] += ds;
         }
+        // issue the next row's loads BEFORE the flush: vmcnt retires in order, so a load queued behind
+        // the 2*NF atomics of a flush would wait for all of them
+        const int npos = c + 3;
+        const int nnode = (npos < L) ? p[npos] : -1;
+        const float nbv = nnode >= 0 ? a.b[nnode] : 0.f;
+        float Rn[NF];
+        {
+            const float *row = a.E + (int64_t)(nnode >= 0 ? nnode : 0) * a.ld;
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const int f = t + 16 * i;
+                Rn[i] = (nnode >= 0 && f < a.ld) ? row[f] : 0.f;
+            }
+        }
         flush(0);  // node c-2 has received its last contribution
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) {
@@ -216,7 +230,9 @@ __global__ __launch_bounds__(256) void path_grad_kernel(const PathArgs a) {
 #pragma unroll
             for (int i = 0; i < NF; ++i) { R[sl][i] = R[sl + 1][i]; A[sl][i] = A[sl + 1][i]; }
         }
-        load(4, c + 3);
+        node[4] = nnode; bv[4] = nbv; gb[4] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NF; ++i) { R[4][i] = Rn[i]; A[4][i] = 0.f; }
     }
     flush(0);
     flush(1);
