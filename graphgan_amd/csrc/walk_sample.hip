@@ -727,7 +727,6 @@ static int reserve_level_buffers(gg_ctx *ctx, WalkArgs &a, int64_t chunks) {
 template <int NCH>
 static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_levels, bool sized, bool *any_alive) {
     const dim3 blk(WAVES_PER_BLOCK * 64);
-    GG_HIP(ctx, hipMemsetAsync(ctx->dev_ctr + CTR_ALIVE, 0, sizeof(unsigned long long) * (CTR_WORDS - CTR_ALIVE), ctx->stream));
     int64_t cap = sized ? 0 : ctx->lv_cap_chunks;
     if (!sized) {
         int rc = reserve_level_buffers(ctx, a, cap);
@@ -860,7 +859,9 @@ int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int fo
     a.abort_walk = ctx->w_abort.as<int32_t>();
     a.ctr = ctx->dev_ctr;
 
+    // per-launch words: ticket [4], per-level counters and the spread hop counters [CTR_ALIVE, CTR_WORDS)
     GG_HIP(ctx, hipMemsetAsync(ctx->dev_ctr + 4, 0, sizeof(unsigned long long), ctx->stream));
+    GG_HIP(ctx, hipMemsetAsync(ctx->dev_ctr + CTR_ALIVE, 0, sizeof(unsigned long long) * (CTR_WORDS - CTR_ALIVE), ctx->stream));
     hipLaunchKernelGGL(walk_init_status_kernel, dim3(cdiv(n_slots, 256)), dim3(256), 0, ctx->stream, a);
     if (total_walks == 0) return GG_OK;
 
