@@ -6,5 +6,5 @@ All numerics live in ``libgraphgan_hip.so`` (hand-written HIP for gfx950, C ABI 
 """
 from ._lib import (GG_OPT_ADAM_DENSE, GG_OPT_ADAM_LAZY, GG_OPT_SGD, GG_ROOT_ABORTED, GG_ROOT_EMPTY, GG_ROOT_OK,  # noqa: F401
                    GraphGANHipError)
-from .engine import (Engine, edges_to_csr, graph_to_csr, host_build_trees, host_write_embeddings,  # noqa: F401
+from .engine import (CSRGraph, Engine, edges_to_csr, read_edges_csr, graph_to_csr, host_build_trees, host_write_embeddings,  # noqa: F401
                      synth_powerlaw)

@@ -37,6 +37,11 @@ class GGCounters(ctypes.Structure):
                 ("score_launches", ctypes.c_int64), ("score_chunks", ctypes.c_int64), ("reserved", ctypes.c_int64 * 1)]
 
 
+class GGGraph(ctypes.Structure):
+    _fields_ = [("n_node", ctypes.c_int32), ("nnz", ctypes.c_int64), ("n_train_edges", ctypes.c_int64),
+                ("n_test_edges", ctypes.c_int64), ("rowptr", ctypes.POINTER(ctypes.c_int64)), ("col", ctypes.POINTER(ctypes.c_int32))]
+
+
 class GraphGANHipError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("%s (%d): %s" % (ERROR_NAMES.get(code, "GG_E?"), code, msg))
@@ -83,6 +88,8 @@ SIGNATURES = {
     "gg_comm_init": (ctypes.c_int, [_P, _P, _i32, _i32]),
     "gg_comm_barrier": (ctypes.c_int, [_P]),
     "gg_synth_powerlaw": (_i64, [_i32, _i32, _u64, _u64, _P, _i64]),
+    "gg_host_read_edges": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(GGGraph)]),
+    "gg_host_free_graph": (None, [ctypes.POINTER(GGGraph)]),
 }
 
 

@@ -68,6 +68,43 @@ def host_build_trees(n_node, rowptr, col, roots, n_threads=0):
     return off, nbr[: int(total)], base, int(dmax[0])
 
 
+def read_edges_csr(train_filename, test_filename=""):
+    """``utils.read_edges`` (utils.py:12-54) natively -> (n_node, rowptr int64 [N+1], col int32), list order kept."""
+    g = _lib.GGGraph()
+    check(lib.gg_host_read_edges(str(train_filename).encode(), str(test_filename or "").encode(), ctypes.byref(g)))
+    try:
+        rowptr = np.ctypeslib.as_array(g.rowptr, shape=(g.n_node + 1,)).copy()
+        col = np.ctypeslib.as_array(g.col, shape=(max(g.nnz, 1),))[: g.nnz].copy()
+        return int(g.n_node), rowptr, col
+    finally:
+        lib.gg_host_free_graph(ctypes.byref(g))
+
+
+class CSRGraph:
+    """Read-only stand-in for the reference's adjacency dict (``graph[i]`` -> list of neighbours)."""
+
+    def __init__(self, rowptr, col):
+        self.rowptr, self.col = rowptr, col
+
+    def __len__(self):
+        return len(self.rowptr) - 1
+
+    def __getitem__(self, v):
+        return self.col[self.rowptr[v]:self.rowptr[v + 1]].tolist()
+
+    def get(self, v, default=None):
+        return self[v] if 0 <= v < len(self) else default
+
+    def keys(self):
+        return range(len(self))
+
+    def __iter__(self):
+        return iter(range(len(self)))
+
+    def __contains__(self, v):
+        return 0 <= v < len(self)
+
+
 def host_write_embeddings(path, emb, n_threads=0):
     """The reference's ``.emb`` text (graph_gan.py:293-306), byte-identical, from host threads."""
     emb = np.ascontiguousarray(emb, dtype=np.float32)

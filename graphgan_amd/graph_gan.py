@@ -6,7 +6,8 @@ calls into ``libgraphgan_hip.so`` (``graphgan_amd.engine.Engine``):
 
     reference                                             here
     ----------------------------------------------------  -------------------------------------------
-    construct_trees (:84-108) + pickle cache (:31-46)     Engine.build_trees (threaded C++ BFS -> HBM)
+    utils.read_edges (utils.py:12-54)                     read_edges_csr (native ingest, same list order)
+    construct_trees (:84-108) + pickle cache (:31-46)     Engine.build_trees (BFS on the GPU, or threaded host BFS)
     sample (:225-270) incl. sess.run(all_score) (:238)    Engine.walk_sample / prepare_d / prepare_g (K1)
     get_node_pairs_from_path (:272-291)                   device kernel inside prepare_g (K6)
     sess.run(discriminator.reward) (:220-222)             device kernel inside prepare_g (K2)
@@ -54,7 +55,9 @@ class GraphGAN(object):
         self.config = cfg if cfg is not None else config
         cfg = self.config
         print("reading graphs...")
-        self.n_node, self.graph = utils.read_edges(cfg.train_filename, cfg.test_filename)
+        # native ingest (same adjacency as utils.read_edges, utils.py:12-47); self.graph[i] still lists i's neighbours
+        self.n_node, self._rowptr, self._col = _engine.read_edges_csr(cfg.train_filename, cfg.test_filename)
+        self.graph = _engine.CSRGraph(self._rowptr, self._col)
         self.root_nodes = [i for i in range(self.n_node)]
 
         print("reading initial embeddings...")
@@ -91,8 +94,7 @@ class GraphGAN(object):
                 self.node_embed_init_g, self.node_embed_init_d, lr_gen=cfg.lr_gen, lr_dis=cfg.lr_dis,
                 lambda_gen=cfg.lambda_gen, lambda_dis=cfg.lambda_dis, window_size=cfg.window_size,
                 optimizer=_OPTIMIZERS[_cfg(cfg, "engine_optimizer", "adam_dense")], device=int(_cfg(cfg, "engine_device", 0)))
-            rowptr, col = _engine.graph_to_csr(self.n_node, self.graph)
-            self.engine.set_graph_csr(rowptr, col)
+            self.engine.set_graph_csr(self._rowptr, self._col)
         return self.engine
 
     def build_generator(self):

@@ -207,6 +207,19 @@ int gg_comm_unique_id(void *id128);
 int gg_comm_init(gg_ctx *ctx, const void *id128, int32_t rank, int32_t world);
 int gg_comm_barrier(gg_ctx *ctx);
 
+/* ---- edge-list ingest: utils.read_edges (utils.py:12-54) natively -- adjacency CSR in the reference's
+ * list order from the train file (+ node ids of the test file); buffers are malloc'ed by the library and
+ * released with gg_host_free_graph.  No GPU, no ctx. */
+typedef struct gg_graph {
+    int32_t n_node;
+    int64_t nnz;            /* = 2 * n_train_edges */
+    int64_t n_train_edges, n_test_edges;
+    int64_t *rowptr;        /* [n_node + 1] */
+    int32_t *col;           /* [nnz] */
+} gg_graph;
+int gg_host_read_edges(const char *train_path, const char *test_path /* may be NULL or "" */, gg_graph *out);
+void gg_host_free_graph(gg_graph *g);
+
 /* ---- synthetic power-law graphs for the benchmark configs (BASELINE.json configs[2..4];
  * recipe in SURVEY.md section 8d): Barabasi-Albert, m edges per new node, node ids permuted.
  * edges_out: [n_edges_cap][2] int32; returns the number of edges written or GG_E*. */

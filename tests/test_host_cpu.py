@@ -107,3 +107,37 @@ def test_native_embedding_writer_is_byte_identical(ga, tmp_path):
         path = tmp_path / ("emb%d.txt" % threads)
         ga.host_write_embeddings(path, emb, n_threads=threads)
         assert open(path).read() == "".join(want)
+
+
+def test_native_edge_ingest_matches_read_edges(ga, tmp_path):
+    """gg_host_read_edges == utils.read_edges semantics (utils.py:12-54): list order, both directions,
+    self-loops listed twice, test-only nodes with empty lists, n_node = number of distinct ids."""
+    from graphgan_amd import utils
+    from tests.helpers import load_ca_grqc
+    d, n, graph = load_ca_grqc()
+    tr, te = tmp_path / "train.txt", tmp_path / "test.txt"
+    with open(tr, "w") as f:
+        f.writelines("%d\t%d\n" % (a, b) for a, b in d["train"].tolist())
+    with open(te, "w") as f:
+        f.writelines("%d %d\r\n" % (a, b) for a, b in d["test"].tolist())  # other separators / line ends
+    n2, rowptr, col = ga.read_edges_csr(tr, te)
+    n3, graph3 = utils.read_edges(str(tr), str(te))
+    want_rowptr, want_col = ga.graph_to_csr(n3, graph3)
+    assert n2 == n3 == n == 5242
+    assert np.array_equal(rowptr, want_rowptr) and np.array_equal(col, want_col)
+    g = ga.CSRGraph(rowptr, col)
+    assert len(g) == n and g[4095] == graph[4095] and g[int(np.flatnonzero(np.diff(rowptr) == 0)[0])] == []
+    # errors are codes with messages
+    bad = tmp_path / "bad.txt"
+    bad.write_text("0 1\n2\n")
+    with pytest.raises(ga.GraphGANHipError) as ei:
+        ga.read_edges_csr(bad)
+    assert ei.value.code == -1 and "one id" in str(ei.value)
+    gap = tmp_path / "gap.txt"
+    gap.write_text("0 1\n1 5\n")
+    with pytest.raises(ga.GraphGANHipError) as ei:
+        ga.read_edges_csr(gap)
+    assert "not 0..N-1" in str(ei.value)
+    with pytest.raises(ga.GraphGANHipError) as ei:
+        ga.read_edges_csr(tmp_path / "missing.txt")
+    assert ei.value.code == -6
