@@ -213,7 +213,8 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     int item = 0, cur = -1, k = 0;
     unsigned long long my_k = 0;
     int64_t beg_abs = 0;
-    if (in_range) {
+    // finished walks (the majority at the deeper hops) leave after ONE load
+    if (in_range && (!do_sample || a.st_alive[w] != 0)) {
         if (!do_sample) {
             item = find_item(a.walk_ptr, a.n_slots, w);
             a.st_item[w] = item;
@@ -231,8 +232,8 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
             a.paths[w * (int64_t)a.stride] = root;
             if (a.for_d) a.first_child[w] = -1;
         } else {
-            alive = a.st_alive[w] != 0;
-            if (alive) {
+            alive = true;
+            {
                 sampled = true;
                 const int kk = a.lv_k[w];
                 my_k = (unsigned long long)kk;
