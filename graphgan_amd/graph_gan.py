@@ -60,13 +60,16 @@ class GraphGAN(object):
         self.graph = _engine.CSRGraph(self._rowptr, self._col)
         self.root_nodes = [i for i in range(self.n_node)]
 
+        self.seed = int(_cfg(cfg, "engine_seed", 0))
+        # rows missing from the pre-trained file are drawn from the global numpy RNG (utils.py:63); the
+        # reference never seeds it (Q5) -- seeding it here makes the whole run reproducible
+        np.random.seed(self.seed)
         print("reading initial embeddings...")
         self.node_embed_init_d = utils.read_embeddings(filename=cfg.pretrain_emb_filename_d, n_node=self.n_node,
                                                        n_embed=cfg.n_emb)
         self.node_embed_init_g = utils.read_embeddings(filename=cfg.pretrain_emb_filename_g, n_node=self.n_node,
                                                        n_embed=cfg.n_emb)
 
-        self.seed = int(_cfg(cfg, "engine_seed", 0))
         self.host_rng = np.random.RandomState(self.seed)
 
         print("building GAN model...")
