@@ -110,6 +110,7 @@ struct gg_ctx {
     // multi-GPU
     void *comm = nullptr;  // ncclComm_t
     int32_t rank = 0, world = 1;
+    bool deterministic = false;  // GG_DETERMINISTIC=1: atomic-free gradient kernel for batches <= 256 pairs
     int32_t fake_world = 0;  // GG_COMM_FAKE_WORLD=k: exercise the k-rank exchange code on one GPU (every rank = this one)
     gg::DevBuf x_cnt, x_send_ids, x_send_rows, x_recv_ids, x_recv_rows;  // sparse gradient exchange
 

@@ -120,6 +120,93 @@ __global__ __launch_bounds__(256) void pair_grad_kernel(const StepArgs a) {
     }
 }
 
+// Deterministic variant for the reference's small batches (n <= DET_MAX_PAIRS; GG_DETERMINISTIC=1):
+// ONE workgroup, no atomics.  Pair coefficients go to LDS; every distinct row of the batch is
+// owned by the first slot that names it (slots = [u_0..u_{n-1}, v_0..v_{n-1}]) and its owner sums
+// the row's contributions in slot order, so two runs give bit-identical tables (the atomic kernel's
+// fp32 sums depend on scheduling).  Used to diff against the atomic mode and for reproducible runs.
+constexpr int DET_MAX_PAIRS = 256;
+
+template <int NF>
+__global__ __launch_bounds__(256) void pair_grad_det_kernel(const StepArgs a) {
+    __shared__ int32_t ids[2 * DET_MAX_PAIRS];
+    __shared__ float coef[DET_MAX_PAIRS], coefb[DET_MAX_PAIRS];
+    __shared__ uint8_t leader[2 * DET_MAX_PAIRS];
+    const int t = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int n = a.n, nchunk = a.ld >> 2;
+    for (int s = threadIdx.x; s < 2 * n; s += 256) ids[s] = s < n ? a.u[s] : a.v[s - n];
+    __syncthreads();
+    for (int p = g; p < n; p += 16) {
+        const int iu = ids[p], iv = ids[n + p];
+        const float4 *ru = (const float4 *)(a.E + (int64_t)iu * a.ld);
+        const float4 *rv = (const float4 *)(a.E + (int64_t)iv * a.ld);
+        float acc = 0.f;
+        for (int c = t; c < nchunk; c += 16) {
+            const float4 x = ru[c], y = rv[c];
+            acc = __builtin_fmaf(x.x, y.x, acc);
+            acc = __builtin_fmaf(x.y, y.y, acc);
+            acc = __builtin_fmaf(x.z, y.z, acc);
+            acc = __builtin_fmaf(x.w, y.w, acc);
+        }
+        acc += __shfl_xor(acc, 8, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 1, 64);
+        const float bv = a.b[iv];
+        const float sc = acc + bv;
+        const float sg = 1.0f / (1.0f + expf(-sc));
+        float ds;
+        if (a.is_d) {
+            ds = sg - a.x[p];
+        } else {
+            const bool inside = (sg >= 1e-5f) && (sg <= 1.0f);
+            ds = inside ? -(a.x[p] * a.inv_n) * (1.0f - sg) : 0.0f;
+        }
+        if (t == 0) {
+            coef[p] = ds;
+            coefb[p] = a.is_d ? ds + a.lambda * bv : ds;
+        }
+    }
+    for (int s = threadIdx.x; s < 2 * n; s += 256) {
+        bool first = true;
+        const int r = ids[s];
+        for (int s2 = 0; s2 < s; ++s2) first &= ids[s2] != r;
+        leader[s] = first;
+    }
+    __syncthreads();
+    for (int s = g; s < 2 * n; s += 16) {
+        if (!leader[s]) continue;
+        const int r = ids[s];
+        const float *own = a.E + (int64_t)r * a.ld;
+        float acc[NF], accb = 0.f;
+#pragma unroll
+        for (int i = 0; i < NF; ++i) acc[i] = 0.f;
+        for (int s2 = s; s2 < 2 * n; ++s2) {
+            if (ids[s2] != r) continue;
+            const int p = s2 < n ? s2 : s2 - n;
+            const int partner = s2 < n ? ids[n + p] : ids[p];
+            const float *prow = a.E + (int64_t)partner * a.ld;
+            const float c = coef[p];
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const int f = t + 16 * i;
+                if (f < a.ld) acc[i] += c * prow[f] + a.lambda * own[f];
+            }
+            if (s2 >= n) accb += coefb[p];
+        }
+        float *gr = a.gE + (int64_t)r * a.ld;
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int f = t + 16 * i;
+            if (f < a.ld) gr[f] = acc[i];
+        }
+        if (t == 0) {
+            a.gb[r] = accb;
+            if (a.track) a.touched[r] = 1;
+        }
+    }
+}
+
 // G pass over whole walks (fast mode: one fused batch = every prepared pair, graph_gan.py:168-176 with
 // batch_size >= train_size).  The pairs of a walk are the window-2 pairs of its path
 // (graph_gan.py:272-291), i.e. every node row is needed by up to 8 pairs.  One 16-lane group per
@@ -386,6 +473,14 @@ int run_step(gg_ctx *ctx, int which, const int32_t *d_u, const int32_t *d_v, con
     s.inv_n = 1.0f / (float)n;
     s.is_d = which == 1;
     s.ppg = n >= 16384 ? PAIRS_PER_GROUP : (n >= 2048 ? 4 : 1);
+    if (ctx->deterministic && n <= DET_MAX_PAIRS) {
+        const int nfd = (ctx->ld + 15) / 16;
+        if (nfd <= 4) hipLaunchKernelGGL(pair_grad_det_kernel<4>, dim3(1), dim3(256), 0, ctx->stream, s);
+        else if (nfd <= 8) hipLaunchKernelGGL(pair_grad_det_kernel<8>, dim3(1), dim3(256), 0, ctx->stream, s);
+        else if (nfd <= 16) hipLaunchKernelGGL(pair_grad_det_kernel<16>, dim3(1), dim3(256), 0, ctx->stream, s);
+        else hipLaunchKernelGGL(pair_grad_det_kernel<32>, dim3(1), dim3(256), 0, ctx->stream, s);
+        return apply_optimizer(ctx, which, n);
+    }
     const int groups = cdiv(n, s.ppg);
     const int blocks = cdiv((int64_t)groups * 16, 256);
     const int nf = (ctx->ld + 15) / 16;
