@@ -227,7 +227,8 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": sc_bytes / max(sc_launches, 1), "avg_launch_ms": sc_ms / max(sc_launches, 1),
                      "launches": int(sc_launches), "rows_per_launch": rows_scored / max(sc_launches, 1),
-                     "gather_microbench_ceiling_GBs": 5600.0},
+                     # tools/gather_bw*.hip on the same chip: random 512 B row gathers with 16-lane groups
+                     "gather_microbench_GBs": {"plain_gather_512MB_table": 7400.0, "with_dot_and_score_store": 7200.0}},
         "walk_phase": {"ms_per_walk_sample_call": walk_ms / max(launches, 1), "calls": int(launches),
                        "reference_equivalent_bytes_per_call": ref_bytes / max(launches, 1),
                        "reference_equivalent_GBs": ref_bytes / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else None,
