@@ -185,6 +185,7 @@ __device__ __forceinline__ int sample_index(Load sbuf, int k, float mx, uint64_t
 // ------------------------------------------------------------------------------------------
 // Level kernels (streaming front end)
 // ------------------------------------------------------------------------------------------
+constexpr int SINGLE_CHUNK = 0x100;  // descriptor flag: the task has one chunk -> the score kernel finishes its prefix sums itself
 constexpr int BIG_TASK = 256;   // owner tasks with more candidates get a whole workgroup for their prefix sums
 constexpr int CTR_ALIVE = 8;    // ctr[CTR_ALIVE + level]: walks alive when hop `level` was set up
 constexpr int CTR_BIG = 72;     // ctr[CTR_BIG + level]:   big owner tasks of hop `level`
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         if (write_desc == 1 && fits) {
             for (int i = 0; i < chunks; ++i) {
                 const int64_t o = beg_abs + (int64_t)i * CHUNK;
-                a.lv_chunk_desc[coff + i] = make_int4(cur, min(CHUNK, k - i * CHUNK), (int)(o & 0xffffffffll), (int)(o >> 32));
+                a.lv_chunk_desc[coff + i] = make_int4(cur, min(CHUNK, k - i * CHUNK) | (k <= CHUNK ? SINGLE_CHUNK : 0), (int)(o & 0xffffffffll), (int)(o >> 32));
             }
         }
     }
@@ -393,8 +394,17 @@ __global__ void level_expand_kernel(const WalkArgs a) {
     const int64_t beg = a.lv_beg[w];
     for (int i = 0; i < n; ++i) {
         const int64_t o = beg + (int64_t)i * CHUNK;
-        a.lv_chunk_desc[c0 + i] = make_int4(cur, min(CHUNK, k - i * CHUNK), (int)(o & 0xffffffffll), (int)(o >> 32));
+        a.lv_chunk_desc[c0 + i] = make_int4(cur, min(CHUNK, k - i * CHUNK) | (k <= CHUNK ? SINGLE_CHUNK : 0), (int)(o & 0xffffffffll), (int)(o >> 32));
     }
+}
+
+__device__ __forceinline__ uint64_t group16_incl_scan_u64(uint64_t v, int t) {
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+        const uint64_t o = __shfl_up(v, off, 16);
+        if (t >= off) v += o;
+    }
+    return v;
 }
 
 // One 16-lane group per 16-candidate chunk (grid-stride): four independent chunks in flight per
@@ -417,7 +427,8 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const
     unsigned long long rows = 0;
     for (int64_t c = (int64_t)lblock * (WAVES_PER_BLOCK * 4) + (threadIdx.x >> 4); c < total_chunks; c += n_groups) {
         const int4 d = a.lv_chunk_desc[c];
-        const int cur = d.x, nblock = d.y;
+        const int cur = d.x, nblock = d.y & 0xff;
+        const bool single = (d.y & SINGLE_CHUNK) != 0;
         const int32_t *const ids = a.t_nbr + (((int64_t)d.w << 32) | (unsigned)d.z);
         float *const out = a.lv_scores + c * CHUNK;
         float4 gc[NCH];
@@ -461,7 +472,18 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const
                 if (t == j0 + u) mysc = acc + mybias;  // lane j keeps the score of candidate j
             }
         }
-        if (t < nblock) out[t] = mysc;  // one coalesced 64-byte store per chunk
+        if (single) {
+            // the whole distribution sits in this group's lanes: max, exact fixed-point weights and their
+            // inclusive prefix sums (spec S2, S3) right here -- no score round trip, no second kernel
+            float mx = (t < nblock) ? mysc : -INFINITY;
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 16));
+            const uint64_t wgt = (t < nblock) ? weight_fix40(exp_spec(mysc - mx)) : 0ull;
+            const uint64_t C = group16_incl_scan_u64(wgt, t);
+            if (t < nblock) a.lv_prefix[c * CHUNK + t] = C;
+        } else if (t < nblock) {
+            out[t] = mysc;  // one coalesced 64-byte store per chunk
+        }
         rows += (unsigned long long)nblock;
     }
     // one counter update per block (same-address atomics serialise at ~12 ns each)
@@ -473,22 +495,13 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const
     }
 }
 
-__device__ __forceinline__ uint64_t group16_incl_scan_u64(uint64_t v, int t) {
-#pragma unroll
-    for (int off = 1; off < 16; off <<= 1) {
-        const uint64_t o = __shfl_up(v, off, 16);
-        if (t >= off) v += o;
-    }
-    return v;
-}
-
 // Small owner tasks (k <= BIG_TASK): one 16-lane group per walk -- max, exact fixed-point weights
 // (spec S2, S3) and their inclusive prefix sums, computed once per (root, node).
 __global__ __launch_bounds__(256) void level_weights_small_kernel(const WalkArgs a, const int64_t cap_chunks) {
     if ((int64_t)a.ctr[CTR_CHUNKS + a.level] > cap_chunks || a.ctr[CTR_CHUNKS + a.level] == 0ull) return;
     const int t = threadIdx.x & 15;
     const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    if (w >= a.total_walks || a.lv_chunks[w] == 0) return;
+    if (w >= a.total_walks || a.lv_chunks[w] <= 1) return;  // non-owners, and single-chunk tasks (done by the score kernel)
     const int k = a.lv_k[w];
     if (k > BIG_TASK) return;
     const int64_t base = a.lv_coff[w] * CHUNK;
