@@ -36,6 +36,7 @@ struct RcclApi {
 static RcclApi g_rccl;
 constexpr int NCCL_FLOAT32 = 7;  // ncclFloat32
 constexpr int NCCL_SUM = 0;      // ncclSum
+constexpr int NCCL_INT32 = 2;    // ncclInt32
 constexpr int NCCL_INT64 = 4;    // ncclInt64
 
 static int load_rccl(gg_ctx *ctx) {
@@ -73,6 +74,13 @@ int comm_allreduce_grads(gg_ctx *ctx) {
     const size_t ne = (size_t)ctx->n_node * ctx->ld;
     GG_NCCL(ctx, g_rccl.AllReduce(ctx->gradE, ctx->gradE, ne, NCCL_FLOAT32, NCCL_SUM, ctx->comm, ctx->stream));
     GG_NCCL(ctx, g_rccl.AllReduce(ctx->gradb, ctx->gradb, (size_t)ctx->n_node, NCCL_FLOAT32, NCCL_SUM, ctx->comm, ctx->stream));
+    return GG_OK;
+}
+
+// sum of the touched-row flags over ranks (the dense fall-back of the sparse exchange needs the union)
+int comm_allreduce_flags(gg_ctx *ctx) {
+    if (!ctx->comm) return GG_OK;
+    GG_NCCL(ctx, g_rccl.AllReduce(ctx->touched, ctx->touched, (size_t)ctx->n_node, NCCL_INT32, NCCL_SUM, ctx->comm, ctx->stream));
     return GG_OK;
 }
 

@@ -223,6 +223,7 @@ int gg_create(int32_t n_node, int32_t n_emb, const float *emb_gen, const float *
     if (const char *lv = getenv("GG_WALK_LEVELS")) ctx->walk_levels = atoi(lv);
     if (const char *fw = getenv("GG_COMM_FAKE_WORLD")) ctx->fake_world = atoi(fw);
     if (const char *dt = getenv("GG_DETERMINISTIC")) ctx->deterministic = atoi(dt) != 0;
+    if (const char *dr = getenv("GG_COMM_DENSE_RATIO")) ctx->dense_exchange_ratio = (float)atof(dr);
 #define GG_TRY(call)                        \
     do {                                    \
         int rc__ = (call);                  \

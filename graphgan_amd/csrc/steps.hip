@@ -518,6 +518,17 @@ int run_path_step(gg_ctx *ctx) {
     return apply_optimizer(ctx, 0, n);
 }
 
+__global__ void normalize_flags_kernel(int32_t *f, int n) {  // after the cross-rank sum: counts -> 0/1
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && f[i] > 1) f[i] = 1;
+}
+
+__global__ void scale_grads_kernel(float *gE, float *gb, int64_t nE, int n, float k) {  // simulated ranks only
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nE; i += stride) gE[i] *= k;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) gb[i] *= k;
+}
+
 // Sparse exchange: see pack_rows_kernel.  One host read-back (the per-rank row counts) per step.
 static int exchange_sparse(gg_ctx *ctx, OptArgs &o, int world) {
     const int n = ctx->n_node, ld = ctx->ld;
@@ -536,6 +547,24 @@ static int exchange_sparse(gg_ctx *ctx, OptArgs &o, int world) {
         maxc = std::max(maxc, cnt[r]);
     }
     if (maxc == 0) return GG_OK;
+    // Packs pay off while few rows are touched: a rank receives (sum of the other ranks' rows) * row bytes,
+    // a ring all-reduce moves ~2 * n_node * row bytes.  When the replicas together touch most of the table
+    // (many roots per step), fall back to the dense all-reduce of the accumulators + the flag union.
+    // cnt[] is identical on every rank, so all ranks take the same branch.
+    int64_t total = 0;
+    for (int r = 0; r < world; ++r) total += cnt[r];
+    if ((double)total >= (double)ctx->dense_exchange_ratio * n) {
+        if (ctx->comm) {
+            rc = comm_allreduce_grads(ctx);
+            if (rc == GG_OK) rc = comm_allreduce_flags(ctx);
+            if (rc != GG_OK) return rc;
+        } else {  // GG_COMM_FAKE_WORLD: every simulated rank holds this rank's gradient
+            hipLaunchKernelGGL(scale_grads_kernel, dim3(2048), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, (int64_t)n * ld, n, (float)world);
+        }
+        hipLaunchKernelGGL(normalize_flags_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, ctx->touched, n);
+        GG_HIP(ctx, hipGetLastError());
+        return GG_OK;
+    }
     const size_t row_f = (size_t)ld + 1;
     GG_HIP(ctx, ctx->x_send_ids.reserve(sizeof(int32_t) * maxc));
     GG_HIP(ctx, ctx->x_send_rows.reserve(sizeof(float) * maxc * row_f));

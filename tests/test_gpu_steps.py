@@ -235,12 +235,15 @@ def test_state_save_restore(ga, tmp_path):
     eng2.close()
 
 
-@pytest.mark.parametrize("mode", ["dense", "lazy"])
+@pytest.mark.parametrize("mode", ["dense", "lazy", "lazy-dense-fallback"])
 def test_rccl_plumbing_with_one_rank_communicator(ga, mode, monkeypatch):
     """gpurun boxes have ONE GPU: a 1-rank RCCL communicator (GG_COMM_FORCE=1) still exercises
     dlopen(librccl), the enum values, the all-reduce on the engine's stream and, in lazy mode, the
     rebuild of the touched-row list from the reduced gradient.  Results must equal the no-comm run."""
     monkeypatch.setenv("GG_COMM_FORCE", "1")
+    if mode.endswith("dense-fallback"):  # all-reduce of accumulators + int32 flag union instead of packs
+        monkeypatch.setenv("GG_COMM_DENSE_RATIO", "0")
+        mode = "lazy"
     n, d = 300, 50
     Eg, Ed, bg, bd = make_models(n, d, 2)
     opt = ga.GG_OPT_ADAM_DENSE if mode == "dense" else ga.GG_OPT_ADAM_LAZY
@@ -313,18 +316,22 @@ def test_all_score_rows_on_mfma(ga, n, d):
     eng.close()
 
 
-@pytest.mark.parametrize("mode", ["sgd", "lazy"])
+@pytest.mark.parametrize("mode", ["sgd", "lazy", "sgd-dense-fallback"])
 def test_sparse_exchange_with_simulated_ranks(ga, mode, monkeypatch):
     """The replica gradient exchange of the lazy / sgd modes packs touched rows, all-gathers the
     packs and adds them in rank order.  gpurun has one GPU, so GG_COMM_FAKE_WORLD=3 feeds the
     3-rank code path with three copies of the local pack: the applied gradient must be exactly
     3x the local one (offsets, counts, per-rank launches, flag union all exercised)."""
     monkeypatch.setenv("GG_COMM_FAKE_WORLD", "3")
+    if mode.endswith("dense-fallback"):  # force the "replicas touch most of the table" branch
+        monkeypatch.setenv("GG_COMM_DENSE_RATIO", "0")
+        mode = "sgd"
     n, d = 400, 64
     Eg, Ed, bg, bd = make_models(n, d, 21)
     opt = ga.GG_OPT_SGD if mode == "sgd" else ga.GG_OPT_ADAM_LAZY
     eng = engine_with(ga, Eg, Ed, bg, bd, optimizer=opt)
     monkeypatch.delenv("GG_COMM_FAKE_WORLD")
+    monkeypatch.delenv("GG_COMM_DENSE_RATIO", raising=False)
     dis = orc.Discriminator(Ed, 1e-3, lazy=True)
     dis.b[:] = bd
     rs = np.random.RandomState(8)
