@@ -141,3 +141,22 @@ def test_script_entry_point_with_user_config(tmp_path):
     assert res[0] == "gen:0.7598343685300207" and len(res) == 4
     for name in ("CA-GrQc_gen_.emb", "CA-GrQc_dis_.emb"):
         assert os.path.getsize(os.path.join(base, "results", "link_prediction", name)) > 1e6
+
+
+def test_update_ratio_below_one_rebuilds_trees_per_prepare(tmp_path):
+    """config.update_ratio < 1 (graph_gan.py:189,209): every prepare draws its own subset of roots; the
+    mirror builds the BFS trees of just that subset (on the GPU) instead of keeping all N trees resident."""
+    base = str(tmp_path)
+    d, n, graph = write_reference_layout(base)
+    cfg = make_cfg(base, n_epochs=1, n_epochs_dis=2, n_epochs_gen=2, dis_interval=1, gen_interval=1, update_ratio=0.05,
+                   engine_optimizer="adam_lazy")
+    from graphgan_amd.graph_gan import GraphGAN
+    g = GraphGAN(cfg)
+    assert g.trees is None
+    g.train()
+    lines = open(cfg.result_filename).read().split()
+    assert len(lines) == 4 and lines[0] == "gen:0.7598343685300207"
+    c = g.engine.counters()
+    assert c["d_steps"] > 0 and c["g_steps"] > 0 and 0 < c["walks"] < 4 * 0.2 * n * 25
+    nroots = len(g.engine.tree_roots)
+    assert 0.02 * n < nroots < 0.09 * n  # ~5 % of the roots in the last prepare
