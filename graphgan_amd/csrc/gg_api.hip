@@ -147,12 +147,13 @@ int gg::walk_finalize(gg_ctx *ctx, bool *retried) {
     }
     // ctr[0], ctr[1]: cumulative counts of the per-walk finisher; the level pipeline's counts of THIS launch
     // sit in 64 spread words each -> fold them into the cumulative device words
-    unsigned long long lv_hops = 0, lv_reads = 0;
-    for (int i = 0; i < 64; ++i) { lv_hops += c[264 + i]; lv_reads += c[328 + i]; }
-    if (lv_hops || lv_reads) {
+    unsigned long long lv_hops = 0, lv_reads = 0, lv_rows = 0;
+    for (int i = 0; i < 64; ++i) { lv_hops += c[264 + i]; lv_reads += c[328 + i]; lv_rows += c[200 + i]; }
+    if (lv_hops || lv_reads || lv_rows) {
         c[0] += lv_hops;
         c[1] += lv_reads;
-        GG_HIP(ctx, hipMemcpy(ctx->dev_ctr, c, sizeof(unsigned long long) * 2, hipMemcpyHostToDevice));
+        c[5] += lv_rows;
+        GG_HIP(ctx, hipMemcpy(ctx->dev_ctr, c, sizeof(unsigned long long) * 6, hipMemcpyHostToDevice));  // [2..4] unchanged
     }
     ctx->ctr.hops = (int64_t)c[0];
     ctx->ctr.nbr_reads = (int64_t)c[1];
@@ -171,8 +172,8 @@ int gg::walk_finalize(gg_ctx *ctx, bool *retried) {
             ctx->ctr.score_launches += 1;
             ctx->ctr.score_chunks += (int64_t)c[136 + i];
             if (getenv("GG_WALK_DEBUG"))
-                fprintf(stderr, "[walk] for_d=%d level %d alive %llu chunks %llu rows %llu big %llu score %.1f us\n", ctx->w_args.for_d, i,
-                        c[8 + i], c[136 + i], c[200 + i], c[72 + i], lms * 1e3);
+                fprintf(stderr, "[walk] for_d=%d level %d alive %llu chunks %llu big %llu score %.1f us\n", ctx->w_args.for_d, i,
+                        c[8 + i], c[136 + i], c[72 + i], lms * 1e3);
         }
     }
     if (c[3]) {
