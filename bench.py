@@ -47,6 +47,9 @@ def parse():
     p.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--seed", type=int, default=6)
+    p.add_argument("--profile-every", type=int, default=3,
+                   help="HIP events around every k-th walk launch of the timed region (an event pair costs ~6 us of stream bubble on "
+                        "each side of every level_score_kernel launch; an odd k alternates between the D-mode and G-mode launches)")
     return p.parse_args()
 
 
@@ -148,6 +151,7 @@ def main():
     if not share_gpu:
         ctl.connect_engine(eng)
     setup_s = time.time() - t_setup
+    eng.set_profiling(args.profile_every)
 
     def step(i):
         # every rank issues both passes (they contain the replicas' gradient exchange), even with no rows
@@ -163,6 +167,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
+    eng.set_profiling(args.profile_every)  # restart the cadence: the first launch of the timed region is a profiled one
     c0 = eng.counters()
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
@@ -174,8 +179,9 @@ def main():
     hops = c1["hops"] - c0["hops"]
     reads = c1["nbr_reads"] - c0["nbr_reads"]
     rows_scored = c1["rows_scored"] - c0["rows_scored"]
-    walk_ms = c1["walk_kernel_ms"] - c0["walk_kernel_ms"]
-    launches = c1["walk_launches"] - c0["walk_launches"]
+    walk_ms = c1["walk_kernel_ms"] - c0["walk_kernel_ms"]      # HIP events of the profiled walk launches ...
+    launches = c1["walk_launches"] - c0["walk_launches"]       # ... and how many of the 2 * steps launches that was
+    calls = 2 * args.steps
     dpairs = c1["d_pairs"] - c0["d_pairs"]
     gpairs = c1["g_pairs"] - c0["g_pairs"]
     sums = ctl.sum([hops, dpairs, gpairs])
@@ -191,7 +197,8 @@ def main():
     sc_ms = c1["score_kernel_ms"] - c0["score_kernel_ms"]
     sc_launches = c1["score_launches"] - c0["score_launches"]
     sc_chunks = c1["score_chunks"] - c0["score_chunks"]
-    sc_bytes = 4.0 * (d + 3) * rows_scored + (4.0 * d + 16.0) * sc_chunks
+    sc_rows = c1["score_rows"] - c0["score_rows"]  # rows / chunks / ms / launches: the same (profiled) launches
+    sc_bytes = 4.0 * (d + 3) * sc_rows + (4.0 * d + 16.0) * sc_chunks
     achieved = sc_bytes / (sc_ms * 1e-3) / 1e9 if sc_ms > 0 else 0.0
     # The reference evaluates every hop's distribution from scratch (4k(d+2) + 4d + 12 per hop);
     # the engine evaluates each distinct (root, node) distribution of a launch once.
@@ -215,7 +222,7 @@ def main():
                    "parallelism": "roots sharded x%d, replicated tables, RCCL sparse gradient all-gather per pass" % world if world > 1 else "single GPU"},
         "d_step_pairs_per_sec": tot[1] / tot[3],
         "g_step_pairs_per_sec": tot[2] / tot[3],
-        "walk_kernel_edges_per_sec": hops / (walk_ms * 1e-3) if walk_ms > 0 else None,
+        "walk_kernel_edges_per_sec": (hops / calls) / (walk_ms / launches * 1e-3) if walk_ms > 0 and launches else None,
         "hops_per_step_rank0": hops / args.steps,
         "mean_k": reads / max(hops, 1),
         "rows_scored_per_step_rank0": rows_scored / args.steps,
@@ -226,12 +233,14 @@ def main():
         "roofline": {"kernel": "level_score_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": sc_bytes / max(sc_launches, 1), "avg_launch_ms": sc_ms / max(sc_launches, 1),
-                     "launches": int(sc_launches), "rows_per_launch": rows_scored / max(sc_launches, 1),
+                     "launches": int(sc_launches), "rows_per_launch": sc_rows / max(sc_launches, 1),
+                     "timed": "HIP events on the engine's stream around every level_score_kernel launch of every %s walk call of the timed region"
+                              % ("" if args.profile_every == 1 else "%d-th" % args.profile_every),
                      # tools/gather_bw*.hip on the same chip: random 512 B row gathers with 16-lane groups
                      "gather_microbench_GBs": {"plain_gather_512MB_table": 7400.0, "with_dot_and_score_store": 7200.0}},
-        "walk_phase": {"ms_per_walk_sample_call": walk_ms / max(launches, 1), "calls": int(launches),
-                       "reference_equivalent_bytes_per_call": ref_bytes / max(launches, 1),
-                       "reference_equivalent_GBs": ref_bytes / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else None,
+        "walk_phase": {"ms_per_walk_sample_call": walk_ms / max(launches, 1), "calls": calls, "calls_timed": int(launches),
+                       "reference_equivalent_bytes_per_call": ref_bytes / calls,
+                       "reference_equivalent_GBs": (ref_bytes / calls) / (walk_ms / launches * 1e-3) / 1e9 if walk_ms > 0 and launches else None,
                        "distributions_shared": reads / max(rows_scored, 1)},
     }
     if world == 1 and not args.no_cpu_baseline:

@@ -34,7 +34,7 @@ class GGCounters(ctypes.Structure):
                 ("d_steps", ctypes.c_int64), ("g_steps", ctypes.c_int64),
                 ("last_kernel_ms", ctypes.c_double), ("walk_kernel_ms", ctypes.c_double),
                 ("walk_launches", ctypes.c_int64), ("rows_scored", ctypes.c_int64), ("score_kernel_ms", ctypes.c_double),
-                ("score_launches", ctypes.c_int64), ("score_chunks", ctypes.c_int64), ("reserved", ctypes.c_int64 * 1)]
+                ("score_launches", ctypes.c_int64), ("score_chunks", ctypes.c_int64), ("score_rows", ctypes.c_int64)]
 
 
 class GGGraph(ctypes.Structure):
@@ -84,6 +84,8 @@ SIGNATURES = {
     "gg_save_state": (ctypes.c_int, [_P, ctypes.c_char_p]),
     "gg_load_state": (ctypes.c_int, [_P, ctypes.c_char_p]),
     "gg_get_counters": (ctypes.c_int, [_P, ctypes.POINTER(GGCounters)]),
+    "gg_set_profiling": (ctypes.c_int, [_P, _i32]),
+    "gg_synchronize": (ctypes.c_int, [_P]),
     "gg_comm_unique_id": (ctypes.c_int, [_P]),
     "gg_comm_init": (ctypes.c_int, [_P, _P, _i32, _i32]),
     "gg_comm_barrier": (ctypes.c_int, [_P]),

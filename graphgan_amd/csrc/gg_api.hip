@@ -128,15 +128,12 @@ int gg::walk_finalize(gg_ctx *ctx, bool *retried) {
         return GG_OK;
     }
     const int64_t total = ctx->w_total;
-    // cumulative device counters as of the previous launch (to restore them if this launch is rerun)
-    unsigned long long c0[6] = {(unsigned long long)ctx->ctr.hops, (unsigned long long)ctx->ctr.nbr_reads, 0, 0, 0,
-                                (unsigned long long)ctx->ctr.rows_scored};
-    unsigned long long *c = ctx->h_ctr;  // 200 words, one read-back
+    unsigned long long *c = ctx->h_pin;  // the launch's counter words, one asynchronous read-back into pinned memory
     GG_HIP(ctx, hipMemcpyAsync(c, ctx->dev_ctr, sizeof(unsigned long long) * 392, hipMemcpyDeviceToHost, ctx->stream));
     GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (c[3] == 2ull) {
-        // nothing the overflowed launch wrote is final (the D-mode post-pass is gated by the same flag)
-        GG_HIP(ctx, hipMemcpy(ctx->dev_ctr, c0, sizeof(c0), hipMemcpyHostToDevice));
+        // nothing the overflowed launch wrote or counted is final (the D-mode post-pass is gated by the same flag,
+        // the counter words are zeroed again by the new launch)
         ctx->walk_force_sized = true;
         int rc = launch_walk_sample(ctx, ctx->w_nslots, total, ctx->w_args.for_d, ctx->w_args.seed, ctx->w_args.stream, ctx->w_stride);
         ctx->walk_force_sized = false;
@@ -145,21 +142,14 @@ int gg::walk_finalize(gg_ctx *ctx, bool *retried) {
         GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (retried) *retried = true;
     }
-    // ctr[0], ctr[1]: cumulative counts of the per-walk finisher; the level pipeline's counts of THIS launch
-    // sit in 64 spread words each -> fold them into the cumulative device words
-    unsigned long long lv_hops = 0, lv_reads = 0, lv_rows = 0;
-    for (int i = 0; i < 64; ++i) { lv_hops += c[264 + i]; lv_reads += c[328 + i]; lv_rows += c[200 + i]; }
-    if (lv_hops || lv_reads || lv_rows) {
-        c[0] += lv_hops;
-        c[1] += lv_reads;
-        c[5] += lv_rows;
-        GG_HIP(ctx, hipMemcpy(ctx->dev_ctr, c, sizeof(unsigned long long) * 6, hipMemcpyHostToDevice));  // [2..4] unchanged
-    }
-    ctx->ctr.hops = (int64_t)c[0];
-    ctx->ctr.nbr_reads = (int64_t)c[1];
-    ctx->ctr.rows_scored = (int64_t)c[5];
+    // c[0], c[1], c[5]: counts of the per-walk finisher; the level pipeline's counts sit in 64 spread words each
+    unsigned long long hops = c[0], reads = c[1], rows = c[5];
+    for (int i = 0; i < 64; ++i) { hops += c[264 + i]; reads += c[328 + i]; rows += c[200 + i]; }
+    ctx->ctr.hops += (int64_t)hops;
+    ctx->ctr.nbr_reads += (int64_t)reads;
+    ctx->ctr.rows_scored += (int64_t)rows;
     ctx->ctr.walks += total;
-    if (total) {
+    if (total && ctx->walk_timed) {
         float ms = 0.f;
         GG_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         ctx->ctr.last_kernel_ms = ms;
@@ -175,12 +165,9 @@ int gg::walk_finalize(gg_ctx *ctx, bool *retried) {
                 fprintf(stderr, "[walk] for_d=%d level %d alive %llu chunks %llu big %llu score %.1f us\n", ctx->w_args.for_d, i,
                         c[8 + i], c[136 + i], c[72 + i], lms * 1e3);
         }
+        if (ctx->lv_ev_used) ctx->ctr.score_rows += (int64_t)(rows - c[5]);  // rows of the timed score launches
     }
-    if (c[3]) {
-        unsigned long long z = 0;
-        (void)hipMemcpy(ctx->dev_ctr + 3, &z, sizeof(z), hipMemcpyHostToDevice);
-        return fail(ctx, GG_ECAPACITY, "walk: a path needed more than stride=%d entries", ctx->w_stride);
-    }
+    if (c[3]) return fail(ctx, GG_ECAPACITY, "walk: a path needed more than stride=%d entries", ctx->w_stride);
     return GG_OK;
 }
 
@@ -222,6 +209,7 @@ int gg_create(int32_t n_node, int32_t n_emb, const float *emb_gen, const float *
     ctx->cfg = *cfg;
     ctx->device = cfg->device;
     if (const char *lv = getenv("GG_WALK_LEVELS")) ctx->walk_levels = atoi(lv);
+    if (const char *pe = getenv("GG_PROFILE_EVERY")) ctx->profile_every = std::max(0, atoi(pe));
     if (const char *fw = getenv("GG_COMM_FAKE_WORLD")) ctx->fake_world = atoi(fw);
     if (const char *dt = getenv("GG_DETERMINISTIC")) ctx->deterministic = atoi(dt) != 0;
     if (const char *dr = getenv("GG_COMM_DENSE_RATIO")) ctx->dense_exchange_ratio = (float)atof(dr);
@@ -238,6 +226,8 @@ int gg_create(int32_t n_node, int32_t n_emb, const float *emb_gen, const float *
         GG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         GG_HIP(ctx, hipEventCreate(&ctx->ev0));
         GG_HIP(ctx, hipEventCreate(&ctx->ev1));
+        GG_HIP(ctx, hipHostMalloc((void **)&ctx->h_pin, sizeof(unsigned long long) * 512, hipHostMallocDefault));
+        memset(ctx->h_pin, 0, sizeof(unsigned long long) * 512);
         const size_t tb = sizeof(float) * (size_t)n_node * ctx->ld, vb = sizeof(float) * (size_t)n_node;
         for (int m = 0; m < 2; ++m) {
             Model &M = ctx->model[m];
@@ -305,6 +295,7 @@ int gg_destroy(gg_ctx *ctx) {
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : ctx->lv_ev)
         if (e) (void)hipEventDestroy(e);
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -455,6 +446,21 @@ int gg_set_bias(gg_ctx *ctx, int32_t which, const float *bias) { return table_io
 int gg_get_counters(gg_ctx *ctx, gg_counters *out) {
     if (!ctx || !out) return fail(ctx, GG_EINVAL, "gg_get_counters: NULL argument");
     *out = ctx->ctr;
+    return GG_OK;
+}
+
+int gg_set_profiling(gg_ctx *ctx, int32_t every_n) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    GG_CHECK(ctx, every_n >= 0, GG_EINVAL, "gg_set_profiling: every_n < 0");
+    ctx->profile_every = every_n;
+    ctx->walk_call_index = 0;
+    return GG_OK;
+}
+
+int gg_synchronize(gg_ctx *ctx) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    GG_HIP(ctx, hipSetDevice(ctx->device));
+    GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GG_OK;
 }
 

@@ -17,7 +17,10 @@ struct DevBuf {
     size_t bytes = 0;
     hipError_t reserve(size_t need) {
         if (need <= bytes) return hipSuccess;
-        if (p) (void)hipFree(p);
+        if (p) {
+            (void)hipDeviceSynchronize();  // kernels of calls that returned early (gg_set_profiling) may still use it
+            (void)hipFree(p);
+        }
         p = nullptr;
         bytes = 0;
         size_t want = need + need / 4 + 256;
@@ -91,8 +94,16 @@ struct gg_ctx {
     int32_t w_stride = 0, w_nslots = 0;
     struct { int32_t for_d; uint64_t seed; uint32_t stream; } w_args{};
     std::vector<int64_t> h_walk_ptr;
-    unsigned long long h_ctr[512] = {};
-    int64_t h_total = 0;  // row / pair count read back at the end of a prepare call
+    // pinned host mirror: [0, 392) the launch's device counters, [H_TOTAL] the row / pair count of a prepare call --
+    // both arrive with asynchronous copies behind the kernels and ONE stream synchronisation (pageable destinations
+    // would make every copy its own host round trip)
+    static constexpr int H_TOTAL = 392;
+    unsigned long long *h_pin = nullptr;  // [512], hipHostMalloc
+    // profiling (gg_set_profiling): HIP events around every profile_every-th walk call; 1 = every call and every pass
+    // (passes then wait for their events), 0 = never; an event pair costs ~6 us of stream bubble on each side
+    int32_t profile_every = 1;
+    int64_t walk_call_index = 0;
+    bool walk_timed = false;  // the launch in flight carries events
 
     // prepared data
     gg::DevBuf d_center, d_neighbor, d_label, d_cnt, d_ptr;
@@ -103,7 +114,8 @@ struct gg_ctx {
     gg::DevBuf touched_ptr;
     gg::DevBuf scan_tmp, step_u, step_v, step_x;
 
-    // device-side counters: [0]=hops [1]=nbr_reads [2]=alive walks [3]=error flag [4]=ticket [5]=rows scored
+    // device-side counters of the walk launch in flight (zeroed at its start): [0]=hops [1]=nbr_reads [3]=error flag
+    // [4]=ticket [5]=rows scored by the finisher; per-level and spread words from [8] on (walk_sample.hip)
     unsigned long long *dev_ctr = nullptr;
     gg_counters ctr{};
 

@@ -225,7 +225,7 @@ static int enqueue_d_rows(gg_ctx *ctx, int32_t n_slots) {
                        ctx->w_slots.as<int32_t>(), ctx->t_root, ctx->g_rowptr, ctx->g_col, ctx->w_samples.as<int32_t>(),
                        ctx->w_ptr.as<int64_t>(), ctx->d_ptr.as<int64_t>(), n_slots, ctx->d_center.as<int32_t>(),
                        ctx->d_neighbor.as<int32_t>(), ctx->d_label.as<float>(), ctx->dev_ctr + 3);
-    GG_HIP(ctx, hipMemcpyAsync(&ctx->h_total, ctx->d_ptr.as<int64_t>() + n_slots, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    GG_HIP(ctx, hipMemcpyAsync(ctx->h_pin + gg_ctx::H_TOTAL, ctx->d_ptr.as<int64_t>() + n_slots, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     GG_HIP(ctx, hipGetLastError());
     return GG_OK;
 }
@@ -258,7 +258,7 @@ int gg_prepare_d(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, uint64_t se
             if (rc != GG_OK) return rc;
             GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
-        ctx->d_rows = ctx->h_total;
+        ctx->d_rows = (int64_t)ctx->h_pin[gg_ctx::H_TOTAL];
         if (root_status) GG_HIP(ctx, hipMemcpy(root_status, ctx->w_status.p, sizeof(int32_t) * n_slots, hipMemcpyDeviceToHost));
     }
     if (n_rows_out) *n_rows_out = ctx->d_rows;
@@ -291,7 +291,7 @@ static int enqueue_g_pairs(gg_ctx *ctx, int64_t nw, int64_t cap) {
     const Model &D = ctx->model[1];
     hipLaunchKernelGGL(pair_reward_kernel, dim3(256 * 16), dim3(256), 0, ctx->stream, D.E, D.b, ctx->ld, ctx->g_node1.as<int32_t>(),
                        ctx->g_node2.as<int32_t>(), (int64_t)-1, ctx->g_ptr.as<int64_t>() + nw, ctx->g_reward.as<float>());
-    GG_HIP(ctx, hipMemcpyAsync(&ctx->h_total, ctx->g_ptr.as<int64_t>() + nw, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    GG_HIP(ctx, hipMemcpyAsync(ctx->h_pin + gg_ctx::H_TOTAL, ctx->g_ptr.as<int64_t>() + nw, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     GG_HIP(ctx, hipGetLastError());
     (void)cap;
     return GG_OK;
@@ -326,7 +326,7 @@ int gg_prepare_g(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, int32_t n_s
             if (rc != GG_OK) return rc;
             GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
-        ctx->g_pairs = ctx->h_total;
+        ctx->g_pairs = (int64_t)ctx->h_pin[gg_ctx::H_TOTAL];
         ctx->ctr.reward_pairs += ctx->g_pairs;
         ctx->g_paths_valid = true;
     }

@@ -678,7 +678,8 @@ static int run_pass(gg_ctx *ctx, int which, const int64_t *starts, int64_t n_bat
         }
         return GG_OK;
     }
-    GG_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    const bool timed = ctx->profile_every == 1;  // gg_set_profiling: otherwise no events and no wait
+    if (timed) GG_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     const bool whole = n_batches == 1 && starts[0] == 0 && batch_size >= rows && rows > 0;
     if (which == 0 && whole && ctx->g_paths_valid && ctx->cfg.window_size <= 2 && ctx->ld <= 256 && !getenv("GG_NO_PATH_GRAD")) {
         int rc = run_path_step(ctx);
@@ -692,11 +693,13 @@ static int run_pass(gg_ctx *ctx, int which, const int64_t *starts, int64_t n_bat
             if (rc != GG_OK) return rc;
         }
     }
-    GG_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-    GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    float ms = 0.f;
-    GG_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-    ctx->ctr.last_kernel_ms = ms;
+    if (timed) {
+        GG_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        float ms = 0.f;
+        GG_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        ctx->ctr.last_kernel_ms = ms;
+    }
     return GG_OK;
 }
 

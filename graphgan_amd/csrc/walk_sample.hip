@@ -771,14 +771,18 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
         if (blocks > 256 * 8) blocks = 256 * 8;
         if (blocks >= 8) blocks -= blocks % 8;
         if (blocks < 1) blocks = 1;
-        if (!ctx->lv_ev[2 * level]) {
-            GG_HIP(ctx, hipEventCreate(&ctx->lv_ev[2 * level]));
-            GG_HIP(ctx, hipEventCreate(&ctx->lv_ev[2 * level + 1]));
+        if (ctx->walk_timed) {
+            if (!ctx->lv_ev[2 * level]) {
+                GG_HIP(ctx, hipEventCreate(&ctx->lv_ev[2 * level]));
+                GG_HIP(ctx, hipEventCreate(&ctx->lv_ev[2 * level + 1]));
+            }
+            GG_HIP(ctx, hipEventRecord(ctx->lv_ev[2 * level], ctx->stream));
         }
-        GG_HIP(ctx, hipEventRecord(ctx->lv_ev[2 * level], ctx->stream));
         hipLaunchKernelGGL(level_score_kernel<NCH>, dim3((unsigned)blocks), blk, 0, ctx->stream, a, cap);
-        GG_HIP(ctx, hipEventRecord(ctx->lv_ev[2 * level + 1], ctx->stream));
-        ctx->lv_ev_used = level + 1;
+        if (ctx->walk_timed) {
+            GG_HIP(ctx, hipEventRecord(ctx->lv_ev[2 * level + 1], ctx->stream));
+            ctx->lv_ev_used = level + 1;
+        }
         hipLaunchKernelGGL(level_weights_small_kernel, dim3((unsigned)cdiv(total_walks * 16, 256)), dim3(256), 0, ctx->stream, a, cap);
         hipLaunchKernelGGL(level_weights_big_kernel, dim3(2048), dim3(256), 0, ctx->stream, a, cap);
     }
@@ -872,14 +876,16 @@ int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int fo
     a.abort_walk = ctx->w_abort.as<int32_t>();
     a.ctr = ctx->dev_ctr;
 
-    // per-launch words: ticket [4], per-level counters and the spread hop counters [CTR_ALIVE, CTR_WORDS)
-    GG_HIP(ctx, hipMemsetAsync(ctx->dev_ctr + 4, 0, sizeof(unsigned long long), ctx->stream));
-    GG_HIP(ctx, hipMemsetAsync(ctx->dev_ctr + CTR_ALIVE, 0, sizeof(unsigned long long) * (CTR_WORDS - CTR_ALIVE), ctx->stream));
+    // every counter word belongs to ONE launch (the host accumulates, walk_finalize): hops / reads / rows, error
+    // flag [3], ticket [4], per-level counters and the spread words
+    GG_HIP(ctx, hipMemsetAsync(ctx->dev_ctr, 0, sizeof(unsigned long long) * CTR_WORDS, ctx->stream));
+    // HIP events around every profile_every-th call (a rerun keeps the decision of the launch it repeats)
+    if (!ctx->walk_force_sized) ctx->walk_timed = ctx->profile_every > 0 && (ctx->walk_call_index++ % ctx->profile_every) == 0;
     hipLaunchKernelGGL(walk_init_status_kernel, dim3(cdiv(n_slots, 256)), dim3(256), 0, ctx->stream, a);
     if (total_walks == 0) return GG_OK;
 
     const int nch = (a.nchunk + 15) / 16;
-    GG_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    if (ctx->walk_timed) GG_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     int rc;
     if (nch <= 1) rc = run_levels_and_finish<1>(ctx, a, total_walks);
     else if (nch == 2) rc = run_levels_and_finish<2>(ctx, a, total_walks);
@@ -887,7 +893,7 @@ int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int fo
     else if (nch <= 8) rc = run_levels_and_finish<8>(ctx, a, total_walks);
     else return fail(ctx, GG_EINVAL, "n_emb %d not supported (max 512)", ctx->n_emb);
     if (rc != GG_OK) return rc;
-    GG_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    if (ctx->walk_timed) GG_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     if (for_d)
         hipLaunchKernelGGL(walk_d_postpass_kernel, dim3(cdiv(total_walks, 256)), dim3(256), 0, ctx->stream, a);
     GG_HIP(ctx, hipGetLastError());

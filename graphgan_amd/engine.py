@@ -210,8 +210,8 @@ class Engine:
         """prepare_data_for_d (graph_gan.py:182-202) -> (center, neighbor, label, root_status)."""
         slots = _i32(slots)
         n = ctypes.c_int64()
-        status = np.zeros(len(slots), dtype=np.int32)
-        self._ck(lib.gg_prepare_d(self._ctx, _ptr(slots), len(slots), seed, stream, ctypes.byref(n), _ptr(status)))
+        status = np.zeros(len(slots), dtype=np.int32) if fetch else None  # no status read-back for resident-only use
+        self._ck(lib.gg_prepare_d(self._ctx, _ptr(slots), len(slots), seed, stream, ctypes.byref(n), _ptr(status) if fetch else None))
         self.d_rows = n.value
         if not fetch:
             return n.value
@@ -223,8 +223,8 @@ class Engine:
         """prepare_data_for_g (graph_gan.py:204-223) -> (node_1, node_2, reward, root_status)."""
         slots = _i32(slots)
         n = ctypes.c_int64()
-        status = np.zeros(len(slots), dtype=np.int32)
-        self._ck(lib.gg_prepare_g(self._ctx, _ptr(slots), len(slots), n_sample, seed, stream, ctypes.byref(n), _ptr(status)))
+        status = np.zeros(len(slots), dtype=np.int32) if fetch else None
+        self._ck(lib.gg_prepare_g(self._ctx, _ptr(slots), len(slots), n_sample, seed, stream, ctypes.byref(n), _ptr(status) if fetch else None))
         self.g_pairs = n.value
         if not fetch:
             return n.value
@@ -306,6 +306,14 @@ class Engine:
         c = GGCounters()
         self._ck(lib.gg_get_counters(self._ctx, ctypes.byref(c)))
         return {k: getattr(c, k) for k, _ in GGCounters._fields_ if k != "reserved"}
+
+    def set_profiling(self, every_n):
+        """HIP events around every ``every_n``-th walk launch (1 = every launch and every pass, the default;
+        0 = none).  With ``every_n != 1`` ``d_pass`` / ``g_pass`` return once their kernels are enqueued."""
+        self._ck(lib.gg_set_profiling(self._ctx, int(every_n)))
+
+    def synchronize(self):
+        self._ck(lib.gg_synchronize(self._ctx))
 
     # ------------------------------------------------------------------ multi-GPU
     @staticmethod

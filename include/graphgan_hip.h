@@ -82,14 +82,15 @@ typedef struct gg_counters {
     int64_t d_steps;
     int64_t g_steps;
     double last_kernel_ms;  /* HIP-event time of the last timed kernel region (walk / pass) */
-    double walk_kernel_ms;  /* cumulative HIP-event time of walk_sample kernels */
-    int64_t walk_launches;
+    double walk_kernel_ms;  /* cumulative HIP-event time of the profiled gg_walk_sample / prepare walk launches */
+    int64_t walk_launches;  /* ... and their number */
     int64_t rows_scored;    /* neighbour rows actually streamed: identical (root, node) distributions of one
                                launch are evaluated once and shared by the walks that need them */
+    /* timing counters cover the PROFILED walk calls only (gg_set_profiling; by default every call) */
     double score_kernel_ms; /* cumulative HIP-event time of level_score_kernel (the dominant kernel) */
     int64_t score_launches;
-    int64_t score_chunks;   /* 16-candidate work items it processed */
-    int64_t reserved[1];
+    int64_t score_chunks;   /* 16-candidate work items those launches processed */
+    int64_t score_rows;     /* neighbour rows those launches streamed */
 } gg_counters;
 
 typedef struct gg_ctx gg_ctx;
@@ -197,6 +198,16 @@ int gg_save_state(gg_ctx *ctx, const char *path);
 int gg_load_state(gg_ctx *ctx, const char *path);
 
 int gg_get_counters(gg_ctx *ctx, gg_counters *out);
+
+/* Profiling cadence.  every_n = 1 (default): HIP events bracket every walk launch, every level_score_kernel launch
+ * and every gg_*_pass, and the passes wait for theirs (synchronous, last_kernel_ms valid).  every_n = k > 1: only
+ * every k-th walk launch carries events (an event pair costs ~6 us of stream bubble on each side, ~0.1 ms per walk
+ * call), and gg_d_pass / gg_g_pass return as soon as their kernels are enqueued -- stream-ordered before whatever
+ * is called next; the next call that returns data, gg_synchronize or gg_comm_barrier waits for them and reports
+ * their errors.  every_n = 0: no events at all.  Also settable as GG_PROFILE_EVERY. */
+int gg_set_profiling(gg_ctx *ctx, int32_t every_n);
+/* Wait for everything enqueued on the context's stream. */
+int gg_synchronize(gg_ctx *ctx);
 
 /* ---- multi-GPU (no reference counterpart: single tf.Session, graph_gan.py:57-61).
  * One process per GPU.  Rank 0 calls gg_comm_unique_id, the 128 bytes travel by any side

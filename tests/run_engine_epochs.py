@@ -2,7 +2,7 @@
 """Run the graph_gan.py mirror on the HIP engine for a few outer epochs of the reference schedule
 on the CA-GrQc fixture (same seed / init as tests/run_oracle_epochs.py) and record the gen/dis
 accuracy after each epoch and the wall time per epoch.
-    python tests/run_engine_epochs.py <n_epochs> <out.json>"""
+    python tests/run_engine_epochs.py <n_epochs> <out.json> [seed]"""
 import json
 import os
 import sys
@@ -19,11 +19,11 @@ from tests.test_gpu_e2e import make_cfg, write_reference_layout  # noqa: E402
 
 def main():
     n_epochs, out = int(sys.argv[1]), sys.argv[2]
+    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # walk / shuffle seed; the initial embeddings stay those of seed 0
     base = tempfile.mkdtemp()
     d, n, graph = write_reference_layout(base)
-    cfg = make_cfg(base, n_epochs=n_epochs, engine_seed=0)
+    cfg = make_cfg(base, n_epochs=n_epochs, engine_seed=seed)
     from graphgan_amd.graph_gan import GraphGAN
-    np.random.seed(0)
     t0 = time.time()
     g = GraphGAN(cfg)
     init = ca_grqc_init_embeddings(d, n, seed=0).astype(np.float32)

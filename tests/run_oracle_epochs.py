@@ -2,7 +2,7 @@
 """Run the CPU oracle trainer (reference schedule, dense TF1-Adam, spec-arithmetic walks) on the
 CA-GrQc fixture for a few outer epochs and record the gen/dis link-prediction accuracy after each
 -- the curve the HIP engine's run with the same seed is compared against.
-    python tests/run_oracle_epochs.py <n_epochs> <out.json>"""
+    python tests/run_oracle_epochs.py <n_epochs> <out.json> [seed]"""
 import json
 import os
 import sys
@@ -18,9 +18,10 @@ from tests.helpers import ca_grqc_init_embeddings, load_ca_grqc  # noqa: E402
 
 def main():
     n_epochs, out = int(sys.argv[1]), sys.argv[2]
+    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # walk / shuffle seed; the initial embeddings stay those of seed 0
     d, n, graph = load_ca_grqc()
     init = ca_grqc_init_embeddings(d, n, seed=0)
-    o = orc.GraphGANOracle(n, graph, init, init, rng="counter", arith="spec", seed=0)
+    o = orc.GraphGANOracle(n, graph, init, init, rng="counter", arith="spec", seed=seed)
     test, neg = d["test"].tolist(), d["test_neg"].tolist()
     res = {"epochs": [], "seconds": []}
     res["epochs"].append([orc.eval_link_prediction(o.generator.E.astype(np.float64), test, neg),

@@ -395,3 +395,35 @@ def test_deterministic_small_batch_mode(ga, monkeypatch):
         assert np.quantile(diff, 0.99) < 1e-4
     for e in (a, b, c):
         e.close()
+
+
+@pytest.mark.parametrize("every", [0, 3])
+def test_sampled_profiling_and_early_returning_passes(ga, every, monkeypatch):
+    """gg_set_profiling(k != 1): events only on every k-th walk launch, gg_*_pass return before their kernels have
+    finished (stream-ordered).  Results and work counters are those of the default (every launch timed,
+    synchronous passes) mode; the timing counters cover exactly the profiled launches."""
+    monkeypatch.setenv("GG_DETERMINISTIC", "1")  # atomic-free B = 64 steps: the two runs are comparable bit for bit
+    g, n, graph, rowptr, col, Ed, eng = _setup_graph_engine(ga)
+    _, _, _, _, _, _, ref = _setup_graph_engine(ga)
+    eng.set_profiling(every)
+    slots = np.arange(n, dtype=np.int32)
+    for e in (eng, ref):
+        for it in range(3):
+            rows = e.prepare_d(slots, 4, 2 * it, fetch=False)
+            starts = np.arange(0, rows, 64)
+            e.d_pass(starts, 64)
+            pairs = e.prepare_g(slots, 20, 4, 2 * it + 1, fetch=False)
+            e.g_pass(np.arange(0, pairs, 64)[:150], 64)
+    eng.synchronize()
+    ca, cb = eng.counters(), ref.counters()
+    for k in ("walks", "hops", "nbr_reads", "rows_scored", "d_pairs", "g_pairs", "d_steps", "g_steps", "reward_pairs"):
+        assert ca[k] == cb[k], k
+    assert cb["walk_launches"] == 6 and ca["walk_launches"] == (2 if every == 3 else 0)
+    assert (ca["score_launches"] > 0) == (every == 3) and (ca["score_rows"] > 0) == (every == 3)
+    assert cb["score_rows"] == cb["rows_scored"]  # every launch profiled: the two row counters agree
+    for which in (0, 1):
+        assert np.array_equal(eng.get_embeddings(which), ref.get_embeddings(which))
+    with pytest.raises(ga.GraphGANHipError):
+        eng.set_profiling(-1)
+    eng.close()
+    ref.close()
