@@ -84,7 +84,7 @@ struct gg_ctx {
     // walk outputs (device resident)
     gg::DevBuf w_slots, w_ptr, w_samples, w_paths, w_len, w_status, w_first, w_abort, w_scratch;
     // level-synchronous front end of the walk sampler (walk_sample.hip): per-walk state + per-level tasks
-    gg::DevBuf st_cur, st_prev, st_len, st_alive, st_item, lv_beg, lv_k, lv_owner, lv_chunks, lv_coff, lv_scores, lv_chunk_owner, lv_prefix, lv_big;
+    gg::DevBuf st_cur, st_prev, st_len, st_alive, st_item, lv_beg, lv_k, lv_chunks, lv_coff, lv_scores, lv_chunk_owner, lv_prefix, lv_big;
     int32_t lv_levels_learned = 0;     // hops earlier (sized) launches needed until every walk had finished
     int64_t lv_cap_chunks = 0;         // learned capacity (chunks per level) for the sync-free launches
     bool walk_force_sized = false;     // retry path after a speculative overflow

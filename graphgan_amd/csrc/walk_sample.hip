@@ -55,14 +55,14 @@ struct WalkArgs {
     int64_t scratch_stride;
     unsigned long long *ctr;  // [0] hops [1] nbr_reads [2] alive walks [3] error flag [4] ticket [5] rows scored
     // walk state carried between levels / into the finisher
-    int32_t *st_cur, *st_prev, *st_len, *st_alive, *st_item;
+    int32_t *st_cur, *st_prev, *st_len, *st_alive;
+    int4 *st_const;        // {item, slot, root, walk index inside the root}: fixed per walk, ONE load per hop
     int32_t level;         // hop index handled by this launch (level kernels) / first hop (finisher)
     // per-level tasks
     int64_t *lv_beg;       // absolute offset of the candidate list in t_nbr
     int32_t *lv_k;         // candidates
-    int32_t *lv_owner;     // walk whose score region this walk reads
-    int32_t *lv_chunks;    // 64-neighbour chunks this walk owns (0 for non-owners / dead walks)
-    int64_t *lv_coff;      // first chunk of this walk's score region (owners)
+    int32_t *lv_chunks;    // 16-candidate chunks this walk owns (0 for non-owners / dead walks)
+    int64_t *lv_coff;      // first chunk of the score / prefix region this walk samples from (its owner's)
     float *lv_scores;      // [CHUNK * total chunks]
     int4 *lv_chunk_desc;   // [total chunks] {cur node, rows in this chunk, list offset lo, hi} of chunk c
     uint64_t *lv_prefix;   // [CHUNK * total chunks] inclusive prefix sums of the fixed-point weights
@@ -216,15 +216,19 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     int64_t beg_abs = 0;
     // finished walks (the majority at the deeper hops) leave after ONE load
     if (in_range && (!do_sample || a.st_alive[w] != 0)) {
+        int slot, root, j;
         if (!do_sample) {
             item = find_item(a.walk_ptr, a.n_slots, w);
-            a.st_item[w] = item;
+            slot = a.slots[item];
+            root = a.t_root[slot];
+            j = (int)(w - a.walk_ptr[item]);
+            a.st_const[w] = make_int4(item, slot, root, j);
         } else {
-            item = a.st_item[w];
+            // every per-walk input of the hop is an independent load (this kernel is one chain of dependent
+            // random reads per walk, a few waves per SIMD: its run time IS the length of that chain)
+            const int4 sc = a.st_const[w];
+            item = sc.x; slot = sc.y; root = sc.z; j = sc.w;
         }
-        const int slot = a.slots[item];
-        const int root = a.t_root[slot];
-        const int j = (int)(w - a.walk_ptr[item]);
         if (!do_sample) {  // level 0: start the walk
             alive = true;
             cur = root;
@@ -238,16 +242,41 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
                 sampled = true;
                 const int kk = a.lv_k[w];
                 my_k = (unsigned long long)kk;
-                const uint64_t *const pf = a.lv_prefix + a.lv_coff[a.lv_owner[w]] * CHUNK;
-                const uint64_t thr = threshold(uniform53(a.seed, a.stream, (uint32_t)root, (uint32_t)j, (uint32_t)(a.level - 1)), pf[kk - 1]);
-                int lo = 0, hi = kk - 1;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (pf[mid] > thr) hi = mid; else lo = mid + 1;
-                }
-                const int nxt = a.t_nbr[a.lv_beg[w] + lo];
+                const uint64_t *const pf = a.lv_prefix + a.lv_coff[w] * CHUNK;
+                const int64_t beg0 = a.lv_beg[w];
                 const int len = a.st_len[w];
                 const int cur0 = a.st_cur[w], prev0 = a.st_prev[w];
+                // first j with C_j > thr by a 16-ary search: 15 independent pivot loads per round, ceil(log16 k)
+                // dependent rounds instead of log2 k (a hub hop was a chain of 12+ dependent random reads); the
+                // first round's pivots do not depend on the threshold and fly together with W = C_{k-1}
+                int lo = 0, n = kk;  // invariant: the answer lies in [lo, lo + n) and C_{lo+n-1} > thr
+                int step = (n + 15) >> 4;
+                uint64_t piv[15];
+#pragma unroll
+                for (int i = 1; i < 16; ++i) {
+                    const int idx = i * step - 1;
+                    piv[i - 1] = (idx < n - 1) ? pf[idx] : ~0ull;
+                }
+                const uint64_t thr = threshold(uniform53(a.seed, a.stream, (uint32_t)root, (uint32_t)j, (uint32_t)(a.level - 1)), pf[kk - 1]);
+                int seg = 0;
+#pragma unroll
+                for (int i = 0; i < 15; ++i) seg += (piv[i] <= thr) ? 1 : 0;  // C is non-decreasing: a prefix of the pivots
+                lo = seg * step;
+                n = min(step, n - seg * step);
+                while (n > 1) {
+                    step = (n + 15) >> 4;
+#pragma unroll
+                    for (int i = 1; i < 16; ++i) {
+                        const int idx = i * step - 1;
+                        piv[i - 1] = (idx < n - 1) ? pf[lo + idx] : ~0ull;
+                    }
+                    seg = 0;
+#pragma unroll
+                    for (int i = 0; i < 15; ++i) seg += (piv[i] <= thr) ? 1 : 0;
+                    lo += seg * step;
+                    n = min(step, n - seg * step);
+                }
+                const int nxt = a.t_nbr[beg0 + lo];
                 if (len >= a.stride) {
                     a.ctr[3] = 1ull;
                     a.path_len[w] = 0;
@@ -353,13 +382,13 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         if (i < wv) { chunks_before += wv_chunks[i]; big_before += wv_big[i]; }
         blk_chunks += wv_chunks[i];
     }
-    const int64_t coff = (int64_t)blk_base[0] + chunks_before + inc - chunks;
+    const int64_t coff_own = (int64_t)blk_base[0] + chunks_before + inc - chunks;
+    const int64_t coff = __shfl(coff_own, owner < 0 ? lane : owner, 64);  // non-owners sample from their owner's region
     const bool fits = (int64_t)blk_base[0] + blk_chunks <= cap_chunks;
     if (write_desc == 1 && !fits && threadIdx.x == 0) a.ctr[3] = 2ull;  // speculative capacity exceeded: the host reruns in sized mode
     if (in_range) {
         a.lv_beg[w] = beg_abs;
         a.lv_k[w] = k;
-        a.lv_owner[w] = (int32_t)((w & ~63ll) + owner);
         a.lv_chunks[w] = chunks;
         a.lv_coff[w] = coff;
         if (big) a.lv_big[blk_base[1] + big_before + __popcll(big_bal & ((1ull << lane) - 1ull))] = (int32_t)w;
@@ -494,8 +523,10 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const
     if (threadIdx.x == 0 && blk_rows) atomicAdd(&a.ctr[CTR_ROWS + (blockIdx.x & 63)], blk_rows);
 }
 
-// Small owner tasks (k <= BIG_TASK): one 16-lane group per walk -- max, exact fixed-point weights
-// (spec S2, S3) and their inclusive prefix sums, computed once per (root, node).
+// Small owner tasks (16 < k <= BIG_TASK): one 16-lane group per walk -- max, exact fixed-point weights
+// (spec S2, S3) and their inclusive prefix sums, computed once per (root, node).  All of the task's
+// scores are fetched with independent loads up front (<= 16 per lane): the kernel used to be two
+// dependent passes of k/16 load -> use steps each.
 __global__ __launch_bounds__(256) void level_weights_small_kernel(const WalkArgs a, const int64_t cap_chunks) {
     if ((int64_t)a.ctr[CTR_CHUNKS + a.level] > cap_chunks || a.ctr[CTR_CHUNKS + a.level] == 0ull) return;
     const int t = threadIdx.x & 15;
@@ -506,21 +537,35 @@ __global__ __launch_bounds__(256) void level_weights_small_kernel(const WalkArgs
     const int64_t base = a.lv_coff[w] * CHUNK;
     const float *const sc = a.lv_scores + base;
     uint64_t *const pf = a.lv_prefix + base;
-    float mx = -INFINITY;
-    for (int jj = t; jj < k; jj += 16) mx = fmaxf(mx, sc[jj]);
+    constexpr int PER_LANE = BIG_TASK / 16;
+    float v[PER_LANE];
+#pragma unroll
+    for (int i = 0; i < PER_LANE; ++i) {
+        const int jj = i * 16 + t;
+        v[i] = (jj < k) ? sc[jj] : -INFINITY;
+    }
+    float mx = v[0];
+#pragma unroll
+    for (int i = 1; i < PER_LANE; ++i) mx = fmaxf(mx, v[i]);
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 16));
     uint64_t carry = 0;
-    for (int j0 = 0; j0 < k; j0 += 16) {
-        const int jj = j0 + t;
-        const uint64_t wgt = (jj < k) ? weight_fix40(exp_spec(sc[jj] - mx)) : 0ull;
-        const uint64_t C = carry + group16_incl_scan_u64(wgt, t);
-        if (jj < k) pf[jj] = C;
-        carry = __shfl(C, 15, 16);
+#pragma unroll
+    for (int i = 0; i < PER_LANE; ++i) {
+        if (i * 16 < k) {  // uniform inside the 16-lane group
+            const int jj = i * 16 + t;
+            const uint64_t wgt = (jj < k) ? weight_fix40(exp_spec(v[i] - mx)) : 0ull;
+            const uint64_t C = carry + group16_incl_scan_u64(wgt, t);
+            if (jj < k) pf[jj] = C;
+            carry = __shfl(C, 15, 16);
+        }
     }
 }
 
-// Big owner tasks (hubs): one 256-thread workgroup per task, from the level's big-task list.
+// Big owner tasks (hubs): one 256-thread workgroup per task, from the level's big-task list.  Tasks of up to
+// BIG_REG candidates keep their scores in registers between the max and the scan pass (one round of
+// independent loads); larger ones re-read them.
+constexpr int BIG_REG = 4096;
 __global__ __launch_bounds__(256) void level_weights_big_kernel(const WalkArgs a, const int64_t cap_chunks) {
     if ((int64_t)a.ctr[CTR_CHUNKS + a.level] > cap_chunks) return;
     __shared__ float red[4];
@@ -533,17 +578,30 @@ __global__ __launch_bounds__(256) void level_weights_big_kernel(const WalkArgs a
         const int64_t base = a.lv_coff[w] * CHUNK;
         const float *const sc = a.lv_scores + base;
         uint64_t *const pf = a.lv_prefix + base;
+        constexpr int PER_THREAD = BIG_REG / 256;
+        const bool in_regs = k <= BIG_REG;  // uniform in the workgroup
+        float v[PER_THREAD];
         float mx = -INFINITY;
-        for (int jj = threadIdx.x; jj < k; jj += 256) mx = fmaxf(mx, sc[jj]);
+        if (in_regs) {
+#pragma unroll
+            for (int i = 0; i < PER_THREAD; ++i) {
+                const int jj = i * 256 + threadIdx.x;
+                v[i] = (jj < k) ? sc[jj] : -INFINITY;
+            }
+#pragma unroll
+            for (int i = 0; i < PER_THREAD; ++i) mx = fmaxf(mx, v[i]);
+        } else {
+            for (int jj = threadIdx.x; jj < k; jj += 256) mx = fmaxf(mx, sc[jj]);
+        }
         mx = wave_max_f32(mx);
         __syncthreads();
         if (lane == 0) red[wv] = mx;
         __syncthreads();
         mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
         uint64_t carry = 0;
-        for (int j0 = 0; j0 < k; j0 += 256) {
+        auto scan_block = [&](int j0, float x) {
             const int jj = j0 + threadIdx.x;
-            const uint64_t wgt = (jj < k) ? weight_fix40(exp_spec(sc[jj] - mx)) : 0ull;
+            const uint64_t wgt = (jj < k) ? weight_fix40(exp_spec(x - mx)) : 0ull;
             const uint64_t inc = wave_incl_scan_u64(wgt, lane);
             __syncthreads();
             if (lane == 63) wave_tot[wv] = inc;
@@ -556,6 +614,13 @@ __global__ __launch_bounds__(256) void level_weights_big_kernel(const WalkArgs a
             }
             if (jj < k) pf[jj] = pre + inc;
             carry += tot;
+        };
+        if (in_regs) {
+#pragma unroll
+            for (int i = 0; i < PER_THREAD; ++i)
+                if (i * 256 < k) scan_block(i * 256, v[i]);
+        } else {
+            for (int j0 = 0; j0 < k; j0 += 256) scan_block(j0, (j0 + threadIdx.x < k) ? sc[j0 + threadIdx.x] : 0.f);
         }
     }
 }
@@ -810,19 +875,17 @@ static int run_levels_and_finish(gg_ctx *ctx, WalkArgs &a, int64_t total_walks) 
         GG_HIP(ctx, ctx->st_alive.reserve(sizeof(int32_t) * total_walks));
         GG_HIP(ctx, ctx->lv_beg.reserve(sizeof(int64_t) * total_walks));
         GG_HIP(ctx, ctx->lv_k.reserve(sizeof(int32_t) * total_walks));
-        GG_HIP(ctx, ctx->lv_owner.reserve(sizeof(int32_t) * total_walks));
         GG_HIP(ctx, ctx->lv_chunks.reserve(sizeof(int32_t) * total_walks));
         GG_HIP(ctx, ctx->lv_big.reserve(sizeof(int32_t) * total_walks));
         GG_HIP(ctx, ctx->lv_coff.reserve(sizeof(int64_t) * (total_walks + 1)));
-        GG_HIP(ctx, ctx->st_item.reserve(sizeof(int32_t) * total_walks));
+        GG_HIP(ctx, ctx->st_item.reserve(sizeof(int4) * total_walks));
         a.st_cur = ctx->st_cur.as<int32_t>();
         a.st_prev = ctx->st_prev.as<int32_t>();
         a.st_len = ctx->st_len.as<int32_t>();
         a.st_alive = ctx->st_alive.as<int32_t>();
-        a.st_item = ctx->st_item.as<int32_t>();
+        a.st_const = ctx->st_item.as<int4>();
         a.lv_beg = ctx->lv_beg.as<int64_t>();
         a.lv_k = ctx->lv_k.as<int32_t>();
-        a.lv_owner = ctx->lv_owner.as<int32_t>();
         a.lv_chunks = ctx->lv_chunks.as<int32_t>();
         a.lv_big = ctx->lv_big.as<int32_t>();
         a.lv_coff = ctx->lv_coff.as<int64_t>();
