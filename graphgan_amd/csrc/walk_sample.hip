@@ -13,8 +13,8 @@
 //   level_score_kernel          one 16-lane group per <= 16-candidate chunk: neighbour rows as
 //                               float4 (256 B contiguous per row per load), fmaf chain, xor
 //                               butterfly (spec S1), + bias -> score buffer.  Dominant, HBM-bound.
-//   level_weights_small / big   max, exact fixed-point weights, uint64 prefix sums (S2, S3),
-//                               once per distribution
+//   level_weights_kernel        max, exact fixed-point weights, uint64 prefix sums (S2, S3), once
+//                               per distribution: 16-lane groups for 16 < k <= 256, workgroups for hubs
 //   walk_sample_kernel          "finisher": one wavefront per walk runs the remaining hops
 //                               (GG_WALK_LEVELS < tree depth + 2; = 0: the whole walk)
 // Scores follow S1 and everything after them is exact integer arithmetic, so the decomposition
@@ -527,10 +527,9 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const
 // (spec S2, S3) and their inclusive prefix sums, computed once per (root, node).  All of the task's
 // scores are fetched with independent loads up front (<= 16 per lane): the kernel used to be two
 // dependent passes of k/16 load -> use steps each.
-__global__ __launch_bounds__(256) void level_weights_small_kernel(const WalkArgs a, const int64_t cap_chunks) {
-    if ((int64_t)a.ctr[CTR_CHUNKS + a.level] > cap_chunks || a.ctr[CTR_CHUNKS + a.level] == 0ull) return;
+__device__ __forceinline__ void weights_small_block(const WalkArgs &a, const int64_t block) {
     const int t = threadIdx.x & 15;
-    const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int64_t w = (block * 256 + threadIdx.x) >> 4;
     if (w >= a.total_walks || a.lv_chunks[w] <= 1) return;  // non-owners, and single-chunk tasks (done by the score kernel)
     const int k = a.lv_k[w];
     if (k > BIG_TASK) return;
@@ -566,13 +565,13 @@ __global__ __launch_bounds__(256) void level_weights_small_kernel(const WalkArgs
 // BIG_REG candidates keep their scores in registers between the max and the scan pass (one round of
 // independent loads); larger ones re-read them.
 constexpr int BIG_REG = 4096;
-__global__ __launch_bounds__(256) void level_weights_big_kernel(const WalkArgs a, const int64_t cap_chunks) {
-    if ((int64_t)a.ctr[CTR_CHUNKS + a.level] > cap_chunks) return;
+constexpr int BIG_BLOCKS = 2048;  // workgroups of the weights launch that serve the big-task list
+__device__ __forceinline__ void weights_big_blocks(const WalkArgs &a) {
     __shared__ float red[4];
     __shared__ uint64_t wave_tot[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int n_big = (int)a.ctr[CTR_BIG + a.level];
-    for (int b = blockIdx.x; b < n_big; b += gridDim.x) {
+    for (int b = blockIdx.x; b < n_big; b += BIG_BLOCKS) {
         const int64_t w = a.lv_big[b];
         const int k = a.lv_k[w];
         const int64_t base = a.lv_coff[w] * CHUNK;
@@ -623,6 +622,16 @@ __global__ __launch_bounds__(256) void level_weights_big_kernel(const WalkArgs a
             for (int j0 = 0; j0 < k; j0 += 256) scan_block(j0, (j0 + threadIdx.x < k) ? sc[j0 + threadIdx.x] : 0.f);
         }
     }
+}
+
+// One launch per level for both task classes: the first BIG_BLOCKS workgroups walk the big-task list (they run
+// longest, so they are dispatched first), the others take 16 walks each.  As two back-to-back launches the two
+// classes cost the sum of their latency-bound run times; together, the longer of the two.
+__global__ __launch_bounds__(256) void level_weights_kernel(const WalkArgs a, const int64_t cap_chunks) {
+    const unsigned long long total_chunks = a.ctr[CTR_CHUNKS + a.level];
+    if ((int64_t)total_chunks > cap_chunks || total_chunks == 0ull) return;
+    if (blockIdx.x < BIG_BLOCKS) weights_big_blocks(a);
+    else weights_small_block(a, (int64_t)blockIdx.x - BIG_BLOCKS);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -848,8 +857,7 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
             GG_HIP(ctx, hipEventRecord(ctx->lv_ev[2 * level + 1], ctx->stream));
             ctx->lv_ev_used = level + 1;
         }
-        hipLaunchKernelGGL(level_weights_small_kernel, dim3((unsigned)cdiv(total_walks * 16, 256)), dim3(256), 0, ctx->stream, a, cap);
-        hipLaunchKernelGGL(level_weights_big_kernel, dim3(2048), dim3(256), 0, ctx->stream, a, cap);
+        hipLaunchKernelGGL(level_weights_kernel, dim3((unsigned)(BIG_BLOCKS + cdiv(total_walks * 16, 256))), dim3(256), 0, ctx->stream, a, cap);
     }
     // finish the last prepared hop
     a.level = level;
