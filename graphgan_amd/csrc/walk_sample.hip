@@ -8,7 +8,7 @@
 //   level_advance_kernel        one thread per walk: finish hop h-1 (Philox uniform, threshold,
 //                               binary search in the shared prefix sums, path append,
 //                               termination), prepare hop h (tree list + the reference's hop
-//                               rules, in-wave dedup of identical (root, node) distributions,
+//                               rules, in-workgroup dedup of identical (root, node) distributions,
 //                               chunk offsets, chunk descriptors)
 //   level_score_kernel          one 16-lane group per <= 16-candidate chunk: neighbour rows as
 //                               float4 (256 B contiguous per row per load), fmaf chain, xor
@@ -201,7 +201,7 @@ constexpr int MAX_LEVELS = 64;
 //              prefix sums (first j with C_j > floor(m W / 2^53), spec S4/S5), path append,
 //              termination (next == previous);
 //   do_setup : prepare hop (level) -- tree list of (root, cur) with the reference's hop rules
-//              (root-only-children, Q2 abort, Q3 father removal) and the in-wave dedup: walks of
+//              (root-only-children, Q2 abort, Q3 father removal) and the in-workgroup dedup: walks of
 //              one root standing on the same node need the SAME distribution -> one owner.
 __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, const int do_sample, const int do_setup, const int write_desc,
                                                             const int64_t cap_chunks) {
@@ -343,14 +343,23 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         }
     }
     if (!do_setup) return;
-    // in-wave dedup: the first lane with the same (item, cur) owns the distribution
-    const long long key = alive ? (((long long)item << 32) | (unsigned)cur) : (-1ll - lane);
-    int owner = -1;
-    for (int l = 0; l < 64; ++l) {
-        const long long kl = __shfl(key, l, 64);
-        if (owner < 0 && kl == key) owner = l;
+    // dedup inside the workgroup (256 consecutive walks): the first walk with the same (item, cur) owns the
+    // distribution.  Walks of one root are consecutive, so a walk scans backwards over its root's walks only
+    // (finished walks are skipped, the first live walk of another root ends the scan).
+    __shared__ long long blk_keys[256];
+    __shared__ long long blk_coff[256];
+    const long long key = alive ? (((long long)item << 32) | (unsigned)cur) : -1ll;
+    blk_keys[threadIdx.x] = key;
+    __syncthreads();
+    int owner = (int)threadIdx.x;
+    if (alive) {
+        for (int jj = (int)threadIdx.x - 1; jj >= 0; --jj) {
+            const long long kj = blk_keys[jj];
+            if (kj == key) owner = jj;
+            else if (kj >= 0 && (int)(kj >> 32) != item) break;
+        }
     }
-    const bool owns = in_range && alive && owner == lane;
+    const bool owns = alive && owner == (int)threadIdx.x;
     const int chunks = owns ? (k + CHUNK - 1) / CHUNK : 0;
     const bool big = owns && k > BIG_TASK;
     // chunk offsets and big-task slots: in-wave exclusive scans, per-block totals through LDS, and ONE
@@ -383,7 +392,9 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         blk_chunks += wv_chunks[i];
     }
     const int64_t coff_own = (int64_t)blk_base[0] + chunks_before + inc - chunks;
-    const int64_t coff = __shfl(coff_own, owner < 0 ? lane : owner, 64);  // non-owners sample from their owner's region
+    blk_coff[threadIdx.x] = coff_own;
+    __syncthreads();
+    const int64_t coff = blk_coff[owner];  // non-owners sample from their owner's region
     const bool fits = (int64_t)blk_base[0] + blk_chunks <= cap_chunks;
     if (write_desc == 1 && !fits && threadIdx.x == 0) a.ctr[3] = 2ull;  // speculative capacity exceeded: the host reruns in sized mode
     if (in_range) {
