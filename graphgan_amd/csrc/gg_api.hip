@@ -77,8 +77,21 @@ using namespace gg;
 
 // Shared by gg_walk_sample and gg_prepare_*: stage the launch on device and enqueue it (no host
 // synchronisation).  n_walks == NULL: CSR degree of each slot's root (D-mode, graph_gan.py:190-191).
+// One walk launch on ctx->walk_stream; a side-stream launch is ordered behind the last generator update and
+// hands its completion back to the main stream, where everything that follows the walk is enqueued.
+static int launch_and_join(gg_ctx *ctx, int32_t n_slots, int64_t total, int32_t for_d, uint64_t seed, uint32_t stream, int32_t stride) {
+    const bool side = ctx->walk_stream != ctx->stream;
+    int rc = launch_walk_sample(ctx, n_slots, total, for_d, seed, stream, stride);
+    if (rc != GG_OK) return rc;
+    if (side) {
+        GG_HIP(ctx, hipEventRecord(ctx->ev_walk_done, ctx->walk_stream));
+        GG_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_walk_done, 0));
+    }
+    return GG_OK;
+}
+
 int gg::walk_launch_async(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, int32_t uniform_walks, int32_t n_slots,
-                          int32_t for_d, uint64_t seed, uint32_t stream, int32_t stride) {
+                          int32_t for_d, uint64_t seed, uint32_t stream, int32_t stride, bool side_stream) {
     GG_CHECK(ctx, ctx->n_tree_roots > 0, GG_EINVAL, "walk: no trees loaded (gg_build_trees / gg_set_trees)");
     GG_CHECK(ctx, n_slots >= 0 && (slots || n_slots == 0), GG_EINVAL, "walk: bad slots");
     GG_CHECK(ctx, stride >= 2, GG_ECAPACITY, "walk: stride %d < 2", stride);
@@ -107,16 +120,27 @@ int gg::walk_launch_async(gg_ctx *ctx, const int32_t *slots, const int32_t *n_wa
     GG_HIP(ctx, ctx->w_len.reserve(sizeof(int32_t) * (total + 1)));
     GG_HIP(ctx, ctx->w_first.reserve(sizeof(int32_t) * (total + 1)));
     GG_HIP(ctx, ctx->w_paths.reserve(sizeof(int32_t) * ((size_t)total * stride + 1)));
+    ctx->walk_stream = side_stream ? ctx->stream2 : ctx->stream;
+    if (side_stream && ctx->gen_dirty) {  // generator steps outside a completed pass: wait for everything on the main stream
+        GG_HIP(ctx, hipEventRecord(ctx->ev_main_mark, ctx->stream));
+        GG_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_main_mark, 0));
+        ctx->gen_dirty = false;
+    } else if (side_stream && ctx->gen_pass_recorded) {
+        GG_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_gen_pass, 0));
+    }
     // h_walk_ptr and the caller's slots outlive the enqueued copies: every public call ends with a stream sync
-    if (n_slots) GG_HIP(ctx, hipMemcpyAsync(ctx->w_slots.p, slots, sizeof(int32_t) * n_slots, hipMemcpyHostToDevice, ctx->stream));
-    GG_HIP(ctx, hipMemcpyAsync(ctx->w_ptr.p, ptr.data(), sizeof(int64_t) * (n_slots + 1), hipMemcpyHostToDevice, ctx->stream));
+    if (n_slots) GG_HIP(ctx, hipMemcpyAsync(ctx->w_slots.p, slots, sizeof(int32_t) * n_slots, hipMemcpyHostToDevice, ctx->walk_stream));
+    GG_HIP(ctx, hipMemcpyAsync(ctx->w_ptr.p, ptr.data(), sizeof(int64_t) * (n_slots + 1), hipMemcpyHostToDevice, ctx->walk_stream));
     ctx->w_total = total;
     ctx->w_stride = stride;
     ctx->w_nslots = n_slots;
     ctx->w_args = {for_d, seed, stream};
     ctx->g_paths_valid = false;
-    if (n_slots == 0) return GG_OK;
-    return launch_walk_sample(ctx, n_slots, total, for_d, seed, stream, stride);
+    if (n_slots == 0) {
+        ctx->walk_stream = ctx->stream;
+        return GG_OK;
+    }
+    return launch_and_join(ctx, n_slots, total, for_d, seed, stream, stride);
 }
 
 // Wait for the enqueued launch (and whatever the caller enqueued behind it), collect counters,
@@ -135,7 +159,7 @@ int gg::walk_finalize(gg_ctx *ctx, bool *retried) {
         // nothing the overflowed launch wrote or counted is final (the D-mode post-pass is gated by the same flag,
         // the counter words are zeroed again by the new launch)
         ctx->walk_force_sized = true;
-        int rc = launch_walk_sample(ctx, ctx->w_nslots, total, ctx->w_args.for_d, ctx->w_args.seed, ctx->w_args.stream, ctx->w_stride);
+        int rc = launch_and_join(ctx, ctx->w_nslots, total, ctx->w_args.for_d, ctx->w_args.seed, ctx->w_args.stream, ctx->w_stride);
         ctx->walk_force_sized = false;
         if (rc != GG_OK) return rc;
         GG_HIP(ctx, hipMemcpyAsync(c, ctx->dev_ctr, sizeof(unsigned long long) * 392, hipMemcpyDeviceToHost, ctx->stream));
@@ -224,8 +248,13 @@ int gg_create(int32_t n_node, int32_t n_emb, const float *emb_gen, const float *
     } while (0)
     auto body = [&]() -> int {
         GG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        GG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        ctx->walk_stream = ctx->stream;
         GG_HIP(ctx, hipEventCreate(&ctx->ev0));
         GG_HIP(ctx, hipEventCreate(&ctx->ev1));
+        GG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_walk_done, hipEventDisableTiming));
+        GG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_gen_pass, hipEventDisableTiming));
+        GG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_main_mark, hipEventDisableTiming));
         GG_HIP(ctx, hipHostMalloc((void **)&ctx->h_pin, sizeof(unsigned long long) * 512, hipHostMallocDefault));
         memset(ctx->h_pin, 0, sizeof(unsigned long long) * 512);
         const size_t tb = sizeof(float) * (size_t)n_node * ctx->ld, vb = sizeof(float) * (size_t)n_node;
@@ -296,6 +325,12 @@ int gg_destroy(gg_ctx *ctx) {
     for (hipEvent_t e : ctx->lv_ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    for (hipEvent_t e : {ctx->ev_walk_done, ctx->ev_gen_pass, ctx->ev_main_mark})
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->stream2) {
+        (void)hipStreamSynchronize(ctx->stream2);
+        (void)hipStreamDestroy(ctx->stream2);
+    }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -54,6 +54,16 @@ struct gg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // Side stream for the walks of gg_prepare_g: they read only the generator's tables and the trees, so they may
+    // run beside whatever discriminator work (gg_d_pass: gradient kernel, replica exchange, optimizer) is still in
+    // flight on `stream`; the pair / reward kernels behind the walk go back to `stream` (ev_walk_done).
+    hipStream_t stream2 = nullptr;
+    hipStream_t walk_stream = nullptr;   // stream of the walk launch in flight (stream or stream2)
+    hipEvent_t ev_walk_done = nullptr;   // side-stream walk finished  -> `stream` waits
+    hipEvent_t ev_gen_pass = nullptr;    // last generator update enqueued on `stream` -> the side stream waits
+    hipEvent_t ev_main_mark = nullptr;   // profiled side-stream launches wait for all of `stream` (measured alone)
+    bool gen_pass_recorded = false;
+    bool gen_dirty = false;  // a generator update was enqueued and ev_gen_pass does not cover it yet (error path, single steps)
     hipEvent_t lv_ev[128] = {};  // per-level event pairs around level_score_kernel
     int lv_ev_used = 0;
     gg::Model model[2];  // 0 = generator, 1 = discriminator (config.modes order)
@@ -159,7 +169,7 @@ int64_t host_tree_sizes(int32_t n, const int64_t *rowptr, const int32_t *col, co
 
 // launchers
 int walk_launch_async(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, int32_t uniform_walks, int32_t n_slots,
-                      int32_t for_d, uint64_t seed, uint32_t stream, int32_t stride);
+                      int32_t for_d, uint64_t seed, uint32_t stream, int32_t stride, bool side_stream = false);
 int walk_finalize(gg_ctx *ctx, bool *retried);
 int walk_resident(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, int32_t uniform_walks, int32_t n_slots,
                   int32_t for_d, uint64_t seed, uint32_t stream, int32_t stride);

@@ -303,7 +303,8 @@ int gg_prepare_g(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, int32_t n_s
     GG_CHECK(ctx, n_sample >= 0, GG_EINVAL, "gg_prepare_g: n_sample < 0");
     const int stride = ctx->tree_max_depth + 3;
     ctx->g_pairs = 0;
-    int rc = walk_launch_async(ctx, slots, nullptr, n_sample, n_slots, 0, seed, stream, stride);
+    // G walks read the generator's tables and the trees only: beside the discriminator update still in flight
+    int rc = walk_launch_async(ctx, slots, nullptr, n_sample, n_slots, 0, seed, stream, stride, /*side_stream=*/true);
     if (rc != GG_OK) return rc;
     const int64_t nw = ctx->w_total;
     // a path of L = len - 1 <= stride - 1 nodes gives at most 2 * window * L pairs

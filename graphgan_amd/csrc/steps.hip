@@ -629,6 +629,7 @@ int apply_optimizer(gg_ctx *ctx, int which, int64_t n) {
         else hipLaunchKernelGGL(sparse_opt_kernel<0>, dim3(nb), dim3(256), 0, ctx->stream, o);
     }
     GG_HIP(ctx, hipGetLastError());
+    if (which == 0) ctx->gen_dirty = true;
     M.t += 1;
     M.b1p = M.b1p * ctx->cfg.adam_beta1;
     M.b2p = M.b2p * ctx->cfg.adam_beta2;
@@ -692,6 +693,11 @@ static int run_pass(gg_ctx *ctx, int which, const int64_t *starts, int64_t n_bat
             int rc = run_step(ctx, which, u + s, v + s, x + s, n);
             if (rc != GG_OK) return rc;
         }
+    }
+    if (which == 0) {  // walks of a later gg_prepare_g run on the side stream: they start behind this generator update
+        GG_HIP(ctx, hipEventRecord(ctx->ev_gen_pass, ctx->stream));
+        ctx->gen_pass_recorded = true;
+        ctx->gen_dirty = false;
     }
     if (timed) {
         GG_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));

@@ -186,6 +186,19 @@ __device__ __forceinline__ int sample_index(Load sbuf, int k, float mx, uint64_t
 // Level kernels (streaming front end)
 // ------------------------------------------------------------------------------------------
 constexpr int SINGLE_CHUNK = 0x100;  // descriptor flag: the task has one chunk -> the score kernel finishes its prefix sums itself
+// Persistent grid of the score kernel: 6 of the 8 wave slots per SIMD.  The two free slots let kernels of the other
+// stream (the discriminator update that runs beside the generator's walks) start at once instead of queueing behind
+// a launch that holds the whole chip for hundreds of microseconds; the stream of rows in flight is deep enough
+// either way.  GG_SCORE_BLOCKS overrides.
+static int score_blocks() {
+    static const int v = [] {
+        const char *e = getenv("GG_SCORE_BLOCKS");
+        int b = e ? atoi(e) : 256 * 6;
+        if (b < 8) b = 8;
+        return b - b % 8;
+    }();
+    return v;
+}
 constexpr int BIG_TASK = 256;   // owner tasks with more candidates get a whole workgroup for their prefix sums
 constexpr int CTR_ALIVE = 8;    // ctr[CTR_ALIVE + level]: walks alive when hop `level` was set up
 constexpr int CTR_BIG = 72;     // ctr[CTR_BIG + level]:   big owner tasks of hop `level`
@@ -838,22 +851,22 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
     int level = 0;
     for (; level < n_levels; ++level) {
         a.level = level;
-        hipLaunchKernelGGL(level_advance_kernel, dim3(wblocks), dim3(256), 0, ctx->stream, a, level > 0 ? 1 : 0, 1, sized ? 0 : 1, cap);
+        hipLaunchKernelGGL(level_advance_kernel, dim3(wblocks), dim3(256), 0, ctx->walk_stream, a, level > 0 ? 1 : 0, 1, sized ? 0 : 1, cap);
         if (sized) {
             unsigned long long total_chunks = 0, alive = 0;
-            GG_HIP(ctx, hipMemcpyAsync(&total_chunks, ctx->dev_ctr + CTR_CHUNKS + level, sizeof(total_chunks), hipMemcpyDeviceToHost, ctx->stream));
-            GG_HIP(ctx, hipMemcpyAsync(&alive, ctx->dev_ctr + CTR_ALIVE + level, sizeof(alive), hipMemcpyDeviceToHost, ctx->stream));
-            GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            GG_HIP(ctx, hipMemcpyAsync(&total_chunks, ctx->dev_ctr + CTR_CHUNKS + level, sizeof(total_chunks), hipMemcpyDeviceToHost, ctx->walk_stream));
+            GG_HIP(ctx, hipMemcpyAsync(&alive, ctx->dev_ctr + CTR_ALIVE + level, sizeof(alive), hipMemcpyDeviceToHost, ctx->walk_stream));
+            GG_HIP(ctx, hipStreamSynchronize(ctx->walk_stream));
             if (alive == 0) { *any_alive = false; return GG_OK; }
             if (level + 1 > ctx->lv_levels_learned) ctx->lv_levels_learned = level + 1;
             cap = (int64_t)total_chunks;
             if (cap + cap / 4 + 4096 > ctx->lv_cap_chunks) ctx->lv_cap_chunks = cap + cap / 4 + 4096;
             int rc = reserve_level_buffers(ctx, a, cap);
             if (rc != GG_OK) return rc;
-            hipLaunchKernelGGL(level_expand_kernel, dim3(wblocks), dim3(256), 0, ctx->stream, a);
+            hipLaunchKernelGGL(level_expand_kernel, dim3(wblocks), dim3(256), 0, ctx->walk_stream, a);
         }
-        int64_t blocks = sized ? (cap + WAVES_PER_BLOCK * 4 - 1) / (WAVES_PER_BLOCK * 4) : 256 * 8;
-        if (blocks > 256 * 8) blocks = 256 * 8;
+        int64_t blocks = sized ? (cap + WAVES_PER_BLOCK * 4 - 1) / (WAVES_PER_BLOCK * 4) : score_blocks();
+        if (blocks > score_blocks()) blocks = score_blocks();
         if (blocks >= 8) blocks -= blocks % 8;
         if (blocks < 1) blocks = 1;
         if (ctx->walk_timed) {
@@ -861,18 +874,18 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
                 GG_HIP(ctx, hipEventCreate(&ctx->lv_ev[2 * level]));
                 GG_HIP(ctx, hipEventCreate(&ctx->lv_ev[2 * level + 1]));
             }
-            GG_HIP(ctx, hipEventRecord(ctx->lv_ev[2 * level], ctx->stream));
+            GG_HIP(ctx, hipEventRecord(ctx->lv_ev[2 * level], ctx->walk_stream));
         }
-        hipLaunchKernelGGL(level_score_kernel<NCH>, dim3((unsigned)blocks), blk, 0, ctx->stream, a, cap);
+        hipLaunchKernelGGL(level_score_kernel<NCH>, dim3((unsigned)blocks), blk, 0, ctx->walk_stream, a, cap);
         if (ctx->walk_timed) {
-            GG_HIP(ctx, hipEventRecord(ctx->lv_ev[2 * level + 1], ctx->stream));
+            GG_HIP(ctx, hipEventRecord(ctx->lv_ev[2 * level + 1], ctx->walk_stream));
             ctx->lv_ev_used = level + 1;
         }
-        hipLaunchKernelGGL(level_weights_kernel, dim3((unsigned)(BIG_BLOCKS + cdiv(total_walks * 16, 256))), dim3(256), 0, ctx->stream, a, cap);
+        hipLaunchKernelGGL(level_weights_kernel, dim3((unsigned)(BIG_BLOCKS + cdiv(total_walks * 16, 256))), dim3(256), 0, ctx->walk_stream, a, cap);
     }
     // finish the last prepared hop
     a.level = level;
-    hipLaunchKernelGGL(level_advance_kernel, dim3(wblocks), dim3(256), 0, ctx->stream, a, 1, 0, (!sized && all_levels) ? 2 : 0, 0);
+    hipLaunchKernelGGL(level_advance_kernel, dim3(wblocks), dim3(256), 0, ctx->walk_stream, a, 1, 0, (!sized && all_levels) ? 2 : 0, 0);
     GG_HIP(ctx, hipGetLastError());
     return GG_OK;
 }
@@ -924,7 +937,7 @@ static int run_levels_and_finish(gg_ctx *ctx, WalkArgs &a, int64_t total_walks) 
         GG_HIP(ctx, ctx->w_scratch.reserve((size_t)need_stride * blocks * WAVES_PER_BLOCK * sizeof(float) + 16));
         a.scratch = ctx->w_scratch.as<float>();
         a.scratch_stride = need_stride;
-        hipLaunchKernelGGL(walk_sample_kernel<NCH>, dim3((unsigned)blocks), blk, 0, ctx->stream, a);
+        hipLaunchKernelGGL(walk_sample_kernel<NCH>, dim3((unsigned)blocks), blk, 0, ctx->walk_stream, a);
     }
     GG_HIP(ctx, hipGetLastError());
     return GG_OK;
@@ -960,14 +973,19 @@ int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int fo
 
     // every counter word belongs to ONE launch (the host accumulates, walk_finalize): hops / reads / rows, error
     // flag [3], ticket [4], per-level counters and the spread words
-    GG_HIP(ctx, hipMemsetAsync(ctx->dev_ctr, 0, sizeof(unsigned long long) * CTR_WORDS, ctx->stream));
+    GG_HIP(ctx, hipMemsetAsync(ctx->dev_ctr, 0, sizeof(unsigned long long) * CTR_WORDS, ctx->walk_stream));
     // HIP events around every profile_every-th call (a rerun keeps the decision of the launch it repeats)
     if (!ctx->walk_force_sized) ctx->walk_timed = ctx->profile_every > 0 && (ctx->walk_call_index++ % ctx->profile_every) == 0;
-    hipLaunchKernelGGL(walk_init_status_kernel, dim3(cdiv(n_slots, 256)), dim3(256), 0, ctx->stream, a);
+    if (ctx->walk_timed && ctx->walk_stream != ctx->stream) {
+        // a profiled launch is measured alone: it does not share the HBM with the discriminator update in flight
+        GG_HIP(ctx, hipEventRecord(ctx->ev_main_mark, ctx->stream));
+        GG_HIP(ctx, hipStreamWaitEvent(ctx->walk_stream, ctx->ev_main_mark, 0));
+    }
+    hipLaunchKernelGGL(walk_init_status_kernel, dim3(cdiv(n_slots, 256)), dim3(256), 0, ctx->walk_stream, a);
     if (total_walks == 0) return GG_OK;
 
     const int nch = (a.nchunk + 15) / 16;
-    if (ctx->walk_timed) GG_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    if (ctx->walk_timed) GG_HIP(ctx, hipEventRecord(ctx->ev0, ctx->walk_stream));
     int rc;
     if (nch <= 1) rc = run_levels_and_finish<1>(ctx, a, total_walks);
     else if (nch == 2) rc = run_levels_and_finish<2>(ctx, a, total_walks);
@@ -975,9 +993,9 @@ int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int fo
     else if (nch <= 8) rc = run_levels_and_finish<8>(ctx, a, total_walks);
     else return fail(ctx, GG_EINVAL, "n_emb %d not supported (max 512)", ctx->n_emb);
     if (rc != GG_OK) return rc;
-    if (ctx->walk_timed) GG_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    if (ctx->walk_timed) GG_HIP(ctx, hipEventRecord(ctx->ev1, ctx->walk_stream));
     if (for_d)
-        hipLaunchKernelGGL(walk_d_postpass_kernel, dim3(cdiv(total_walks, 256)), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(walk_d_postpass_kernel, dim3(cdiv(total_walks, 256)), dim3(256), 0, ctx->walk_stream, a);
     GG_HIP(ctx, hipGetLastError());
     return GG_OK;
 }
