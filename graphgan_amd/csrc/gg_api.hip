@@ -75,14 +75,15 @@ static int upload_table(gg_ctx *ctx, float *dst, const float *src) {
 
 using namespace gg;
 
-// Shared by gg_walk_sample and gg_prepare_*: stage the launch on device and enqueue it (no host
-// synchronisation).  n_walks == NULL: CSR degree of each slot's root (D-mode, graph_gan.py:190-191).
 // One walk launch on ctx->walk_stream; a side-stream launch is ordered behind the last generator update and
 // hands its completion back to the main stream, where everything that follows the walk is enqueued.
 static int launch_and_join(gg_ctx *ctx, int32_t n_slots, int64_t total, int32_t for_d, uint64_t seed, uint32_t stream, int32_t stride) {
     const bool side = ctx->walk_stream != ctx->stream;
     int rc = launch_walk_sample(ctx, n_slots, total, for_d, seed, stream, stride);
-    if (rc != GG_OK) return rc;
+    if (rc != GG_OK) {
+        if (side) (void)hipStreamSynchronize(ctx->walk_stream);  // nothing half-enqueued may outlive the failed call
+        return rc;
+    }
     if (side) {
         GG_HIP(ctx, hipEventRecord(ctx->ev_walk_done, ctx->walk_stream));
         GG_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_walk_done, 0));
@@ -90,6 +91,8 @@ static int launch_and_join(gg_ctx *ctx, int32_t n_slots, int64_t total, int32_t 
     return GG_OK;
 }
 
+// Shared by gg_walk_sample and gg_prepare_*: stage the launch on device and enqueue it (no host
+// synchronisation).  n_walks == NULL: CSR degree of each slot's root (D-mode, graph_gan.py:190-191).
 int gg::walk_launch_async(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, int32_t uniform_walks, int32_t n_slots,
                           int32_t for_d, uint64_t seed, uint32_t stream, int32_t stride, bool side_stream) {
     GG_CHECK(ctx, ctx->n_tree_roots > 0, GG_EINVAL, "walk: no trees loaded (gg_build_trees / gg_set_trees)");
