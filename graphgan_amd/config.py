@@ -54,3 +54,4 @@ engine_optimizer = "adam_dense"  # "adam_dense" = TF1.8 semantics (parity); "ada
 engine_device = 0
 engine_tree_device = True    # BFS trees on the GPU (False: threaded host BFS, same trees)
 engine_tree_threads = 0       # host BFS only; 0 = all host cores
+engine_profile_every = 1      # HIP events on every k-th walk launch; 1 = every launch and pass (passes synchronous); 0 = none

@@ -97,6 +97,8 @@ class GraphGAN(object):
                 self.node_embed_init_g, self.node_embed_init_d, lr_gen=cfg.lr_gen, lr_dis=cfg.lr_dis,
                 lambda_gen=cfg.lambda_gen, lambda_dis=cfg.lambda_dis, window_size=cfg.window_size,
                 optimizer=_OPTIMIZERS[_cfg(cfg, "engine_optimizer", "adam_dense")], device=int(_cfg(cfg, "engine_device", 0)))
+            if int(_cfg(cfg, "engine_profile_every", 1)) != 1:
+                self.engine.set_profiling(int(_cfg(cfg, "engine_profile_every", 1)))
             self.engine.set_graph_csr(self._rowptr, self._col)
         return self.engine
 

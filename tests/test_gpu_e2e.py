@@ -149,7 +149,7 @@ def test_update_ratio_below_one_rebuilds_trees_per_prepare(tmp_path):
     base = str(tmp_path)
     d, n, graph = write_reference_layout(base)
     cfg = make_cfg(base, n_epochs=1, n_epochs_dis=2, n_epochs_gen=2, dis_interval=1, gen_interval=1, update_ratio=0.05,
-                   engine_optimizer="adam_lazy")
+                   engine_optimizer="adam_lazy", engine_profile_every=0)  # no events: passes return early, G walks beside D updates
     from graphgan_amd.graph_gan import GraphGAN
     g = GraphGAN(cfg)
     assert g.trees is None
