@@ -237,10 +237,10 @@ def main():
                      "timed": "HIP events on the engine's stream around every level_score_kernel launch of every %s walk call of the timed region"
                               % ("" if args.profile_every == 1 else "%d-th" % args.profile_every),
                      # tools/gather_bw*.hip on the same chip: random 512 B row gathers with 16-lane groups
-                     # (64-row work items: 7400 plain / 7200 with dot + score store); tools/gather_bw3.hip = the kernel's own shape:
-                     # a descriptor per 16-row chunk, ragged chunks, ids scattered over 16 GB (profiles/r1_gather_bw3.txt)
-                     "gather_microbench_GBs": {"plain_gather_64_row_items": 7400.0, "with_dot_and_score_store_64_row_items": 7200.0,
-                                               "kernel_shape_16_row_chunks": 6350.0, "kernel_shape_ragged_chunks_scattered_ids": 6200.0}},
+                     # tools/gather_bw2.hip / gather_bw3.hip on the same chip (profiles/r1_gather_bw*.txt), TB/s of rows resp. in this
+                     # kernel's accounting: the separate bias gather is what costs a fifth of the plain gather's rate
+                     "gather_microbench_GBs": {"plain_row_gather": 7400.0, "with_dot_and_score_store": 7200.0, "with_bias_gather": 5650.0,
+                                               "kernel_shape_16_row_items": 6300.0, "kernel_shape_64_row_items": 6200.0}},
         "walk_phase": {"ms_per_walk_sample_call": walk_ms / max(launches, 1), "calls": calls, "calls_timed": int(launches),
                        "reference_equivalent_bytes_per_call": ref_bytes / calls,
                        "reference_equivalent_GBs": (ref_bytes / calls) / (walk_ms / launches * 1e-3) / 1e9 if walk_ms > 0 and launches else None,

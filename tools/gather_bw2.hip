@@ -4,10 +4,12 @@
 #include <cstdio>
 #include <vector>
 #include <random>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_nt(const float4 *p) { const f32x4 v = __builtin_nontemporal_load((const f32x4 *)p); return make_float4(v.x, v.y, v.z, v.w); }
 
 // V=0 plain gather+sum; V=1 + dot with a current row (fma) + butterfly; V=2 + 4-byte store per row;
 // V=3 + bias gather; V=4 + ids through a per-64-row descriptor (extra dependent load)
-template <int V>
+template <int V, bool NT>
 __global__ __launch_bounds__(256) void k(const float4 *E, const int *ids, const int4 *desc, const float *bias, long n, float *out) {
     const int t = threadIdx.x & 15;
     const long g0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -25,8 +27,8 @@ __global__ __launch_bounds__(256) void k(const float4 *E, const int *ids, const 
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     id[u] = __shfl(myid, j0 + u, 16);
-                    y[u][0] = E[(long)id[u] * 32 + t];
-                    y[u][1] = E[(long)id[u] * 32 + t + 16];
+                    y[u][0] = NT ? ld_nt(&E[(long)id[u] * 32 + t]) : E[(long)id[u] * 32 + t];
+                    y[u][1] = NT ? ld_nt(&E[(long)id[u] * 32 + t + 16]) : E[(long)id[u] * 32 + t + 16];
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -46,12 +48,12 @@ __global__ __launch_bounds__(256) void k(const float4 *E, const int *ids, const 
     if (accs == 123.456f) out[0] = accs;
 }
 
-template <int V>
+template <int V, bool NT = false>
 double run(const float4 *E, const int *ids, const int4 *desc, const float *bias, long n, float *out, int blocks) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    k<V><<<blocks, 256>>>(E, ids, desc, bias, n, out); hipDeviceSynchronize();
+    k<V, NT><<<blocks, 256>>>(E, ids, desc, bias, n, out); hipDeviceSynchronize();
     hipEventRecord(a);
-    for (int r = 0; r < 5; ++r) k<V><<<blocks, 256>>>(E, ids, desc, bias, n, out);
+    for (int r = 0; r < 5; ++r) k<V, NT><<<blocks, 256>>>(E, ids, desc, bias, n, out);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     return 5.0 * n * 512.0 / (ms * 1e-3) / 1e12;
@@ -69,6 +71,8 @@ int main() {
     for (long c = 0; c < n / 64; ++c) { long cc = (c * 7919) % (n / 64); hd[c] = make_int4((int)(rg() % rows), 64, (int)(cc * 64), 0); }
     hipMemcpy(desc, hd.data(), n / 64 * 16, hipMemcpyHostToDevice);
     for (int blocks : {2048, 4096}) {
+        printf("blocks %d, rows with the non-temporal hint: V2 %.2f  V3(+bias) %.2f  V4(+desc) %.2f TB/s\n", blocks,
+               run<2, true>(E, ids, desc, bias, n, out, blocks), run<3, true>(E, ids, desc, bias, n, out, blocks), run<4, true>(E, ids, desc, bias, n, out, blocks));
         printf("blocks %d: V0 %.2f  V1(dot) %.2f  V2(+store) %.2f  V3(+bias) %.2f  V4(+desc) %.2f TB/s\n", blocks,
                run<0>(E, ids, desc, bias, n, out, blocks), run<1>(E, ids, desc, bias, n, out, blocks), run<2>(E, ids, desc, bias, n, out, blocks),
                run<3>(E, ids, desc, bias, n, out, blocks), run<4>(E, ids, desc, bias, n, out, blocks));
