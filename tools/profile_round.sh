@@ -1,3 +1,9 @@
+#!/bin/bash
+# One box session that produces every file of profiles/ for a round (run through gpurun from the repo root:
+#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh'), then on the host:
+#   python profiles/summarize.py r<N> gpurun_out/r1e_kt gpurun_out/r1e_fetch gpurun_out/r1e_write
+# GPU tests + smoke, rocprofv3 kernel trace of the default bench, separate PMC passes (FETCH_SIZE, WRITE_SIZE,
+# TCC hit / miss; never combined with trace domains), un-profiled bench with the CPU baseline.
 R=$GRAFT_REPO_ROOT
 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $R/gpurun_out/r1e_tests.txt
 python -c "import __graft_entry__ as g; g.smoke()" > $R/gpurun_out/r1e_smoke.txt 2>&1
