@@ -92,3 +92,30 @@ def test_window_pairs_count_and_content(path, window):
     b = np.zeros_like(a)
     n = lib.orc_pairs_from_path(p.ctypes.data, len(p), window, a.ctypes.data, b.ctypes.data)
     assert np.stack([a[:n], b[:n]], 1).tolist() == pairs
+
+
+def _search16(pf, thr):
+    """The 16-ary search of level_advance_kernel (graphgan_amd/csrc/walk_sample.hip), restated: first j with
+    pf[j] > thr for a non-decreasing pf whose last element exceeds thr; 15 pivots per round."""
+    lo, n = 0, len(pf)
+    while n > 1:
+        step = (n + 15) >> 4
+        seg = 0
+        for i in range(1, 16):
+            idx = i * step - 1
+            if idx < n - 1 and pf[lo + idx] <= thr:
+                seg += 1
+        lo += seg * step
+        n = min(step, n - seg * step)
+    return lo
+
+
+@settings(max_examples=300, deadline=None)
+@given(st.lists(st.integers(min_value=0, max_value=5), min_size=1, max_size=700), st.data())
+def test_16ary_prefix_search_equals_searchsorted(weights, data):
+    """Spec S5 picks the first j whose inclusive prefix sum exceeds the threshold = searchsorted(side='right');
+    the GPU finds it with a 16-ary search whose rounds are independent loads.  Zero weights (ties in the prefix
+    sums) and every length class (1 round <= 16, 2 rounds <= 256, 3 rounds) are covered."""
+    pf = np.cumsum(np.asarray(weights, dtype=np.uint64) + (np.arange(len(weights)) == len(weights) - 1).astype(np.uint64))
+    thr = data.draw(st.integers(min_value=0, max_value=int(pf[-1]) - 1))
+    assert _search16([int(x) for x in pf], thr) == int(np.searchsorted(pf, thr, side="right"))
