@@ -151,7 +151,9 @@ int gg_walk_sample(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, in
  * gg_prepare_d: prepare_data_for_d (graph_gan.py:182-202) for the given root slots: D-mode
  * walks (n_walks = CSR degree), then rows [pos..., neg...] per non-aborted root, in slot order.
  * gg_prepare_g: prepare_data_for_g (:204-223): n_sample walks per root, window pairs
- * (get_node_pairs_from_path, :272-291) and reward (discriminator.py:33-34) for all pairs. */
+ * (get_node_pairs_from_path, :272-291) and reward (discriminator.py:33-34) for all pairs.  Its walks read only the
+ * generator's tables and the trees, so they are enqueued on a side stream and run beside a gg_d_pass that is still
+ * in flight (gg_set_profiling); pairs and rewards follow on the main stream, behind that discriminator update. */
 int gg_prepare_d(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, uint64_t seed, uint32_t stream,
                  int64_t *n_rows_out, int32_t *root_status /*[n_slots] or NULL*/);
 int gg_get_d_data(gg_ctx *ctx, int32_t *center, int32_t *neighbor, float *label);
