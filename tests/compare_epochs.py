@@ -17,17 +17,18 @@ def main():
     fe = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r1_engine_epochs_multiseed.json")
     o, e = json.load(open(fo))["epochs"], json.load(open(fe))["epochs"]
     seeds = sorted(set(o) & set(e), key=int)
-    n_ep = min(min(len(o[s]) for s in seeds), min(len(e[s]) for s in seeds))
-    O = np.array([o[s][:n_ep] for s in seeds])
-    E = np.array([e[s][:n_ep] for s in seeds])
-    print("seeds: %s" % ", ".join(seeds))
-    print("%-16s %-19s %-19s %-21s %s" % ("after epoch", "oracle mean g/d", "engine mean g/d", "diff of means g/d [%]", "max per-seed |diff| g/d [%]"))
+    n_ep = max(min(len(o[s]), len(e[s])) for s in seeds)
+    print("%-12s %-6s %-19s %-19s %-30s %s" % ("after epoch", "seeds", "oracle mean g/d", "engine mean g/d", "mean paired diff g/d [%] (+-sem)", "max per-seed |diff| g/d [%]"))
     for k in range(n_ep):
-        mo, me = O[:, k].mean(0), E[:, k].mean(0)
-        dm = 100 * (me - mo)
-        mx = 100 * np.abs(E[:, k] - O[:, k]).max(0)
-        print("%-16s %.5f / %.5f   %.5f / %.5f   %+.2f / %+.2f          %.2f / %.2f" % (
-            "(before)" if k == 0 else str(k - 1), mo[0], mo[1], me[0], me[1], dm[0], dm[1], mx[0], mx[1]))
+        have = [s for s in seeds if min(len(o[s]), len(e[s])) > k]
+        O = np.array([o[s][k] for s in have])
+        E = np.array([e[s][k] for s in have])
+        d = 100 * (E - O)
+        sem = d.std(0, ddof=1) / np.sqrt(len(have)) if len(have) > 1 else np.zeros(2)
+        mx = np.abs(d).max(0)
+        print("%-12s %-6d %.5f / %.5f   %.5f / %.5f   %+.2f (%.2f) / %+.2f (%.2f)        %.2f / %.2f" % (
+            "(before)" if k == 0 else str(k - 1), len(have), O[:, 0].mean(), O[:, 1].mean(), E[:, 0].mean(), E[:, 1].mean(),
+            d[:, 0].mean(), sem[0], d[:, 1].mean(), sem[1], mx[0], mx[1]))
 
 
 if __name__ == "__main__":
