@@ -201,3 +201,18 @@ def test_gpu_bfs_builds_the_reference_trees(ga, case):
     assert np.array_equal(base, wbase) and np.array_equal(off, woff) and np.array_equal(nbr, wnbr)
     assert eng.max_depth == wdepth
     eng.close()
+
+
+def test_deep_chain_crosses_the_level_cap(ga):
+    """A path graph whose embeddings pull every walk to the far end: trees up to 149 levels deep, paths of up to
+    150 hops -- more than the 64 hops the level pipeline handles, so the per-walk finisher takes over the
+    survivors mid-walk.  Same bit-exact comparison as everywhere else."""
+    n = 150
+    graph = {v: [u for u in (v - 1, v + 1) if 0 <= u < n] for v in range(n)}
+    rowptr, col = ga.graph_to_csr(n, graph)
+    E = np.zeros((n, 8), dtype=np.float32)
+    E[:, 0] = np.sqrt(0.05) * np.arange(n)          # score(v, u) = 0.05 v u: the higher-numbered neighbour wins
+    E[:, 1] = 0.01 * np.cos(np.arange(n))
+    b = (0.1 * np.sin(np.arange(n))).astype(np.float32)
+    hops = run_both(ga, n, rowptr, col, np.arange(n), E, b, rounds=4, seed=4242)
+    assert hops > 64 * 150  # many walks ran past the level cap
