@@ -81,3 +81,73 @@ def test_window_pairs_docstring_vector(pkg):
         assert GraphGAN.get_node_pairs_from_path(c["path"]) == c["pairs"]
     assert GraphGAN.stream_id(0, 0, 30, True) == 0 and GraphGAN.stream_id(0, 0, 30, False) == 1
     assert GraphGAN.stream_id(2, 0, 30, True) == 120 and len({GraphGAN.stream_id(e, i, 30, f) for e in range(3) for i in range(30) for f in (0, 1)}) == 180
+
+
+class _FakeEngine(object):
+    """Records what graph_gan.GraphGAN asks of the engine (the five sess.run call sites + sampler), no GPU."""
+
+    def __init__(self, emb_g, emb_d, **kw):
+        self.kw = kw
+        self.E = [np.array(emb_g, np.float32), np.array(emb_d, np.float32)]
+        self.n_node, self.n_emb = self.E[0].shape
+        self.calls = []
+        self.tree_roots = None
+
+    def set_profiling(self, k): self.calls.append(("set_profiling", k))
+    def set_graph_csr(self, rowptr, col): self.calls.append(("set_graph_csr", len(rowptr) - 1, len(col)))
+    def build_trees(self, roots, **kw): self.tree_roots = list(roots); self.calls.append(("build_trees", len(roots), kw.get("device")))
+    def load_state(self, path): self.calls.append(("load_state", path))
+    def save_state(self, path): open(path, "w").write("x"); self.calls.append(("save_state", path))
+    def prepare_d(self, slots, seed, stream, fetch=True): self.calls.append(("prepare_d", len(slots), seed, stream, fetch)); return 200
+    def prepare_g(self, slots, n_sample, seed, stream, fetch=True): self.calls.append(("prepare_g", len(slots), n_sample, seed, stream, fetch)); return 333
+    def d_pass(self, starts, batch): self.calls.append(("d_pass", list(starts), batch))
+    def g_pass(self, starts, batch): self.calls.append(("g_pass", list(starts), batch))
+    def get_embeddings(self, which): return self.E[which]
+    def get_bias(self, which): return np.zeros(self.n_node, np.float32)
+    def write_embeddings(self, which, path):
+        from graphgan_amd import engine
+        engine.host_write_embeddings(path, self.E[which])
+        self.calls.append(("write_embeddings", which))
+
+
+def test_training_schedule_drives_the_engine_like_the_reference(pkg, tmp_path, monkeypatch):
+    """graph_gan.py:133-178 on a fake engine: prepare cadence (dis_interval / gen_interval), one shuffled list of
+    contiguous batch starts per inner epoch (a13), Philox stream per (epoch, inner epoch, phase), checkpoint
+    cadence (save_steps, load_model), embeddings + results written before training and after every epoch."""
+    from tests.test_gpu_e2e import make_cfg, write_reference_layout
+    from graphgan_amd import engine as eng_mod, graph_gan
+    base = str(tmp_path)
+    d, n, graph = write_reference_layout(base)
+    monkeypatch.setattr(eng_mod, "Engine", _FakeEngine)
+    cfg = make_cfg(base, n_epochs=3, n_epochs_dis=4, n_epochs_gen=5, dis_interval=2, gen_interval=3, save_steps=2,
+                   load_model=True, engine_seed=11, engine_profile_every=0)
+    os.makedirs(cfg.model_log)
+    open(os.path.join(cfg.model_log, "model.checkpoint.ggst"), "w").write("x")
+    g = graph_gan.GraphGAN(cfg)
+    g.train()
+    calls = g.engine.calls
+    names = [c[0] for c in calls]
+    assert names[:3] == ["set_profiling", "set_graph_csr", "build_trees"] and calls[2][1] == n and calls[2][2] is True
+    assert names[3] == "load_state"                                 # load_model and the checkpoint exists (:124-127)
+    assert names[4:6] == ["write_embeddings", "write_embeddings"]  # before training (:129)
+    per_epoch = ["prepare_d", "d_pass", "d_pass", "prepare_d", "d_pass", "d_pass",
+                 "prepare_g", "g_pass", "g_pass", "g_pass", "prepare_g", "g_pass", "g_pass", "write_embeddings", "write_embeddings"]
+    want = per_epoch + per_epoch + ["save_state"] + per_epoch  # save at epoch 2 (epoch > 0 and epoch % save_steps == 0, :136-138)
+    assert names[6:] == want
+    # streams: 2 * (epoch * n_inner + inner) + {0: D, 1: G}; every root slot, fetch=False (resident data)
+    pd = [c for c in calls if c[0] == "prepare_d"]
+    pg = [c for c in calls if c[0] == "prepare_g"]
+    assert [c[3] for c in pd] == [2 * (e * 4 + i) for e in range(3) for i in (0, 2)]
+    assert [c[4] for c in pg] == [2 * (e * 5 + i) + 1 for e in range(3) for i in (0, 3)]
+    assert all(c[1] == n and c[2] == 11 and c[4] is False for c in pd) and all(c[2] == 20 for c in pg)
+    # batches: a permutation of the contiguous starts 0, 64, ... of the prepared size
+    for c in calls:
+        if c[0] == "d_pass":
+            assert sorted(c[1]) == list(range(0, 200, 64)) and c[2] == 64
+        if c[0] == "g_pass":
+            assert sorted(c[1]) == list(range(0, 333, 64)) and c[2] == 64
+    orders = [tuple(c[1]) for c in calls if c[0] == "g_pass"]
+    assert len(set(orders)) > 1                                     # reshuffled per inner epoch (:151,170)
+    res = open(cfg.result_filename).read().split()
+    assert len(res) == 8 and res[0] == "gen:0.7598343685300207" and all(r[:4] in ("gen:", "dis:") for r in res)
+    assert open(cfg.emb_filenames[0]).readline() == "5242\t50\n"
