@@ -151,3 +151,27 @@ def test_training_schedule_drives_the_engine_like_the_reference(pkg, tmp_path, m
     res = open(cfg.result_filename).read().split()
     assert len(res) == 8 and res[0] == "gen:0.7598343685300207" and all(r[:4] in ("gen:", "dis:") for r in res)
     assert open(cfg.emb_filenames[0]).readline() == "5242\t50\n"
+
+
+def test_update_ratio_selects_roots_per_prepare(pkg, tmp_path, monkeypatch):
+    """``np.random.rand() < update_ratio`` per root (graph_gan.py:189,209): with update_ratio < 1 no tree is built
+    up front; every prepare draws its own subset, builds exactly those trees and samples from all of their slots."""
+    from tests.test_gpu_e2e import make_cfg, write_reference_layout
+    from graphgan_amd import engine as eng_mod, graph_gan
+    base = str(tmp_path)
+    d, n, graph = write_reference_layout(base)
+    monkeypatch.setattr(eng_mod, "Engine", _FakeEngine)
+    cfg = make_cfg(base, n_epochs=1, n_epochs_dis=2, n_epochs_gen=2, dis_interval=1, gen_interval=2, update_ratio=0.1, engine_seed=3)
+    g = graph_gan.GraphGAN(cfg)
+    assert g.trees is None and not any(c[0] == "build_trees" for c in g.engine.calls)
+    g.train()
+    calls = g.engine.calls
+    builds = [c for c in calls if c[0] == "build_trees"]
+    prepares = [c for c in calls if c[0] in ("prepare_d", "prepare_g")]
+    assert len(builds) == len(prepares) == 3                      # D at inner epochs 0, 1; G at inner epoch 0
+    for b, p in zip(builds, prepares):
+        assert 0.06 * n < b[1] < 0.14 * n and p[1] == b[1]      # ~10 % of the roots, all of their slots
+        assert calls.index(b) + 1 == calls.index(p)             # trees of the subset right before its prepare
+    assert len({b[1] for b in builds}) > 1                        # a fresh draw per prepare
+    roots = g.engine.tree_roots
+    assert roots == sorted(roots) and len(set(roots)) == len(roots) and g._slot_of_root[roots[5]] == 5
