@@ -395,6 +395,11 @@ class TF1Adam:
 def _sigmoid(x):
     """tf.nn.sigmoid on fp32 tensors: evaluated in fp32 (saturates to exactly 1.0 for x > ~16.6, like
     TF's fp32 kernel), not in fp64."""
+    if os.environ.get("GG_ORACLE_SIGMOID64") == "1":
+        # numeric-variant switch for sensitivity studies (tests/run_oracle_epochs.py): the sigmoid evaluated in fp64 and
+        # rounded once, instead of TF-like fp32 -- a difference of at most 1 ulp per value
+        with np.errstate(over="ignore"):
+            return (1.0 / (1.0 + np.exp(-x.astype(np.float64)))).astype(np.float32)
     x = x.astype(np.float32)
     with np.errstate(over="ignore"):
         return (np.float32(1) / (np.float32(1) + np.exp(-x))).astype(np.float32)
