@@ -29,6 +29,21 @@ def main():
         print("%-12s %-6d %.5f / %.5f   %.5f / %.5f   %+.2f (%.2f) / %+.2f (%.2f)        %.2f / %.2f" % (
             "(before)" if k == 0 else str(k - 1), len(have), O[:, 0].mean(), O[:, 1].mean(), E[:, 0].mean(), E[:, 1].mean(),
             d[:, 0].mean(), sem[0], d[:, 1].mean(), sem[1], mx[0], mx[1]))
+    variant_table(fo)
+
+
+def variant_table(fo):
+    d = json.load(open(fo))
+    if "epochs_sigmoid64" not in d:
+        return
+    o, v = d["epochs"], d["epochs_sigmoid64"]
+    seeds = sorted(set(o) & set(v), key=int)
+    n_ep = min(min(len(o[s]), len(v[s])) for s in seeds)
+    print("\noracle with the fp64-evaluated sigmoid (<= 1 ulp per value) minus the committed oracle, seeds %s:" % ", ".join(seeds))
+    for k in range(n_ep):
+        dd = 100 * (np.array([v[s][k] for s in seeds]) - np.array([o[s][k] for s in seeds]))
+        sem = dd.std(0, ddof=1) / np.sqrt(len(seeds))
+        print("%-12s mean paired diff g/d [%%]: %+.2f (%.2f) / %+.2f (%.2f)" % ("(before)" if k == 0 else str(k - 1), dd[:, 0].mean(), sem[0], dd[:, 1].mean(), sem[1]))
 
 
 if __name__ == "__main__":
