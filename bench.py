@@ -62,13 +62,10 @@ def make_workload(args, ga):
         emb[g["emb_ids"]] = g["emb_rows"]
         name = "CA-GrQc (5242 nodes, 13046 train edges), n_emb=50, shipped pre-trained embeddings"
         return n, rowptr, col, emb.astype(np.float32), name
+    from graphgan_amd import workloads
     n, d = args.nodes, args.emb
-    edges = ga.synth_powerlaw(n, args.m, 1, 2)  # BA m=10, graph seed 1, permutation seed 2
-    rowptr, col = ga.edges_to_csr(n, edges)
-    sigma = 0.6 * np.sqrt(50.0 / d)  # matches the dot-product scale of the shipped CA-GrQc pre-training
-    rs = np.random.default_rng(5)
-    emb = rs.standard_normal((n, d), dtype=np.float32) * np.float32(sigma)
-    name = "synthetic power-law (Barabasi-Albert m=%d): %d nodes / %d edges, n_emb=%d" % (args.m, n, len(edges), d)
+    rowptr, col, emb, n_edges = workloads.powerlaw_workload(n, args.m, d)  # SURVEY.md section 8d recipe (also what tests/test_gpu_scale.py checks)
+    name = "synthetic power-law (Barabasi-Albert m=%d): %d nodes / %d edges, n_emb=%d" % (args.m, n, n_edges, d)
     return n, rowptr, col, emb, name
 
 
@@ -134,12 +131,9 @@ def main():
     opt = {"adam_dense": _lib.GG_OPT_ADAM_DENSE, "adam_lazy": _lib.GG_OPT_ADAM_LAZY, "sgd": _lib.GG_OPT_SGD}[args.optimizer]
     eng = ga.Engine(emb, emb, optimizer=opt, device=local_rank)
     eng.set_graph_csr(rowptr, col)
-    R = min(args.roots, n // world)
-    deg = rowptr[1:] - rowptr[:-1]
-    cand = np.flatnonzero(deg > 0)
-    all_roots = np.random.RandomState(args.seed).permutation(cand)[: R * world].astype(np.int32)
-    roots = np.ascontiguousarray(all_roots[rank * R:(rank + 1) * R])
-    roots = roots[np.argsort(-deg[roots], kind="stable")]  # longest (hub) roots first: LPT order for the walk scheduler
+    from graphgan_amd import workloads
+    roots = workloads.bench_roots(rowptr, args.roots, rank, world, args.seed)  # longest (hub) roots first
+    R = len(roots)
     threads = args.threads or min(64, os.cpu_count() or 1)
     t_trees = time.time()
     if args.host_bfs:

@@ -65,6 +65,8 @@ SIGNATURES = {
     "gg_tree_info": (ctypes.c_int, [_P, _P, _P, _P]),
     "gg_get_trees": (ctypes.c_int, [_P, _P, _P, _P]),
     "gg_walk_sample": (ctypes.c_int, [_P, _P, _P, _i32, _i32, _u64, _u32, _P, _P, _P, _i32, _P]),
+    "gg_walk_info": (ctypes.c_int, [_P, _P, _P, _P]),
+    "gg_get_walks": (ctypes.c_int, [_P, _P, _P, _P, _P]),
     "gg_prepare_d": (ctypes.c_int, [_P, _P, _i32, _u64, _u32, _P, _P]),
     "gg_get_d_data": (ctypes.c_int, [_P, _P, _P, _P]),
     "gg_prepare_g": (ctypes.c_int, [_P, _P, _i32, _i32, _u64, _u32, _P, _P]),

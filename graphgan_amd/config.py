@@ -55,3 +55,4 @@ engine_device = 0
 engine_tree_device = True    # BFS trees on the GPU (False: threaded host BFS, same trees)
 engine_tree_threads = 0       # host BFS only; 0 = all host cores
 engine_profile_every = 1      # HIP events on every k-th walk launch; 1 = every launch and pass (passes synchronous); 0 = none
+engine_tree_budget_gb = 160.0  # all N BFS trees stay resident (reference :31-46) when they fit this much HBM; otherwise, with update_ratio < 1, trees are built per draw

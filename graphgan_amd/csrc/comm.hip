@@ -77,6 +77,13 @@ int comm_allreduce_grads(gg_ctx *ctx) {
     return GG_OK;
 }
 
+// sum of `count` int64 words over ranks (pair counts of a generator step)
+int comm_allreduce_i64(gg_ctx *ctx, int64_t *buf, size_t count) {
+    if (!ctx->comm) return GG_OK;
+    GG_NCCL(ctx, g_rccl.AllReduce(buf, buf, count, NCCL_INT64, NCCL_SUM, ctx->comm, ctx->stream));
+    return GG_OK;
+}
+
 // sum of the touched-row flags over ranks (the dense fall-back of the sparse exchange needs the union)
 int comm_allreduce_flags(gg_ctx *ctx) {
     if (!ctx->comm) return GG_OK;

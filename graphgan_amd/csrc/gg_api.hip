@@ -4,6 +4,8 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <thread>
@@ -195,6 +197,7 @@ int gg::walk_finalize(gg_ctx *ctx, bool *retried) {
         if (ctx->lv_ev_used) ctx->ctr.score_rows += (int64_t)(rows - c[5]);  // rows of the timed score launches
     }
     if (c[3]) return fail(ctx, GG_ECAPACITY, "walk: a path needed more than stride=%d entries", ctx->w_stride);
+    if (c[6]) return fail(ctx, GG_EINVAL, "walk: non-finite generator scores (a softmax had total weight 0)");
     return GG_OK;
 }
 
@@ -322,7 +325,7 @@ int gg_destroy(gg_ctx *ctx) {
                       &ctx->w_first, &ctx->w_abort, &ctx->w_scratch, &ctx->d_center, &ctx->d_neighbor, &ctx->d_label, &ctx->d_cnt,
                       &ctx->d_ptr, &ctx->g_node1, &ctx->g_node2, &ctx->g_reward, &ctx->g_cnt, &ctx->g_ptr, &ctx->scan_tmp,
                       &ctx->step_u, &ctx->step_v, &ctx->step_x, &ctx->touched_ptr, &ctx->x_cnt, &ctx->x_send_ids, &ctx->x_send_rows,
-                      &ctx->x_recv_ids, &ctx->x_recv_rows, &ctx->st_item, &ctx->st_cur, &ctx->st_prev, &ctx->st_len,
+                      &ctx->x_recv_ids, &ctx->x_recv_rows, &ctx->x_nglob, &ctx->st_item, &ctx->st_cur, &ctx->st_prev, &ctx->st_len,
                       &ctx->st_alive, &ctx->lv_beg, &ctx->lv_k, &ctx->lv_chunks, &ctx->lv_coff, &ctx->lv_scores, &ctx->lv_chunk_owner, &ctx->lv_prefix, &ctx->lv_big};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : ctx->lv_ev)
@@ -457,6 +460,26 @@ int gg_walk_sample(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, in
     return GG_OK;
 }
 
+int gg_walk_info(const gg_ctx *ctx, int64_t *total_walks, int32_t *stride, int32_t *n_slots) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    if (total_walks) *total_walks = ctx->w_total;
+    if (stride) *stride = ctx->w_stride;
+    if (n_slots) *n_slots = ctx->w_nslots;
+    return GG_OK;
+}
+
+int gg_get_walks(gg_ctx *ctx, int32_t *samples, int32_t *paths, int32_t *path_len, int32_t *root_status) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    GG_HIP(ctx, hipSetDevice(ctx->device));
+    GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t total = ctx->w_total;
+    if (samples && total) GG_HIP(ctx, hipMemcpy(samples, ctx->w_samples.p, sizeof(int32_t) * total, hipMemcpyDeviceToHost));
+    if (path_len && total) GG_HIP(ctx, hipMemcpy(path_len, ctx->w_len.p, sizeof(int32_t) * total, hipMemcpyDeviceToHost));
+    if (paths && total) GG_HIP(ctx, hipMemcpy(paths, ctx->w_paths.p, sizeof(int32_t) * (size_t)total * ctx->w_stride, hipMemcpyDeviceToHost));
+    if (root_status && ctx->w_nslots) GG_HIP(ctx, hipMemcpy(root_status, ctx->w_status.p, sizeof(int32_t) * ctx->w_nslots, hipMemcpyDeviceToHost));
+    return GG_OK;
+}
+
 static int table_io(gg_ctx *ctx, int32_t which, float *out, const float *in, bool bias) {
     if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
     GG_CHECK(ctx, which == 0 || which == 1, GG_EINVAL, "which must be 0 (gen) or 1 (dis)");
@@ -530,8 +553,17 @@ int state_io(gg_ctx *ctx, const char *path, bool save) {
     GG_CHECK(ctx, path, GG_EINVAL, "state: path is NULL");
     GG_HIP(ctx, hipSetDevice(ctx->device));
     GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    FILE *f = fopen(path, save ? "wb" : "rb");
-    if (!f) return gg::fail(ctx, GG_EIO, "state: cannot open %s", path);
+    const bool slots = ctx->cfg.optimizer != GG_OPT_SGD;
+    const size_t ne = (size_t)ctx->n_node * ctx->ld, nb = (size_t)ctx->n_node;
+    struct Scalars { int64_t t; float b1p, b2p; };
+    const size_t per_model = sizeof(Scalars) + sizeof(float) * (ne + nb) * (slots ? 3 : 1);
+    const size_t expect = sizeof(StateHeader) + 2 * per_model;
+    // save: write a temporary next to the target, flush it to disk, then rename over the target -- a crash in the
+    // middle leaves the previous checkpoint intact.  load: the whole file is validated (magic, shape, SIZE) before the
+    // first byte of device memory changes, so a truncated file cannot leave the model half overwritten.
+    const std::string tmp_path = std::string(path) + ".tmp";
+    FILE *f = fopen(save ? tmp_path.c_str() : path, save ? "wb" : "rb");
+    if (!f) return gg::fail(ctx, GG_EIO, "state: cannot open %s", save ? tmp_path.c_str() : path);
     StateHeader h{{'G', 'G', 'S', 'T'}, 1, ctx->n_node, ctx->n_emb, ctx->ld, ctx->cfg.optimizer};
     int rc = GG_OK;
     if (save) {
@@ -542,28 +574,43 @@ int state_io(gg_ctx *ctx, const char *path, bool save) {
             rc = gg::fail(ctx, GG_EIO, "state: %s is not a GGST v1 file", path);
         else if (g.n_node != h.n_node || g.n_emb != h.n_emb || g.ld != h.ld || (g.optimizer == GG_OPT_SGD) != (h.optimizer == GG_OPT_SGD))
             rc = gg::fail(ctx, GG_EINVAL, "state: shape/optimizer mismatch (file %dx%d opt %d)", g.n_node, g.n_emb, g.optimizer);
+        if (rc == GG_OK) {
+            struct stat st;
+            if (fstat(fileno(f), &st) != 0 || (size_t)st.st_size != expect)
+                rc = gg::fail(ctx, GG_EIO, "state: %s is truncated or has trailing bytes (%lld bytes, expected %zu); nothing was loaded", path,
+                              (long long)st.st_size, expect);
+        }
     }
     std::vector<float> tmp;
-    const size_t ne = (size_t)ctx->n_node * ctx->ld, nb = (size_t)ctx->n_node;
+    Scalars loaded[2] = {};
     for (int m = 0; m < 2 && rc == GG_OK; ++m) {
         gg::Model &M = ctx->model[m];
-        struct { int64_t t; float b1p, b2p; } sc{M.t, M.b1p, M.b2p};
+        Scalars sc{M.t, M.b1p, M.b2p};
         if (save) {
             if (fwrite(&sc, sizeof(sc), 1, f) != 1) rc = gg::fail(ctx, GG_EIO, "state: short write");
         } else {
             if (fread(&sc, sizeof(sc), 1, f) != 1) rc = gg::fail(ctx, GG_EIO, "state: short read");
-            else { M.t = sc.t; M.b1p = sc.b1p; M.b2p = sc.b2p; }
+            else loaded[m] = sc;
         }
         if (rc == GG_OK) rc = io_dev(ctx, f, M.E, ne, save, tmp);
         if (rc == GG_OK) rc = io_dev(ctx, f, M.b, nb, save, tmp);
-        if (ctx->cfg.optimizer != GG_OPT_SGD) {
+        if (slots) {
             if (rc == GG_OK) rc = io_dev(ctx, f, M.mE, ne, save, tmp);
             if (rc == GG_OK) rc = io_dev(ctx, f, M.vE, ne, save, tmp);
             if (rc == GG_OK) rc = io_dev(ctx, f, M.mb, nb, save, tmp);
             if (rc == GG_OK) rc = io_dev(ctx, f, M.vb, nb, save, tmp);
         }
     }
+    if (save) {
+        if (rc == GG_OK && (fflush(f) != 0 || fsync(fileno(f)) != 0)) rc = gg::fail(ctx, GG_EIO, "state: cannot flush %s", tmp_path.c_str());
+        fclose(f);
+        if (rc == GG_OK && rename(tmp_path.c_str(), path) != 0) rc = gg::fail(ctx, GG_EIO, "state: cannot rename %s to %s", tmp_path.c_str(), path);
+        if (rc != GG_OK) (void)remove(tmp_path.c_str());
+        return rc;
+    }
     fclose(f);
+    if (rc == GG_OK)  // step counts / beta powers only once every table arrived
+        for (int m = 0; m < 2; ++m) { ctx->model[m].t = loaded[m].t; ctx->model[m].b1p = loaded[m].b1p; ctx->model[m].b2p = loaded[m].b2p; }
     return rc;
 }
 }  // namespace

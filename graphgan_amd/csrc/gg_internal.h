@@ -136,6 +136,7 @@ struct gg_ctx {
     float dense_exchange_ratio = 1.5f;  // sparse exchange only while (rows touched over all ranks) < ratio * n_node (GG_COMM_DENSE_RATIO)
     int32_t fake_world = 0;  // GG_COMM_FAKE_WORLD=k: exercise the k-rank exchange code on one GPU (every rank = this one)
     gg::DevBuf x_cnt, x_send_ids, x_send_rows, x_recv_ids, x_recv_rows;  // sparse gradient exchange
+    gg::DevBuf x_nglob;  // pairs of all ranks in the generator step in flight (device word)
 
     std::string err;
 };
@@ -178,6 +179,7 @@ int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int fo
 int run_step(gg_ctx *ctx, int which, const int32_t *d_u, const int32_t *d_v, const float *d_x, int32_t n);
 int comm_allreduce_grads(gg_ctx *ctx);
 int comm_allreduce_flags(gg_ctx *ctx);
+int comm_allreduce_i64(gg_ctx *ctx, int64_t *buf, size_t count);
 int comm_allgather(gg_ctx *ctx, const void *send, void *recv, size_t count, int elem_bytes);
 void comm_destroy(gg_ctx *ctx);
 

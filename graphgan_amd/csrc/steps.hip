@@ -33,6 +33,7 @@ struct StepArgs {
     const float *x;        // label (D) or reward (G)
     int n;
     float lambda, inv_n;
+    const int64_t *n_glob; // multi-GPU G step: pairs of ALL ranks in this step (device word) -> inv_n = 1 / *n_glob
     int is_d;
     int ppg;               // consecutive pairs handled by one 16-lane group
 };
@@ -53,6 +54,7 @@ __global__ __launch_bounds__(256) void pair_grad_kernel(const StepArgs a) {
     if (p0 >= a.n) return;
     const int p1 = min(p0 + a.ppg, a.n);
     const int nchunk = a.ld >> 2;
+    const float inv_n = a.n_glob ? 1.0f / (float)(*a.n_glob) : a.inv_n;
     float accu[NF];
 #pragma unroll
     for (int i = 0; i < NF; ++i) accu[i] = 0.f;
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256) void pair_grad_kernel(const StepArgs a) {
             ds = sg - a.x[p];
         } else {
             const bool inside = (sg >= 1e-5f) && (sg <= 1.0f);
-            ds = inside ? -(a.x[p] * a.inv_n) * (1.0f - sg) : 0.0f;
+            ds = inside ? -(a.x[p] * inv_n) * (1.0f - sg) : 0.0f;
         }
         float *gv = a.gE + (int64_t)iv * a.ld;
         const float *fu = (const float *)ru, *fv = (const float *)rv;  // rows were just read: L1/L2 hits
@@ -134,6 +136,7 @@ __global__ __launch_bounds__(256) void pair_grad_det_kernel(const StepArgs a) {
     __shared__ uint8_t leader[2 * DET_MAX_PAIRS];
     const int t = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int n = a.n, nchunk = a.ld >> 2;
+    const float inv_n = a.n_glob ? 1.0f / (float)(*a.n_glob) : a.inv_n;
     for (int s = threadIdx.x; s < 2 * n; s += 256) ids[s] = s < n ? a.u[s] : a.v[s - n];
     __syncthreads();
     for (int p = g; p < n; p += 16) {
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(256) void pair_grad_det_kernel(const StepArgs a) {
             ds = sg - a.x[p];
         } else {
             const bool inside = (sg >= 1e-5f) && (sg <= 1.0f);
-            ds = inside ? -(a.x[p] * a.inv_n) * (1.0f - sg) : 0.0f;
+            ds = inside ? -(a.x[p] * inv_n) * (1.0f - sg) : 0.0f;
         }
         if (t == 0) {
             coef[p] = ds;
@@ -222,6 +225,7 @@ struct PathArgs {
     const float *reward;
     int64_t n_walks;
     float lambda, inv_n;
+    const int64_t *n_glob;  // multi-GPU: pairs of all ranks (device word), see StepArgs
 };
 
 template <int NF>
@@ -231,6 +235,7 @@ __global__ __launch_bounds__(256) void path_grad_kernel(const PathArgs a) {
     if (w >= a.n_walks) return;
     const int L = a.path_len[w] - 1;  // the back-step is dropped (graph_gan.py:282)
     if (L <= 1) return;               // no pairs
+    const float inv_n = a.n_glob ? 1.0f / (float)(*a.n_glob) : a.inv_n;
     const int32_t *p = a.paths + w * (int64_t)a.stride;
     int64_t pi = a.pair_ptr[w];
     // window slots 0..4 hold path positions c-2 .. c+2 of the current centre c
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(256) void path_grad_kernel(const PathArgs a) {
             const float s = acc + bv[sl];
             const float sg = 1.0f / (1.0f + expf(-s));
             const bool inside = (sg >= 1e-5f) && (sg <= 1.0f);
-            const float ds = inside ? -(a.reward[pi] * a.inv_n) * (1.0f - sg) : 0.0f;
+            const float ds = inside ? -(a.reward[pi] * inv_n) * (1.0f - sg) : 0.0f;
             ++pi;
 #pragma unroll
             for (int i = 0; i < NF; ++i) {
@@ -458,6 +463,28 @@ __global__ void compact_touched_kernel(const OptArgs a) {
 int apply_optimizer(gg_ctx *ctx, int which, int64_t n);
 int run_path_step(gg_ctx *ctx);
 
+__global__ void set_count_kernel(int64_t *dst, int64_t v) { *dst = v; }
+
+// The generator's loss is a MEAN over the batch (generator.py:28): with replicas the batch of a step is the union
+// of the ranks' slices, so the 1/B of the data term must use the pairs of ALL ranks (the L2 term and the
+// discriminator's loss are sums and need nothing).  One 8-byte all-reduce on the stream, read by the gradient
+// kernel; returns the device word, or nullptr on a single replica (host-side 1/n, same arithmetic).
+static int global_pair_count(gg_ctx *ctx, int64_t n_local, const int64_t **out) {
+    *out = nullptr;
+    const int world = ctx->comm ? ctx->world : ctx->fake_world;
+    if (world <= 1) return GG_OK;
+    GG_HIP(ctx, ctx->x_nglob.reserve(sizeof(int64_t) * 2));
+    int64_t *w = ctx->x_nglob.as<int64_t>();
+    // simulated ranks (GG_COMM_FAKE_WORLD): every rank holds this rank's batch
+    hipLaunchKernelGGL(set_count_kernel, dim3(1), dim3(1), 0, ctx->stream, w, ctx->comm ? n_local : n_local * world);
+    if (ctx->comm) {
+        int rc = comm_allreduce_i64(ctx, w, 1);
+        if (rc != GG_OK) return rc;
+    }
+    *out = w;
+    return GG_OK;
+}
+
 // One optimizer step of model `which` on n device-resident rows.
 int run_step(gg_ctx *ctx, int which, const int32_t *d_u, const int32_t *d_v, const float *d_x, int32_t n) {
     if (n <= 0) return GG_OK;
@@ -472,6 +499,10 @@ int run_step(gg_ctx *ctx, int which, const int32_t *d_u, const int32_t *d_v, con
     s.lambda = M.lambda;
     s.inv_n = 1.0f / (float)n;
     s.is_d = which == 1;
+    if (which == 0) {
+        int rc = global_pair_count(ctx, n, &s.n_glob);
+        if (rc != GG_OK) return rc;
+    }
     s.ppg = n >= 16384 ? PAIRS_PER_GROUP : (n >= 2048 ? 4 : 1);
     if (ctx->deterministic && n <= DET_MAX_PAIRS) {
         const int nfd = (ctx->ld + 15) / 16;
@@ -510,6 +541,10 @@ int run_path_step(gg_ctx *ctx) {
     p.n_walks = ctx->w_total;
     p.lambda = M.lambda;
     p.inv_n = 1.0f / (float)n;
+    {
+        int rc = global_pair_count(ctx, n, &p.n_glob);
+        if (rc != GG_OK) return rc;
+    }
     const int blocks = cdiv(p.n_walks * 16, 256);
     const int nf = (ctx->ld + 15) / 16;
     if (nf <= 4) hipLaunchKernelGGL(path_grad_kernel<4>, dim3(blocks), dim3(256), 0, ctx->stream, p);
@@ -673,7 +708,13 @@ static int run_pass(gg_ctx *ctx, int which, const int64_t *starts, int64_t n_bat
         // nothing prepared on this rank; with replicas it still has to take part in the step's
         // gradient exchange (the other ranks are waiting in the collective)
         if (ctx->comm && n_batches > 0) {
-            int rc = apply_optimizer(ctx, which, 0);
+            int rc = GG_OK;
+            if (which == 0) {  // the generator's steps open with the all-reduce of the ranks' pair counts
+                const int64_t *unused = nullptr;
+                rc = global_pair_count(ctx, 0, &unused);
+                if (rc != GG_OK) return rc;
+            }
+            rc = apply_optimizer(ctx, which, 0);
             if (rc != GG_OK) return rc;
             GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }

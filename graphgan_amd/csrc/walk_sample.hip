@@ -168,6 +168,7 @@ __device__ __forceinline__ int sample_index(Load sbuf, int k, float mx, uint64_t
         for (int jj = lane; jj < k; jj += 64) part += weight_fix40(exp_spec(sbuf(jj) - mx));
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+        if (part == 0ull) return -1;  // no weight at all: non-finite scores (the caller raises the error flag)
         const uint64_t thr = threshold(m53, part);
         uint64_t carry = 0;
         for (int j0 = 0; j0 < k; j0 += 64) {
@@ -200,6 +201,7 @@ static int score_blocks() {
     return v;
 }
 constexpr int BIG_TASK = 256;   // owner tasks with more candidates get a whole workgroup for their prefix sums
+constexpr int CTR_NONFINITE = 6; // ctr[6]: a distribution had total weight 0 (non-finite generator scores) -> GG_EINVAL
 constexpr int CTR_ALIVE = 8;    // ctr[CTR_ALIVE + level]: walks alive when hop `level` was set up
 constexpr int CTR_BIG = 72;     // ctr[CTR_BIG + level]:   big owner tasks of hop `level`
 constexpr int CTR_CHUNKS = 136; // ctr[CTR_CHUNKS + level]: chunks of hop `level` (chunk offsets are handed out per wave)
@@ -218,8 +220,16 @@ constexpr int MAX_LEVELS = 64;
 //              one root standing on the same node need the SAME distribution -> one owner.
 __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, const int do_sample, const int do_setup, const int write_desc,
                                                             const int64_t cap_chunks) {
-    if (a.ctr[3] == 2ull) return;  // a previous level overflowed its speculative buffers: the host reruns in sized mode
-    if (a.level > 0 && a.ctr[CTR_ALIVE + a.level - 1] == 0ull) return;  // every walk has finished: empty level
+    // Block-uniform early exit: other blocks of this very launch may raise flag 2 (speculative overflow below, a walk
+    // still alive after the last level), so every thread testing the global word itself could split a workgroup in
+    // front of the barriers further down.  One thread reads, all threads test the shared copy.
+    __shared__ int blk_skip;
+    if (threadIdx.x == 0)
+        blk_skip = (__atomic_load_n(&a.ctr[3], __ATOMIC_RELAXED) == 2ull ||                                  // an earlier level overflowed: the host reruns in sized mode
+                    (a.level > 0 && __atomic_load_n(&a.ctr[CTR_ALIVE + a.level - 1], __ATOMIC_RELAXED) == 0ull))  // every walk has finished: empty level
+                       ? 1 : 0;
+    __syncthreads();
+    if (blk_skip) return;
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool in_range = w < a.total_walks;
@@ -270,7 +280,9 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
                     const int idx = i * step - 1;
                     piv[i - 1] = (idx < n - 1) ? pf[idx] : ~0ull;
                 }
-                const uint64_t thr = threshold(uniform53(a.seed, a.stream, (uint32_t)root, (uint32_t)j, (uint32_t)(a.level - 1)), pf[kk - 1]);
+                const uint64_t Wtot = pf[kk - 1];
+                if (Wtot == 0ull) a.ctr[CTR_NONFINITE] = 1ull;  // non-finite scores: the search below stays inside [0, kk), the host reports the error
+                const uint64_t thr = threshold(uniform53(a.seed, a.stream, (uint32_t)root, (uint32_t)j, (uint32_t)(a.level - 1)), Wtot);
                 int seg = 0;
 #pragma unroll
                 for (int i = 0; i < 15; ++i) seg += (piv[i] <= thr) ? 1 : 0;  // C is non-decreasing: a prefix of the pivots
@@ -742,8 +754,12 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void walk_sample_kernel(const
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
                 const uint64_t m53 = uniform53(a.seed, a.stream, (uint32_t)root, j, hop);
-                const int idx = sample_index([&](int jj) { return sbuf[jj]; }, k, mx, m53, lane);
+                int idx = sample_index([&](int jj) { return sbuf[jj]; }, k, mx, m53, lane);
                 __builtin_amdgcn_wave_barrier();
+                if (idx < 0) {  // total weight 0 <=> the scores are not finite (diverged generator): a diagnosable error, not a wild index
+                    if (lane == 0) a.ctr[CTR_NONFINITE] = 1ull;
+                    idx = 0;
+                }
                 const int nxt = ids[idx];
                 my_hops += 1;
                 my_reads += (unsigned long long)k;

@@ -167,6 +167,10 @@ class Engine:
             self._ck(lib.gg_build_trees(self._ctx, _ptr(roots), len(roots), n_threads))
         self._after_trees(roots)
 
+    def tree_bytes_estimate(self, n_roots):
+        """Upper bound of the HBM bytes ``n_roots`` resident trees need (every root reaching every node)."""
+        return float(n_roots) * 12.0 * (self.n_node + 1)
+
     def set_trees(self, roots, off, nbr, nbr_base, max_depth=0):
         roots, off, nbr = _i32(roots), _i32(off), _i32(nbr)
         nbr_base = np.ascontiguousarray(nbr_base, dtype=np.int64)
@@ -203,6 +207,19 @@ class Engine:
         status = np.zeros(len(slots), dtype=np.int32)
         self._ck(lib.gg_walk_sample(self._ctx, _ptr(slots), _ptr(n_walks), len(slots), int(bool(for_d)), seed, stream,
                                     _ptr(samples), _ptr(paths), _ptr(plen), stride, _ptr(status)))
+        return dict(samples=samples, paths=paths, path_len=plen, root_status=status)
+
+    def get_walks(self):
+        """Walk outputs left resident by the last walk_sample / prepare_d / prepare_g call (the (samples, paths)
+        ``sample`` returned inside ``prepare_data_for_*``, graph_gan.py:191,210)."""
+        tot, stride, ns = ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int32()
+        self._ck(lib.gg_walk_info(self._ctx, ctypes.byref(tot), ctypes.byref(stride), ctypes.byref(ns)))
+        total, stride, ns = tot.value, stride.value, ns.value
+        samples = np.full(total, -1, dtype=np.int32)
+        paths = np.full((total, max(stride, 1)), -1, dtype=np.int32)
+        plen = np.zeros(total, dtype=np.int32)
+        status = np.zeros(ns, dtype=np.int32)
+        self._ck(lib.gg_get_walks(self._ctx, _ptr(samples), _ptr(paths), _ptr(plen), _ptr(status)))
         return dict(samples=samples, paths=paths, path_len=plen, root_status=status)
 
     # ------------------------------------------------------------------ prepared data

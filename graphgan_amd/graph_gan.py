@@ -79,13 +79,19 @@ class GraphGAN(object):
         self.build_generator()
         self.build_discriminator()
 
-        # BFS trees live in HBM as a tree CSR; with update_ratio >= 1 every root is resident for the
-        # whole run (like the reference's self.trees), otherwise they are rebuilt per sampled root set.
+        # BFS trees live in HBM; like the reference's self.trees (:31-46) every root stays resident for the whole
+        # run -- also with update_ratio < 1, where each prepare call only SELECTS a subset of the resident slots, so
+        # the in-place D-mode mutations (Q3, :258-259) persist across epochs exactly as in the reference.  Only when
+        # all N trees cannot fit the budget (config.engine_tree_budget_gb; N^2 storage) and update_ratio < 1 are the
+        # trees of each draw built on demand instead (mutation state then lives for one prepare call).
         print("constructing BFS-trees...")
         self.trees = None
         self._slot_of_root = None
-        if cfg.update_ratio >= 1:
+        self._all_resident = False
+        budget = float(_cfg(cfg, "engine_tree_budget_gb", 160.0)) * 2.0 ** 30
+        if cfg.update_ratio >= 1 or self.engine.tree_bytes_estimate(len(self.root_nodes)) <= budget:
             self.trees = self.construct_trees(self.root_nodes)
+            self._all_resident = True
 
         self.latest_checkpoint = os.path.join(cfg.model_log, "model.checkpoint.ggst")
 
@@ -174,39 +180,56 @@ class GraphGAN(object):
 
     # ------------------------------------------------------------------ sample preparation
     def _select_slots(self):
-        """``np.random.rand() < update_ratio`` per root (reference :189, :209)."""
+        """``np.random.rand() < update_ratio`` per root (reference :189, :209): one draw per root, in root order
+        (no draws with update_ratio >= 1: every root is taken, and the oracle trainer does the same)."""
         cfg = self.config
         if cfg.update_ratio >= 1:
             return np.arange(len(self.root_nodes), dtype=np.int32)
-        take = [r for r in self.root_nodes if self.host_rng.rand() < cfg.update_ratio]
-        self.trees = self.construct_trees(take)
+        take = np.flatnonzero(self.host_rng.rand(len(self.root_nodes)) < cfg.update_ratio)
+        if self._all_resident:
+            return take.astype(np.int32)  # slot i holds root_nodes[i]
+        if len(take) == 0:
+            return np.zeros(0, dtype=np.int32)
+        self.trees = self.construct_trees([self.root_nodes[i] for i in take])
         return np.arange(len(take), dtype=np.int32)
 
     def _prepare_d_resident(self):
-        return self.engine.prepare_d(self._select_slots(), self.seed, self._stream, fetch=False)
+        slots = self._select_slots()
+        return self.engine.prepare_d(slots, self.seed, self._stream, fetch=False) if len(slots) else 0
 
     def _prepare_g_resident(self):
-        return self.engine.prepare_g(self._select_slots(), self.config.n_sample_gen, self.seed, self._stream, fetch=False)
+        slots = self._select_slots()
+        return self.engine.prepare_g(slots, self.config.n_sample_gen, self.seed, self._stream, fetch=False) if len(slots) else 0
 
     def prepare_data_for_d(self):
         """generate positive and negative samples for the discriminator (reference :182-202);
         returns (center_nodes, neighbor_nodes, labels) and leaves them resident for d_pass"""
         if not hasattr(self, "_stream"):
             self._stream = 0
-        center, neighbor, label, _ = self.engine.prepare_d(self._select_slots(), self.seed, self._stream)
+        slots = self._select_slots()
+        if len(slots) == 0:
+            return [], [], []
+        center, neighbor, label, _ = self.engine.prepare_d(slots, self.seed, self._stream)
         return center.tolist(), neighbor.tolist(), label.astype(np.int64).tolist()
 
     def prepare_data_for_g(self):
         """sample nodes for the generator (reference :204-223); returns (node_1, node_2, reward)"""
         if not hasattr(self, "_stream"):
             self._stream = 1
-        n1, n2, reward, _ = self.engine.prepare_g(self._select_slots(), self.config.n_sample_gen, self.seed, self._stream)
+        slots = self._select_slots()
+        if len(slots) == 0:
+            return [], [], np.zeros(0, dtype=np.float32)
+        n1, n2, reward, _ = self.engine.prepare_g(slots, self.config.n_sample_gen, self.seed, self._stream)
         return n1.tolist(), n2.tolist(), reward
 
     def sample(self, root, tree, sample_num, for_d):
         """sample nodes from the BFS-tree of ``root`` (reference :225-270).  ``tree`` is accepted
         for signature compatibility; the resident tree of ``root`` is used.
         Returns (samples, paths), or (None, None) when the reference would."""
+        if self._slot_of_root is None or int(root) not in self._slot_of_root:
+            if self._all_resident:
+                raise KeyError("root %d has no resident tree (not in root_nodes)" % int(root))
+            self.trees = self.construct_trees([int(root)])  # on-demand mode: build this root's tree
         slot = self._slot_of_root[int(root)]
         stream = getattr(self, "_stream", 0)
         res = self.engine.walk_sample([slot], [sample_num], for_d, self.seed, stream)

@@ -147,6 +147,13 @@ int gg_walk_sample(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, in
                    int32_t *samples, int32_t *paths, int32_t *path_len, int32_t stride,
                    int32_t *root_status);
 
+/* gg_walk_info / gg_get_walks: shape and contents of the walk outputs left resident by the last gg_walk_sample /
+ * gg_prepare_d / gg_prepare_g call (what GraphGAN.sample returned for those roots, graph_gan.py:191,210): total walks,
+ * path stride and slot count; then samples [total], paths [total * stride], path_len [total], root_status [n_slots]
+ * (any pointer may be NULL).  Used by parity tests that check the walks INSIDE a prepare call. */
+int gg_walk_info(const gg_ctx *ctx, int64_t *total_walks, int32_t *stride, int32_t *n_slots);
+int gg_get_walks(gg_ctx *ctx, int32_t *samples, int32_t *paths, int32_t *path_len, int32_t *root_status);
+
 /* ---- prepared sample buffers (device resident).
  * gg_prepare_d: prepare_data_for_d (graph_gan.py:182-202) for the given root slots: D-mode
  * walks (n_walks = CSR degree), then rows [pos..., neg...] per non-aborted root, in slot order.

@@ -143,38 +143,46 @@ def test_script_entry_point_with_user_config(tmp_path):
         assert os.path.getsize(os.path.join(base, "results", "link_prediction", name)) > 1e6
 
 
-def test_update_ratio_below_one_rebuilds_trees_per_prepare(tmp_path):
-    """config.update_ratio < 1 (graph_gan.py:189,209): every prepare draws its own subset of roots; the
-    mirror builds the BFS trees of just that subset (on the GPU) instead of keeping all N trees resident."""
+def test_update_ratio_below_one_selects_resident_slots(tmp_path):
+    """config.update_ratio < 1 (graph_gan.py:189,209): every prepare draws its own subset of roots.  All trees stay
+    resident (the reference's self.trees): the draw only selects slots, so the D-mode mutations (Q3) persist; with
+    engine_tree_budget_gb = 0 the mirror falls back to building the trees of each draw on the GPU."""
     base = str(tmp_path)
     d, n, graph = write_reference_layout(base)
-    cfg = make_cfg(base, n_epochs=1, n_epochs_dis=2, n_epochs_gen=2, dis_interval=1, gen_interval=1, update_ratio=0.05,
-                   engine_optimizer="adam_lazy", engine_profile_every=0)  # no events: passes return early, G walks beside D updates
-    from graphgan_amd.graph_gan import GraphGAN
-    g = GraphGAN(cfg)
-    assert g.trees is None
-    g.train()
-    lines = open(cfg.result_filename).read().split()
-    assert len(lines) == 4 and lines[0] == "gen:0.7598343685300207"
-    c = g.engine.counters()
-    assert c["d_steps"] > 0 and c["g_steps"] > 0 and 0 < c["walks"] < 4 * 0.2 * n * 25
-    nroots = len(g.engine.tree_roots)
-    assert 0.02 * n < nroots < 0.09 * n  # ~5 % of the roots in the last prepare
+    for budget, resident in ((160.0, True), (0.0, False)):
+        cfg = make_cfg(base, n_epochs=1, n_epochs_dis=2, n_epochs_gen=2, dis_interval=1, gen_interval=1, update_ratio=0.05,
+                       engine_optimizer="adam_lazy", engine_profile_every=0, engine_tree_budget_gb=budget)  # no events: passes return early, G walks beside D updates
+        if os.path.exists(cfg.result_filename):
+            os.remove(cfg.result_filename)
+        from graphgan_amd.graph_gan import GraphGAN
+        g = GraphGAN(cfg)
+        assert (g.trees is not None) == resident
+        g.train()
+        lines = open(cfg.result_filename).read().split()
+        assert len(lines) == 4 and lines[0] == "gen:0.7598343685300207"
+        c = g.engine.counters()
+        assert c["d_steps"] > 0 and c["g_steps"] > 0 and 0 < c["walks"] < 4 * 0.2 * n * 25
+        nroots = len(g.engine.tree_roots)
+        assert nroots == n if resident else 0.02 * n < nroots < 0.09 * n  # ~5 % of the roots in the last prepare
+        g.engine.close()
 
 
-def test_full_schedule_epoch_matches_committed_oracle_run(tmp_path):
-    """One outer epoch of the reference's DEFAULT schedule (30 + 30 inner passes, batch 64, dense TF1-Adam,
-    ~330 k optimizer steps) against the CPU oracle's result for the same seed (tests/golden/
-    oracle_epochs_multiseed.json, ~7 CPU-minutes per epoch; 7 seeds x 3 epochs are compared in DESIGN.md section 8).
-    The discriminator's accuracy after the epoch has matched the oracle to the digit in every run so far; the
-    gate allows two of the 2 898 test edges (fp32 atomic order) and the north star's 0.5 % for the generator."""
+@pytest.mark.parametrize("seed", [4, 11])
+def test_full_schedule_epochs_match_committed_oracle_runs(tmp_path, seed):
+    """TWO outer epochs of the reference's DEFAULT schedule (30 + 30 inner passes, batch 64, dense TF1-Adam,
+    ~330 k optimizer steps each) against the CPU oracle's results for the same seed (tests/golden/
+    oracle_epochs_multiseed.json, ~7 CPU-minutes per epoch; 15 seeds are compared in DESIGN.md section 8).
+    Epoch 0: the discriminator's accuracy has matched the oracle to the digit in every run so far -- the gate allows
+    two of the 2 898 test edges (fp32 atomic order) -- and the north star's 0.5 % for the generator.  Epoch 1: the
+    two trajectories are then different samples of the same chaotic process (one flipped walk changes everything
+    after it; the generator has fallen to chance on BOTH sides); the gate is the per-seed spread observed over 15
+    seeds with margin -- discriminator 1.0 % (largest seen 0.55 %), generator 3.0 % (largest seen 2.3 %)."""
     import json
     from tests.helpers import ca_grqc_init_embeddings
-    seed = 4
     want = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_epochs_multiseed.json")))["epochs"][str(seed)]
     base = str(tmp_path)
     d, n, graph = write_reference_layout(base)
-    cfg = make_cfg(base, n_epochs=1, engine_seed=seed)
+    cfg = make_cfg(base, n_epochs=2, engine_seed=seed)
     from graphgan_amd.graph_gan import GraphGAN
     g = GraphGAN(cfg)
     init = ca_grqc_init_embeddings(d, n, seed=0).astype(np.float32)
@@ -183,8 +191,13 @@ def test_full_schedule_epoch_matches_committed_oracle_run(tmp_path):
     g.train()
     lines = open(cfg.result_filename).read().split()
     acc = [[float(lines[2 * i][4:]), float(lines[2 * i + 1][4:])] for i in range(len(lines) // 2)]
+    print("seed %d engine %s oracle %s" % (seed, acc, want[:3]))
+    assert len(acc) == 3
     assert acc[0] == want[0]  # before training: the shipped embeddings under the shipped evaluator
     assert abs(acc[1][1] - want[1][1]) <= 2.0 / 2898 + 1e-12
     assert abs(acc[1][0] - want[1][0]) <= 0.005
+    assert abs(acc[2][1] - want[2][1]) <= 0.010
+    assert abs(acc[2][0] - want[2][0]) <= 0.030
     c = g.engine.counters()
-    assert c["d_steps"] > 3000 and c["g_steps"] > 200000
+    assert c["d_steps"] > 6000 and c["g_steps"] > 400000
+    g.engine.close()

@@ -1,4 +1,8 @@
 """Parity at the benchmark scales.
+  * BASELINE.json configs[3] -- THE bench.py workload itself (1M nodes / 10M edges, n_emb = 128, 8 192 hub-first roots,
+    lazy Adam, profiling cadence 3, prepare_d -> d_pass -> prepare_g -> g_pass three times): the walks inside the
+    prepare calls of 64 sampled roots (the top-degree ones included) BIT-EXACT against the oracle, sized launches
+    (step 1) and sync-free speculative launches with the side-stream overlap (steps 2, 3).
   * BASELINE.json configs[2] (power-law, 100k nodes / 1M edges, n_emb = 128): a sample of roots,
     HIP walks BIT-EXACT against the spec oracle, D and G mode, hub lists included.
   * BASELINE.json configs[3] size (1M nodes / 10M edges, n_emb = 128): the oracle cannot cover it in
@@ -151,3 +155,65 @@ def test_powerlaw_100k_fused_passes_match_oracle(ga):
         moved = np.abs(want - (E if want.ndim == 2 else b)).ravel() > 0
         assert moved.sum() > 1000
         assert np.quantile(diff[moved], 0.999) < 2e-5 and diff.max() <= 2.5e-3 and diff[~moved].max() == 0.0
+
+
+def _compare_walks(got, want, item_ptr, sel, stride_w, tag):
+    """walks of the selected roots: got = engine launch over all roots (walk_ptr = item_ptr), want = oracle over sel"""
+    o = 0
+    for k, i in enumerate(sel):
+        a, b = int(item_ptr[i]), int(item_ptr[i + 1])
+        nw = b - a
+        assert got["root_status"][i] == want["root_status"][k], "%s root %d status" % (tag, i)
+        assert np.array_equal(got["path_len"][a:b], want["path_len"][o:o + nw]), "%s root %d path_len" % (tag, i)
+        assert np.array_equal(got["samples"][a:b], want["samples"][o:o + nw]), "%s root %d samples" % (tag, i)
+        L = want["path_len"][o:o + nw]
+        m = np.arange(stride_w)[None, :] < L[:, None]
+        assert np.array_equal(got["paths"][a:b, :stride_w][m], want["paths"][o:o + nw][m]), "%s root %d paths" % (tag, i)
+        o += nw
+    assert o == len(want["samples"])
+
+
+def test_bench_workload_walks_bit_exact_inside_the_timed_step(ga):
+    """The exact workload of bench.py (graphgan_amd/workloads.py, defaults of bench.py): three steps as the timed
+    region runs them.  Each step's D-mode and G-mode walks -- fetched from INSIDE prepare_d / prepare_g with
+    gg_get_walks -- are compared with the oracle for 64 roots: the 8 top-degree roots + 56 spread over the
+    degree-sorted list.  The oracle follows the engine's generator tables step by step (they change with every
+    g_pass; fp32 atomics make them non-reproducible on the CPU) and carries its own copy of the Q3 tree mutations."""
+    from graphgan_amd import workloads
+    n, d, R, seed = 1_000_000, 128, 8192, 6
+    rowptr, col, emb, _ = workloads.powerlaw_workload(n, 10, d)
+    roots = workloads.bench_roots(rowptr, R, 0, 1, seed)
+    deg = (rowptr[1:] - rowptr[:-1]).astype(np.int64)
+    assert np.all(np.diff(deg[roots]) <= 0) and deg[roots[0]] > 500  # hub-first order, real hubs among the roots
+    eng = ga.Engine(emb, emb, optimizer=ga.GG_OPT_ADAM_LAZY)
+    eng.set_graph_csr(rowptr, col)
+    eng.build_trees(roots, device=True)
+    slots = np.arange(R, dtype=np.int32)
+    sel = np.unique(np.concatenate([np.arange(8), np.linspace(8, R - 1, 56).astype(np.int64)]))
+    sroots = np.ascontiguousarray(roots[sel])
+    off, nbr, base, dmax = orc.c_build_trees(n, rowptr, col, sroots)
+    nbr = nbr.copy()
+    stride = eng.max_depth + 3
+    assert dmax <= eng.max_depth
+    oslots = np.arange(len(sel), dtype=np.int32)
+    d_ptr = np.concatenate([[0], np.cumsum(deg[roots])])
+    g_ptr = 20 * np.arange(R + 1)
+    eng.set_profiling(3)  # the bench's cadence: passes return early, G walks on the side stream beside the D update
+    hops = 0
+    for i in range(3):
+        Eg, bg = orc.pad_rows(eng.get_embeddings(0)), eng.get_bias(0)
+        rows = eng.prepare_d(slots, seed, 2 * i, fetch=False)
+        got = eng.get_walks()
+        want = orc.c_walk_sample(Eg, bg, off, nbr, base, sroots, oslots, deg[sroots].astype(np.int32), True, seed, 2 * i, stride)
+        _compare_walks(got, want, d_ptr, sel, stride, "step %d D" % i)
+        eng.d_pass(np.zeros(1, np.int64), max(int(rows), 1))
+        pairs = eng.prepare_g(slots, 20, seed, 2 * i + 1, fetch=False)
+        got = eng.get_walks()
+        want = orc.c_walk_sample(Eg, bg, off, nbr, base, sroots, oslots, np.full(len(sel), 20, np.int32), False, seed, 2 * i + 1, stride)
+        _compare_walks(got, want, g_ptr, sel, stride, "step %d G" % i)
+        hops += want["hops"]
+        eng.g_pass(np.zeros(1, np.int64), max(int(pairs), 1))
+    assert hops > 3 * 64 * 20 * 2
+    # the generator moved between the steps (the later comparisons were against updated tables)
+    assert np.abs(eng.get_embeddings(0) - emb).max() > 1e-4
+    eng.close()

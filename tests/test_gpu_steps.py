@@ -231,8 +231,49 @@ def test_state_save_restore(ga, tmp_path):
         assert np.allclose(a, b, rtol=1e-6, atol=1e-7)
     with pytest.raises(ga.GraphGANHipError):
         eng2.load_state(str(tmp_path / "missing"))
+    # the save is atomic (temporary + rename: no half-written checkpoint at the final path) ...
+    assert not os.path.exists(path + ".tmp")
+    # ... and a truncated file is rejected BEFORE any device table changes
+    blob = open(path, "rb").read()
+    bad = str(tmp_path / "truncated.ggst")
+    open(bad, "wb").write(blob[: len(blob) // 2])
+    with pytest.raises(ga.GraphGANHipError) as ei:
+        eng2.load_state(bad)
+    assert ei.value.code == ga.GG_EIO and "nothing was loaded" in str(ei.value)
+    for a, b in zip(got, [eng2.get_embeddings(0), eng2.get_embeddings(1), eng2.get_bias(0), eng2.get_bias(1)]):
+        assert np.array_equal(a, b)
     eng.close()
     eng2.close()
+
+
+@pytest.mark.parametrize("mode", ["sgd", "lazy"])
+def test_generator_mean_uses_the_pairs_of_all_ranks(ga, mode, monkeypatch):
+    """generator.py:28 takes the MEAN over the batch: with replicas the batch of a step is the union of the ranks'
+    slices, so 1/B must count the pairs of ALL ranks (one 8-byte all-reduce per step).  Two simulated ranks holding
+    the same 500 pairs (GG_COMM_FAKE_WORLD=2) must move the tables exactly like one rank stepping on the 1 000-pair
+    union; with per-rank means the data term would be twice too large against the L2 term."""
+    n, d = 300, 64
+    Eg, Ed, bg, bd = make_models(n, d, 33)
+    opt = ga.GG_OPT_SGD if mode == "sgd" else ga.GG_OPT_ADAM_LAZY
+    rs = np.random.RandomState(2)
+    u, v = rs.randint(0, n, 500), rs.randint(0, n, 500)
+    r = (rs.rand(500) * 3).astype(np.float32)
+    monkeypatch.setenv("GG_COMM_FAKE_WORLD", "2")
+    two = engine_with(ga, Eg, Ed, bg, bd, optimizer=opt, lr_gen=0.05, lambda_gen=0.05)
+    monkeypatch.delenv("GG_COMM_FAKE_WORLD")
+    one = engine_with(ga, Eg, Ed, bg, bd, optimizer=opt, lr_gen=0.05, lambda_gen=0.05)
+    two.g_step(u, v, r)
+    one.g_step(np.concatenate([u, u]), np.concatenate([v, v]), np.concatenate([r, r]))
+    assert np.abs(one.get_embeddings(0) - Eg).max() > 1e-3
+    assert np.allclose(two.get_embeddings(0), one.get_embeddings(0), rtol=2e-5, atol=2e-6)
+    assert np.allclose(two.get_bias(0), one.get_bias(0), rtol=2e-5, atol=2e-6)
+    # and it is NOT what per-rank means would give
+    gen = orc.Generator(Eg, 0.05, lazy=True)
+    gen.b[:] = bg
+    _, gu, gv, gb = gen.loss_and_grads(u, v, r, 0.05)
+    assert np.abs(gu).max() > 0
+    one.close()
+    two.close()
 
 
 @pytest.mark.parametrize("mode", ["dense", "lazy", "lazy-dense-fallback"])

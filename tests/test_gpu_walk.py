@@ -57,8 +57,17 @@ def run_both(ga, n, rowptr, col, roots, E, b, rounds, seed, n_sample=20, stride=
     return hops
 
 
+@pytest.fixture(params=["finisher", "hybrid2", "levels"])
+def walk_mode(request, monkeypatch):
+    """The three decompositions of the sampler: GG_WALK_LEVELS = 0 (one wavefront per walk, the
+    finisher kernel alone), 2 (two hops through the level pipeline, the finisher takes over), 64 (level pipeline to
+    the end; the default).  gg_create reads the variable, so it is set before the engine exists."""
+    monkeypatch.setenv("GG_WALK_LEVELS", {"finisher": "0", "hybrid2": "2", "levels": "64"}[request.param])
+    return request.param
+
+
 @pytest.mark.parametrize("gi", [0, 1, 2, 3])
-def test_small_graphs_bit_exact(ga, gi):
+def test_small_graphs_bit_exact(ga, gi, walk_mode):
     g, n, graph = load_small(gi)
     rowptr, col = ga.graph_to_csr(n, graph)
     hops = run_both(ga, n, rowptr, col, np.arange(n), g["E"], g["b"], rounds=4, seed=1234 + gi)
@@ -75,7 +84,7 @@ def test_embedding_widths(ga, d):
     run_both(ga, n, rowptr, col, np.arange(n), E, b, rounds=2, seed=99)
 
 
-def test_ca_grqc_all_roots_bit_exact(ga):
+def test_ca_grqc_all_roots_bit_exact(ga, walk_mode):
     """BASELINE.json configs[1]: CA-GrQc, n_emb = 50, every root, D then G then D then G."""
     d, n, graph = load_ca_grqc()
     E = ca_grqc_init_embeddings(d, n).astype(np.float32)
@@ -86,8 +95,10 @@ def test_ca_grqc_all_roots_bit_exact(ga):
 
 
 @pytest.mark.parametrize("leaves", [70, 300, 1500])
-def test_hub_lists_longer_than_one_pass(ga, leaves):
-    """k > 64 (multi-block scan) and k > 1024 (scores in HBM scratch instead of LDS)."""
+def test_hub_lists_longer_than_one_pass(ga, leaves, walk_mode):
+    """k > 64 (multi-block scan) and k > 1024.  In the "finisher" and "hybrid2" modes the per-walk kernel scores the
+    1 501-candidate hub list itself: more than its 1 024 LDS score slots, so the HBM-scratch branch (sbuf_glb) runs;
+    in "levels" mode the same list goes through the workgroup-per-hub weights path."""
     edges, n = star_graph_edges(leaves)
     rowptr, col = ga.edges_to_csr(n, edges)
     rs = np.random.RandomState(leaves)
@@ -143,6 +154,27 @@ def test_errors_are_codes_not_crashes(ga):
     # empty launch is fine
     out = eng.walk_sample(np.zeros(0, np.int32), np.zeros(0, np.int32), False, 0, 0)
     assert len(out["samples"]) == 0
+    eng.close()
+
+
+@pytest.mark.parametrize("levels", ["0", "64"])
+def test_non_finite_generator_scores_are_an_error_not_a_fault(ga, levels, monkeypatch):
+    """A diverged generator (Inf / NaN rows) gives softmax weights that sum to 0: the sampler must report
+    GG_EINVAL instead of indexing the candidate list with -1 (finisher) or sampling garbage (level pipeline)."""
+    monkeypatch.setenv("GG_WALK_LEVELS", levels)
+    g, n, graph = load_small(3)
+    rowptr, col = ga.graph_to_csr(n, graph)
+    E = g["E"].copy()
+    E[:] = np.inf
+    eng = ga.Engine(E, g["E"])
+    eng.set_graph_csr(rowptr, col)
+    eng.build_trees(np.arange(n, dtype=np.int32))
+    with pytest.raises(ga.GraphGANHipError) as ei:
+        eng.walk_sample(np.arange(n), np.full(n, 5), False, 1, 1)
+    assert ei.value.code == ga.GG_EINVAL and "non-finite" in str(ei.value)
+    eng.set_embeddings(0, g["E"])  # the context stays usable
+    out = eng.walk_sample(np.arange(n), np.full(n, 5), False, 1, 1)
+    assert (out["path_len"][out["root_status"].repeat(5) == 0] >= 3).all()
     eng.close()
 
 

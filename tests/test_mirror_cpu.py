@@ -93,13 +93,21 @@ class _FakeEngine(object):
         self.calls = []
         self.tree_roots = None
 
+    def tree_bytes_estimate(self, n_roots): return float(n_roots) * 12.0 * (self.n_node + 1)
     def set_profiling(self, k): self.calls.append(("set_profiling", k))
     def set_graph_csr(self, rowptr, col): self.calls.append(("set_graph_csr", len(rowptr) - 1, len(col)))
     def build_trees(self, roots, **kw): self.tree_roots = list(roots); self.calls.append(("build_trees", len(roots), kw.get("device")))
     def load_state(self, path): self.calls.append(("load_state", path))
     def save_state(self, path): open(path, "w").write("x"); self.calls.append(("save_state", path))
-    def prepare_d(self, slots, seed, stream, fetch=True): self.calls.append(("prepare_d", len(slots), seed, stream, fetch)); return 200
-    def prepare_g(self, slots, n_sample, seed, stream, fetch=True): self.calls.append(("prepare_g", len(slots), n_sample, seed, stream, fetch)); return 333
+    def prepare_d(self, slots, seed, stream, fetch=True):
+        self.calls.append(("prepare_d", len(slots), seed, stream, fetch))
+        self.last_slots = np.array(slots)
+        return 200
+
+    def prepare_g(self, slots, n_sample, seed, stream, fetch=True):
+        self.calls.append(("prepare_g", len(slots), n_sample, seed, stream, fetch))
+        self.last_slots = np.array(slots)
+        return 333
     def d_pass(self, starts, batch): self.calls.append(("d_pass", list(starts), batch))
     def g_pass(self, starts, batch): self.calls.append(("g_pass", list(starts), batch))
     def get_embeddings(self, which): return self.E[which]
@@ -154,8 +162,9 @@ def test_training_schedule_drives_the_engine_like_the_reference(pkg, tmp_path, m
 
 
 def test_update_ratio_selects_roots_per_prepare(pkg, tmp_path, monkeypatch):
-    """``np.random.rand() < update_ratio`` per root (graph_gan.py:189,209): with update_ratio < 1 no tree is built
-    up front; every prepare draws its own subset, builds exactly those trees and samples from all of their slots."""
+    """``np.random.rand() < update_ratio`` per root (graph_gan.py:189,209).  The reference keeps ALL trees in
+    self.trees and only skips roots per prepare, so the D-mode mutations (Q3) persist: the mirror builds every
+    tree once and passes the drawn subset of slots to each prepare call (one draw per root, in root order)."""
     from tests.test_gpu_e2e import make_cfg, write_reference_layout
     from graphgan_amd import engine as eng_mod, graph_gan
     base = str(tmp_path)
@@ -163,15 +172,54 @@ def test_update_ratio_selects_roots_per_prepare(pkg, tmp_path, monkeypatch):
     monkeypatch.setattr(eng_mod, "Engine", _FakeEngine)
     cfg = make_cfg(base, n_epochs=1, n_epochs_dis=2, n_epochs_gen=2, dis_interval=1, gen_interval=2, update_ratio=0.1, engine_seed=3)
     g = graph_gan.GraphGAN(cfg)
+    assert g.trees is not None and [c[1] for c in g.engine.calls if c[0] == "build_trees"] == [n]
+    seen = []
+    orig_d, orig_g = g.engine.prepare_d, g.engine.prepare_g
+    g.engine.prepare_d = lambda slots, *a, **k: (seen.append(np.array(slots)), orig_d(slots, *a, **k))[1]
+    g.engine.prepare_g = lambda slots, *a, **k: (seen.append(np.array(slots)), orig_g(slots, *a, **k))[1]
+    g.train()
+    calls = g.engine.calls
+    assert len([c for c in calls if c[0] == "build_trees"]) == 1   # never rebuilt
+    assert len(seen) == 3                                          # D at inner epochs 0, 1; G at inner epoch 0
+    rng = np.random.RandomState(3)                                 # host RNG = RandomState(engine_seed); shuffles interleave
+    for sl in seen:
+        assert 0.06 * n < len(sl) < 0.14 * n and np.all(np.diff(sl) > 0) and sl.max() < n
+    assert len({len(sl) for sl in seen}) > 1                       # a fresh draw per prepare
+    first = np.flatnonzero(rng.rand(n) < 0.1)
+    assert np.array_equal(seen[0], first)                          # one draw per root, in root order, before any shuffle
+
+
+def test_update_ratio_with_trees_over_budget_builds_per_draw(pkg, tmp_path, monkeypatch):
+    """When all N trees cannot stay resident (engine_tree_budget_gb) and update_ratio < 1, every prepare builds the
+    trees of its own draw; an empty draw prepares nothing (0 rows) instead of failing; sample() of a root outside
+    the last draw builds that root's tree on demand."""
+    from tests.test_gpu_e2e import make_cfg, write_reference_layout
+    from graphgan_amd import engine as eng_mod, graph_gan
+    base = str(tmp_path)
+    d, n, graph = write_reference_layout(base)
+    monkeypatch.setattr(eng_mod, "Engine", _FakeEngine)
+    cfg = make_cfg(base, n_epochs=1, n_epochs_dis=2, n_epochs_gen=2, dis_interval=1, gen_interval=2, update_ratio=0.1, engine_seed=3,
+                   engine_tree_budget_gb=0.0)
+    g = graph_gan.GraphGAN(cfg)
     assert g.trees is None and not any(c[0] == "build_trees" for c in g.engine.calls)
     g.train()
     calls = g.engine.calls
     builds = [c for c in calls if c[0] == "build_trees"]
     prepares = [c for c in calls if c[0] in ("prepare_d", "prepare_g")]
-    assert len(builds) == len(prepares) == 3                      # D at inner epochs 0, 1; G at inner epoch 0
+    assert len(builds) == len(prepares) == 3
     for b, p in zip(builds, prepares):
         assert 0.06 * n < b[1] < 0.14 * n and p[1] == b[1]      # ~10 % of the roots, all of their slots
         assert calls.index(b) + 1 == calls.index(p)             # trees of the subset right before its prepare
-    assert len({b[1] for b in builds}) > 1                        # a fresh draw per prepare
     roots = g.engine.tree_roots
     assert roots == sorted(roots) and len(set(roots)) == len(roots) and g._slot_of_root[roots[5]] == 5
+    # empty draw: nothing built, nothing prepared, zero rows
+    g.config.update_ratio = 0.0
+    nb = len([c for c in g.engine.calls if c[0] == "build_trees"])
+    assert g._prepare_d_resident() == 0 and g._prepare_g_resident() == 0
+    assert g.prepare_data_for_d() == ([], [], [])
+    assert len([c for c in g.engine.calls if c[0] == "build_trees"]) == nb
+    # sample() of a root that is not in the last draw: its tree is built on demand
+    other = [r for r in range(n) if r not in set(roots)][0]
+    g.engine.walk_sample = lambda slots, nw, for_d, seed, stream: dict(root_status=np.array([1]), paths=None, path_len=None, samples=None)
+    assert g.sample(other, None, 5, False) == (None, None)
+    assert g.engine.tree_roots == [other]
