@@ -34,7 +34,8 @@ class GGCounters(ctypes.Structure):
                 ("d_steps", ctypes.c_int64), ("g_steps", ctypes.c_int64),
                 ("last_kernel_ms", ctypes.c_double), ("walk_kernel_ms", ctypes.c_double),
                 ("walk_launches", ctypes.c_int64), ("rows_scored", ctypes.c_int64), ("score_kernel_ms", ctypes.c_double),
-                ("score_launches", ctypes.c_int64), ("score_chunks", ctypes.c_int64), ("score_rows", ctypes.c_int64)]
+                ("score_launches", ctypes.c_int64), ("score_chunks", ctypes.c_int64), ("score_rows", ctypes.c_int64),
+                ("bfs_kernel_ms", ctypes.c_double), ("bfs_trees", ctypes.c_int64)]
 
 
 class GGGraph(ctypes.Structure):

@@ -1,18 +1,32 @@
 // bfs_gpu.hip -- BFS-tree construction on the GPU: the same trees as
 // GraphGAN.construct_trees (reference src/GraphGAN/graph_gan.py:84-108) -- FIFO BFS, children in
-// adjacency (file) order, self-loops / already-used nodes skipped -- for a batch of roots at once,
-// written straight into the context's tree CSR without touching the host.
+// adjacency (file) order, self-loops / already-used nodes skipped -- written straight into the
+// context's BFS-order tree arrays (gg_internal.h) without touching the host.
 //
-// The reference's queue order is reproduced level by level.  Let F_d be the nodes of depth d in
-// pop order.  A node w of depth d+1 is appended by the FIRST frontier node (in pop order) that
-// lists it, at that node's FIRST edge to it; so
-//   claim : cand[w] = min over frontier edges (rank(v) << 32 | position of the edge in adj(v))
-//   count : v's children = its edges that won the claim (in adjacency order)
-//   scan  : exclusive scan of the child counts over F_d in pop order
-//   write : F_{d+1}[base(v) + i] = i-th child of v; father, child index recorded
-// After the last level: list length of v = 1 + #children, exclusive scan over node ids gives the
-// tree CSR offsets, and every node drops itself into its father's list at its child index.
-// All roots of a batch run in the same launches (grid.y = root); one small read-back per level.
+// One WORKGROUP per root, one root per CU at a time (persistent grid, roots drawn from a ticket counter).
+// The reference's BFS is sequential: pop v, scan adj(v) in order, append every node not seen before.  The
+// edges it inspects form ONE STREAM -- (pop order of v, position in adj(v)) -- and a node is appended by the
+// FIRST edge of that stream that reaches it.  The workgroup replays that stream 4 096 edges at a time:
+//
+//   * the "seen" set is a BITMAP IN LDS (1 bit per node: 122 KB for 10^6 nodes, of the CU's 160 KB), so
+//     the test that dominates a BFS -- 20 M of them per tree of the 1M-node / 10M-edge graph -- never leaves the
+//     CU.  (The round-1 kernels kept 36 B of state per (root, node) in HBM for 238 roots at once: every test
+//     was a random HBM access, 4.9 GB of traffic per tree.)  Graphs whose bitmap exceeds the LDS use a per-
+//     workgroup bitmap in global memory (L2 / MALL resident) through the same code.
+//   * a chunk = 1 024 threads x 4 consecutive stream positions.  Test (all threads) | barrier | claim: the
+//     unseen targets set their bit with an LDS atomic-or; exactly one edge per new node sees the bit clear
+//     (the hardware winner), the others (duplicates INSIDE the chunk: rare) append {node, position} to a short
+//     LDS list | barrier | every hardware winner takes the smallest stream position among its own and the
+//     list's entries for its node -- the edge the sequential BFS would have appended it at -- and marks that
+//     position in a 4 096-bit LDS mask | barrier | the marked positions are compacted in stream order (wave
+//     scan + 16 wave totals) onto the queue, and the thread holding the LAST edge of a queue node records
+//     where that node's children end: cstart[] comes out of the same pass.  If the duplicate list overflows
+//     (many edges of one chunk into the same few new nodes) the chunk is resolved through a per-workgroup
+//     atomic-min key array in global memory instead -- exact as well, just slower.
+//   * the queue IS the output (t_order), cstart the second output: no offsets scan, no fill pass.
+//
+// Traffic per tree: the adjacency (80 MB, shared by all 256 concurrent roots: L2 / MALL hits), 16 B of row
+// pointers per node, and 8 B per node of output -- the only part that has to reach HBM.
 #include <algorithm>
 #include <vector>
 
@@ -20,184 +34,227 @@
 
 namespace gg {
 
+constexpr int BFS_T = 1024;             // threads per workgroup
+constexpr int BFS_WAVES = BFS_T / 64;
+constexpr int BFS_U = 4;                // consecutive stream positions per thread and chunk
+constexpr int BFS_CH = BFS_T * BFS_U;   // edges per chunk
+constexpr int BFS_NB = BFS_T;           // queue nodes per batch (one per thread)
+constexpr int BFS_LCAP = 1024;          // in-chunk duplicate list
+
 struct BfsArgs {
-    int n_node, n_batch;
+    int n_node, n_roots;
     const int64_t *rowptr;
     const int32_t *col;
-    int32_t *father;               // [B][N]  -1 = not reached
-    unsigned long long *cand;      // [B][N]  claim key, ~0 = unclaimed
-    int32_t *queue;                // [B][N]  nodes in pop order
-    int32_t *qcnt;                 // [B][N]  children of the node at queue position q
-    int64_t *qbase;                // [B][N]  exclusive scan of qcnt over the current frontier
-    int32_t *ccnt;                 // [B][N]  children per node id
-    int32_t *cidx;                 // [B][N]  index of a node among its father's children
-    int32_t *lo, *hi;              // [B]     current frontier = queue[lo, hi)
-    int32_t *next_hi;              // [B]
+    const int32_t *roots;    // [n_roots] device (t_root)
+    const int64_t *base;     // [n_roots + 1] device (t_base)
+    int32_t *order;          // t_order
+    int32_t *cstart;         // t_cstart
+    unsigned int *ticket;    // next root to take
+    int32_t *stats;          // [0] max depth, [1] longest list (1 + most children), [2] error flag
+    uint32_t *gbitmap;       // [grid][bm_words]  (graphs too large for the LDS bitmap)
+    uint32_t *gkey;          // [grid][n_node]    all-ones between uses (duplicate-list overflow path)
+    int bm_words;
 };
 
-// one wavefront per frontier node: claim the unvisited neighbours
-__global__ __launch_bounds__(256) void bfs_claim_kernel(const BfsArgs a) {
-    const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int lo = a.lo[b], hi = a.hi[b];
-    const int64_t o = (int64_t)b * a.n_node;
-    for (int q = lo + blockIdx.x * 4 + (threadIdx.x >> 6); q < hi; q += gridDim.x * 4) {
-        const int v = a.queue[o + q];
-        const int64_t e0 = a.rowptr[v], e1 = a.rowptr[v + 1];
-        const unsigned long long rank = (unsigned long long)(q - lo) << 32;
-        for (int64_t e = e0 + lane; e < e1; e += 64) {
-            const int w = a.col[e];
-            if (a.father[o + w] < 0) atomicMin(&a.cand[o + w], rank | (unsigned long long)(e - e0));
-        }
-    }
-}
+template <bool LDS_BM>
+__global__ __launch_bounds__(BFS_T) void bfs_order_kernel(const BfsArgs a) {
+    extern __shared__ uint32_t lds_bm[];          // [bm_words] when LDS_BM
+    __shared__ int32_t eoff[BFS_NB + 1];          // exclusive scan of the batch's degrees
+    __shared__ int64_t e0s[BFS_NB];               // first edge of each batch node
+    __shared__ int32_t L_w[BFS_LCAP], L_pos[BFS_LCAP];
+    __shared__ uint32_t winbits[BFS_CH / 32];
+    __shared__ int32_t wave_cnt[BFS_WAVES], wave_tot[BFS_WAVES];
+    __shared__ int32_t Lcount, s_root, s_max;
 
-// one wavefront per frontier node.  WRITE == 0: count the edges that won their claim;
-// WRITE == 1: append those children to the next frontier in adjacency order.
-template <int WRITE>
-__global__ __launch_bounds__(256) void bfs_children_kernel(const BfsArgs a) {
-    const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int lo = a.lo[b], hi = a.hi[b];
-    const int64_t o = (int64_t)b * a.n_node;
-    for (int q = lo + blockIdx.x * 4 + (threadIdx.x >> 6); q < hi; q += gridDim.x * 4) {
-        const int v = a.queue[o + q];
-        const int64_t e0 = a.rowptr[v], e1 = a.rowptr[v + 1];
-        const unsigned long long rank = (unsigned long long)(q - lo) << 32;
-        const int64_t base = WRITE ? (int64_t)hi + a.qbase[o + q] : 0;
-        int run = 0;
-        for (int64_t eb = e0; eb < e1; eb += 64) {
-            const int64_t e = eb + lane;
-            int w = -1;
-            bool child = false;
-            if (e < e1) {
-                w = a.col[e];
-                // not reached before this level (in the write pass father[w] is only ever set by the one
-                // edge whose key matches, i.e. by this very lane) and claimed by exactly this edge
-                child = a.father[o + w] < 0 && a.cand[o + w] == (rank | (unsigned long long)(e - e0));
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t *const bm = LDS_BM ? lds_bm : a.gbitmap + (size_t)blockIdx.x * a.bm_words;
+    uint32_t *const gkey = a.gkey + (size_t)blockIdx.x * a.n_node;
+
+    auto seen = [&](int w) -> bool {
+        if (LDS_BM) return (bm[w >> 5] >> (w & 31)) & 1u;
+        return (__hip_atomic_load(&bm[w >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (w & 31)) & 1u;
+    };
+
+    for (;;) {
+        if (tid == 0) {
+            s_root = (int)atomicAdd(a.ticket, 1u);
+            Lcount = 0;
+            s_max = 0;
+        }
+        for (int i = tid; i < BFS_CH / 32; i += BFS_T) winbits[i] = 0u;
+        __syncthreads();
+        const int r = s_root;
+        if (r >= a.n_roots) return;
+        const int root = a.roots[r];
+        int32_t *const order = a.order + a.base[r];
+        int32_t *const cstart = a.cstart + a.base[r] + r;
+        const int expect = (int)(a.base[r + 1] - a.base[r]);
+        for (int i = tid; i < a.bm_words; i += BFS_T) bm[i] = 0u;
+        __syncthreads();
+        if (tid == 0) {
+            bm[root >> 5] = 1u << (root & 31);
+            order[0] = root;
+            cstart[0] = 1;
+            if (a.rowptr[root + 1] == a.rowptr[root]) cstart[1] = 1;  // isolated root: no edge ever closes its (empty) child range
+        }
+        __syncthreads();
+
+        int head = 0, tail = 1, level_end = 1, depth = 0;
+        while (head < tail) {
+            if (head == level_end) {  // the next level starts: everything up to `tail` belongs to it
+                level_end = tail;
+                ++depth;
             }
-            const unsigned long long bal = __ballot(child);
-            if (WRITE && child) {
-                const int idx = run + __popcll(bal & ((1ull << lane) - 1ull));
-                a.queue[o + base + idx] = w;
-                a.father[o + w] = v;
-                a.cidx[o + w] = idx;
+            const int nb = min(BFS_NB, level_end - head);
+            // ---- the batch's nodes: first edge and degree, exclusive scan of the degrees
+            int64_t e0 = 0;
+            int deg = 0;
+            if (tid < nb) {
+                const int v = __hip_atomic_load(&order[head + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                e0 = a.rowptr[v];
+                deg = (int)(a.rowptr[v + 1] - e0);
             }
-            run += __popcll(bal);
+            int inc = deg;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += o;
+            }
+            if (lane == 63) wave_tot[wv] = inc;
+            __syncthreads();
+            int pre = 0, TE = 0;
+#pragma unroll
+            for (int i = 0; i < BFS_WAVES; ++i) {
+                if (i < wv) pre += wave_tot[i];
+                TE += wave_tot[i];
+            }
+            eoff[tid] = pre + inc - deg;
+            e0s[tid] = e0;
+            if (tid == 0) eoff[nb] = TE;
+            __syncthreads();
+
+            // ---- the batch's edge stream, BFS_CH positions at a time
+            for (int P = 0; P < TE; P += BFS_CH) {
+                const int p0 = P + BFS_U * tid;
+                int w[BFS_U], q[BFS_U];
+                bool valid[BFS_U], last[BFS_U], cand[BFS_U], hw[BFS_U];
+                int idx = 0;
+                if (p0 < TE) {  // largest idx with eoff[idx] <= p0 (every batch node has at least one edge)
+                    int lo = 0, hi = nb;
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (eoff[mid] <= p0) lo = mid; else hi = mid;
+                    }
+                    idx = lo;
+                }
+#pragma unroll
+                for (int j = 0; j < BFS_U; ++j) {
+                    const int p = p0 + j;
+                    valid[j] = p < TE;
+                    w[j] = 0; q[j] = 0; last[j] = false;
+                    if (valid[j]) {
+                        while (p >= eoff[idx + 1]) ++idx;
+                        q[j] = idx;
+                        w[j] = a.col[e0s[idx] + (p - eoff[idx])];
+                        last[j] = (p + 1 == eoff[idx + 1]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < BFS_U; ++j) cand[j] = valid[j] && !seen(w[j]);
+                __syncthreads();  // every test before any set: a later edge must not hide an earlier one
+#pragma unroll
+                for (int j = 0; j < BFS_U; ++j) {
+                    hw[j] = false;
+                    if (cand[j]) {
+                        const uint32_t bit = 1u << (w[j] & 31);
+                        const uint32_t old = atomicOr(&bm[w[j] >> 5], bit);
+                        if (old & bit) {  // another edge of this chunk reaches the same new node
+                            const int li = atomicAdd(&Lcount, 1);
+                            if (li < BFS_LCAP) { L_w[li] = w[j]; L_pos[li] = p0 + j - P; }
+                        } else {
+                            hw[j] = true;
+                        }
+                    }
+                }
+                __syncthreads();
+                const int nL = Lcount;
+                if (nL <= BFS_LCAP) {
+#pragma unroll
+                    for (int j = 0; j < BFS_U; ++j) {
+                        if (hw[j]) {
+                            int eff = p0 + j - P;
+                            for (int i = 0; i < nL; ++i)
+                                if (L_w[i] == w[j]) eff = min(eff, L_pos[i]);
+                            atomicOr(&winbits[eff >> 5], 1u << (eff & 31));
+                        }
+                    }
+                } else {
+                    // too many in-chunk duplicates for the list: smallest position per node through the key array
+#pragma unroll
+                    for (int j = 0; j < BFS_U; ++j)
+                        if (cand[j]) atomicMin(&gkey[w[j]], (uint32_t)(p0 + j - P));
+                    __syncthreads();
+#pragma unroll
+                    for (int j = 0; j < BFS_U; ++j)
+                        if (cand[j] && atomicMin(&gkey[w[j]], 0xFFFFFFFFu) == (uint32_t)(p0 + j - P))
+                            atomicOr(&winbits[(p0 + j - P) >> 5], 1u << ((p0 + j - P) & 31));
+                    __syncthreads();
+#pragma unroll
+                    for (int j = 0; j < BFS_U; ++j)
+                        if (cand[j]) __hip_atomic_store(&gkey[w[j]], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+                // ---- the marked positions, in stream order, are the next queue entries
+                const uint32_t mine = (winbits[(BFS_U * tid) >> 5] >> ((BFS_U * tid) & 31)) & ((1u << BFS_U) - 1u);
+                const int cnt = __popc(mine);
+                int cinc = cnt;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int o = __shfl_up(cinc, off, 64);
+                    if (lane >= off) cinc += o;
+                }
+                if (lane == 63) wave_cnt[wv] = cinc;
+                __syncthreads();
+                int wpre = 0, total = 0;
+#pragma unroll
+                for (int i = 0; i < BFS_WAVES; ++i) {
+                    if (i < wv) wpre += wave_cnt[i];
+                    total += wave_cnt[i];
+                }
+                int rank = tail + wpre + cinc - cnt;
+#pragma unroll
+                for (int j = 0; j < BFS_U; ++j) {
+                    if ((mine >> j) & 1u) {
+                        if (rank < expect) order[rank] = w[j];
+                        ++rank;
+                    }
+                    if (last[j]) cstart[head + q[j] + 1] = rank;  // children of this queue node end here
+                }
+                tail += total;
+                if (tid < BFS_CH / 32) winbits[tid] = 0u;  // everyone has read its bits (barrier above); next set is two barriers away
+                if (tid == 0) Lcount = 0;
+                if (tail > expect) break;  // more nodes than the component sweep promised: the graph is not the one set (uniform)
+            }
+            if (tail > expect) break;
+            head += nb;
+            __syncthreads();
         }
-        if (!WRITE && lane == 0) {
-            a.qcnt[o + q] = run;
-            a.ccnt[o + v] = run;
+
+        // ---- per-root results: node count check, depth, longest list (1 + most children)
+        int mc = 0;
+        if (tail == expect)
+            for (int i = tid; i < tail; i += BFS_T) mc = max(mc, cstart[i + 1] - cstart[i]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mc = max(mc, __shfl_xor(mc, off, 64));
+        if (lane == 0) atomicMax(&s_max, mc);
+        __syncthreads();
+        if (tid == 0) {
+            if (tail != expect) a.stats[2] = 1;
+            atomicMax(&a.stats[0], depth);
+            atomicMax(&a.stats[1], s_max + 1);
         }
+        __syncthreads();
     }
-}
-
-// one block per root: exclusive scan of qcnt over the frontier [lo, hi) -> qbase, next_hi = hi + total
-__global__ __launch_bounds__(1024) void bfs_scan_frontier_kernel(const BfsArgs a) {
-    __shared__ int64_t wave_tot[16];
-    __shared__ int64_t carry_sh;
-    const int b = blockIdx.x;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int lo = a.lo[b], hi = a.hi[b];
-    const int64_t o = (int64_t)b * a.n_node;
-    if (threadIdx.x == 0) carry_sh = 0;
-    __syncthreads();
-    for (int base = lo; base < hi; base += 1024) {
-        const int q = base + threadIdx.x;
-        const int64_t v = q < hi ? a.qcnt[o + q] : 0;
-        int64_t inc = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int64_t t = __shfl_up(inc, off, 64);
-            if (lane >= off) inc += t;
-        }
-        if (lane == 63) wave_tot[wv] = inc;
-        __syncthreads();
-        int64_t pre = carry_sh, tot = 0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if (i < wv) pre += wave_tot[i];
-            tot += wave_tot[i];
-        }
-        if (q < hi) a.qbase[o + q] = pre + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 0) carry_sh += tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) a.next_hi[b] = hi + (int)carry_sh;
-}
-
-__global__ void bfs_advance_kernel(const BfsArgs a) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= a.n_batch) return;
-    a.lo[b] = a.hi[b];
-    a.hi[b] = a.next_hi[b];
-}
-
-__global__ void bfs_seed_kernel(const BfsArgs a, const int32_t *roots) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= a.n_batch) return;
-    const int64_t o = (int64_t)b * a.n_node;
-    const int r = roots[b];
-    a.father[o + r] = r;
-    a.queue[o] = r;
-    a.lo[b] = 0;
-    a.hi[b] = 1;
-}
-
-// one block per root: tree-CSR offsets = exclusive scan over node ids of (reached ? 1 + #children : 0)
-__global__ __launch_bounds__(1024) void bfs_offsets_kernel(const BfsArgs a, int32_t *t_off /* rows of this batch */, int32_t *max_list) {
-    __shared__ int64_t wave_tot[16];
-    __shared__ int64_t carry_sh;
-    const int b = blockIdx.x;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t o = (int64_t)b * a.n_node;
-    int32_t *off = t_off + (int64_t)b * (a.n_node + 1);
-    if (threadIdx.x == 0) carry_sh = 0;
-    __syncthreads();
-    int mx = 0;
-    for (int base = 0; base < a.n_node; base += 1024) {
-        const int v = base + threadIdx.x;
-        const int64_t len = (v < a.n_node && a.father[o + v] >= 0) ? 1 + a.ccnt[o + v] : 0;
-        mx = max(mx, (int)len);
-        int64_t inc = len;
-#pragma unroll
-        for (int s = 1; s < 64; s <<= 1) {
-            const int64_t t = __shfl_up(inc, s, 64);
-            if (lane >= s) inc += t;
-        }
-        if (lane == 63) wave_tot[wv] = inc;
-        __syncthreads();
-        int64_t pre = carry_sh, tot = 0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if (i < wv) pre += wave_tot[i];
-            tot += wave_tot[i];
-        }
-        if (v < a.n_node) off[v] = (int32_t)(pre + inc - len);
-        __syncthreads();
-        if (threadIdx.x == 0) carry_sh += tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) off[a.n_node] = (int32_t)carry_sh;
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) mx = max(mx, __shfl_xor(mx, s, 64));
-    if (lane == 0) atomicMax(max_list, mx);
-}
-
-// every reached node writes its father slot and drops itself into its father's list
-__global__ void bfs_fill_kernel(const BfsArgs a, const int32_t *t_off, int32_t *t_nbr, const int64_t *t_base /* of this batch */,
-                                const int32_t *roots) {
-    const int b = blockIdx.y;
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= a.n_node) return;
-    const int64_t o = (int64_t)b * a.n_node;
-    const int f = a.father[o + v];
-    if (f < 0) return;
-    const int32_t *off = t_off + (int64_t)b * (a.n_node + 1);
-    int32_t *nb = t_nbr + t_base[b];
-    nb[off[v]] = f;
-    if (v != roots[b]) nb[off[f] + 1 + a.cidx[o + v]] = v;
 }
 
 }  // namespace gg
@@ -210,86 +267,66 @@ extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t 
     GG_CHECK(ctx, n_roots >= 0 && (roots || n_roots == 0), GG_EINVAL, "gg_build_trees_device: bad roots");
     const int n = ctx->n_node;
     for (int r = 0; r < n_roots; ++r) GG_CHECK(ctx, roots[r] >= 0 && roots[r] < n, GG_EINVAL, "gg_build_trees_device: root %d out of range", roots[r]);
+    GG_CHECK(ctx, ctx->g_nnz < (1ll << 31), GG_EINVAL, "gg_build_trees_device: %lld adjacency entries (limit 2^31 - 1)", (long long)ctx->g_nnz);
     GG_HIP(ctx, hipSetDevice(ctx->device));
-    // entries per root = 2 * |component| - 1: component sizes from one host sweep
-    std::vector<int64_t> base(n_roots + 1);
-    host_tree_sizes(n, ctx->h_rowptr.data(), ctx->h_col.data(), roots, n_roots, base.data());
-    int rc = alloc_trees(ctx, roots, n_roots, base.data());
+    int rc = alloc_trees(ctx, roots, n_roots, nullptr, nullptr);  // node counts from the (cached) component sweep
     if (rc != GG_OK) return rc;
     if (n_roots == 0) return GG_OK;
 
-    // batch size: 36 bytes of working set per (root, node), at most ~8 GiB
-    int B = (int)std::min<int64_t>(n_roots, std::max<int64_t>(1, (8ll << 30) / (36ll * n)));
-    if (B > 65535) B = 65535;
-    DevBuf father, cand, queue, qcnt, qbase, ccnt, cidx, misc;
-    const size_t bn = (size_t)B * n;
-    GG_HIP(ctx, father.reserve(4 * bn));
-    GG_HIP(ctx, cand.reserve(8 * bn));
-    GG_HIP(ctx, queue.reserve(4 * bn));
-    GG_HIP(ctx, qcnt.reserve(4 * bn));
-    GG_HIP(ctx, qbase.reserve(8 * bn));
-    GG_HIP(ctx, ccnt.reserve(4 * bn));
-    GG_HIP(ctx, cidx.reserve(4 * bn));
-    GG_HIP(ctx, misc.reserve(sizeof(int32_t) * (3 * (size_t)B + 8)));
+    hipDeviceProp_t prop;
+    GG_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    const int grid = std::min<int>(n_roots, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+    const int bm_words = (n + 31) / 32;
+    // static LDS of the kernel (eoff, e0s, duplicate list, mask, counters) ~ 21.5 KB; the CU has 160 KB
+    hipFuncAttributes fa;
+    GG_HIP(ctx, hipFuncGetAttributes(&fa, (const void *)bfs_order_kernel<true>));
+    const size_t lds_total = 160 * 1024;
+    const bool lds_bm = !getenv("GG_BFS_GLOBAL_BITMAP") && fa.sharedSizeBytes + (size_t)bm_words * 4 <= lds_total;
+
+    DevBuf gkey, gbm, misc;
+    auto cleanup = [&]() { gkey.release(); gbm.release(); misc.release(); };
+    hipError_t e = gkey.reserve(sizeof(uint32_t) * (size_t)grid * n);
+    if (e == hipSuccess && !lds_bm) e = gbm.reserve(sizeof(uint32_t) * (size_t)grid * bm_words);
+    if (e == hipSuccess) e = misc.reserve(sizeof(int32_t) * 8);
+    if (e != hipSuccess) { cleanup(); return fail(ctx, GG_ENOMEM, "gg_build_trees_device: scratch: %s", hipGetErrorString(e)); }
     BfsArgs a{};
     a.n_node = n;
+    a.n_roots = n_roots;
     a.rowptr = ctx->g_rowptr;
     a.col = ctx->g_col;
-    a.father = father.as<int32_t>();
-    a.cand = cand.as<unsigned long long>();
-    a.queue = queue.as<int32_t>();
-    a.qcnt = qcnt.as<int32_t>();
-    a.qbase = qbase.as<int64_t>();
-    a.ccnt = ccnt.as<int32_t>();
-    a.cidx = cidx.as<int32_t>();
-    a.lo = misc.as<int32_t>();
-    a.hi = a.lo + B;
-    a.next_hi = a.hi + B;
-    int32_t *d_maxlist = a.next_hi + B;
-    GG_HIP(ctx, hipMemsetAsync(d_maxlist, 0, sizeof(int32_t), ctx->stream));
-    std::vector<int32_t> h_lo(B), h_hi(B);
-    int max_depth = 0;
-    auto cleanup = [&]() {
-        father.release(); cand.release(); queue.release(); qcnt.release(); qbase.release(); ccnt.release(); cidx.release(); misc.release();
-    };
-    for (int r0 = 0; r0 < n_roots; r0 += B) {
-        const int nb = std::min(B, n_roots - r0);
-        a.n_batch = nb;
-        const size_t cur = (size_t)nb * n;
-        GG_HIP(ctx, hipMemsetAsync(a.father, 0xFF, 4 * cur, ctx->stream));
-        GG_HIP(ctx, hipMemsetAsync(a.cand, 0xFF, 8 * cur, ctx->stream));
-        GG_HIP(ctx, hipMemsetAsync(a.ccnt, 0, 4 * cur, ctx->stream));
-        hipLaunchKernelGGL(bfs_seed_kernel, dim3(cdiv(nb, 256)), dim3(256), 0, ctx->stream, a, ctx->t_root + r0);
-        int64_t max_front = 1;
-        for (int depth = 0;; ++depth) {
-            int gx = (int)std::min<int64_t>((max_front + 3) / 4, 4096);
-            if (gx < 1) gx = 1;
-            hipLaunchKernelGGL(bfs_claim_kernel, dim3(gx, nb), dim3(256), 0, ctx->stream, a);
-            hipLaunchKernelGGL(bfs_children_kernel<0>, dim3(gx, nb), dim3(256), 0, ctx->stream, a);
-            hipLaunchKernelGGL(bfs_scan_frontier_kernel, dim3(nb), dim3(1024), 0, ctx->stream, a);
-            hipLaunchKernelGGL(bfs_children_kernel<1>, dim3(gx, nb), dim3(256), 0, ctx->stream, a);
-            hipLaunchKernelGGL(bfs_advance_kernel, dim3(cdiv(nb, 256)), dim3(256), 0, ctx->stream, a);
-            GG_HIP(ctx, hipMemcpyAsync(h_lo.data(), a.lo, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, ctx->stream));
-            GG_HIP(ctx, hipMemcpyAsync(h_hi.data(), a.hi, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, ctx->stream));
-            hipError_t e = hipStreamSynchronize(ctx->stream);
-            if (e != hipSuccess) { cleanup(); return fail(ctx, GG_EHIP, "gg_build_trees_device: %s", hipGetErrorString(e)); }
-            max_front = 0;
-            for (int b = 0; b < nb; ++b) max_front = std::max<int64_t>(max_front, h_hi[b] - h_lo[b]);
-            if (max_front == 0) break;
-            max_depth = std::max(max_depth, depth + 1);
-        }
-        int32_t *off = ctx->t_off + (size_t)r0 * (n + 1);
-        hipLaunchKernelGGL(bfs_offsets_kernel, dim3(nb), dim3(1024), 0, ctx->stream, a, off, d_maxlist);
-        hipLaunchKernelGGL(bfs_fill_kernel, dim3(cdiv(n, 256), nb), dim3(256), 0, ctx->stream, a, off, ctx->t_nbr, ctx->t_base + r0,
-                           ctx->t_root + r0);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) { cleanup(); return fail(ctx, GG_EHIP, "gg_build_trees_device: %s", hipGetErrorString(e)); }
+    a.roots = ctx->t_root;
+    a.base = ctx->t_base;
+    a.order = ctx->t_order;
+    a.cstart = ctx->t_cstart;
+    a.ticket = misc.as<unsigned int>();
+    a.stats = misc.as<int32_t>() + 1;
+    a.gbitmap = gbm.as<uint32_t>();
+    a.gkey = gkey.as<uint32_t>();
+    a.bm_words = bm_words;
+    (void)hipMemsetAsync(misc.p, 0, sizeof(int32_t) * 8, ctx->stream);
+    (void)hipMemsetAsync(gkey.p, 0xFF, sizeof(uint32_t) * (size_t)grid * n, ctx->stream);
+    (void)hipEventRecord(ctx->ev0, ctx->stream);
+    if (lds_bm) {
+        const size_t dyn = (size_t)bm_words * 4;
+        e = hipFuncSetAttribute((const void *)bfs_order_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        if (e != hipSuccess) { cleanup(); return fail(ctx, GG_EHIP, "gg_build_trees_device: %zu bytes of LDS: %s", dyn, hipGetErrorString(e)); }
+        hipLaunchKernelGGL(bfs_order_kernel<true>, dim3(grid), dim3(BFS_T), dyn, ctx->stream, a);
+    } else {
+        hipLaunchKernelGGL(bfs_order_kernel<false>, dim3(grid), dim3(BFS_T), 0, ctx->stream, a);
     }
-    int32_t ml = 0;
-    hipError_t e = hipMemcpy(&ml, d_maxlist, sizeof(int32_t), hipMemcpyDeviceToHost);
+    (void)hipEventRecord(ctx->ev1, ctx->stream);
+    int32_t stats[3] = {0, 0, 0};
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(stats, a.stats, sizeof(stats), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    float ms = 0.f;
+    if (e == hipSuccess) (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     cleanup();
     if (e != hipSuccess) return fail(ctx, GG_EHIP, "gg_build_trees_device: %s", hipGetErrorString(e));
-    ctx->tree_max_depth = max_depth;
-    ctx->tree_max_list = ml;
+    GG_CHECK(ctx, stats[2] == 0, GG_EINVAL, "gg_build_trees_device: a BFS reached a different number of nodes than the component sweep of the graph");
+    ctx->tree_max_depth = stats[0];
+    ctx->tree_max_list = stats[1];
+    ctx->ctr.bfs_kernel_ms += ms;
+    ctx->ctr.bfs_trees += n_roots;
     return GG_OK;
 }

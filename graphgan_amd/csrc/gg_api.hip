@@ -8,6 +8,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <thread>
 
 #include "gg_internal.h"
@@ -27,37 +28,51 @@ int fail(gg_ctx *ctx, int code, const char *fmt, ...) {
     return code;
 }
 
-int64_t host_tree_sizes(int32_t n, const int64_t *rowptr, const int32_t *col, const int32_t *roots, int32_t n_roots,
-                        int64_t *nbr_base);
-void host_fill_trees(int32_t n, const int64_t *rowptr, const int32_t *col, const int32_t *roots, int32_t r0, int32_t r1,
-                     const int64_t *nbr_base, int32_t *off, int32_t off_row0, int32_t *nbr, int64_t nbr_origin,
-                     int32_t n_threads, int32_t *max_depth_out, int32_t *max_list_out);
-
 static void free_trees(gg_ctx *ctx) {
-    if (ctx->t_root) (void)hipFree(ctx->t_root);
-    if (ctx->t_off) (void)hipFree(ctx->t_off);
-    if (ctx->t_nbr) (void)hipFree(ctx->t_nbr);
-    if (ctx->t_base) (void)hipFree(ctx->t_base);
-    ctx->t_root = ctx->t_off = ctx->t_nbr = nullptr;
-    ctx->t_base = nullptr;
+    void *ps[] = {ctx->t_root, ctx->t_order, ctx->t_cstart, ctx->t_base, ctx->t_q3, ctx->t_q3off};
+    for (void *p : ps)
+        if (p) (void)hipFree(p);
+    ctx->t_root = ctx->t_order = ctx->t_cstart = nullptr;
+    ctx->t_base = ctx->t_q3off = nullptr;
+    ctx->t_q3 = nullptr;
     ctx->n_tree_roots = 0;
-    ctx->tree_entries = 0;
+    ctx->tree_nodes = ctx->tree_entries = 0;
     ctx->tree_max_depth = ctx->tree_max_list = 0;
     ctx->h_troot.clear();
+    ctx->h_tbase.clear();
+    ctx->h_q3off.clear();
 }
 
-int alloc_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int64_t *nbr_base) {
+// Device arrays for the BFS-order trees of `roots`: node counts C_r (NULL: component sizes from a cached host sweep of
+// the graph), Q3 bit rows sized by the roots' child counts (NULL: their degrees, an upper bound), zero-initialised.
+int alloc_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int64_t *node_counts, const int64_t *root_children) {
+    (void)hipDeviceSynchronize();  // walks of calls that returned early may still read the old trees
     free_trees(ctx);
-    const int64_t entries = nbr_base[n_roots];
-    GG_HIP(ctx, hipMalloc((void **)&ctx->t_root, sizeof(int32_t) * std::max(n_roots, 1)));
-    GG_HIP(ctx, hipMalloc((void **)&ctx->t_off, sizeof(int32_t) * (size_t)std::max(n_roots, 1) * (ctx->n_node + 1)));
-    GG_HIP(ctx, hipMalloc((void **)&ctx->t_nbr, sizeof(int32_t) * (size_t)std::max<int64_t>(entries, 1)));
+    const int n = ctx->n_node;
+    if (!node_counts && ctx->h_comp_size.empty()) component_sizes(n, ctx->h_rowptr.data(), ctx->h_col.data(), ctx->h_comp_size);
+    ctx->h_tbase.assign(n_roots + 1, 0);
+    ctx->h_q3off.assign(n_roots + 1, 0);
+    for (int r = 0; r < n_roots; ++r) {
+        ctx->h_tbase[r + 1] = ctx->h_tbase[r] + (node_counts ? node_counts[r] : ctx->h_comp_size[roots[r]]);
+        const int64_t deg = root_children ? root_children[r] : ctx->h_rowptr[roots[r] + 1] - ctx->h_rowptr[roots[r]];
+        ctx->h_q3off[r + 1] = ctx->h_q3off[r] + (deg + 31) / 32;
+    }
+    const int64_t nodes = ctx->h_tbase[n_roots], q3w = ctx->h_q3off[n_roots];
+    const int nr = std::max(n_roots, 1);
+    GG_HIP(ctx, hipMalloc((void **)&ctx->t_root, sizeof(int32_t) * nr));
+    GG_HIP(ctx, hipMalloc((void **)&ctx->t_order, sizeof(int32_t) * (size_t)std::max<int64_t>(nodes, 1)));
+    GG_HIP(ctx, hipMalloc((void **)&ctx->t_cstart, sizeof(int32_t) * (size_t)(nodes + nr)));
     GG_HIP(ctx, hipMalloc((void **)&ctx->t_base, sizeof(int64_t) * (n_roots + 1)));
+    GG_HIP(ctx, hipMalloc((void **)&ctx->t_q3, sizeof(uint32_t) * (size_t)std::max<int64_t>(q3w, 1)));
+    GG_HIP(ctx, hipMalloc((void **)&ctx->t_q3off, sizeof(int64_t) * (n_roots + 1)));
     GG_HIP(ctx, hipMemcpyAsync(ctx->t_root, roots, sizeof(int32_t) * n_roots, hipMemcpyHostToDevice, ctx->stream));
-    GG_HIP(ctx, hipMemcpyAsync(ctx->t_base, nbr_base, sizeof(int64_t) * (n_roots + 1), hipMemcpyHostToDevice, ctx->stream));
+    GG_HIP(ctx, hipMemcpyAsync(ctx->t_base, ctx->h_tbase.data(), sizeof(int64_t) * (n_roots + 1), hipMemcpyHostToDevice, ctx->stream));
+    GG_HIP(ctx, hipMemcpyAsync(ctx->t_q3off, ctx->h_q3off.data(), sizeof(int64_t) * (n_roots + 1), hipMemcpyHostToDevice, ctx->stream));
+    GG_HIP(ctx, hipMemsetAsync(ctx->t_q3, 0, sizeof(uint32_t) * (size_t)std::max<int64_t>(q3w, 1), ctx->stream));
     GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->n_tree_roots = n_roots;
-    ctx->tree_entries = entries;
+    ctx->tree_nodes = nodes;
+    ctx->tree_entries = 2 * nodes - n_roots;
     ctx->h_troot.assign(roots, roots + n_roots);
     return GG_OK;
 }
@@ -326,7 +341,7 @@ int gg_destroy(gg_ctx *ctx) {
                       &ctx->d_ptr, &ctx->g_node1, &ctx->g_node2, &ctx->g_reward, &ctx->g_cnt, &ctx->g_ptr, &ctx->scan_tmp,
                       &ctx->step_u, &ctx->step_v, &ctx->step_x, &ctx->touched_ptr, &ctx->x_cnt, &ctx->x_send_ids, &ctx->x_send_rows,
                       &ctx->x_recv_ids, &ctx->x_recv_rows, &ctx->x_nglob, &ctx->st_item, &ctx->st_cur, &ctx->st_prev, &ctx->st_len,
-                      &ctx->st_alive, &ctx->lv_beg, &ctx->lv_k, &ctx->lv_chunks, &ctx->lv_coff, &ctx->lv_scores, &ctx->lv_chunk_owner, &ctx->lv_prefix, &ctx->lv_big};
+                      &ctx->st_alive, &ctx->st_rank, &ctx->lv_beg, &ctx->lv_k, &ctx->lv_chunks, &ctx->lv_coff, &ctx->lv_scores, &ctx->lv_chunk_owner, &ctx->lv_prefix, &ctx->lv_big};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : ctx->lv_ev)
         if (e) (void)hipEventDestroy(e);
@@ -364,6 +379,7 @@ int gg_set_graph_csr(gg_ctx *ctx, const int64_t *rowptr, const int32_t *col) {
     ctx->g_nnz = nnz;
     ctx->h_rowptr.assign(rowptr, rowptr + n + 1);
     ctx->h_col.assign(col, col + nnz);
+    ctx->h_comp_size.clear();
     return GG_OK;
 }
 
@@ -375,24 +391,41 @@ int gg_build_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, int32_t n
     for (int r = 0; r < n_roots; ++r) GG_CHECK(ctx, roots[r] >= 0 && roots[r] < n, GG_EINVAL, "gg_build_trees: root %d out of range", roots[r]);
     GG_HIP(ctx, hipSetDevice(ctx->device));
     if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
-    std::vector<int64_t> base(n_roots + 1);
-    host_tree_sizes(n, ctx->h_rowptr.data(), ctx->h_col.data(), roots, n_roots, base.data());
-    int rc = alloc_trees(ctx, roots, n_roots, base.data());
+    int rc = alloc_trees(ctx, roots, n_roots, nullptr, nullptr);
     if (rc != GG_OK) return rc;
-    // batches of roots bounded by ~2 GiB of host staging
-    const int64_t budget = 512ll << 20;  // int32 entries (2 GiB)
+    // batches of roots bounded by ~2 GiB of host staging; roots of a batch are striped over threads
+    const int64_t budget = 256ll << 20;  // (order + cstart) entries
+    const std::vector<int64_t> &base = ctx->h_tbase;
     int32_t md = 0, ml = 0;
-    std::vector<int32_t> off_h, nbr_h;
+    std::vector<int32_t> order_h, cstart_h;
     for (int r0 = 0; r0 < n_roots;) {
         int r1 = r0 + 1;
-        while (r1 < n_roots && (base[r1 + 1] - base[r0]) + (int64_t)(r1 + 1 - r0) * (n + 1) <= budget) ++r1;
-        off_h.resize((size_t)(r1 - r0) * (n + 1));
-        nbr_h.resize((size_t)(base[r1] - base[r0]));
-        host_fill_trees(n, ctx->h_rowptr.data(), ctx->h_col.data(), roots, r0, r1, base.data(), off_h.data(), r0, nbr_h.data(),
-                        base[r0], n_threads, &md, &ml);
-        GG_HIP(ctx, hipMemcpy(ctx->t_off + (size_t)r0 * (n + 1), off_h.data(), sizeof(int32_t) * off_h.size(), hipMemcpyHostToDevice));
-        if (!nbr_h.empty())
-            GG_HIP(ctx, hipMemcpy(ctx->t_nbr + base[r0], nbr_h.data(), sizeof(int32_t) * nbr_h.size(), hipMemcpyHostToDevice));
+        while (r1 < n_roots && base[r1 + 1] - base[r0] <= budget) ++r1;
+        order_h.resize((size_t)(base[r1] - base[r0]));
+        cstart_h.resize((size_t)(base[r1] - base[r0]) + (r1 - r0));
+        const int nt = std::max(1, std::min(n_threads, r1 - r0));
+        std::atomic<int> next(r0);
+        std::vector<int32_t> tmd(nt, 0), tml(nt, 0);
+        auto work = [&](int tid) {
+            std::vector<uint32_t> stamp(n, 0u);
+            uint32_t epoch = 0;
+            for (;;) {
+                const int r = next.fetch_add(1);
+                if (r >= r1) break;
+                int32_t depth = 0, mc = 0;
+                (void)host_bfs_order(ctx->h_rowptr.data(), ctx->h_col.data(), roots[r], order_h.data() + (base[r] - base[r0]),
+                                     cstart_h.data() + (base[r] - base[r0]) + (r - r0), stamp, epoch, &depth, &mc);
+                tmd[tid] = std::max(tmd[tid], depth);
+                tml[tid] = std::max(tml[tid], mc + 1);
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto &t : th) t.join();
+        for (int t = 0; t < nt; ++t) { md = std::max(md, tmd[t]); ml = std::max(ml, tml[t]); }
+        if (!order_h.empty()) GG_HIP(ctx, hipMemcpy(ctx->t_order + base[r0], order_h.data(), sizeof(int32_t) * order_h.size(), hipMemcpyHostToDevice));
+        GG_HIP(ctx, hipMemcpy(ctx->t_cstart + base[r0] + r0, cstart_h.data(), sizeof(int32_t) * cstart_h.size(), hipMemcpyHostToDevice));
         r0 = r1;
     }
     ctx->tree_max_depth = md;
@@ -400,28 +433,46 @@ int gg_build_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, int32_t n
     return GG_OK;
 }
 
+// Upload trees given in the reference's shape (per node the list [father, child...]): converted to BFS-order form.
 int gg_set_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int32_t *off, const int32_t *nbr,
                  const int64_t *nbr_base, int32_t max_depth) {
     if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
     GG_CHECK(ctx, n_roots >= 0 && roots && off && nbr_base && (nbr || nbr_base[n_roots] == 0), GG_EINVAL, "gg_set_trees: bad argument");
     const int n = ctx->n_node;
     GG_HIP(ctx, hipSetDevice(ctx->device));
-    int32_t ml = 0;
+    std::vector<int64_t> counts(n_roots), kids(n_roots);
     for (int r = 0; r < n_roots; ++r) {
         GG_CHECK(ctx, roots[r] >= 0 && roots[r] < n, GG_EINVAL, "gg_set_trees: root out of range");
         const int32_t *o = off + (size_t)r * (n + 1);
-        GG_CHECK(ctx, o[0] == 0 && o[n] == nbr_base[r + 1] - nbr_base[r], GG_EINVAL, "gg_set_trees: offsets of slot %d inconsistent", r);
-        for (int v = 0; v < n; ++v) {
-            GG_CHECK(ctx, o[v + 1] >= o[v], GG_EINVAL, "gg_set_trees: offsets not monotone");
-            ml = std::max(ml, o[v + 1] - o[v]);
-        }
+        GG_CHECK(ctx, o[0] == 0 && o[n] == nbr_base[r + 1] - nbr_base[r] && o[n] >= 1 && (o[n] & 1), GG_EINVAL,
+                 "gg_set_trees: offsets of slot %d inconsistent (a tree over C nodes has 2C - 1 entries)", r);
+        for (int v = 0; v < n; ++v) GG_CHECK(ctx, o[v + 1] >= o[v], GG_EINVAL, "gg_set_trees: offsets not monotone");
+        counts[r] = (o[n] + 1) / 2;
+        kids[r] = o[roots[r] + 1] - o[roots[r]];
     }
-    int rc = alloc_trees(ctx, roots, n_roots, nbr_base);
+    int rc = alloc_trees(ctx, roots, n_roots, counts.data(), kids.data());
     if (rc != GG_OK) return rc;
-    GG_HIP(ctx, hipMemcpy(ctx->t_off, off, sizeof(int32_t) * (size_t)n_roots * (n + 1), hipMemcpyHostToDevice));
-    if (nbr_base[n_roots])
-        GG_HIP(ctx, hipMemcpy(ctx->t_nbr, nbr, sizeof(int32_t) * (size_t)nbr_base[n_roots], hipMemcpyHostToDevice));
-    ctx->tree_max_depth = max_depth > 0 ? max_depth : n;
+    const std::vector<int64_t> &base = ctx->h_tbase;
+    std::vector<int32_t> order_h((size_t)base[n_roots]), cstart_h((size_t)base[n_roots] + n_roots);
+    std::vector<uint32_t> q3_h((size_t)std::max<int64_t>(ctx->h_q3off[n_roots], 1), 0u);
+    int32_t md = 0, ml = 0;
+    for (int r = 0; r < n_roots; ++r) {
+        const int64_t C_expect = base[r + 1] - base[r];
+        GG_CHECK(ctx, nbr_base[r + 1] - nbr_base[r] == 2 * C_expect - 1, GG_EINVAL,
+                 "gg_set_trees: slot %d has %lld entries, the component of root %d needs %lld", r, (long long)(nbr_base[r + 1] - nbr_base[r]),
+                 roots[r], (long long)(2 * C_expect - 1));
+        int32_t depth = 0, mc = 0;
+        const int32_t C = lists_to_order(n, roots[r], off + (size_t)r * (n + 1), nbr + nbr_base[r], order_h.data() + base[r],
+                                         cstart_h.data() + base[r] + r, q3_h.data() + ctx->h_q3off[r],
+                                         (int32_t)(ctx->h_q3off[r + 1] - ctx->h_q3off[r]), &depth, &mc);
+        GG_CHECK(ctx, C == C_expect, GG_EINVAL, "gg_set_trees: the lists of slot %d are not a BFS tree of root %d", r, roots[r]);
+        md = std::max(md, depth);
+        ml = std::max(ml, mc + 1);
+    }
+    if (!order_h.empty()) GG_HIP(ctx, hipMemcpy(ctx->t_order, order_h.data(), sizeof(int32_t) * order_h.size(), hipMemcpyHostToDevice));
+    if (!cstart_h.empty()) GG_HIP(ctx, hipMemcpy(ctx->t_cstart, cstart_h.data(), sizeof(int32_t) * cstart_h.size(), hipMemcpyHostToDevice));
+    if (ctx->h_q3off[n_roots]) GG_HIP(ctx, hipMemcpy(ctx->t_q3, q3_h.data(), sizeof(uint32_t) * (size_t)ctx->h_q3off[n_roots], hipMemcpyHostToDevice));
+    ctx->tree_max_depth = max_depth > 0 ? std::max(max_depth, md) : md;
     ctx->tree_max_list = ml;
     return GG_OK;
 }
@@ -434,14 +485,37 @@ int gg_tree_info(const gg_ctx *ctx, int32_t *n_roots, int64_t *n_entries, int32_
     return GG_OK;
 }
 
+// Download the resident trees in the reference's shape, including the D-mode mutations (removed father entries = -1).
 int gg_get_trees(gg_ctx *ctx, int32_t *off, int32_t *nbr, int64_t *nbr_base) {
     if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
     GG_CHECK(ctx, ctx->n_tree_roots > 0, GG_EINVAL, "gg_get_trees: no trees loaded");
     GG_HIP(ctx, hipSetDevice(ctx->device));
-    GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (off) GG_HIP(ctx, hipMemcpy(off, ctx->t_off, sizeof(int32_t) * (size_t)ctx->n_tree_roots * (ctx->n_node + 1), hipMemcpyDeviceToHost));
-    if (nbr && ctx->tree_entries) GG_HIP(ctx, hipMemcpy(nbr, ctx->t_nbr, sizeof(int32_t) * (size_t)ctx->tree_entries, hipMemcpyDeviceToHost));
-    if (nbr_base) GG_HIP(ctx, hipMemcpy(nbr_base, ctx->t_base, sizeof(int64_t) * (ctx->n_tree_roots + 1), hipMemcpyDeviceToHost));
+    GG_HIP(ctx, hipDeviceSynchronize());
+    const int n = ctx->n_node, R = ctx->n_tree_roots;
+    const std::vector<int64_t> &base = ctx->h_tbase;
+    if (nbr_base)
+        for (int r = 0; r <= R; ++r) nbr_base[r] = 2 * base[r] - r;
+    if (!off && !nbr) return GG_OK;
+    GG_CHECK(ctx, off && nbr, GG_EINVAL, "gg_get_trees: off and nbr go together");
+    std::vector<int32_t> order_h((size_t)base[R]), cstart_h((size_t)base[R] + R);
+    std::vector<uint32_t> q3_h((size_t)std::max<int64_t>(ctx->h_q3off[R], 1), 0u);
+    if (!order_h.empty()) GG_HIP(ctx, hipMemcpy(order_h.data(), ctx->t_order, sizeof(int32_t) * order_h.size(), hipMemcpyDeviceToHost));
+    GG_HIP(ctx, hipMemcpy(cstart_h.data(), ctx->t_cstart, sizeof(int32_t) * cstart_h.size(), hipMemcpyDeviceToHost));
+    if (ctx->h_q3off[R]) GG_HIP(ctx, hipMemcpy(q3_h.data(), ctx->t_q3, sizeof(uint32_t) * (size_t)ctx->h_q3off[R], hipMemcpyDeviceToHost));
+    const int nt = (int)std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), (unsigned)R));
+    std::atomic<int> next(0);
+    auto work = [&]() {
+        for (;;) {
+            const int r = next.fetch_add(1);
+            if (r >= R) break;
+            order_to_lists(n, (int32_t)(base[r + 1] - base[r]), order_h.data() + base[r], cstart_h.data() + base[r] + r,
+                           q3_h.data() + ctx->h_q3off[r], off + (size_t)r * (n + 1), nbr + (2 * base[r] - r));
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
     return GG_OK;
 }
 

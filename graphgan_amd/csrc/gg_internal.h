@@ -82,19 +82,33 @@ struct gg_ctx {
     std::vector<int64_t> h_rowptr;  // host copies (tree builder, degrees)
     std::vector<int32_t> h_col;
 
-    // tree CSR for n_tree_roots root slots
+    // BFS trees of n_tree_roots root slots in BFS-ORDER form.  For slot r with C_r reached nodes:
+    //   t_order [t_base[r] + i]       node id of BFS pop rank i (rank 0 = the root): the reference's queue
+    //   t_cstart[t_base[r] + r + i]   first child rank of rank i (i = 0 .. C_r; cstart[0] = 1, cstart[C_r] = C_r):
+    //                                 the children of rank i are the CONSECUTIVE ranks [cstart[i], cstart[i+1]) -- a FIFO
+    //                                 BFS appends the children of one node next to each other, in adjacency order
+    // so tree[v] of the reference = [father] ++ order[cstart[i] .. cstart[i+1]) and a walk (which only ever moves DOWN
+    // until its terminating back-step) needs no father array: the father of its current node is its previous node.
+    // 8 B per (root, node) instead of the 12 B of a node-id-indexed offsets array + lists, written front to back by the BFS.
+    // Q3 (graph_gan.py:258-259: D-mode removes the father entry of visited depth-1 children for good): one bit per
+    // (root, child of the root), t_q3[t_q3off[r] * 32 + (rank - 1)].
     int32_t n_tree_roots = 0, tree_max_depth = 0, tree_max_list = 0;
-    int64_t tree_entries = 0;
+    int64_t tree_nodes = 0;      // sum of C_r
+    int64_t tree_entries = 0;    // entries of the reference-shaped lists: sum of 2 C_r - 1 (gg_tree_info / gg_get_trees)
     int32_t *t_root = nullptr;   // [R] root node id of each slot
-    int32_t *t_off = nullptr;    // [R * (n_node+1)]
-    int32_t *t_nbr = nullptr;    // [entries]
+    int32_t *t_order = nullptr;  // [tree_nodes]
+    int32_t *t_cstart = nullptr; // [tree_nodes + R]
     int64_t *t_base = nullptr;   // [R+1]
+    uint32_t *t_q3 = nullptr;    // [t_q3off[R]] words
+    int64_t *t_q3off = nullptr;  // [R+1] word offsets (ceil(deg(root) / 32) words per slot: children of the root <= its degree)
     std::vector<int32_t> h_troot;
+    std::vector<int64_t> h_tbase, h_q3off;
+    std::vector<int32_t> h_comp_size;  // |component| of every node (one host sweep per graph, cached): C_r before any BFS runs
 
     // walk outputs (device resident)
     gg::DevBuf w_slots, w_ptr, w_samples, w_paths, w_len, w_status, w_first, w_abort, w_scratch;
     // level-synchronous front end of the walk sampler (walk_sample.hip): per-walk state + per-level tasks
-    gg::DevBuf st_cur, st_prev, st_len, st_alive, st_item, lv_beg, lv_k, lv_chunks, lv_coff, lv_scores, lv_chunk_owner, lv_prefix, lv_big;
+    gg::DevBuf st_cur, st_prev, st_len, st_alive, st_rank, st_item, lv_beg, lv_k, lv_chunks, lv_coff, lv_scores, lv_chunk_owner, lv_prefix, lv_big;
     int32_t lv_levels_learned = 0;     // hops earlier (sized) launches needed until every walk had finished
     int64_t lv_cap_chunks = 0;         // learned capacity (chunks per level) for the sync-free launches
     bool walk_force_sized = false;     // retry path after a speculative overflow
@@ -163,10 +177,17 @@ int fail(gg_ctx *ctx, int code, const char *fmt, ...);
 // exclusive scan of n int32 counts into n+1 int64 offsets (prepare.hip)
 int device_exclusive_scan(gg_ctx *ctx, const int32_t *cnt, int64_t *ptr, int64_t n);
 
-// trees
-int alloc_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int64_t *nbr_base);
-int64_t host_tree_sizes(int32_t n, const int64_t *rowptr, const int32_t *col, const int32_t *roots, int32_t n_roots,
-                        int64_t *nbr_base);
+// trees (gg_api.hip / tree_builder.cpp)
+int alloc_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int64_t *node_counts, const int64_t *root_children);
+void component_sizes(int n, const int64_t *rowptr, const int32_t *col, std::vector<int32_t> &comp_size);
+// FIFO BFS of one root into BFS-order form; returns C (order[0..C), cstart[0..C]); scratch: n-entry stamp array + epoch
+int32_t host_bfs_order(const int64_t *rowptr, const int32_t *col, int32_t root, int32_t *order, int32_t *cstart,
+                       std::vector<uint32_t> &stamp, uint32_t &epoch, int32_t *depth_out, int32_t *max_children_out);
+// BFS-order form (+ Q3 bits, may be NULL) of one root -> the reference-shaped lists: off[n+1], nbr[2C-1]
+void order_to_lists(int32_t n, int32_t C, const int32_t *order, const int32_t *cstart, const uint32_t *q3, int32_t *off, int32_t *nbr);
+// reference-shaped lists of one root -> BFS-order form; returns C or -1 if the lists are not a tree of `root`
+int32_t lists_to_order(int32_t n, int32_t root, const int32_t *off, const int32_t *nbr, int32_t *order, int32_t *cstart,
+                       uint32_t *q3, int32_t q3_words, int32_t *depth_out, int32_t *max_children_out);
 
 // launchers
 int walk_launch_async(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, int32_t uniform_walks, int32_t n_slots,

@@ -36,9 +36,11 @@ struct WalkArgs {
     const float *bias;
     int32_t n_node, ld, nchunk;  // nchunk = ld / 4 float4 chunks per row
     const int32_t *t_root;
-    const int32_t *t_off;
-    int32_t *t_nbr;
+    const int32_t *t_order;   // BFS-order trees (gg_internal.h): node id of rank i of slot r at t_base[r] + i
+    const int32_t *t_cstart;  // first child rank of rank i at t_base[r] + r + i; children = consecutive ranks
     const int64_t *t_base;
+    uint32_t *t_q3;           // removed-father bits of the roots' children (quirk Q3), row r at word t_q3off[r]
+    const int64_t *t_q3off;
     const int32_t *slots;
     const int64_t *walk_ptr;  // [n_slots + 1]
     int32_t n_slots;
@@ -49,22 +51,23 @@ struct WalkArgs {
     int32_t *samples, *paths, *path_len;
     int32_t stride;
     int32_t *status;       // [n_slots]
-    int32_t *first_child;  // [total_walks]  D-mode: depth-1 child whose father entry this walk removes
+    int32_t *first_child;  // [total_walks]  D-mode: rank (>= 1) of the depth-1 child whose father entry this walk removes
     int32_t *abort_walk;   // [n_slots]      D-mode: smallest walk index that hit a leaf child
     float *scratch;        // per-wave score rows for k > SCORE_CAP (finisher)
     int64_t scratch_stride;
     unsigned long long *ctr;  // [0] hops [1] nbr_reads [2] alive walks [3] error flag [4] ticket [5] rows scored
     // walk state carried between levels / into the finisher
     int32_t *st_cur, *st_prev, *st_len, *st_alive;
+    int32_t *st_rank;      // BFS rank of st_cur in its root's tree
     int4 *st_const;        // {item, slot, root, walk index inside the root}: fixed per walk, ONE load per hop
     int32_t level;         // hop index handled by this launch (level kernels) / first hop (finisher)
     // per-level tasks
-    int64_t *lv_beg;       // absolute offset of the candidate list in t_nbr
-    int32_t *lv_k;         // candidates
+    int64_t *lv_beg;       // absolute index in t_order of the first CHILD candidate
+    int32_t *lv_k;         // candidates (father entry included); bit 31: candidate 0 is the father (= the walk's previous node)
     int32_t *lv_chunks;    // 16-candidate chunks this walk owns (0 for non-owners / dead walks)
     int64_t *lv_coff;      // first chunk of the score / prefix region this walk samples from (its owner's)
     float *lv_scores;      // [CHUNK * total chunks]
-    int4 *lv_chunk_desc;   // [total chunks] {cur node, rows in this chunk, list offset lo, hi} of chunk c
+    int4 *lv_chunk_desc;   // [total chunks] {cur node, rows | flags | offset bits 32..47, offset bits 0..31, father id} of chunk c
     uint64_t *lv_prefix;   // [CHUNK * total chunks] inclusive prefix sums of the fixed-point weights
     int32_t *lv_big;       // [total_walks] owner walks with k > BIG_TASK, appended per level
 };
@@ -96,10 +99,11 @@ __device__ __forceinline__ int find_item(const int64_t *walk_ptr, int n_slots, i
 // Scores of up to 64 candidates ids[0..nblock) against the row of `cur` (spec S1), handed to
 // store(j, score).  The whole wave participates; group q = lane >> 4 handles candidates q, q+4, ...
 template <int NCH, class Store>
-__device__ __forceinline__ float score_block(const WalkArgs &a, const float4 (&gc)[NCH], const int32_t *ids, int nblock,
+__device__ __forceinline__ float score_block(const WalkArgs &a, const float4 (&gc)[NCH], const int32_t *ids, int first_id, int nblock,
                                              int lane, Store store) {
     const int t = lane & 15, q = lane >> 4;
-    const int myid = (lane < nblock) ? ids[lane] : 0;
+    // first_id >= 0: candidate 0 of this block is the father entry (not stored in the children range ids[1..])
+    const int myid = (lane < nblock) ? ((lane == 0 && first_id >= 0) ? first_id : ids[lane]) : 0;
     float mx = -INFINITY;
     for (int s = 0; s < nblock; s += 16) {
         float4 y[4][NCH];
@@ -211,6 +215,17 @@ constexpr int CTR_READS_V = 328; // (same-address atomics serialise at ~12 ns ea
 constexpr int CTR_WORDS = 392;
 constexpr int MAX_LEVELS = 64;
 
+// Descriptor of chunk i of a k-candidate distribution: {cur, rows | flags | offset bits 32..47, offset bits 0..31, father id}.
+// Candidate c of the distribution is the father (c == 0, only if hf) or the child order[beg_abs + c - hf]; `offset` is the
+// t_order index of the chunk's candidate 0 (for the first chunk of a list with a father entry that is ONE BEFORE the first
+// child -- never dereferenced: lane 0 takes the father id from the descriptor instead).
+constexpr int DESC_HAS_FATHER = 0x200;
+__device__ __forceinline__ int4 chunk_desc(int cur, int k, int hf, int father, int64_t beg_abs, int i) {
+    const int64_t o = beg_abs + (int64_t)i * CHUNK - hf;
+    const int flags = (k <= CHUNK ? SINGLE_CHUNK : 0) | ((hf && i == 0) ? DESC_HAS_FATHER : 0);
+    return make_int4(cur, min(CHUNK, k - i * CHUNK) | flags | (int)((o >> 32) << 16), (int)(o & 0xffffffffll), father);
+}
+
 // One thread per walk (a wave = 64 consecutive walks), fused per hop boundary:
 //   do_sample: finish hop (level-1) -- Philox uniform, threshold, binary search in the owner's
 //              prefix sums (first j with C_j > floor(m W / 2^53), spec S4/S5), path append,
@@ -234,12 +249,12 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     const int lane = threadIdx.x & 63;
     const bool in_range = w < a.total_walks;
     bool alive = false, sampled = false;
-    int item = 0, cur = -1, k = 0;
+    int item = 0, cur = -1, k = 0, hf = 0, father = -1;
     unsigned long long my_k = 0;
     int64_t beg_abs = 0;
     // finished walks (the majority at the deeper hops) leave after ONE load
     if (in_range && (!do_sample || a.st_alive[w] != 0)) {
-        int slot, root, j;
+        int slot, root, j, rank = 0;
         if (!do_sample) {
             item = find_item(a.walk_ptr, a.n_slots, w);
             slot = a.slots[item];
@@ -252,6 +267,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
             const int4 sc = a.st_const[w];
             item = sc.x; slot = sc.y; root = sc.z; j = sc.w;
         }
+        const int64_t tbase = a.t_base[slot];
         if (!do_sample) {  // level 0: start the walk
             alive = true;
             cur = root;
@@ -263,7 +279,8 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
             alive = true;
             {
                 sampled = true;
-                const int kk = a.lv_k[w];
+                const int kraw = a.lv_k[w];
+                const int kk = kraw & 0x7fffffff, hf0 = (int)((unsigned)kraw >> 31);
                 my_k = (unsigned long long)kk;
                 const uint64_t *const pf = a.lv_prefix + a.lv_coff[w] * CHUNK;
                 const int64_t beg0 = a.lv_beg[w];
@@ -301,7 +318,13 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
                     lo += seg * step;
                     n = min(step, n - seg * step);
                 }
-                const int nxt = a.t_nbr[beg0 + lo];
+                // Candidate 0 of a list with a father entry IS the previous node (walks only move down the tree until
+                // their back-step), so the terminating condition (:264-266) needs no load: the walk ends iff it picked
+                // that entry.  Otherwise the pick is a child: its rank follows from the index alone, and the setup of
+                // the next hop (the cstart pair of that rank) does not wait for the node id.
+                const bool back = hf0 && lo == 0;
+                const int64_t pick = beg0 + lo - hf0;  // index in t_order (children only)
+                const int nxt = back ? prev0 : a.t_order[pick];
                 if (len >= a.stride) {
                     a.ctr[3] = 1ull;
                     a.path_len[w] = 0;
@@ -309,38 +332,42 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
                     alive = false;
                 } else {
                     a.paths[w * (int64_t)a.stride + len] = nxt;
-                    if (nxt == prev0) {          // terminating condition (:264-266): sample = cur
+                    if (back) {                   // next == previous: sample = cur
                         a.path_len[w] = len + 1;
                         a.samples[w] = cur0;
                         alive = false;
                     } else {
                         a.st_len[w] = len + 1;
                         a.st_prev[w] = cur0;
+                        father = cur0;
                         cur = nxt;
+                        rank = (int)(pick - tbase);
                     }
                 }
             }
         }
         if (alive && do_setup) {
-            const int32_t *const o = a.t_off + (int64_t)slot * (a.n_node + 1);
-            const int32_t *const nb = a.t_nbr + a.t_base[slot];
-            int beg = o[cur];
-            const int end = o[cur + 1];
-            if (a.level == 0) beg += 1;           // tree[root][1:]  (graph_gan.py:250)
-            else if (nb[beg] < 0) beg += 1;       // father entry removed earlier (Q3)
-            k = end - beg;
+            const int32_t *const cs = a.t_cstart + tbase + slot;
+            const int cbeg = cs[rank], cend = cs[rank + 1];  // children of cur = ranks [cbeg, cend)
+            const int nchild = cend - cbeg;
+            // list of cur (graph_gan.py:250): the root's is children only (tree[root][1:]); any other node's is
+            // [father] ++ children unless D-mode removed the father entry of this depth-1 child earlier (Q3)
+            hf = 1;
+            if (a.level == 0) hf = 0;
+            else if (a.level == 1 && ((a.t_q3[a.t_q3off[slot] + ((rank - 1) >> 5)] >> ((rank - 1) & 31)) & 1u)) hf = 0;
+            k = nchild + hf;
             bool aborted = false;
             if (k == 0) {                          // "the tree only has a root" (:252-253)
                 aborted = true;
                 if (a.for_d) atomicMin(&a.abort_walk[item], 0);
                 else a.status[item] = GG_ROOT_ABORTED;
-            } else if (a.for_d && a.level == 1 && nb[beg] == root) {
-                if (k == 1) {                      // node_neighbor == [root] (:255-257)
+            } else if (a.for_d && a.level == 1 && hf) {  // the list still starts with the root
+                if (nchild == 0) {                 // node_neighbor == [root] (:255-257)
                     atomicMin(&a.abort_walk[item], j);
                     aborted = true;
                 } else {                           // node_neighbor.remove(root) (:258-259), applied by the post-pass
-                    a.first_child[w] = cur;
-                    beg += 1;
+                    a.first_child[w] = rank;
+                    hf = 0;
                     k -= 1;
                 }
             }
@@ -350,9 +377,12 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
                 a.path_len[w] = 0;
                 a.samples[w] = -1;
             }
-            beg_abs = a.t_base[slot] + beg;
+            beg_abs = tbase + cbeg;
         }
-        if (alive) a.st_cur[w] = cur;
+        if (alive) {
+            a.st_cur[w] = cur;
+            a.st_rank[w] = rank;  // also behind the last streamed level: the finisher resumes from it
+        }
         a.st_alive[w] = alive ? 1 : 0;
         // the sync-free launch ran only as many levels as earlier launches needed: a walk that is
         // still going after the last one sends the launch to the sized rerun
@@ -424,16 +454,12 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     if (write_desc == 1 && !fits && threadIdx.x == 0) a.ctr[3] = 2ull;  // speculative capacity exceeded: the host reruns in sized mode
     if (in_range) {
         a.lv_beg[w] = beg_abs;
-        a.lv_k[w] = k;
+        a.lv_k[w] = k | (hf << 31);
         a.lv_chunks[w] = chunks;
         a.lv_coff[w] = coff;
         if (big) a.lv_big[blk_base[1] + big_before + __popcll(big_bal & ((1ull << lane) - 1ull))] = (int32_t)w;
-        if (write_desc == 1 && fits) {
-            for (int i = 0; i < chunks; ++i) {
-                const int64_t o = beg_abs + (int64_t)i * CHUNK;
-                a.lv_chunk_desc[coff + i] = make_int4(cur, min(CHUNK, k - i * CHUNK) | (k <= CHUNK ? SINGLE_CHUNK : 0), (int)(o & 0xffffffffll), (int)(o >> 32));
-            }
-        }
+        if (write_desc == 1 && fits)
+            for (int i = 0; i < chunks; ++i) a.lv_chunk_desc[coff + i] = chunk_desc(cur, k, hf, father, beg_abs, i);
     }
     // walks still alive at this hop: one atomic per block
     __shared__ int wv_alive[4];
@@ -455,12 +481,11 @@ __global__ void level_expand_kernel(const WalkArgs a) {
     const int n = a.lv_chunks[w];
     if (n == 0) return;
     const int64_t c0 = a.lv_coff[w];
-    const int k = a.lv_k[w], cur = a.st_cur[w];
+    const int kraw = a.lv_k[w], cur = a.st_cur[w];
+    const int k = kraw & 0x7fffffff, hf = (int)((unsigned)kraw >> 31);
+    const int father = hf ? a.st_prev[w] : -1;
     const int64_t beg = a.lv_beg[w];
-    for (int i = 0; i < n; ++i) {
-        const int64_t o = beg + (int64_t)i * CHUNK;
-        a.lv_chunk_desc[c0 + i] = make_int4(cur, min(CHUNK, k - i * CHUNK) | (k <= CHUNK ? SINGLE_CHUNK : 0), (int)(o & 0xffffffffll), (int)(o >> 32));
-    }
+    for (int i = 0; i < n; ++i) a.lv_chunk_desc[c0 + i] = chunk_desc(cur, k, hf, father, beg, i);
 }
 
 __device__ __forceinline__ uint64_t group16_incl_scan_u64(uint64_t v, int t) {
@@ -495,7 +520,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const
         const int4 d = a.lv_chunk_desc[c];
         const int cur = d.x, nblock = d.y & 0xff;
         const bool single = (d.y & SINGLE_CHUNK) != 0;
-        const int32_t *const ids = a.t_nbr + (((int64_t)d.w << 32) | (unsigned)d.z);
+        const int32_t *const ids = a.t_order + (((int64_t)((unsigned)d.y >> 16) << 32) | (unsigned)d.z);
         float *const out = a.lv_scores + c * CHUNK;
         float4 gc[NCH];
         const float4 *const crow = (const float4 *)(a.E + (int64_t)cur * a.ld);
@@ -504,7 +529,8 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const
             const int ch = t + 16 * cc;
             gc[cc] = (ch < a.nchunk) ? crow[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        const int myid = (t < nblock) ? ids[t] : -1;  // the chunk's ids with one coalesced load
+        // the chunk's ids with one coalesced load (candidate 0 of a list with a father entry comes with the descriptor)
+        const int myid = (t < nblock) ? (((d.y & DESC_HAS_FATHER) && t == 0) ? d.w : ids[t]) : -1;
         const float mybias = (t < nblock) ? a.bias[myid] : 0.f;  // ... and its biases with one 16-lane gather
         float mysc = 0.f;
         for (int j0 = 0; j0 < nblock; j0 += UNROLL) {
@@ -567,7 +593,7 @@ __device__ __forceinline__ void weights_small_block(const WalkArgs &a, const int
     const int t = threadIdx.x & 15;
     const int64_t w = (block * 256 + threadIdx.x) >> 4;
     if (w >= a.total_walks || a.lv_chunks[w] <= 1) return;  // non-owners, and single-chunk tasks (done by the score kernel)
-    const int k = a.lv_k[w];
+    const int k = a.lv_k[w] & 0x7fffffff;
     if (k > BIG_TASK) return;
     const int64_t base = a.lv_coff[w] * CHUNK;
     const float *const sc = a.lv_scores + base;
@@ -609,7 +635,7 @@ __device__ __forceinline__ void weights_big_blocks(const WalkArgs &a) {
     const int n_big = (int)a.ctr[CTR_BIG + a.level];
     for (int b = blockIdx.x; b < n_big; b += BIG_BLOCKS) {
         const int64_t w = a.lv_big[b];
-        const int k = a.lv_k[w];
+        const int k = a.lv_k[w] & 0x7fffffff;
         const int64_t base = a.lv_coff[w] * CHUNK;
         const float *const sc = a.lv_scores + base;
         uint64_t *const pf = a.lv_prefix + base;
@@ -704,16 +730,18 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void walk_sample_kernel(const
             const uint32_t j = (uint32_t)(w - a.walk_ptr[item]);
             const int slot = a.slots[item];
             const int root = a.t_root[slot];
-            const int32_t *const o = a.t_off + (int64_t)slot * (a.n_node + 1);
-            int32_t *const nb = a.t_nbr + a.t_base[slot];
+            const int64_t tbase = a.t_base[slot];
+            const int32_t *const cs = a.t_cstart + tbase + slot;
+            const int32_t *const order = a.t_order + tbase;
             int32_t *const path = a.paths + w * (int64_t)a.stride;
 
-            int cur = root, prev = -1, len = 1;
-            uint32_t hop = 0;
+            int cur = root, prev = -1, len = 1, rank = 0;
+            uint32_t hop = 0;  // = depth of cur: a walk only moves down the tree until its back-step
             if (resume) {
                 cur = a.st_cur[w];
                 prev = a.st_prev[w];
                 len = a.st_len[w];
+                rank = a.st_rank[w];
                 hop = (uint32_t)a.level;
             } else {
                 if (lane == 0) path[0] = root;
@@ -722,23 +750,25 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void walk_sample_kernel(const
             bool aborted = false, overflow = false;
 
             for (;;) {
-                int beg = o[cur];
-                const int end = o[cur + 1];
-                if (hop == 0) beg += 1;                 // tree[root][1:]  (graph_gan.py:250)
-                else if (nb[beg] < 0) beg += 1;         // father entry removed earlier (Q3)
-                int k = end - beg;
-                if (k == 0) { aborted = true; break; }  // "the tree only has a root" (:252-253)
-                if (a.for_d && hop == 1 && nb[beg] == root) {
-                    if (k == 1) {                       // node_neighbor == [root] (:255-257)
+                const int cbeg = cs[rank], cend = cs[rank + 1];
+                const int nchild = cend - cbeg;
+                int hf = 1;                                 // list = [father] ++ children ...
+                if (hop == 0) hf = 0;                       // ... tree[root][1:]  (graph_gan.py:250)
+                else if (hop == 1 && ((a.t_q3[a.t_q3off[slot] + ((rank - 1) >> 5)] >> ((rank - 1) & 31)) & 1u)) hf = 0;  // father entry removed earlier (Q3)
+                int k = nchild + hf;
+                if (k == 0) { aborted = true; break; }      // "the tree only has a root" (:252-253)
+                if (a.for_d && hop == 1 && hf) {
+                    if (nchild == 0) {                      // node_neighbor == [root] (:255-257)
                         if (lane == 0) atomicMin(&a.abort_walk[item], (int)j);
                         aborted = true;
                         break;
                     }
-                    if (lane == 0) a.first_child[w] = cur;  // node_neighbor.remove(root) (:258-259), applied by the post-pass
-                    beg += 1;
+                    if (lane == 0) a.first_child[w] = rank;  // node_neighbor.remove(root) (:258-259), applied by the post-pass
+                    hf = 0;
                     k -= 1;
                 }
-                const int32_t *const ids = nb + beg;
+                // candidate c: the father (= prev) if hf and c == 0, else the child order[cbeg + c - hf]
+                const int32_t *const ids = order + cbeg - hf;
                 float *const sbuf = (k <= SCORE_CAP) ? sbuf_lds : sbuf_glb;
 
                 float4 gc[NCH];
@@ -746,7 +776,8 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void walk_sample_kernel(const
                 float mx = -INFINITY;
                 for (int j0 = 0; j0 < k; j0 += 64) {
                     const int nblock = min(64, k - j0);
-                    mx = fmaxf(mx, score_block<NCH>(a, gc, ids + j0, nblock, lane, [&](int jj, float sc) { sbuf[j0 + jj] = sc; }));
+                    mx = fmaxf(mx, score_block<NCH>(a, gc, ids + j0, (hf && j0 == 0) ? prev : -1, nblock, lane,
+                                                    [&](int jj, float sc) { sbuf[j0 + jj] = sc; }));
                 }
                 mx = wave_max_f32(mx);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -760,16 +791,18 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void walk_sample_kernel(const
                     if (lane == 0) a.ctr[CTR_NONFINITE] = 1ull;
                     idx = 0;
                 }
-                const int nxt = ids[idx];
+                const bool back = hf && idx == 0;
+                const int nxt = back ? prev : ids[idx];
                 my_hops += 1;
                 my_reads += (unsigned long long)k;
                 if (len >= a.stride) { overflow = true; break; }
                 if (lane == 0) path[len] = nxt;
                 len += 1;
                 hop += 1;
-                if (nxt == prev) break;  // terminating condition (:264-266): sample = cur
+                if (back) break;  // terminating condition (:264-266): next == previous, sample = cur
                 prev = cur;
                 cur = nxt;
+                rank = cbeg + idx - hf;
             }
 
             if (lane == 0) {
@@ -817,11 +850,8 @@ __global__ void walk_d_postpass_kernel(const WalkArgs a) {
     const int ab = a.abort_walk[item];
     const int slot = a.slots[item];
     if (j < ab) {
-        const int c = a.first_child[w];
-        if (c >= 0) {
-            const int32_t *o = a.t_off + (int64_t)slot * (a.n_node + 1);
-            a.t_nbr[a.t_base[slot] + o[c]] = -1;
-        }
+        const int c = a.first_child[w];  // rank (>= 1) of the depth-1 child this walk stood on
+        if (c >= 1) atomicOr(&a.t_q3[a.t_q3off[slot] + ((c - 1) >> 5)], 1u << ((c - 1) & 31));
     }
     if (ab != 0x7fffffff) {
         a.samples[w] = -1;
@@ -921,6 +951,7 @@ static int run_levels_and_finish(gg_ctx *ctx, WalkArgs &a, int64_t total_walks) 
         GG_HIP(ctx, ctx->st_prev.reserve(sizeof(int32_t) * total_walks));
         GG_HIP(ctx, ctx->st_len.reserve(sizeof(int32_t) * total_walks));
         GG_HIP(ctx, ctx->st_alive.reserve(sizeof(int32_t) * total_walks));
+        GG_HIP(ctx, ctx->st_rank.reserve(sizeof(int32_t) * total_walks));
         GG_HIP(ctx, ctx->lv_beg.reserve(sizeof(int64_t) * total_walks));
         GG_HIP(ctx, ctx->lv_k.reserve(sizeof(int32_t) * total_walks));
         GG_HIP(ctx, ctx->lv_chunks.reserve(sizeof(int32_t) * total_walks));
@@ -931,6 +962,7 @@ static int run_levels_and_finish(gg_ctx *ctx, WalkArgs &a, int64_t total_walks) 
         a.st_prev = ctx->st_prev.as<int32_t>();
         a.st_len = ctx->st_len.as<int32_t>();
         a.st_alive = ctx->st_alive.as<int32_t>();
+        a.st_rank = ctx->st_rank.as<int32_t>();
         a.st_const = ctx->st_item.as<int4>();
         a.lv_beg = ctx->lv_beg.as<int64_t>();
         a.lv_k = ctx->lv_k.as<int32_t>();
@@ -968,9 +1000,11 @@ int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int fo
     a.ld = ctx->ld;
     a.nchunk = ctx->ld / 4;
     a.t_root = ctx->t_root;
-    a.t_off = ctx->t_off;
-    a.t_nbr = ctx->t_nbr;
+    a.t_order = ctx->t_order;
+    a.t_cstart = ctx->t_cstart;
     a.t_base = ctx->t_base;
+    a.t_q3 = ctx->t_q3;
+    a.t_q3off = ctx->t_q3off;
     a.slots = ctx->w_slots.as<int32_t>();
     a.walk_ptr = ctx->w_ptr.as<int64_t>();
     a.n_slots = n_slots;

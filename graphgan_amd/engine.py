@@ -169,7 +169,7 @@ class Engine:
 
     def tree_bytes_estimate(self, n_roots):
         """Upper bound of the HBM bytes ``n_roots`` resident trees need (every root reaching every node)."""
-        return float(n_roots) * 12.0 * (self.n_node + 1)
+        return float(n_roots) * 8.0 * (self.n_node + 1)
 
     def set_trees(self, roots, off, nbr, nbr_base, max_depth=0):
         roots, off, nbr = _i32(roots), _i32(off), _i32(nbr)

@@ -91,6 +91,8 @@ typedef struct gg_counters {
     int64_t score_launches;
     int64_t score_chunks;   /* 16-candidate work items those launches processed */
     int64_t score_rows;     /* neighbour rows those launches streamed */
+    double bfs_kernel_ms;   /* cumulative HIP-event time of the BFS-tree kernel (gg_build_trees_device) */
+    int64_t bfs_trees;      /* ... and the trees it built */
 } gg_counters;
 
 typedef struct gg_ctx gg_ctx;
@@ -110,9 +112,11 @@ int gg_destroy(gg_ctx *ctx);
  * neighbour order = list order (it decides BFS child order and D-step positives). */
 int gg_set_graph_csr(gg_ctx *ctx, const int64_t *rowptr /*[n_node+1]*/, const int32_t *col);
 
-/* gg_host_build_trees: construct_trees (graph_gan.py:84-108) on host threads, no GPU, no ctx.
- * Tree CSR of root slot r: node v's list [father, child_0, ...] (root: [root, child...]) is
- * nbr[nbr_base[r] + off[r*(n_node+1)+v] .. off[r*(n_node+1)+v+1]), lists in node-id order.
+/* Trees cross the ABI in the REFERENCE'S SHAPE (graph_gan.py:90,96): for root slot r, node v's list
+ * [father, child_0, ...] (root: [root, child...]) is nbr[nbr_base[r] + off[r*(n_node+1)+v] .. off[r*(n_node+1)+v+1]),
+ * lists in node-id order; 2 * |component| - 1 entries per root.  Inside the context they live in BFS-order form
+ * (pop order + first-child rank per rank, 8 bytes per node and root).
+ * gg_host_build_trees: construct_trees (graph_gan.py:84-108) on host threads, no GPU, no ctx.
  * nbr == NULL sizes only.  Returns total entries (>= 0) or GG_E*. */
 int64_t gg_host_build_trees(int32_t n_node, const int64_t *rowptr, const int32_t *col,
                             const int32_t *roots, int32_t n_roots,
@@ -122,12 +126,12 @@ int64_t gg_host_build_trees(int32_t n_node, const int64_t *rowptr, const int32_t
 /* gg_build_trees: same, built in batches and uploaded into the context (replaces the pickle
  * cache load/construct branch, graph_gan.py:31-46).  Root slot i holds the tree of roots[i]. */
 int gg_build_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, int32_t n_threads);
-/* gg_build_trees_device: the same trees built ON THE GPU (level-synchronous BFS that reproduces the
- * reference's pop order: a node is appended by the first frontier node, in pop order, that lists it),
- * for batches of roots at once, written straight into the resident tree CSR. */
+/* gg_build_trees_device: the same trees built ON THE GPU: one workgroup per root replays the reference's edge
+ * stream (pop order x adjacency order) 4 096 edges at a time against a visited bitmap in LDS; a node is appended
+ * at the first edge of the stream that reaches it.  Written straight into the resident BFS-order arrays. */
 int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t n_roots);
-/* gg_set_trees / gg_get_trees: upload / download a tree CSR (cache files, tests; download
- * includes the in-place D-mode mutations, graph_gan.py:258-259). */
+/* gg_set_trees / gg_get_trees: upload / download trees in the reference's shape (tests, foreign caches; the
+ * download shows the in-place D-mode mutations, graph_gan.py:258-259, as father entries of -1). */
 int gg_set_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int32_t *off,
                  const int32_t *nbr, const int64_t *nbr_base, int32_t max_depth);
 int gg_tree_info(const gg_ctx *ctx, int32_t *n_roots, int64_t *n_entries, int32_t *max_depth);

@@ -93,7 +93,7 @@ class _FakeEngine(object):
         self.calls = []
         self.tree_roots = None
 
-    def tree_bytes_estimate(self, n_roots): return float(n_roots) * 12.0 * (self.n_node + 1)
+    def tree_bytes_estimate(self, n_roots): return float(n_roots) * 8.0 * (self.n_node + 1)
     def set_profiling(self, k): self.calls.append(("set_profiling", k))
     def set_graph_csr(self, rowptr, col): self.calls.append(("set_graph_csr", len(rowptr) - 1, len(col)))
     def build_trees(self, roots, **kw): self.tree_roots = list(roots); self.calls.append(("build_trees", len(roots), kw.get("device")))
