@@ -39,7 +39,7 @@ def parse():
     p.add_argument("--nodes", type=int, default=1_000_000)
     p.add_argument("--m", type=int, default=10)
     p.add_argument("--emb", type=int, default=128)
-    p.add_argument("--roots", type=int, default=8192, help="root slots per rank per step (8192 trees of the 1M-node graph = 96 GB of the 288 GB HBM)")
+    p.add_argument("--roots", type=int, default=8192, help="root slots per rank per step (8192 trees of the 1M-node graph = 64 GB of the 288 GB HBM)")
     p.add_argument("--n-sample-gen", type=int, default=20)
     p.add_argument("--optimizer", default="adam_lazy", choices=["adam_dense", "adam_lazy", "sgd"])
     p.add_argument("--threads", type=int, default=0, help="host BFS threads (0 = min(64, cores))")
@@ -47,6 +47,9 @@ def parse():
     p.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--seed", type=int, default=6)
+    p.add_argument("--overlap-steps", type=int, default=6, help="steps behind the timed region whose profiled launches are NOT isolated (overlapped roofline figure)")
+    p.add_argument("--fresh-batches", type=int, default=2, help="behind the timed region: root batches whose trees are built first (end-to-end figure); 0 = skip")
+    p.add_argument("--no-strict", action="store_true", help="skip the strict-mode (batch 64, dense TF1-Adam, CA-GrQc) pairs/s line")
     p.add_argument("--profile-every", type=int, default=3,
                    help="HIP events around every k-th walk launch of the timed region (an event pair costs ~6 us of stream bubble on "
                         "each side of every level_score_kernel launch; an odd k alternates between the D-mode and G-mode launches)")
@@ -107,6 +110,46 @@ def pmc_traffic(kernel_substr):
     return None, None
 
 
+def delta(c1, c0):
+    return {k: c1[k] - c0[k] for k in c1}
+
+
+def strict_mode_line(ga, _lib, seconds=1.5):
+    """SURVEY.md section 8d metric 2(i): the reference's own schedule -- batch 64, dense TF1-Adam over the whole table per
+    step (graph_gan.py:149-157,168-176) -- on the CA-GrQc fixture (N = 5 242, d = 50), pairs/s through gg_d_pass /
+    gg_g_pass over resident prepared data, wall clock around whole inner passes."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ca_grqc.npz"))
+    n = int(g["n_node"])
+    rowptr, col = ga.edges_to_csr(n, g["train"])
+    emb = np.random.RandomState(5).rand(n, g["emb_rows"].shape[1])
+    emb[g["emb_ids"]] = g["emb_rows"]
+    eng = ga.Engine(emb, emb, optimizer=_lib.GG_OPT_ADAM_DENSE)
+    eng.set_graph_csr(rowptr, col)
+    roots = np.arange(n, dtype=np.int32)
+    eng.build_trees(roots, device=True)
+    eng.set_profiling(0)
+    out = {}
+    rows = eng.prepare_d(roots, 1, 0, fetch=False)
+    pairs = eng.prepare_g(roots, 20, 1, 1, fetch=False)
+    rs = np.random.RandomState(0)
+    for name, total, fn in (("d", rows, eng.d_pass), ("g", min(pairs, 64 * 6000), eng.g_pass)):
+        starts = np.arange(0, total, 64, dtype=np.int64)
+        fn(starts[:50], 64)
+        eng.synchronize()
+        done, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            rs.shuffle(starts)
+            fn(starts, 64)
+            eng.synchronize()
+            done += len(starts)
+        dt = time.perf_counter() - t0
+        out["%s_pairs_per_sec" % name] = 64.0 * done / dt
+        out["%s_us_per_step" % name] = 1e6 * dt / done
+    out["config"] = "CA-GrQc (5242 nodes), n_emb=50, batch 64, dense TF1-Adam (24*N*(d+1) B per step), resident prepared data"
+    eng.close()
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -141,6 +184,7 @@ def main():
     else:
         eng.build_trees(roots, device=True)
     trees_s = time.time() - t_trees
+    c_trees = eng.counters()
     slots = np.arange(len(roots), dtype=np.int32)
     if not share_gpu:
         ctl.connect_engine(eng)
@@ -169,35 +213,78 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     c1 = eng.counters()
+    c = delta(c1, c0)
 
-    hops = c1["hops"] - c0["hops"]
-    reads = c1["nbr_reads"] - c0["nbr_reads"]
-    rows_scored = c1["rows_scored"] - c0["rows_scored"]
-    walk_ms = c1["walk_kernel_ms"] - c0["walk_kernel_ms"]      # HIP events of the profiled walk launches ...
-    launches = c1["walk_launches"] - c0["walk_launches"]       # ... and how many of the 2 * steps launches that was
+    # ---- behind the timed region (every rank takes part: the steps contain collectives) -------------------------
+    nxt = args.warmup + args.steps
+    # (1) the same kernel events with the profiled launches NOT isolated: G-mode walks beside the discriminator update
+    eng.set_profiling_solo(False)
+    eng.set_profiling(args.profile_every)
+    c2 = eng.counters()
+    for i in range(nxt, nxt + args.overlap_steps):
+        step(i)
+    barrier()
+    co = delta(eng.counters(), c2)
+    eng.set_profiling_solo(True)
+    nxt += args.overlap_steps
+    # (2) end to end for roots whose trees are NOT resident: build the BFS trees of a fresh batch of R roots on the GPU,
+    #     then one step on them (an epoch over all N roots is a sequence of exactly this)
+    e2e = None
+    if args.fresh_batches > 0 and not args.host_bfs:
+        c3 = eng.counters()
+        barrier()
+        t3 = time.perf_counter()
+        for k in range(args.fresh_batches):
+            fresh = workloads.bench_roots(rowptr, args.roots, rank, world, args.seed + 101 + k)
+            eng.build_trees(fresh, device=True)
+            step(nxt + k)
+        barrier()
+        dt3 = time.perf_counter() - t3
+        c4 = delta(eng.counters(), c3)
+        e2e = (c4["hops"], dt3, c4["bfs_kernel_ms"], c4["bfs_trees"])
+
+    hops, reads, rows_scored = c["hops"], c["nbr_reads"], c["rows_scored"]
+    walk_ms, launches = c["walk_kernel_ms"], c["walk_launches"]  # HIP events of the profiled walk launches and how many that was
     calls = 2 * args.steps
-    dpairs = c1["d_pairs"] - c0["d_pairs"]
-    gpairs = c1["g_pairs"] - c0["g_pairs"]
-    sums = ctl.sum([hops, dpairs, gpairs])
+    sums = ctl.sum([hops, c["d_pairs"], c["g_pairs"], e2e[0] if e2e else 0.0])
     tot = np.array([sums[0], sums[1], sums[2], ctl.max(dt)])
+    e2e_dt = ctl.max(e2e[1]) if e2e else 0.0
     if rank != 0:
         eng.close()
         return
 
     d = eng.n_emb
-    # Dominant kernel: level_score_kernel (streams the neighbour rows).  Algorithmic bytes per 16-lane work
-    # item ("chunk" of <= 16 candidates of one (root, node) distribution): 16 B descriptor + 4d current row;
-    # per candidate row: 4 B id + 4d row + 4 B bias + 4 B score written = 4(d+3)   
-    sc_ms = c1["score_kernel_ms"] - c0["score_kernel_ms"]
-    sc_launches = c1["score_launches"] - c0["score_launches"]
-    sc_chunks = c1["score_chunks"] - c0["score_chunks"]
-    sc_rows = c1["score_rows"] - c0["score_rows"]  # rows / chunks / ms / launches: the same (profiled) launches
-    sc_bytes = 4.0 * (d + 3) * sc_rows + (4.0 * d + 16.0) * sc_chunks
-    achieved = sc_bytes / (sc_ms * 1e-3) / 1e9 if sc_ms > 0 else 0.0
-    # The reference evaluates every hop's distribution from scratch (SURVEY.md section 8d: 4k(d+2) + 4d + 12 per hop);
+
+    def gbs(nbytes, ms):
+        return nbytes / (ms * 1e-3) / 1e9 if ms > 0 else None
+
+    def frac(x):
+        return x / HBM_PEAK_GBS if x else None
+
+    # K1, dominant kernel level_score_kernel.  Algorithmic bytes as SURVEY.md section 8d defines them: per candidate row
+    # scored 4(d+2) (id + embedding row + bias), per evaluated (root, node) distribution 4d+12 (ONE current row, tree
+    # pointers, output id); rows / distributions / milliseconds / launches are counted over the same profiled launches.
+    # (The kernel re-reads the current row once per 16-candidate work item and writes scores: that is traffic, not algorithm.)
+    def k1(cc):
+        b = 4.0 * (d + 2) * cc["score_rows"] + (4.0 * d + 12.0) * cc["score_dists"]
+        return b, gbs(b, cc["score_kernel_ms"])
+
+    sc_bytes, achieved = k1(c)
+    _, achieved_ovl = k1(co)
+    sc_launches = c["score_launches"]
+    # The reference evaluates every hop's distribution from scratch (4k(d+2) + 4d + 12 per hop);
     # the engine evaluates each distinct (root, node) distribution of a launch once.
     ref_bytes = 4.0 * (d + 2) * reads + (4.0 * d + 12.0) * hops
     traffic, traffic_src = pmc_traffic("level_score_kernel") if args.workload == "powerlaw" and args.nodes == 1_000_000 else (None, None)
+    # K2 pair_reward: 8d + 16 per pair.  K3 / K4 (fast mode, lazy Adam) per section 8d: gradient kernel 16d + 20 per pair
+    # (two rows read, two rows of gradient added), whole step 48d + 36 per pair; K5 optimizer kernel per touched row:
+    # E, m, v read + written, gradient read + cleared = 32d, plus 32 for the bias and its slots.
+    row_b = 32.0 * d + 32.0 if args.optimizer != "sgd" else 16.0 * d + 16.0
+    k2 = gbs((8.0 * d + 16.0) * c["reward_pairs_timed"], c["reward_kernel_ms"])
+    kd_g, kd_o = gbs((16.0 * d + 20.0) * c["d_pairs_timed"], c["d_grad_ms"]), gbs(row_b * c["d_rows_timed"], c["d_opt_ms"])
+    kg_g, kg_o = gbs((16.0 * d + 20.0) * c["g_pairs_timed"], c["g_grad_ms"]), gbs(row_b * c["g_rows_timed"], c["g_opt_ms"])
+    kd_s = gbs((48.0 * d + 36.0) * c["d_pairs_timed"], c["d_grad_ms"] + c["d_opt_ms"])
+    kg_s = gbs((48.0 * d + 36.0) * c["g_pairs_timed"], c["g_grad_ms"] + c["g_opt_ms"])
     out = {
         "metric": "sampled_edges_per_sec",
         "value": tot[0] / tot[3],
@@ -214,37 +301,61 @@ def main():
         "config": {"workload": wl_name, "roots_per_gpu_per_step": int(R), "n_sample_gen": args.n_sample_gen,
                    "optimizer": args.optimizer, "step": "prepare_d + d_pass + prepare_g + g_pass (graph_gan.py:144-176, one inner pass each)",
                    "parallelism": "roots sharded x%d, replicated tables, RCCL sparse gradient all-gather per pass" % world if world > 1 else "single GPU"},
-        "d_step_pairs_per_sec": tot[1] / tot[3],
-        "g_step_pairs_per_sec": tot[2] / tot[3],
+        # pairs through the update kernels / HIP-event time of those kernels (gradient + optimizer) on the profiled passes
+        "d_step_pairs_per_sec": c["d_pairs_timed"] / ((c["d_grad_ms"] + c["d_opt_ms"]) * 1e-3) if c["d_grad_ms"] > 0 else None,
+        "g_step_pairs_per_sec": c["g_pairs_timed"] / ((c["g_grad_ms"] + c["g_opt_ms"]) * 1e-3) if c["g_grad_ms"] > 0 else None,
+        "d_pairs_per_step_all_ranks": tot[1] / args.steps,
+        "g_pairs_per_step_all_ranks": tot[2] / args.steps,
         "walk_kernel_edges_per_sec": (hops / calls) / (walk_ms / launches * 1e-3) if walk_ms > 0 and launches else None,
         "hops_per_step_rank0": hops / args.steps,
         "mean_k": reads / max(hops, 1),
         "rows_scored_per_step_rank0": rows_scored / args.steps,
         "nbr_reads_per_step_rank0": reads / args.steps,
         "setup_s": setup_s,
-        "tree_build_s": trees_s,
-        "tree_build": "host threads" if args.host_bfs else "gpu bfs",
+        "tree_build": {"where": "host threads" if args.host_bfs else "gpu bfs (one workgroup per root, visited bitmap in LDS)", "trees": int(R), "call_s": trees_s,
+                       "kernel_ms": c_trees["bfs_kernel_ms"], "us_per_tree": 1e3 * c_trees["bfs_kernel_ms"] / max(c_trees["bfs_trees"], 1) if c_trees["bfs_trees"] else None,
+                       "resident_bytes_per_tree": 8.0 * n},
         "roofline": {"kernel": "level_score_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "algorithmic_bytes_per_launch": sc_bytes / max(sc_launches, 1), "avg_launch_ms": sc_ms / max(sc_launches, 1),
-                     "launches": int(sc_launches), "rows_per_launch": sc_rows / max(sc_launches, 1),
-                     "timed": "HIP events on the engine's stream around every level_score_kernel launch of every %s walk call of the timed region"
-                              % ("" if args.profile_every == 1 else "%d-th" % args.profile_every),
-                     # tools/gather_bw*.hip on the same chip: random 512 B row gathers with 16-lane groups
-                     # tools/gather_bw2.hip / gather_bw3.hip on the same chip (profiles/r1_gather_bw*.txt), TB/s of rows resp. in this
-                     # kernel's accounting: the separate bias gather is what costs a fifth of the plain gather's rate
-                     "gather_microbench_GBs": {"plain_row_gather": 7400.0, "with_dot_and_score_store": 7200.0, "with_bias_gather": 5650.0,
-                                               "kernel_shape_16_row_items": 6300.0, "kernel_shape_64_row_items": 6200.0}},
+                     "frac": frac(achieved), "traffic": traffic, "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": sc_bytes / max(sc_launches, 1), "avg_launch_ms": c["score_kernel_ms"] / max(sc_launches, 1),
+                     "launches": int(sc_launches), "rows_per_launch": c["score_rows"] / max(sc_launches, 1),
+                     "distributions_per_launch": c["score_dists"] / max(sc_launches, 1),
+                     "bytes_model": "SURVEY 8d: 4(d+2) per candidate row + (4d+12) per (root, node) distribution",
+                     "timed": "HIP events on the engine's stream around every level_score_kernel launch of every %s walk call of the timed region; "
+                              "profiled side-stream launches run alone (solo)" % ("" if args.profile_every == 1 else "%d-th" % args.profile_every),
+                     "overlapped": {"achieved": achieved_ovl, "frac": frac(achieved_ovl), "launches": int(co["score_launches"]),
+                                    "what": "%d further steps with the profiled G-mode launches left beside the discriminator update" % args.overlap_steps},
+                     "microbenchmarks": "profiles/r1_gather_bw2.txt, profiles/r1_gather_bw3.txt (tools/gather_bw*.hip on the same chip)"},
+        "roofline_k2": {"kernel": "pair_reward_kernel", "bound": "hbm", "achieved": k2, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac(k2),
+                        "bytes_model": "8d + 16 per pair", "pairs": int(c["reward_pairs_timed"]), "ms": c["reward_kernel_ms"]},
+        "roofline_k34": {"bound": "hbm (fp32 atomics in L2)", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "bytes_model": "gradient kernel 16d + 20 per pair; whole step (gradient + optimizer) 48d + 36 per pair (SURVEY 8d, lazy Adam)",
+                         "d": {"kernel": "pair_grad_kernel", "achieved": kd_g, "frac": frac(kd_g), "step_achieved": kd_s, "step_frac": frac(kd_s),
+                               "pairs": int(c["d_pairs_timed"]), "grad_ms": c["d_grad_ms"], "passes": int(c["d_passes_timed"])},
+                         "g": {"kernel": "path_grad_kernel (reads every path node once: its traffic is below the per-pair model)", "achieved": kg_g, "frac": frac(kg_g),
+                               "step_achieved": kg_s, "step_frac": frac(kg_s), "pairs": int(c["g_pairs_timed"]), "grad_ms": c["g_grad_ms"], "passes": int(c["g_passes_timed"])}},
+        "roofline_opt": {"kernel": "sparse_opt_kernel (+ flag scan / compaction%s)" % (", replica exchange" if world > 1 else ""), "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "bytes_model": "%s per touched row" % ("32d + 32 (E, m, v read + written, gradient read + cleared)" if args.optimizer != "sgd" else "16d + 16"),
+                         "d": {"achieved": kd_o, "frac": frac(kd_o), "rows": int(c["d_rows_timed"]), "ms": c["d_opt_ms"]},
+                         "g": {"achieved": kg_o, "frac": frac(kg_o), "rows": int(c["g_rows_timed"]), "ms": c["g_opt_ms"]}},
         "walk_phase": {"ms_per_walk_sample_call": walk_ms / max(launches, 1), "calls": calls, "calls_timed": int(launches),
                        "reference_equivalent_bytes_per_call": ref_bytes / calls,
                        "reference_equivalent_GBs": (ref_bytes / calls) / (walk_ms / launches * 1e-3) / 1e9 if walk_ms > 0 and launches else None,
                        "distributions_shared": reads / max(rows_scored, 1)},
     }
+    if e2e:
+        out["end_to_end_with_tree_build"] = {
+            "value": sums[3] / e2e_dt, "unit": "edges/s",
+            "what": "%d fresh batches of %d roots per GPU: gg_build_trees_device + one step each (trees not resident)" % (args.fresh_batches, R),
+            "s_per_batch": e2e_dt / args.fresh_batches, "bfs_kernel_ms_per_batch": e2e[2] / args.fresh_batches,
+            "bfs_us_per_tree": 1e3 * e2e[2] / max(e2e[3], 1)}
+    if world == 1 and not args.no_strict:
+        out["strict_mode"] = strict_mode_line(ga, _lib)
     if world == 1 and not args.no_cpu_baseline:
         bias = eng.get_bias(0)
         embg = eng.get_embeddings(0)
         v, sample = cpu_baseline(args, n, rowptr, col, embg, bias, roots, args.cpu_baseline_seconds)
-        out["cpu_baseline"] = {"value": v, "unit": "edges/s", "cores": 1, "kind": "port", "sample": sample}
+        out["cpu_baseline"] = {"value": v, "unit": "edges/s", "cores": 1, "host_cores_on_box": os.cpu_count(), "kind": "port", "sample": sample}
         out["walk_kernel_vs_cpu"] = out["walk_kernel_edges_per_sec"] / v if v > 0 and out["walk_kernel_edges_per_sec"] else None
     eng.close()
     print(json.dumps(out))

@@ -35,7 +35,11 @@ class GGCounters(ctypes.Structure):
                 ("last_kernel_ms", ctypes.c_double), ("walk_kernel_ms", ctypes.c_double),
                 ("walk_launches", ctypes.c_int64), ("rows_scored", ctypes.c_int64), ("score_kernel_ms", ctypes.c_double),
                 ("score_launches", ctypes.c_int64), ("score_chunks", ctypes.c_int64), ("score_rows", ctypes.c_int64),
-                ("bfs_kernel_ms", ctypes.c_double), ("bfs_trees", ctypes.c_int64)]
+                ("bfs_kernel_ms", ctypes.c_double), ("bfs_trees", ctypes.c_int64), ("score_dists", ctypes.c_int64),
+                ("reward_kernel_ms", ctypes.c_double), ("reward_pairs_timed", ctypes.c_int64),
+                ("d_grad_ms", ctypes.c_double), ("d_opt_ms", ctypes.c_double), ("d_pairs_timed", ctypes.c_int64), ("d_rows_timed", ctypes.c_int64),
+                ("g_grad_ms", ctypes.c_double), ("g_opt_ms", ctypes.c_double), ("g_pairs_timed", ctypes.c_int64), ("g_rows_timed", ctypes.c_int64),
+                ("d_passes_timed", ctypes.c_int64), ("g_passes_timed", ctypes.c_int64)]
 
 
 class GGGraph(ctypes.Structure):
@@ -64,6 +68,9 @@ SIGNATURES = {
     "gg_build_trees_device": (ctypes.c_int, [_P, _P, _i32]),
     "gg_set_trees": (ctypes.c_int, [_P, _P, _i32, _P, _P, _P, _i32]),
     "gg_tree_info": (ctypes.c_int, [_P, _P, _P, _P]),
+    "gg_tree_roots": (ctypes.c_int, [_P, _P]),
+    "gg_save_trees": (ctypes.c_int, [_P, ctypes.c_char_p]),
+    "gg_load_trees": (ctypes.c_int, [_P, ctypes.c_char_p]),
     "gg_get_trees": (ctypes.c_int, [_P, _P, _P, _P]),
     "gg_walk_sample": (ctypes.c_int, [_P, _P, _P, _i32, _i32, _u64, _u32, _P, _P, _P, _i32, _P]),
     "gg_walk_info": (ctypes.c_int, [_P, _P, _P, _P]),
@@ -88,6 +95,7 @@ SIGNATURES = {
     "gg_load_state": (ctypes.c_int, [_P, ctypes.c_char_p]),
     "gg_get_counters": (ctypes.c_int, [_P, ctypes.POINTER(GGCounters)]),
     "gg_set_profiling": (ctypes.c_int, [_P, _i32]),
+    "gg_set_profiling_solo": (ctypes.c_int, [_P, _i32]),
     "gg_synchronize": (ctypes.c_int, [_P]),
     "gg_comm_unique_id": (ctypes.c_int, [_P]),
     "gg_comm_init": (ctypes.c_int, [_P, _P, _i32, _i32]),

@@ -6,19 +6,19 @@
 // One WORKGROUP per root, one root per CU at a time (persistent grid, roots drawn from a ticket counter).
 // The reference's BFS is sequential: pop v, scan adj(v) in order, append every node not seen before.  The
 // edges it inspects form ONE STREAM -- (pop order of v, position in adj(v)) -- and a node is appended by the
-// FIRST edge of that stream that reaches it.  The workgroup replays that stream 4 096 edges at a time:
+// FIRST edge of that stream that reaches it.  The workgroup replays that stream 8 192 edges at a time:
 //
 //   * the "seen" set is a BITMAP IN LDS (1 bit per node: 122 KB for 10^6 nodes, of the CU's 160 KB), so
 //     the test that dominates a BFS -- 20 M of them per tree of the 1M-node / 10M-edge graph -- never leaves the
 //     CU.  (The round-1 kernels kept 36 B of state per (root, node) in HBM for 238 roots at once: every test
 //     was a random HBM access, 4.9 GB of traffic per tree.)  Graphs whose bitmap exceeds the LDS use a per-
 //     workgroup bitmap in global memory (L2 / MALL resident) through the same code.
-//   * a chunk = 1 024 threads x 4 consecutive stream positions.  Test (all threads) | barrier | claim: the
+//   * a chunk = 1 024 threads x 8 consecutive stream positions.  Test (all threads) | barrier | claim: the
 //     unseen targets set their bit with an LDS atomic-or; exactly one edge per new node sees the bit clear
 //     (the hardware winner), the others (duplicates INSIDE the chunk: rare) append {node, position} to a short
 //     LDS list | barrier | every hardware winner takes the smallest stream position among its own and the
 //     list's entries for its node -- the edge the sequential BFS would have appended it at -- and marks that
-//     position in a 4 096-bit LDS mask | barrier | the marked positions are compacted in stream order (wave
+//     position in an 8 192-bit LDS mask | barrier | the marked positions are compacted in stream order (wave
 //     scan + 16 wave totals) onto the queue, and the thread holding the LAST edge of a queue node records
 //     where that node's children end: cstart[] comes out of the same pass.  If the duplicate list overflows
 //     (many edges of one chunk into the same few new nodes) the chunk is resolved through a per-workgroup
@@ -34,12 +34,14 @@
 
 namespace gg {
 
-constexpr int BFS_T = 1024;             // threads per workgroup
+constexpr int BFS_T = 1024;              // threads per workgroup
 constexpr int BFS_WAVES = BFS_T / 64;
-constexpr int BFS_U = 4;                // consecutive stream positions per thread and chunk
-constexpr int BFS_CH = BFS_T * BFS_U;   // edges per chunk
-constexpr int BFS_NB = BFS_T;           // queue nodes per batch (one per thread)
-constexpr int BFS_LCAP = 1024;          // in-chunk duplicate list
+constexpr int BFS_U = 8;                 // consecutive stream positions per thread and chunk
+constexpr int BFS_CH = BFS_T * BFS_U;    // edges per chunk
+constexpr int BFS_NB = BFS_T;            // queue nodes per batch (one per thread)
+constexpr int BFS_TE_CAP = 32768;        // edges per batch (the batch -> node map below has TE_CAP / U entries)
+constexpr int BFS_BIG = 1024;            // a node with more edges forms a batch of its own (trivial map)
+constexpr int BFS_LCAP = 512;            // in-chunk duplicate list
 
 struct BfsArgs {
     int n_node, n_roots;
@@ -54,17 +56,33 @@ struct BfsArgs {
     uint32_t *gbitmap;       // [grid][bm_words]  (graphs too large for the LDS bitmap)
     uint32_t *gkey;          // [grid][n_node]    all-ones between uses (duplicate-list overflow path)
     int bm_words;
+    int exp;                   // GG_BFS_EXPERIMENT: timing ablations (results are then WRONG): 1 = no cstart stores, 2 = synthetic targets instead of adjacency loads, 4 = no queue stores beyond level 1
+    unsigned long long *prof;  // GG_BFS_PROFILE: [16] shader-clock cycles of wave 0 per phase + event counts (NULL: off)
 };
 
+__device__ __forceinline__ int lanes_below(unsigned long long m) {  // popcount of m restricted to the lanes below this one
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+// What bounds the kernel (GG_BFS_PROFILE, rocprof SQ counters, GG_BFS_EXPERIMENT ablations): instruction issue.  The
+// adjacency loads return within 3 % of the time (replacing them by computed targets saves a quarter), stores cost
+// nothing; 16 wavefronts share 4 SIMDs and one scalar unit, and every edge costs a map step, a load, a bit test and
+// its share of the compaction.  So the per-edge path is kept short: 8 consecutive stream positions per thread whose
+// owner is found with ONE LDS read (a per-batch map position / 8 -> batch node) and then followed along, per-position
+// flags in bit masks, ballot + mbcnt compaction (no LDS shuffles), and chunks that discover nothing -- half of all
+// chunks, most of the last two levels -- leave after one barrier.  (Measured and not kept: lane-consecutive positions
+// for fully coalesced loads, and a per-wave node-start bitmap instead of the map -- same speed or slower: more
+// instructions per edge, and the loads were never the limit.)
 template <bool LDS_BM>
 __global__ __launch_bounds__(BFS_T) void bfs_order_kernel(const BfsArgs a) {
-    extern __shared__ uint32_t lds_bm[];          // [bm_words] when LDS_BM
-    __shared__ int32_t eoff[BFS_NB + 1];          // exclusive scan of the batch's degrees
-    __shared__ int64_t e0s[BFS_NB];               // first edge of each batch node
+    extern __shared__ uint32_t lds_bm[];           // [bm_words] when LDS_BM
+    __shared__ int32_t eoff[BFS_NB + 1];           // exclusive scan of the batch's degrees
+    __shared__ uint32_t e0s[BFS_NB];               // first edge of each batch node
+    __shared__ uint16_t emap[BFS_TE_CAP / BFS_U];  // batch node that owns stream position U * g
     __shared__ int32_t L_w[BFS_LCAP], L_pos[BFS_LCAP];
     __shared__ uint32_t winbits[BFS_CH / 32];
     __shared__ int32_t wave_cnt[BFS_WAVES], wave_tot[BFS_WAVES];
-    __shared__ int32_t Lcount, s_root, s_max;
+    __shared__ int32_t Lcount, s_root, s_max, s_cap, s_fb, s_any[3];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     uint32_t *const bm = LDS_BM ? lds_bm : a.gbitmap + (size_t)blockIdx.x * a.bm_words;
@@ -80,6 +98,7 @@ __global__ __launch_bounds__(BFS_T) void bfs_order_kernel(const BfsArgs a) {
             s_root = (int)atomicAdd(a.ticket, 1u);
             Lcount = 0;
             s_max = 0;
+            s_any[0] = s_any[1] = s_any[2] = 0;
         }
         for (int i = tid; i < BFS_CH / 32; i += BFS_T) winbits[i] = 0u;
         __syncthreads();
@@ -100,19 +119,38 @@ __global__ __launch_bounds__(BFS_T) void bfs_order_kernel(const BfsArgs a) {
         __syncthreads();
 
         int head = 0, tail = 1, level_end = 1, depth = 0;
+        // phase clocks of wave 0 (time to the barrier that ends the phase = what the whole workgroup waited for)
+        unsigned long long pc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        long long tprev = a.prof ? (long long)clock64() : 0;
+#define BFS_TICK(k)                                             \
+    if (a.prof) {                                               \
+        const long long tn = (long long)clock64();              \
+        pc[k] += (unsigned long long)(tn - tprev);              \
+        tprev = tn;                                             \
+    }
+        int pf_q = -1;          // queue index whose node this thread has prefetched for the NEXT batch
+        uint32_t pf_e0 = 0;
+        int pf_deg = 0;
+        unsigned chunk_no = 0;  // rotates the "any new node" flags
         while (head < tail) {
             if (head == level_end) {  // the next level starts: everything up to `tail` belongs to it
                 level_end = tail;
                 ++depth;
             }
-            const int nb = min(BFS_NB, level_end - head);
-            // ---- the batch's nodes: first edge and degree, exclusive scan of the degrees
-            int64_t e0 = 0;
+            const int navail = min(BFS_NB, level_end - head);
+            // ---- the batch's nodes: first edge and degree (prefetched during the previous batch when the queue was that far)
+            uint32_t e0 = 0;
             int deg = 0;
-            if (tid < nb) {
-                const int v = __hip_atomic_load(&order[head + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                e0 = a.rowptr[v];
-                deg = (int)(a.rowptr[v + 1] - e0);
+            if (tid < navail) {
+                if (pf_q == head + tid) {
+                    e0 = pf_e0;
+                    deg = pf_deg;
+                } else {
+                    const int v = __hip_atomic_load(&order[head + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int64_t b = a.rowptr[v];
+                    e0 = (uint32_t)b;
+                    deg = (int)(a.rowptr[v + 1] - b);
+                }
             }
             int inc = deg;
 #pragma unroll
@@ -121,124 +159,203 @@ __global__ __launch_bounds__(BFS_T) void bfs_order_kernel(const BfsArgs a) {
                 if (lane >= off) inc += o;
             }
             if (lane == 63) wave_tot[wv] = inc;
+            if (tid == 0) { s_cap = 0; s_fb = BFS_NB; }
             __syncthreads();
-            int pre = 0, TE = 0;
+            BFS_TICK(0)  // node info + scan
+            int pre = 0;
 #pragma unroll
-            for (int i = 0; i < BFS_WAVES; ++i) {
+            for (int i = 0; i < BFS_WAVES; ++i)
                 if (i < wv) pre += wave_tot[i];
-                TE += wave_tot[i];
-            }
-            eoff[tid] = pre + inc - deg;
-            e0s[tid] = e0;
-            if (tid == 0) eoff[nb] = TE;
+            const int incl = pre + inc, excl = incl - deg;
+            // batch = the longest prefix of the available nodes that has at most TE_CAP edges and no big node,
+            // or one big node alone
+            const bool capok = tid < navail && incl <= BFS_TE_CAP;
+            const unsigned long long capbal = __ballot(capok);
+            if (lane == 0 && capbal) atomicAdd(&s_cap, (int)__popcll(capbal));
+            if (tid < navail && deg > BFS_BIG) atomicMin(&s_fb, tid);
             __syncthreads();
+            const int fb = s_fb;
+            const bool single = fb == 0;
+            const int nb = single ? 1 : min(fb, s_cap);
+            if (tid < nb) {
+                eoff[tid] = excl;
+                e0s[tid] = e0;
+                if (tid == nb - 1) eoff[nb] = incl;
+                if (!single) {
+                    const int g1 = (incl + BFS_U - 1) / BFS_U;
+                    for (int g = (excl + BFS_U - 1) / BFS_U; g < g1; ++g) emap[g] = (uint16_t)tid;
+                }
+            }
+            // ---- prefetch the next batch's nodes (queue entries below `tail` are final)
+            {
+                const int q2 = head + nb + tid;
+                pf_q = -1;
+                if (q2 < tail) {
+                    const int v2 = __hip_atomic_load(&order[q2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int64_t b2 = a.rowptr[v2];
+                    pf_e0 = (uint32_t)b2;
+                    pf_deg = (int)(a.rowptr[v2 + 1] - b2);
+                    pf_q = q2;
+                }
+            }
+            __syncthreads();
+            BFS_TICK(1)  // batch formation, map fill, prefetch issue
+            pc[8] += 1;
+            const int TE = eoff[nb];
 
             // ---- the batch's edge stream, BFS_CH positions at a time
-            for (int P = 0; P < TE; P += BFS_CH) {
+            for (int P = 0; P < TE; P += BFS_CH, ++chunk_no) {
                 const int p0 = P + BFS_U * tid;
-                int w[BFS_U], q[BFS_U];
-                bool valid[BFS_U], last[BFS_U], cand[BFS_U], hw[BFS_U];
-                int idx = 0;
-                if (p0 < TE) {  // largest idx with eoff[idx] <= p0 (every batch node has at least one edge)
-                    int lo = 0, hi = nb;
-                    while (hi - lo > 1) {
-                        const int mid = (lo + hi) >> 1;
-                        if (eoff[mid] <= p0) lo = mid; else hi = mid;
-                    }
-                    idx = lo;
-                }
+                int w[BFS_U];
+                uint32_t vmask = 0, lmask = 0, cmask = 0;  // valid / last edge of its node / unseen target
+                int qfirst = 0;
+                if (p0 < TE) {
+                    int idx = single ? 0 : (int)emap[p0 / BFS_U];
+                    qfirst = idx;
+                    uint32_t e = e0s[idx] + (uint32_t)(p0 - eoff[idx]);
+                    int nextb = eoff[idx + 1];
 #pragma unroll
-                for (int j = 0; j < BFS_U; ++j) {
-                    const int p = p0 + j;
-                    valid[j] = p < TE;
-                    w[j] = 0; q[j] = 0; last[j] = false;
-                    if (valid[j]) {
-                        while (p >= eoff[idx + 1]) ++idx;
-                        q[j] = idx;
-                        w[j] = a.col[e0s[idx] + (p - eoff[idx])];
-                        last[j] = (p + 1 == eoff[idx + 1]);
+                    for (int j = 0; j < BFS_U; ++j) {
+                        const int p = p0 + j;
+                        w[j] = 0;
+                        if (p < TE) {
+                            if (p == nextb) {  // every batch node has at least one edge: at most one boundary per step
+                                ++idx;
+                                e = e0s[idx];
+                                nextb = eoff[idx + 1];
+                            }
+                            w[j] = (a.exp & 2) ? (int)((e * 2654435761u) % (uint32_t)a.n_node) : a.col[e];
+                            ++e;
+                            vmask |= 1u << j;
+                            if (p + 1 == nextb) lmask |= 1u << j;
+                        }
                     }
-                }
 #pragma unroll
-                for (int j = 0; j < BFS_U; ++j) cand[j] = valid[j] && !seen(w[j]);
+                    for (int j = 0; j < BFS_U; ++j)
+                        if (((vmask >> j) & 1u) && !seen(w[j])) cmask |= 1u << j;
+                }
+                const int slot = (int)(chunk_no % 3u);
+                if (__ballot(cmask != 0u) && lane == 0) s_any[slot] = 1;
                 __syncthreads();  // every test before any set: a later edge must not hide an earlier one
+                BFS_TICK(2)  // map, adjacency loads, tests
+                pc[9] += 1;
+                if (tid == 0) s_any[(slot + 2) % 3] = 0;  // the previous chunk's flag: everyone is past reading it
+                if (!s_any[slot]) {
+                    // nothing new in this chunk: every node that ends here has its children end at `tail`
+                    uint32_t lm = lmask;
+                    while (lm) {
+                        const int j = __ffs(lm) - 1;
+                        lm &= lm - 1;
+                        if (!(a.exp & 1)) cstart[head + qfirst + __popc(lmask & ((1u << j) - 1u)) + 1] = tail;
+                    }
+                    BFS_TICK(3)  // chunk without new nodes
+                    pc[10] += 1;
+                    continue;
+                }
+                uint32_t hmask = 0;  // this edge cleared -> set the bit (the hardware winner among the chunk's edges to its node)
 #pragma unroll
                 for (int j = 0; j < BFS_U; ++j) {
-                    hw[j] = false;
-                    if (cand[j]) {
+                    if ((cmask >> j) & 1u) {
                         const uint32_t bit = 1u << (w[j] & 31);
                         const uint32_t old = atomicOr(&bm[w[j] >> 5], bit);
                         if (old & bit) {  // another edge of this chunk reaches the same new node
                             const int li = atomicAdd(&Lcount, 1);
                             if (li < BFS_LCAP) { L_w[li] = w[j]; L_pos[li] = p0 + j - P; }
                         } else {
-                            hw[j] = true;
+                            hmask |= 1u << j;
                         }
                     }
                 }
                 __syncthreads();
+                BFS_TICK(4)  // claim
                 const int nL = Lcount;
-                if (nL <= BFS_LCAP) {
+                if (nL > 0) pc[11] += 1;
+                uint32_t mine = hmask;  // positions that append their target; without in-chunk duplicates: the winners themselves
+                if (nL > 0) {
+                    if (nL <= BFS_LCAP) {
+                        // the sequential BFS appends a node at the FIRST edge that reaches it: smallest position among the
+                        // hardware winner's and the duplicates'
+                        if (hmask) {
+                            int eff[BFS_U];
 #pragma unroll
-                    for (int j = 0; j < BFS_U; ++j) {
-                        if (hw[j]) {
-                            int eff = p0 + j - P;
-                            for (int i = 0; i < nL; ++i)
-                                if (L_w[i] == w[j]) eff = min(eff, L_pos[i]);
-                            atomicOr(&winbits[eff >> 5], 1u << (eff & 31));
+                            for (int j = 0; j < BFS_U; ++j) eff[j] = p0 + j - P;
+                            for (int i = 0; i < nL; ++i) {
+                                const int lw = L_w[i], lp = L_pos[i];
+#pragma unroll
+                                for (int j = 0; j < BFS_U; ++j)
+                                    if (lw == w[j]) eff[j] = min(eff[j], lp);
+                            }
+#pragma unroll
+                            for (int j = 0; j < BFS_U; ++j)
+                                if ((hmask >> j) & 1u) atomicOr(&winbits[eff[j] >> 5], 1u << (eff[j] & 31));
                         }
+                    } else {
+                        // too many in-chunk duplicates for the list: smallest position per node through the key array
+#pragma unroll
+                        for (int j = 0; j < BFS_U; ++j)
+                            if ((cmask >> j) & 1u) atomicMin(&gkey[w[j]], (uint32_t)(p0 + j - P));
+                        __syncthreads();
+#pragma unroll
+                        for (int j = 0; j < BFS_U; ++j)
+                            if (((cmask >> j) & 1u) && atomicMin(&gkey[w[j]], 0xFFFFFFFFu) == (uint32_t)(p0 + j - P))
+                                atomicOr(&winbits[(p0 + j - P) >> 5], 1u << ((p0 + j - P) & 31));
+                        __syncthreads();
+#pragma unroll
+                        for (int j = 0; j < BFS_U; ++j)
+                            if ((cmask >> j) & 1u) __hip_atomic_store(&gkey[w[j]], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
-                } else {
-                    // too many in-chunk duplicates for the list: smallest position per node through the key array
-#pragma unroll
-                    for (int j = 0; j < BFS_U; ++j)
-                        if (cand[j]) atomicMin(&gkey[w[j]], (uint32_t)(p0 + j - P));
                     __syncthreads();
-#pragma unroll
-                    for (int j = 0; j < BFS_U; ++j)
-                        if (cand[j] && atomicMin(&gkey[w[j]], 0xFFFFFFFFu) == (uint32_t)(p0 + j - P))
-                            atomicOr(&winbits[(p0 + j - P) >> 5], 1u << ((p0 + j - P) & 31));
-                    __syncthreads();
-#pragma unroll
-                    for (int j = 0; j < BFS_U; ++j)
-                        if (cand[j]) __hip_atomic_store(&gkey[w[j]], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    BFS_TICK(5)  // duplicate resolution
+                    mine = (winbits[(BFS_U * tid) >> 5] >> ((BFS_U * tid) & 31)) & ((1u << BFS_U) - 1u);
                 }
-                __syncthreads();
-                // ---- the marked positions, in stream order, are the next queue entries
-                const uint32_t mine = (winbits[(BFS_U * tid) >> 5] >> ((BFS_U * tid) & 31)) & ((1u << BFS_U) - 1u);
-                const int cnt = __popc(mine);
-                int cinc = cnt;
+                // ---- the appending positions, in stream order, are the next queue entries
+                int before = 0, wtotal = 0;
 #pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int o = __shfl_up(cinc, off, 64);
-                    if (lane >= off) cinc += o;
+                for (int j = 0; j < BFS_U; ++j) {
+                    const unsigned long long bal = __ballot((mine >> j) & 1u);
+                    before += lanes_below(bal);
+                    wtotal += (int)__popcll(bal);
                 }
-                if (lane == 63) wave_cnt[wv] = cinc;
+                if (lane == 0) wave_cnt[wv] = wtotal;
                 __syncthreads();
+                BFS_TICK(6)  // in-wave compaction
                 int wpre = 0, total = 0;
 #pragma unroll
                 for (int i = 0; i < BFS_WAVES; ++i) {
-                    if (i < wv) wpre += wave_cnt[i];
-                    total += wave_cnt[i];
+                    const int c = wave_cnt[i];
+                    if (i < wv) wpre += c;
+                    total += c;
                 }
-                int rank = tail + wpre + cinc - cnt;
+                int rank = tail + wpre + before;
+                int q = head + qfirst + 1;
+                if (mine | lmask) {
 #pragma unroll
-                for (int j = 0; j < BFS_U; ++j) {
-                    if ((mine >> j) & 1u) {
-                        if (rank < expect) order[rank] = w[j];
-                        ++rank;
+                    for (int j = 0; j < BFS_U; ++j) {
+                        if ((mine >> j) & 1u) {
+                            if (rank < expect) order[rank] = w[j];
+                            ++rank;
+                        }
+                        if ((lmask >> j) & 1u) {  // children of this queue node end here
+                            if (!(a.exp & 1)) cstart[q] = rank;
+                            ++q;
+                        }
                     }
-                    if (last[j]) cstart[head + q[j] + 1] = rank;  // children of this queue node end here
                 }
                 tail += total;
-                if (tid < BFS_CH / 32) winbits[tid] = 0u;  // everyone has read its bits (barrier above); next set is two barriers away
-                if (tid == 0) Lcount = 0;
+                if (nL > 0) {  // everyone has read its bits (barrier above); the next set is two barriers away
+                    if (tid < BFS_CH / 32) winbits[tid] = 0u;
+                    if (tid == 0) Lcount = 0;
+                }
+                BFS_TICK(7)  // queue / cstart stores issued
                 if (tail > expect) break;  // more nodes than the component sweep promised: the graph is not the one set (uniform)
             }
             if (tail > expect) break;
             head += nb;
             __syncthreads();
         }
+        if (a.prof && tid == 0)
+            for (int k = 0; k < 12; ++k) atomicAdd(&a.prof[k], pc[k]);
+#undef BFS_TICK
 
         // ---- per-root results: node count check, depth, longest list (1 + most children)
         int mc = 0;
@@ -287,7 +404,7 @@ extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t 
     auto cleanup = [&]() { gkey.release(); gbm.release(); misc.release(); };
     hipError_t e = gkey.reserve(sizeof(uint32_t) * (size_t)grid * n);
     if (e == hipSuccess && !lds_bm) e = gbm.reserve(sizeof(uint32_t) * (size_t)grid * bm_words);
-    if (e == hipSuccess) e = misc.reserve(sizeof(int32_t) * 8);
+    if (e == hipSuccess) e = misc.reserve(sizeof(int32_t) * 8 + sizeof(unsigned long long) * 16);
     if (e != hipSuccess) { cleanup(); return fail(ctx, GG_ENOMEM, "gg_build_trees_device: scratch: %s", hipGetErrorString(e)); }
     BfsArgs a{};
     a.n_node = n;
@@ -303,7 +420,10 @@ extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t 
     a.gbitmap = gbm.as<uint32_t>();
     a.gkey = gkey.as<uint32_t>();
     a.bm_words = bm_words;
-    (void)hipMemsetAsync(misc.p, 0, sizeof(int32_t) * 8, ctx->stream);
+    const bool prof = getenv("GG_BFS_PROFILE") != nullptr;
+    a.exp = getenv("GG_BFS_EXPERIMENT") ? atoi(getenv("GG_BFS_EXPERIMENT")) : 0;
+    a.prof = prof ? (unsigned long long *)(misc.as<int32_t>() + 8) : nullptr;
+    (void)hipMemsetAsync(misc.p, 0, sizeof(int32_t) * 8 + sizeof(unsigned long long) * 16, ctx->stream);
     (void)hipMemsetAsync(gkey.p, 0xFF, sizeof(uint32_t) * (size_t)grid * n, ctx->stream);
     (void)hipEventRecord(ctx->ev0, ctx->stream);
     if (lds_bm) {
@@ -319,11 +439,23 @@ extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t 
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(stats, a.stats, sizeof(stats), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && prof) {
+        unsigned long long pc[16];
+        if (hipMemcpy(pc, a.prof, sizeof(pc), hipMemcpyDeviceToHost) == hipSuccess) {
+            const char *names[8] = {"nodes+scan", "batch form", "map+load+test", "empty chunk", "claim", "dup resolve", "compaction", "stores"};
+            double tot = 0;
+            for (int k = 0; k < 8; ++k) tot += (double)pc[k];
+            fprintf(stderr, "[bfs profile] %d roots, grid %d: batches %llu chunks %llu (empty %llu, with dups %llu); wave-0 shader-clock share:", n_roots, grid, pc[8], pc[9], pc[10], pc[11]);
+            for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.1f%%", names[k], 100.0 * (double)pc[k] / (tot > 0 ? tot : 1));
+            fprintf(stderr, "; cycles per chunk %.0f\n", tot / (double)(pc[9] ? pc[9] : 1));
+        }
+    }
     float ms = 0.f;
     if (e == hipSuccess) (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     cleanup();
     if (e != hipSuccess) return fail(ctx, GG_EHIP, "gg_build_trees_device: %s", hipGetErrorString(e));
-    GG_CHECK(ctx, stats[2] == 0, GG_EINVAL, "gg_build_trees_device: a BFS reached a different number of nodes than the component sweep of the graph");
+    if (a.exp) fprintf(stderr, "[bfs experiment %d] kernel %.1f ms for %d roots (results invalid)\n", a.exp, ms, n_roots);
+    GG_CHECK(ctx, stats[2] == 0 || a.exp, GG_EINVAL, "gg_build_trees_device: a BFS reached a different number of nodes than the component sweep of the graph");
     ctx->tree_max_depth = stats[0];
     ctx->tree_max_list = stats[1];
     ctx->ctr.bfs_kernel_ms += ms;

@@ -156,6 +156,7 @@ int gg_comm_barrier(gg_ctx *ctx) {
         GG_NCCL(ctx, g_rccl.AllReduce(w, w, 1, NCCL_FLOAT32, NCCL_SUM, ctx->comm, ctx->stream));
     }
     GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    harvest_timings(ctx);
     return GG_OK;
 }
 

@@ -173,8 +173,9 @@ int gg::walk_finalize(gg_ctx *ctx, bool *retried) {
     }
     const int64_t total = ctx->w_total;
     unsigned long long *c = ctx->h_pin;  // the launch's counter words, one asynchronous read-back into pinned memory
-    GG_HIP(ctx, hipMemcpyAsync(c, ctx->dev_ctr, sizeof(unsigned long long) * 392, hipMemcpyDeviceToHost, ctx->stream));
+    GG_HIP(ctx, hipMemcpyAsync(c, ctx->dev_ctr, sizeof(unsigned long long) * 456, hipMemcpyDeviceToHost, ctx->stream));
     GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    harvest_timings(ctx);
     if (c[3] == 2ull) {
         // nothing the overflowed launch wrote or counted is final (the D-mode post-pass is gated by the same flag,
         // the counter words are zeroed again by the new launch)
@@ -182,7 +183,7 @@ int gg::walk_finalize(gg_ctx *ctx, bool *retried) {
         int rc = launch_and_join(ctx, ctx->w_nslots, total, ctx->w_args.for_d, ctx->w_args.seed, ctx->w_args.stream, ctx->w_stride);
         ctx->walk_force_sized = false;
         if (rc != GG_OK) return rc;
-        GG_HIP(ctx, hipMemcpyAsync(c, ctx->dev_ctr, sizeof(unsigned long long) * 392, hipMemcpyDeviceToHost, ctx->stream));
+        GG_HIP(ctx, hipMemcpyAsync(c, ctx->dev_ctr, sizeof(unsigned long long) * 456, hipMemcpyDeviceToHost, ctx->stream));
         GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (retried) *retried = true;
     }
@@ -209,7 +210,12 @@ int gg::walk_finalize(gg_ctx *ctx, bool *retried) {
                 fprintf(stderr, "[walk] for_d=%d level %d alive %llu chunks %llu big %llu score %.1f us\n", ctx->w_args.for_d, i,
                         c[8 + i], c[136 + i], c[72 + i], lms * 1e3);
         }
-        if (ctx->lv_ev_used) ctx->ctr.score_rows += (int64_t)(rows - c[5]);  // rows of the timed score launches
+        if (ctx->lv_ev_used) {
+            ctx->ctr.score_rows += (int64_t)(rows - c[5]);  // rows of the timed score launches
+            unsigned long long dists = 0;
+            for (int i = 0; i < 64; ++i) dists += c[392 + i];
+            ctx->ctr.score_dists += (int64_t)dists;
+        }
     }
     if (c[3]) return fail(ctx, GG_ECAPACITY, "walk: a path needed more than stride=%d entries", ctx->w_stride);
     if (c[6]) return fail(ctx, GG_EINVAL, "walk: non-finite generator scores (a softmax had total weight 0)");
@@ -345,6 +351,9 @@ int gg_destroy(gg_ctx *ctx) {
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : ctx->lv_ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto &tr : ctx->tm_ev)
+        for (hipEvent_t e : tr)
+            if (e) (void)hipEventDestroy(e);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     for (hipEvent_t e : {ctx->ev_walk_done, ctx->ev_gen_pass, ctx->ev_main_mark})
         if (e) (void)hipEventDestroy(e);
@@ -380,6 +389,12 @@ int gg_set_graph_csr(gg_ctx *ctx, const int64_t *rowptr, const int32_t *col) {
     ctx->h_rowptr.assign(rowptr, rowptr + n + 1);
     ctx->h_col.assign(col, col + nnz);
     ctx->h_comp_size.clear();
+    // fingerprint of the adjacency (tree cache files are only valid for the graph they were built from): FNV-1a over 8-byte words
+    uint64_t h = 1469598103934665603ull;
+    for (int v = 0; v <= n; ++v) h = (h ^ (uint64_t)rowptr[v]) * 1099511628211ull;
+    for (int64_t e = 0; e + 1 < nnz; e += 2) h = (h ^ ((uint64_t)(uint32_t)col[e] | ((uint64_t)(uint32_t)col[e + 1] << 32))) * 1099511628211ull;
+    if (nnz & 1) h = (h ^ (uint64_t)(uint32_t)col[nnz - 1]) * 1099511628211ull;
+    ctx->g_hash = h;
     return GG_OK;
 }
 
@@ -485,6 +500,12 @@ int gg_tree_info(const gg_ctx *ctx, int32_t *n_roots, int64_t *n_entries, int32_
     return GG_OK;
 }
 
+int gg_tree_roots(const gg_ctx *ctx, int32_t *roots) {
+    if (!ctx || !roots) return fail(nullptr, GG_EINVAL, "gg_tree_roots: NULL argument");
+    for (int r = 0; r < ctx->n_tree_roots; ++r) roots[r] = ctx->h_troot[r];
+    return GG_OK;
+}
+
 // Download the resident trees in the reference's shape, including the D-mode mutations (removed father entries = -1).
 int gg_get_trees(gg_ctx *ctx, int32_t *off, int32_t *nbr, int64_t *nbr_base) {
     if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
@@ -516,6 +537,109 @@ int gg_get_trees(gg_ctx *ctx, int32_t *off, int32_t *nbr, int64_t *nbr_base) {
     for (int t = 1; t < nt; ++t) th.emplace_back(work);
     work();
     for (auto &t : th) t.join();
+    return GG_OK;
+}
+
+// ---- tree cache (replaces the pickle of graph_gan.py:31-46).  Flat little-endian file:
+//   {magic "GGTR", version 1, n_node i32, n_roots i32, nnz i64, graph fingerprint u64, max_depth i32, max_list i32, nodes i64}
+//   roots i32[n_roots], base i64[n_roots + 1], order i32[nodes], cstart i32[nodes + n_roots]
+// i.e. the resident BFS-order arrays as they are (no conversion on either side).  Like the reference's cache it holds
+// the trees as built: the in-place D-mode mutations are not part of it (the pickle is written before any, :45).
+namespace {
+struct TreeHeader {
+    char magic[4];
+    int32_t version, n_node, n_roots;
+    int64_t nnz;
+    uint64_t graph_hash;
+    int32_t max_depth, max_list;
+    int64_t nodes;
+};
+
+int stream_dev(gg_ctx *ctx, FILE *f, int32_t *dev, size_t count, bool save) {
+    const size_t step = 64u << 20;  // entries per staging round (256 MB)
+    std::vector<int32_t> tmp(std::min(count, step));
+    for (size_t o = 0; o < count; o += step) {
+        const size_t n = std::min(step, count - o);
+        if (save) {
+            GG_HIP(ctx, hipMemcpy(tmp.data(), dev + o, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+            if (fwrite(tmp.data(), sizeof(int32_t), n, f) != n) return gg::fail(ctx, GG_EIO, "tree cache: short write");
+        } else {
+            if (fread(tmp.data(), sizeof(int32_t), n, f) != n) return gg::fail(ctx, GG_EIO, "tree cache: short read");
+            GG_HIP(ctx, hipMemcpy(dev + o, tmp.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+        }
+    }
+    return GG_OK;
+}
+}  // namespace
+
+int gg_save_trees(gg_ctx *ctx, const char *path) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    GG_CHECK(ctx, path, GG_EINVAL, "gg_save_trees: path is NULL");
+    GG_CHECK(ctx, ctx->n_tree_roots > 0, GG_EINVAL, "gg_save_trees: no trees loaded");
+    GG_HIP(ctx, hipSetDevice(ctx->device));
+    GG_HIP(ctx, hipDeviceSynchronize());
+    const int R = ctx->n_tree_roots;
+    const std::string tmp_path = std::string(path) + ".tmp";
+    FILE *f = fopen(tmp_path.c_str(), "wb");
+    if (!f) return fail(ctx, GG_EIO, "gg_save_trees: cannot open %s", tmp_path.c_str());
+    TreeHeader h{{'G', 'G', 'T', 'R'}, 1, ctx->n_node, R, ctx->g_nnz, ctx->g_hash, ctx->tree_max_depth, ctx->tree_max_list, ctx->tree_nodes};
+    int rc = GG_OK;
+    if (fwrite(&h, sizeof(h), 1, f) != 1 || fwrite(ctx->h_troot.data(), sizeof(int32_t), R, f) != (size_t)R ||
+        fwrite(ctx->h_tbase.data(), sizeof(int64_t), R + 1, f) != (size_t)R + 1)
+        rc = fail(ctx, GG_EIO, "gg_save_trees: short write");
+    if (rc == GG_OK) rc = stream_dev(ctx, f, ctx->t_order, (size_t)ctx->tree_nodes, true);
+    if (rc == GG_OK) rc = stream_dev(ctx, f, ctx->t_cstart, (size_t)ctx->tree_nodes + R, true);
+    if (rc == GG_OK && (fflush(f) != 0 || fsync(fileno(f)) != 0)) rc = fail(ctx, GG_EIO, "gg_save_trees: cannot flush %s", tmp_path.c_str());
+    fclose(f);
+    if (rc == GG_OK && rename(tmp_path.c_str(), path) != 0) rc = fail(ctx, GG_EIO, "gg_save_trees: cannot rename %s to %s", tmp_path.c_str(), path);
+    if (rc != GG_OK) (void)remove(tmp_path.c_str());
+    return rc;
+}
+
+int gg_load_trees(gg_ctx *ctx, const char *path) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    GG_CHECK(ctx, path, GG_EINVAL, "gg_load_trees: path is NULL");
+    GG_CHECK(ctx, !ctx->h_rowptr.empty(), GG_EINVAL, "gg_load_trees: call gg_set_graph_csr first");
+    GG_HIP(ctx, hipSetDevice(ctx->device));
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(ctx, GG_EIO, "gg_load_trees: cannot open %s", path);
+    TreeHeader h;
+    int rc = GG_OK;
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "GGTR", 4) != 0 || h.version != 1)
+        rc = fail(ctx, GG_EIO, "gg_load_trees: %s is not a GGTR v1 file", path);
+    else if (h.n_node != ctx->n_node || h.nnz != ctx->g_nnz || h.graph_hash != ctx->g_hash)
+        rc = fail(ctx, GG_EINVAL, "gg_load_trees: %s was built from another graph (%d nodes, %lld adjacency entries)", path, h.n_node, (long long)h.nnz);
+    else if (h.n_roots <= 0 || h.nodes < h.n_roots) rc = fail(ctx, GG_EIO, "gg_load_trees: %s: bad header", path);
+    std::vector<int32_t> roots;
+    std::vector<int64_t> base, counts, kids;
+    if (rc == GG_OK) {
+        struct stat st;
+        const size_t expect = sizeof(h) + sizeof(int32_t) * (size_t)h.n_roots + sizeof(int64_t) * ((size_t)h.n_roots + 1) +
+                              sizeof(int32_t) * (2 * (size_t)h.nodes + (size_t)h.n_roots);
+        if (fstat(fileno(f), &st) != 0 || (size_t)st.st_size != expect)
+            rc = fail(ctx, GG_EIO, "gg_load_trees: %s is truncated (%lld bytes, expected %zu)", path, (long long)st.st_size, expect);
+    }
+    if (rc == GG_OK) {
+        roots.resize(h.n_roots);
+        base.resize((size_t)h.n_roots + 1);
+        if (fread(roots.data(), sizeof(int32_t), h.n_roots, f) != (size_t)h.n_roots || fread(base.data(), sizeof(int64_t), (size_t)h.n_roots + 1, f) != (size_t)h.n_roots + 1)
+            rc = fail(ctx, GG_EIO, "gg_load_trees: short read");
+    }
+    if (rc == GG_OK) {
+        counts.resize(h.n_roots);
+        for (int r = 0; r < h.n_roots && rc == GG_OK; ++r) {
+            counts[r] = base[r + 1] - base[r];
+            if (roots[r] < 0 || roots[r] >= ctx->n_node || counts[r] < 1 || counts[r] > ctx->n_node) rc = fail(ctx, GG_EIO, "gg_load_trees: %s: bad root table", path);
+        }
+        if (rc == GG_OK && (base[0] != 0 || base[h.n_roots] != h.nodes)) rc = fail(ctx, GG_EIO, "gg_load_trees: %s: bad root table", path);
+    }
+    if (rc == GG_OK) rc = alloc_trees(ctx, roots.data(), h.n_roots, counts.data(), nullptr);
+    if (rc == GG_OK) rc = stream_dev(ctx, f, ctx->t_order, (size_t)h.nodes, false);
+    if (rc == GG_OK) rc = stream_dev(ctx, f, ctx->t_cstart, (size_t)h.nodes + h.n_roots, false);
+    fclose(f);
+    if (rc != GG_OK) return rc;
+    ctx->tree_max_depth = h.max_depth;
+    ctx->tree_max_list = h.max_list;
     return GG_OK;
 }
 
@@ -580,7 +704,18 @@ int gg_set_bias(gg_ctx *ctx, int32_t which, const float *bias) { return table_io
 
 int gg_get_counters(gg_ctx *ctx, gg_counters *out) {
     if (!ctx || !out) return fail(ctx, GG_EINVAL, "gg_get_counters: NULL argument");
+    if (!ctx->tm_pending.empty()) {  // per-kernel timings still in flight: wait for them
+        GG_HIP(ctx, hipSetDevice(ctx->device));
+        GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        harvest_timings(ctx);
+    }
     *out = ctx->ctr;
+    return GG_OK;
+}
+
+int gg_set_profiling_solo(gg_ctx *ctx, int32_t solo) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    ctx->profile_solo = solo != 0;
     return GG_OK;
 }
 
@@ -596,10 +731,53 @@ int gg_synchronize(gg_ctx *ctx) {
     if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
     GG_HIP(ctx, hipSetDevice(ctx->device));
     GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    harvest_timings(ctx);
     return GG_OK;
 }
 
 }  // extern "C"
+
+// Event triples {before the gradient / reward kernel, between gradient and optimizer, after} recorded by profiled
+// prepare / pass calls; folded into the counters once the stream has passed them (called after host synchronisations).
+void gg::harvest_timings(gg_ctx *ctx) {
+    size_t keep = 0;
+    for (size_t i = 0; i < ctx->tm_pending.size(); ++i) {
+        const gg_ctx::PendingTiming t = ctx->tm_pending[i];
+        hipEvent_t *ev = ctx->tm_ev[t.slot];
+        if (hipEventQuery(ev[2]) != hipSuccess) {
+            ctx->tm_pending[keep++] = t;
+            continue;
+        }
+        float a = 0.f, b = 0.f;
+        (void)hipEventElapsedTime(&a, ev[0], ev[1]);
+        (void)hipEventElapsedTime(&b, ev[1], ev[2]);
+        const int64_t rows = t.has_rows ? (int64_t)ctx->h_pin[gg_ctx::H_ROWS + t.slot] : (int64_t)ctx->n_node;
+        if (t.kind == 0) {
+            ctx->ctr.reward_kernel_ms += a + b;
+            ctx->ctr.reward_pairs_timed += t.units;
+        } else if (t.kind == 1) {
+            ctx->ctr.d_grad_ms += a; ctx->ctr.d_opt_ms += b;
+            ctx->ctr.d_pairs_timed += t.units; ctx->ctr.d_rows_timed += rows; ctx->ctr.d_passes_timed += 1;
+        } else {
+            ctx->ctr.g_grad_ms += a; ctx->ctr.g_opt_ms += b;
+            ctx->ctr.g_pairs_timed += t.units; ctx->ctr.g_rows_timed += rows; ctx->ctr.g_passes_timed += 1;
+        }
+    }
+    ctx->tm_pending.resize(keep);
+}
+
+// A free event triple for a profiled call, or -1 (all in flight).
+int gg::timing_slot(gg_ctx *ctx) {
+    for (int s = 0; s < 8; ++s) {
+        bool busy = false;
+        for (const auto &t : ctx->tm_pending) busy |= t.slot == s;
+        if (busy) continue;
+        for (int k = 0; k < 3; ++k)
+            if (!ctx->tm_ev[s][k] && hipEventCreate(&ctx->tm_ev[s][k]) != hipSuccess) return -1;
+        return s;
+    }
+    return -1;
+}
 
 // ---- tf.train.Saver replacement (graph_gan.py:55,124-127,137-138).  Flat binary:
 // header {magic "GGST", version, n_node, n_emb, ld, optimizer} then for gen, dis:

@@ -79,6 +79,7 @@ struct gg_ctx {
     int64_t *g_rowptr = nullptr;
     int32_t *g_col = nullptr;
     int64_t g_nnz = 0;
+    uint64_t g_hash = 0;  // fingerprint of the adjacency (tree cache validation)
     std::vector<int64_t> h_rowptr;  // host copies (tree builder, degrees)
     std::vector<int32_t> h_col;
 
@@ -118,16 +119,24 @@ struct gg_ctx {
     int32_t w_stride = 0, w_nslots = 0;
     struct { int32_t for_d; uint64_t seed; uint32_t stream; } w_args{};
     std::vector<int64_t> h_walk_ptr;
-    // pinned host mirror: [0, 392) the launch's device counters, [H_TOTAL] the row / pair count of a prepare call --
+    // pinned host mirror: [0, 456) the launch's device counters, [H_TOTAL] the row / pair count of a prepare call --
     // both arrive with asynchronous copies behind the kernels and ONE stream synchronisation (pageable destinations
     // would make every copy its own host round trip)
-    static constexpr int H_TOTAL = 392;
+    static constexpr int H_TOTAL = 500;
+    static constexpr int H_ROWS = 480;    // [H_ROWS + k]: touched-row count of pending pass timing k (copied behind its optimizer kernel)
     unsigned long long *h_pin = nullptr;  // [512], hipHostMalloc
     // profiling (gg_set_profiling): HIP events around every profile_every-th walk call; 1 = every call and every pass
     // (passes then wait for their events), 0 = never; an event pair costs ~6 us of stream bubble on each side
     int32_t profile_every = 1;
     int64_t walk_call_index = 0;
     bool walk_timed = false;  // the launch in flight carries events
+    bool profile_solo = true; // profiled side-stream walks wait for the main stream first (measured alone)
+    // per-kernel timing of prepare / pass calls: event triples recorded on `stream`, harvested at the next host sync
+    struct PendingTiming { int kind; int64_t units; int slot; bool has_rows; };  // kind 0 = reward, 1 = D pass, 2 = G pass
+    hipEvent_t tm_ev[8][3] = {};
+    std::vector<PendingTiming> tm_pending;
+    int64_t pass_call_index[2] = {0, 0};
+    int tm_cur = -1;  // event triple of the pass being enqueued (steps.hip records its middle event behind the gradient kernel)
 
     // prepared data
     gg::DevBuf d_center, d_neighbor, d_label, d_cnt, d_ptr;
@@ -193,6 +202,8 @@ int32_t lists_to_order(int32_t n, int32_t root, const int32_t *off, const int32_
 int walk_launch_async(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, int32_t uniform_walks, int32_t n_slots,
                       int32_t for_d, uint64_t seed, uint32_t stream, int32_t stride, bool side_stream = false);
 int walk_finalize(gg_ctx *ctx, bool *retried);
+int timing_slot(gg_ctx *ctx);
+void harvest_timings(gg_ctx *ctx);  // after a synchronisation of ctx->stream: fold finished event triples into the counters
 int walk_resident(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, int32_t uniform_walks, int32_t n_slots,
                   int32_t for_d, uint64_t seed, uint32_t stream, int32_t stride);
 int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int for_d, uint64_t seed, uint32_t stream,

@@ -289,8 +289,16 @@ static int enqueue_g_pairs(gg_ctx *ctx, int64_t nw, int64_t cap) {
                        ctx->g_node1.as<int32_t>(), ctx->g_node2.as<int32_t>(), ctx->dev_ctr + 3);
     // rewards for the device-side pair count (the host does not know it yet)
     const Model &D = ctx->model[1];
+    const int ts = ctx->walk_timed ? timing_slot(ctx) : -1;  // profiled call: HIP events around the reward kernel
+    if (ts >= 0) GG_HIP(ctx, hipEventRecord(ctx->tm_ev[ts][0], ctx->stream));
     hipLaunchKernelGGL(pair_reward_kernel, dim3(256 * 16), dim3(256), 0, ctx->stream, D.E, D.b, ctx->ld, ctx->g_node1.as<int32_t>(),
                        ctx->g_node2.as<int32_t>(), (int64_t)-1, ctx->g_ptr.as<int64_t>() + nw, ctx->g_reward.as<float>());
+    if (ts >= 0) {
+        GG_HIP(ctx, hipEventRecord(ctx->tm_ev[ts][1], ctx->stream));
+        GG_HIP(ctx, hipEventRecord(ctx->tm_ev[ts][2], ctx->stream));
+        // the pair count arrives with the call's one synchronisation: units are filled in by gg_prepare_g
+        ctx->tm_pending.push_back({0, 0, ts, false});
+    }
     GG_HIP(ctx, hipMemcpyAsync(ctx->h_pin + gg_ctx::H_TOTAL, ctx->g_ptr.as<int64_t>() + nw, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     GG_HIP(ctx, hipGetLastError());
     (void)cap;
@@ -329,6 +337,7 @@ int gg_prepare_g(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, int32_t n_s
         }
         ctx->g_pairs = (int64_t)ctx->h_pin[gg_ctx::H_TOTAL];
         ctx->ctr.reward_pairs += ctx->g_pairs;
+        if (ctx->walk_timed) ctx->ctr.reward_pairs_timed += ctx->g_pairs;  // its kernel time is folded in by harvest_timings
         ctx->g_paths_valid = true;
     }
     if (root_status && n_slots) GG_HIP(ctx, hipMemcpy(root_status, ctx->w_status.p, sizeof(int32_t) * n_slots, hipMemcpyDeviceToHost));

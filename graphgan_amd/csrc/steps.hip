@@ -519,6 +519,7 @@ int run_step(gg_ctx *ctx, int which, const int32_t *d_u, const int32_t *d_v, con
     else if (nf <= 8) hipLaunchKernelGGL(pair_grad_kernel<8>, dim3(blocks), dim3(256), 0, ctx->stream, s);
     else if (nf <= 16) hipLaunchKernelGGL(pair_grad_kernel<16>, dim3(blocks), dim3(256), 0, ctx->stream, s);
     else hipLaunchKernelGGL(pair_grad_kernel<32>, dim3(blocks), dim3(256), 0, ctx->stream, s);
+    if (ctx->tm_cur >= 0) GG_HIP(ctx, hipEventRecord(ctx->tm_ev[ctx->tm_cur][1], ctx->stream));  // gradient | exchange + optimizer
 
     return apply_optimizer(ctx, which, n);
 }
@@ -550,6 +551,7 @@ int run_path_step(gg_ctx *ctx) {
     if (nf <= 4) hipLaunchKernelGGL(path_grad_kernel<4>, dim3(blocks), dim3(256), 0, ctx->stream, p);
     else if (nf <= 8) hipLaunchKernelGGL(path_grad_kernel<8>, dim3(blocks), dim3(256), 0, ctx->stream, p);
     else hipLaunchKernelGGL(path_grad_kernel<16>, dim3(blocks), dim3(256), 0, ctx->stream, p);
+    if (ctx->tm_cur >= 0) GG_HIP(ctx, hipEventRecord(ctx->tm_ev[ctx->tm_cur][1], ctx->stream));  // gradient | exchange + optimizer
     return apply_optimizer(ctx, 0, n);
 }
 
@@ -723,9 +725,16 @@ static int run_pass(gg_ctx *ctx, int which, const int64_t *starts, int64_t n_bat
     const bool timed = ctx->profile_every == 1;  // gg_set_profiling: otherwise no events and no wait
     if (timed) GG_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     const bool whole = n_batches == 1 && starts[0] == 0 && batch_size >= rows && rows > 0;
+    // per-kernel timing (gradient kernel | exchange + optimizer kernel) of every profile_every-th fused pass; the events
+    // are read at the next host synchronisation (harvest_timings), the pass itself does not wait for them
+    ctx->tm_cur = -1;
+    if (whole && ctx->profile_every > 0 && (ctx->pass_call_index[which]++ % ctx->profile_every) == 0 && !ctx->deterministic) {
+        ctx->tm_cur = timing_slot(ctx);
+        if (ctx->tm_cur >= 0) GG_HIP(ctx, hipEventRecord(ctx->tm_ev[ctx->tm_cur][0], ctx->stream));
+    }
     if (which == 0 && whole && ctx->g_paths_valid && ctx->cfg.window_size <= 2 && ctx->ld <= 256 && !getenv("GG_NO_PATH_GRAD")) {
         int rc = run_path_step(ctx);
-        if (rc != GG_OK) return rc;
+        if (rc != GG_OK) { ctx->tm_cur = -1; return rc; }
     } else {
         for (int64_t k = 0; k < n_batches; ++k) {
             const int64_t s = starts[k];
@@ -735,6 +744,16 @@ static int run_pass(gg_ctx *ctx, int which, const int64_t *starts, int64_t n_bat
             if (rc != GG_OK) return rc;
         }
     }
+    if (ctx->tm_cur >= 0) {
+        const int ts = ctx->tm_cur;
+        ctx->tm_cur = -1;
+        GG_HIP(ctx, hipEventRecord(ctx->tm_ev[ts][2], ctx->stream));
+        const bool has_rows = ctx->cfg.optimizer != GG_OPT_ADAM_DENSE;
+        if (has_rows)  // rows the optimizer kernel updated: device-side count, copied behind it into pinned memory
+            GG_HIP(ctx, hipMemcpyAsync(ctx->h_pin + gg_ctx::H_ROWS + ts, ctx->touched_ptr.as<int64_t>() + ctx->n_node, sizeof(int64_t),
+                                       hipMemcpyDeviceToHost, ctx->stream));
+        ctx->tm_pending.push_back({which == 1 ? 1 : 2, rows, ts, has_rows});
+    }
     if (which == 0) {  // walks of a later gg_prepare_g run on the side stream: they start behind this generator update
         GG_HIP(ctx, hipEventRecord(ctx->ev_gen_pass, ctx->stream));
         ctx->gen_pass_recorded = true;
@@ -743,6 +762,7 @@ static int run_pass(gg_ctx *ctx, int which, const int64_t *starts, int64_t n_bat
     if (timed) {
         GG_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
         GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        harvest_timings(ctx);
         float ms = 0.f;
         GG_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         ctx->ctr.last_kernel_ms = ms;

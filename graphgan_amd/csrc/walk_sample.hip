@@ -212,7 +212,8 @@ constexpr int CTR_CHUNKS = 136; // ctr[CTR_CHUNKS + level]: chunks of hop `level
 constexpr int CTR_ROWS = 200;   // ctr[CTR_ROWS + (block & 63)]: candidate rows scored by this launch (spread words, folded by the host)
 constexpr int CTR_HOPS_V = 264;  // ctr[CTR_HOPS_V + (block & 63)]: hop counts of the level pipeline, spread over 64 words
 constexpr int CTR_READS_V = 328; // (same-address atomics serialise at ~12 ns each); summed by the host
-constexpr int CTR_WORDS = 392;
+constexpr int CTR_DISTS = 392;   // ctr[CTR_DISTS + (block & 63)]: (root, node) distributions set up by the level pipeline (owners), spread words
+constexpr int CTR_WORDS = 456;
 constexpr int MAX_LEVELS = 64;
 
 // Descriptor of chunk i of a k-candidate distribution: {cur, rows | flags | offset bits 32..47, offset bits 0..31, father id}.
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     // chunk offsets and big-task slots: in-wave exclusive scans, per-block totals through LDS, and ONE
     // returning atomic per block and counter (a single word serves only ~88 returning atomics per us);
     // the order of the blocks' regions in the score buffer is irrelevant
-    __shared__ int wv_chunks[4], wv_big[4];
+    __shared__ int wv_chunks[4], wv_big[4], wv_own[4];
     __shared__ unsigned long long blk_base[2];
     int inc = chunks;
 #pragma unroll
@@ -432,12 +433,16 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     const int wv = threadIdx.x >> 6;
     if (lane == 63) wv_chunks[wv] = inc;
     if (lane == 0) wv_big[wv] = __popcll(big_bal);
+    const unsigned long long own_bal = __ballot(owns);
+    if (lane == 0) wv_own[wv] = __popcll(own_bal);
     __syncthreads();
     if (threadIdx.x == 0) {
         const int tc = wv_chunks[0] + wv_chunks[1] + wv_chunks[2] + wv_chunks[3];
         const int tb = wv_big[0] + wv_big[1] + wv_big[2] + wv_big[3];
         blk_base[0] = tc ? atomicAdd(&a.ctr[CTR_CHUNKS + a.level], (unsigned long long)tc) : 0ull;
         blk_base[1] = tb ? atomicAdd(&a.ctr[CTR_BIG + a.level], (unsigned long long)tb) : 0ull;
+        const int to = wv_own[0] + wv_own[1] + wv_own[2] + wv_own[3];
+        if (to) atomicAdd(&a.ctr[CTR_DISTS + (blockIdx.x & 63)], (unsigned long long)to);
     }
     __syncthreads();
     int chunks_before = 0, big_before = 0, blk_chunks = 0;
@@ -1026,7 +1031,7 @@ int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int fo
     GG_HIP(ctx, hipMemsetAsync(ctx->dev_ctr, 0, sizeof(unsigned long long) * CTR_WORDS, ctx->walk_stream));
     // HIP events around every profile_every-th call (a rerun keeps the decision of the launch it repeats)
     if (!ctx->walk_force_sized) ctx->walk_timed = ctx->profile_every > 0 && (ctx->walk_call_index++ % ctx->profile_every) == 0;
-    if (ctx->walk_timed && ctx->walk_stream != ctx->stream) {
+    if (ctx->walk_timed && ctx->walk_stream != ctx->stream && ctx->profile_solo) {
         // a profiled launch is measured alone: it does not share the HBM with the discriminator update in flight
         GG_HIP(ctx, hipEventRecord(ctx->ev_main_mark, ctx->stream));
         GG_HIP(ctx, hipStreamWaitEvent(ctx->walk_stream, ctx->ev_main_mark, 0));

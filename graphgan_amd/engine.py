@@ -183,6 +183,20 @@ class Engine:
         self._ck(lib.gg_tree_info(self._ctx, ctypes.byref(nr), ctypes.byref(ne), ctypes.byref(md)))
         self.tree_entries, self.max_depth = ne.value, md.value
 
+    def save_trees(self, path):
+        """The tree cache (reference: pickle.dump(self.trees), graph_gan.py:43-46)."""
+        self._ck(lib.gg_save_trees(self._ctx, str(path).encode()))
+
+    def load_trees(self, path):
+        """pickle.load of the cache (graph_gan.py:35-38): the resident trees as saved by ``save_trees``; refuses a
+        cache built from another graph."""
+        self._ck(lib.gg_load_trees(self._ctx, str(path).encode()))
+        nr = ctypes.c_int32()
+        self._ck(lib.gg_tree_info(self._ctx, ctypes.byref(nr), None, None))
+        roots = np.zeros(nr.value, dtype=np.int32)
+        self._ck(lib.gg_tree_roots(self._ctx, _ptr(roots)))
+        self._after_trees(roots)
+
     def get_trees(self):
         R = len(self.tree_roots)
         off = np.zeros((R, self.n_node + 1), dtype=np.int32)
@@ -328,6 +342,10 @@ class Engine:
         """HIP events around every ``every_n``-th walk launch (1 = every launch and every pass, the default;
         0 = none).  With ``every_n != 1`` ``d_pass`` / ``g_pass`` return once their kernels are enqueued."""
         self._ck(lib.gg_set_profiling(self._ctx, int(every_n)))
+
+    def set_profiling_solo(self, solo):
+        """solo=True (default): profiled side-stream walks are measured alone; False: overlapped with the D update."""
+        self._ck(lib.gg_set_profiling_solo(self._ctx, int(bool(solo))))
 
     def synchronize(self):
         self._ck(lib.gg_synchronize(self._ctx))

@@ -90,7 +90,14 @@ class GraphGAN(object):
         self._all_resident = False
         budget = float(_cfg(cfg, "engine_tree_budget_gb", 160.0)) * 2.0 ** 30
         if cfg.update_ratio >= 1 or self.engine.tree_bytes_estimate(len(self.root_nodes)) <= budget:
-            self.trees = self.construct_trees(self.root_nodes)
+            # construct or read BFS-trees (reference :31-46; the cache is a flat GGTR file instead of a pickle)
+            cache = _cfg(cfg, "cache_filename", None)
+            if cache and os.path.isfile(cache) and self._load_tree_cache(cache):
+                print("reading BFS-trees from cache...")
+            else:
+                self.trees = self.construct_trees(self.root_nodes)
+                if cache and os.path.isdir(os.path.dirname(cache) or "."):  # the reference needs `mkdir cache` too (README.md:43)
+                    self.engine.save_trees(cache)
             self._all_resident = True
 
         self.latest_checkpoint = os.path.join(cfg.model_log, "model.checkpoint.ggst")
@@ -126,6 +133,21 @@ class GraphGAN(object):
                                 device=bool(_cfg(self.config, "engine_tree_device", True)))
         self._slot_of_root = {int(r): i for i, r in enumerate(nodes)}
         return self._slot_of_root
+
+    def _load_tree_cache(self, path):
+        """Resident trees from the cache file if it holds exactly the trees of ``root_nodes`` for this graph."""
+        try:
+            self.engine.load_trees(path)
+        except _lib.GraphGANHipError as e:  # foreign / stale / truncated file: rebuild (and overwrite) instead of failing
+            print("tree cache %s not used: %s" % (path, e))
+            return False
+        roots = np.asarray(self.engine.tree_roots)
+        if len(roots) != len(self.root_nodes) or not np.array_equal(roots, np.asarray(self.root_nodes, dtype=np.int32)):
+            print("tree cache %s holds other roots: rebuilding" % path)
+            return False
+        self._slot_of_root = {int(r): i for i, r in enumerate(roots)}
+        self.trees = self._slot_of_root
+        return True
 
     def construct_trees_with_mp(self, nodes):
         """kept for API compatibility (reference :63-82): the C++ builder is always multi-threaded"""

@@ -93,6 +93,16 @@ typedef struct gg_counters {
     int64_t score_rows;     /* neighbour rows those launches streamed */
     double bfs_kernel_ms;   /* cumulative HIP-event time of the BFS-tree kernel (gg_build_trees_device) */
     int64_t bfs_trees;      /* ... and the trees it built */
+    int64_t score_dists;    /* (root, node) distributions the timed score launches evaluated (one current row each) */
+    /* per-kernel HIP-event times of the PROFILED prepare / pass calls (same cadence as the walks), with the units they
+     * processed: K2 pair_reward; K3 / K4 gradient kernel and K5 optimizer kernel of the discriminator / generator pass */
+    double reward_kernel_ms;
+    int64_t reward_pairs_timed;
+    double d_grad_ms, d_opt_ms;
+    int64_t d_pairs_timed, d_rows_timed;   /* pairs of those passes; table rows their optimizer kernels updated */
+    double g_grad_ms, g_opt_ms;
+    int64_t g_pairs_timed, g_rows_timed;
+    int64_t d_passes_timed, g_passes_timed;
 } gg_counters;
 
 typedef struct gg_ctx gg_ctx;
@@ -135,6 +145,13 @@ int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t n_roots);
 int gg_set_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int32_t *off,
                  const int32_t *nbr, const int64_t *nbr_base, int32_t max_depth);
 int gg_tree_info(const gg_ctx *ctx, int32_t *n_roots, int64_t *n_entries, int32_t *max_depth);
+int gg_tree_roots(const gg_ctx *ctx, int32_t *roots /*[n_roots]*/);  /* root node of every resident slot */
+/* gg_save_trees / gg_load_trees: the tree cache, replacing the pickle of graph_gan.py:31-46 (config.cache_filename).
+ * One flat file holding the resident BFS-order arrays as built (roots, bases, pop order, first-child ranks; the
+ * reference also pickles before any in-place mutation, :45) behind a header with the graph's fingerprint: a cache
+ * built from another graph is refused with GG_EINVAL, a truncated or foreign file with GG_EIO (nothing loaded). */
+int gg_save_trees(gg_ctx *ctx, const char *path);
+int gg_load_trees(gg_ctx *ctx, const char *path);
 int gg_get_trees(gg_ctx *ctx, int32_t *off, int32_t *nbr, int64_t *nbr_base);
 
 /* ---- K1 walk_sample.  Replaces GraphGAN.sample (graph_gan.py:225-270) including the
@@ -219,6 +236,9 @@ int gg_get_counters(gg_ctx *ctx, gg_counters *out);
  * is called next; the next call that returns data, gg_synchronize or gg_comm_barrier waits for them and reports
  * their errors.  every_n = 0: no events at all.  Also settable as GG_PROFILE_EVERY. */
 int gg_set_profiling(gg_ctx *ctx, int32_t every_n);
+/* gg_set_profiling_solo: solo = 1 (default): a profiled side-stream walk first waits for the main stream, so its kernels
+ * are measured ALONE; solo = 0: it runs beside the discriminator update like every other launch (overlapped figure). */
+int gg_set_profiling_solo(gg_ctx *ctx, int32_t solo);
 /* Wait for everything enqueued on the context's stream. */
 int gg_synchronize(gg_ctx *ctx);
 

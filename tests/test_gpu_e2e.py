@@ -43,6 +43,7 @@ def make_cfg(base, **over):
     cfg.emb_filenames = ["%s/results/%s/%s_gen_.emb" % (base, app, ds), "%s/results/%s/%s_dis_.emb" % (base, app, ds)]
     cfg.result_filename = "%s/results/%s/%s.txt" % (base, app, ds)
     cfg.model_log = "%s/log/" % base
+    cfg.cache_filename = "%s/cache/%s.pkl" % (base, ds)  # used only when the directory exists (README.md:43: `mkdir cache`)
     for k, v in over.items():
         setattr(cfg, k, v)
     return cfg
@@ -201,3 +202,48 @@ def test_full_schedule_epochs_match_committed_oracle_runs(tmp_path, seed):
     c = g.engine.counters()
     assert c["d_steps"] > 6000 and c["g_steps"] > 400000
     g.engine.close()
+
+
+def test_tree_cache_file_replaces_the_pickle(tmp_path):
+    """graph_gan.py:31-46: build the trees once, cache them, read them back in the next process.  The second GraphGAN
+    must come up from the cache (no BFS), hold the same trees, and sample the same walks; a cache of another graph or a
+    truncated file is refused and rebuilt."""
+    import graphgan_amd as ga
+    base = str(tmp_path)
+    d, n, graph = write_reference_layout(base)
+    os.makedirs(os.path.join(base, "cache"))
+    cfg = make_cfg(base, engine_seed=5)
+    from graphgan_amd.graph_gan import GraphGAN
+    g1 = GraphGAN(cfg)
+    assert os.path.getsize(cfg.cache_filename) > 8 * 16e6 and not os.path.exists(cfg.cache_filename + ".tmp")  # 16.3 M (root, node) pairs
+    assert g1.engine.counters()["bfs_trees"] == n
+    t1 = g1.engine.get_trees()
+    w1 = g1.engine.walk_sample(np.arange(n), np.full(n, 5), False, 3, 1)
+    g1.engine.close()
+    g2 = GraphGAN(cfg)
+    assert g2.engine.counters()["bfs_trees"] == 0 and g2.trees is not None and g2._slot_of_root[17] == 17
+    t2 = g2.engine.get_trees()
+    for a, b in zip(t1, t2):
+        assert np.array_equal(a, b)
+    assert g2.engine.max_depth == g1.engine.max_depth
+    w2 = g2.engine.walk_sample(np.arange(n), np.full(n, 5), False, 3, 1)
+    for k in ("samples", "path_len", "paths", "root_status"):
+        assert np.array_equal(w1[k], w2[k])
+    # another graph: refused with GG_EINVAL, nothing loaded
+    rowptr, col = ga.edges_to_csr(n, d["train"][:-7])
+    other = ga.Engine(np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32))
+    other.set_graph_csr(rowptr, col)
+    with pytest.raises(ga.GraphGANHipError) as ei:
+        other.load_trees(cfg.cache_filename)
+    assert ei.value.code == ga.GG_EINVAL
+    other.close()
+    # truncated: refused with GG_EIO; the trainer rebuilds and rewrites it
+    blob = open(cfg.cache_filename, "rb").read()
+    open(cfg.cache_filename, "wb").write(blob[: len(blob) // 3])
+    with pytest.raises(ga.GraphGANHipError) as ei:
+        g2.engine.load_trees(cfg.cache_filename)
+    assert ei.value.code == ga.GG_EIO
+    g2.engine.close()
+    g3 = GraphGAN(cfg)
+    assert g3.engine.counters()["bfs_trees"] == n and os.path.getsize(cfg.cache_filename) == len(blob)
+    g3.engine.close()

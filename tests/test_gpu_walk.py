@@ -248,3 +248,36 @@ def test_deep_chain_crosses_the_level_cap(ga):
     b = (0.1 * np.sin(np.arange(n))).astype(np.float32)
     hops = run_both(ga, n, rowptr, col, np.arange(n), E, b, rounds=4, seed=4242)
     assert hops > 64 * 150  # many walks ran past the level cap
+
+
+def test_trees_in_the_reference_shape_round_trip_through_set_trees(ga):
+    """gg_get_trees hands the resident trees over as the reference's lists (father entries removed by D-mode shown as
+    -1); gg_set_trees takes such lists back.  A second engine fed that way samples the same walks, mutation state included."""
+    g, n, graph = load_small(2)
+    rowptr, col = ga.graph_to_csr(n, graph)
+    deg = (rowptr[1:] - rowptr[:-1]).astype(np.int32)
+    roots = np.arange(n, dtype=np.int32)
+    a = ga.Engine(g["E"], g["E"])
+    a.set_bias(0, g["b"])
+    a.set_graph_csr(rowptr, col)
+    a.build_trees(roots, device=True)
+    a.walk_sample(roots, deg, True, 9, 0)              # D-mode: removes father entries (Q3)
+    off, nbr, base = a.get_trees()
+    assert (nbr < 0).any()
+    b = ga.Engine(g["E"], g["E"])
+    b.set_bias(0, g["b"])
+    b.set_trees(roots, off, nbr, base)                # no graph needed for that
+    assert b.max_depth == a.max_depth
+    off2, nbr2, base2 = b.get_trees()
+    assert np.array_equal(off, off2) and np.array_equal(nbr, nbr2) and np.array_equal(base, base2)
+    for stream, for_d, nw in ((1, False, np.full(n, 20, np.int32)),):
+        wa = a.walk_sample(roots, nw, for_d, 9, stream)
+        wb = b.walk_sample(roots, nw, for_d, 9, stream)
+        for k in ("samples", "path_len", "paths", "root_status"):
+            assert np.array_equal(wa[k], wb[k]), k
+    bad = nbr.copy()
+    bad[base[3] + off[3, roots[3]] + 1:base[3] + off[3, roots[3]] + 2] = n + 5  # a child id out of range
+    with pytest.raises(ga.GraphGANHipError):
+        b.set_trees(roots, off, bad, base)
+    a.close()
+    b.close()

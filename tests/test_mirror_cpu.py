@@ -97,6 +97,8 @@ class _FakeEngine(object):
     def set_profiling(self, k): self.calls.append(("set_profiling", k))
     def set_graph_csr(self, rowptr, col): self.calls.append(("set_graph_csr", len(rowptr) - 1, len(col)))
     def build_trees(self, roots, **kw): self.tree_roots = list(roots); self.calls.append(("build_trees", len(roots), kw.get("device")))
+    def save_trees(self, path): open(path, "w").write("trees"); self.calls.append(("save_trees", path))
+    def load_trees(self, path): self.tree_roots = list(range(self.n_node)); self.calls.append(("load_trees", path))
     def load_state(self, path): self.calls.append(("load_state", path))
     def save_state(self, path): open(path, "w").write("x"); self.calls.append(("save_state", path))
     def prepare_d(self, slots, seed, stream, fetch=True):
@@ -223,3 +225,24 @@ def test_update_ratio_with_trees_over_budget_builds_per_draw(pkg, tmp_path, monk
     g.engine.walk_sample = lambda slots, nw, for_d, seed, stream: dict(root_status=np.array([1]), paths=None, path_len=None, samples=None)
     assert g.sample(other, None, 5, False) == (None, None)
     assert g.engine.tree_roots == [other]
+
+
+def test_tree_cache_is_read_or_written_like_the_pickle(pkg, tmp_path, monkeypatch):
+    """graph_gan.py:31-46 on the fake engine: no cache directory -> build only; directory but no file -> build + save;
+    file present -> load, no build."""
+    from tests.test_gpu_e2e import make_cfg, write_reference_layout
+    from graphgan_amd import engine as eng_mod, graph_gan
+    base = str(tmp_path)
+    d, n, graph = write_reference_layout(base)
+    monkeypatch.setattr(eng_mod, "Engine", _FakeEngine)
+    cfg = make_cfg(base)
+    g = graph_gan.GraphGAN(cfg)
+    names = [c[0] for c in g.engine.calls]
+    assert "build_trees" in names and "save_trees" not in names and "load_trees" not in names
+    os.makedirs(os.path.dirname(cfg.cache_filename))
+    g = graph_gan.GraphGAN(cfg)
+    names = [c[0] for c in g.engine.calls]
+    assert names.index("build_trees") < names.index("save_trees") and os.path.isfile(cfg.cache_filename)
+    g = graph_gan.GraphGAN(cfg)
+    names = [c[0] for c in g.engine.calls]
+    assert "load_trees" in names and "build_trees" not in names and g.trees[5] == 5 and g._all_resident
