@@ -85,10 +85,13 @@ SIGNATURES = {
     "gg_d_step": (ctypes.c_int, [_P, _P, _P, _P, _i32]),
     "gg_g_step": (ctypes.c_int, [_P, _P, _P, _P, _i32]),
     "gg_all_score": (ctypes.c_int, [_P, _P, _i32, _P]),
+    "gg_all_score_reduce": (ctypes.c_int, [_P, _P, _i32, _i32, _i32, _P, _P, _P, _P]),
     "gg_get_embeddings": (ctypes.c_int, [_P, _i32, _P]),
     "gg_get_bias": (ctypes.c_int, [_P, _i32, _P]),
     "gg_write_embeddings": (ctypes.c_int, [_P, _i32, ctypes.c_char_p, _i32]),
     "gg_host_write_embeddings": (ctypes.c_int, [_P, _i64, _i32, ctypes.c_char_p, _i32]),
+    "gg_write_embeddings_bin": (ctypes.c_int, [_P, _i32, ctypes.c_char_p]),
+    "gg_edge_scores": (ctypes.c_int, [_P, _i32, _P, _P, _i64, _P]),
     "gg_set_embeddings": (ctypes.c_int, [_P, _i32, _P]),
     "gg_set_bias": (ctypes.c_int, [_P, _i32, _P]),
     "gg_save_state": (ctypes.c_int, [_P, ctypes.c_char_p]),

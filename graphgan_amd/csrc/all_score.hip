@@ -13,6 +13,11 @@
 // +1 padded row stride (conflict-free fragment reads: lane l reads [l & 31][k + (l >> 5)]); each
 // wavefront owns a 32 x 32 accumulator (16 registers per lane).  Memory-bound on the S write
 // (4 N bytes per row) and the single sweep over E; never materialises more than the requested rows.
+#include <math.h>
+
+#include <algorithm>
+#include <vector>
+
 #include "gg_internal.h"
 
 namespace gg {
@@ -69,6 +74,198 @@ __global__ __launch_bounds__(256) void all_score_kernel(const float *E, const fl
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Streamed all-pairs consumer: the rows of S = E . E^T + b are produced tile by tile on the matrix cores and CONSUMED
+// in registers -- per requested row the maximum, its column (argmax) and log sum_j exp(S[i, j]), the normaliser of the
+// full softmax over all nodes that the graph softmax of the walk sampler approximates -- so nothing of size N^2 (or
+// n_rows x N) ever exists.  At N = 10^7 a materialised row block would be 40 MB per row; the stream needs 12 bytes.
+//   fp32 (default): v_mfma_f32_32x32x2_f32, exact fp32 scores (the same arithmetic as gg_all_score);
+//   bf16 (optional): v_mfma_f32_32x32x16_bf16 on a bf16 copy of the table (round to nearest even), fp32 accumulate:
+//                    16x the matrix-core rate, scores differ from fp32 by the input rounding.
+// Work split: grid = (column splits, row tiles); a workgroup walks its column range in 128-column tiles, its 4 wavefronts
+// take 32 columns each; every lane keeps the running (max, argmax, sum exp) of the 16 (row, column-lane) cells it owns and
+// the cross-lane / cross-wave merge happens once per workgroup.  Partials per (row, split) are merged on the host.
+struct Running {
+    float m, s;
+    int arg;
+};
+
+__device__ __forceinline__ void run_update(Running &r, float x, int col, bool lse) {
+    if (x > r.m) {
+        if (lse) r.s = r.s * __expf(r.m - x) + 1.0f;
+        r.m = x;
+        r.arg = col;
+    } else if (lse) {
+        r.s += __expf(x - r.m);
+    }
+}
+
+__device__ __forceinline__ void run_merge(Running &a, float m, float s, int arg, bool lse) {
+    if (m == -INFINITY) return;  // the other cell saw no column at all
+    if (a.m == -INFINITY) { a.m = m; a.s = s; a.arg = arg; return; }
+    if (m > a.m || (m == a.m && arg < a.arg)) {
+        if (lse) a.s = a.s * __expf(a.m - m) + s;
+        a.m = m;
+        a.arg = arg;
+    } else if (lse) {
+        a.s += s * __expf(m - a.m);
+    }
+}
+
+// merge the 16 per-lane cells of a wave over its 32 column lanes (lanes l and l ^ 32 hold different rows) and the
+// 4 waves of the workgroup through LDS; rows of the tile: row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+template <int NR>
+__device__ __forceinline__ void tile_finish(Running (&run)[NR], bool lse, int rows_base, int n_rows, int split, int n_splits, float *part_max,
+                                            int32_t *part_arg, float *part_sum, float (*sh_m)[32 * (NR / 16)], float (*sh_s)[32 * (NR / 16)],
+                                            int (*sh_a)[32 * (NR / 16)]) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) {
+            const float m = __shfl_xor(run[i].m, off, 64), sx = __shfl_xor(run[i].s, off, 64);
+            const int ar = __shfl_xor(run[i].arg, off, 64);
+            run_merge(run[i], m, sx, ar, lse);
+        }
+        if ((lane & 31) == 0) {
+            const int rb = i / 16, reg = i % 16;
+            const int row = rb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            sh_m[wv][row] = run[i].m;
+            sh_s[wv][row] = run[i].s;
+            sh_a[wv][row] = run[i].arg;
+        }
+    }
+    __syncthreads();
+    const int tr = threadIdx.x;
+    if (tr < 32 * (NR / 16) && rows_base + tr < n_rows) {
+        Running r{sh_m[0][tr], sh_s[0][tr], sh_a[0][tr]};
+#pragma unroll
+        for (int w = 1; w < 4; ++w) run_merge(r, sh_m[w][tr], sh_s[w][tr], sh_a[w][tr], lse);
+        const int64_t o = (int64_t)(rows_base + tr) * n_splits + split;
+        part_max[o] = r.m;
+        part_arg[o] = r.arg;
+        part_sum[o] = r.s;
+    }
+}
+
+__global__ __launch_bounds__(256) void all_score_reduce_f32_kernel(const float *E, const float *bias, int n_node, int ld, const int32_t *rows,
+                                                                   int n_rows, int cols_per_split, int lse, float *part_max, int32_t *part_arg,
+                                                                   float *part_sum) {
+    extern __shared__ float As_all[];  // [32][ld + 1]: the tile's 32 rows, staged once
+    __shared__ float Bs[128][AS_KC + 1];
+    __shared__ float sh_m[4][32], sh_s[4][32];
+    __shared__ int sh_a[4][32];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int split = blockIdx.x, r0 = blockIdx.y * 32;
+    const int lda = ld + 1;
+    for (int i = tid; i < 32 * (ld / 4); i += 256) {
+        const int r = i / (ld / 4), kk = (i % (ld / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 + r < n_rows) {
+            const int node = rows ? rows[r0 + r] : r0 + r;
+            v = *(const float4 *)(E + (int64_t)node * ld + kk);
+        }
+        float *d = As_all + r * lda + kk;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    Running run[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) run[i] = Running{-INFINITY, 0.f, 0x7fffffff};
+    const int cbeg = split * cols_per_split, cend = min(n_node, cbeg + cols_per_split);
+    for (int c0 = cbeg; c0 < cend; c0 += 128) {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        for (int k0 = 0; k0 < ld; k0 += AS_KC) {
+            __syncthreads();  // also orders the A staging before its first use
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = (tid >> 3) + 32 * i, kk = (tid & 7) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c0 + r < cend && k0 + kk < ld) v = *(const float4 *)(E + (int64_t)(c0 + r) * ld + k0 + kk);
+                Bs[r][kk] = v.x; Bs[r][kk + 1] = v.y; Bs[r][kk + 2] = v.z; Bs[r][kk + 3] = v.w;
+            }
+            __syncthreads();
+            const int kmax = min(AS_KC, ld - k0);
+            for (int kk = 0; kk < kmax; kk += 2) {
+                const float a = As_all[(lane & 31) * lda + k0 + kk + (lane >> 5)];
+                const float b = Bs[wv * 32 + (lane & 31)][kk + (lane >> 5)];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
+        }
+        const int col = c0 + wv * 32 + (lane & 31);
+        if (col < cend) {
+            const float bj = bias[col];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) run_update(run[reg], acc[reg] + bj, col, lse != 0);
+        }
+    }
+    __syncthreads();
+    tile_finish<16>(run, lse != 0, r0, n_rows, split, gridDim.x, part_max, part_arg, part_sum, sh_m, sh_s, sh_a);
+}
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// fp32 table -> bf16 copy [n][ld16] (ld16 = n_emb rounded up to 16, zero padded), round to nearest even
+__global__ void to_bf16_kernel(const float *E, int64_t n, int ld, int ld16, __bf16 *out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * ld16) return;
+    const int64_t r = i / ld16;
+    const int k = (int)(i % ld16);
+    out[i] = (__bf16)(k < ld ? E[r * ld + k] : 0.0f);
+}
+
+// KS = ld16 / 16 k-steps, RB row blocks of 32 rows per workgroup.  No LDS for the operands: the A fragments of the
+// tile's rows stay in registers for the whole column sweep, every lane streams the 8-element k-slices of its own column
+// straight from the bf16 table (16 bytes per load; the two half-waves read the two halves of a 32-byte piece).
+template <int KS, int RB>
+__global__ __launch_bounds__(256) void all_score_reduce_bf16_kernel(const uint4 *Eb, const float *bias, int n_node, const int32_t *rows, int n_rows,
+                                                                    int cols_per_split, int lse, float *part_max, int32_t *part_arg, float *part_sum) {
+    __shared__ float sh_m[4][32 * RB], sh_s[4][32 * RB];
+    __shared__ int sh_a[4][32 * RB];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, half = lane >> 5;
+    const int split = blockIdx.x, r0 = blockIdx.y * (32 * RB);
+    union Frag { uint4 u; bf16x8 v; };
+    Frag afrag[RB][KS];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int r = r0 + rb * 32 + (lane & 31);
+        const int node = r < n_rows ? (rows ? rows[r] : r) : -1;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) afrag[rb][s].u = node >= 0 ? Eb[(int64_t)node * (2 * KS) + 2 * s + half] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    Running run[16 * RB];
+#pragma unroll
+    for (int i = 0; i < 16 * RB; ++i) run[i] = Running{-INFINITY, 0.f, 0x7fffffff};
+    const int cbeg = split * cols_per_split, cend = min(n_node, cbeg + cols_per_split);
+    for (int c0 = cbeg + wv * 32; c0 < cend; c0 += 128) {
+        const int col = c0 + (lane & 31);
+        const bool ok = col < cend;
+        const uint4 *brow = Eb + (int64_t)(ok ? col : cbeg) * (2 * KS) + half;
+        f32x16 acc[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rb][i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            Frag b;
+            b.u = brow[2 * s];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[rb][s].v, b.v, acc[rb], 0, 0, 0);
+        }
+        if (ok) {
+            const float bj = bias[col];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) run_update(run[rb * 16 + reg], acc[rb][reg] + bj, col, lse != 0);
+        }
+    }
+    tile_finish<16 * RB>(run, lse != 0, r0, n_rows, split, gridDim.x, part_max, part_arg, part_sum, sh_m, sh_s, sh_a);
+}
+
 }  // namespace gg
 
 using namespace gg;
@@ -99,5 +296,95 @@ extern "C" int gg_all_score(gg_ctx *ctx, const int32_t *rows, int32_t n_rows, fl
     d_rows.release();
     d_out.release();
     if (e != hipSuccess) return fail(ctx, GG_EHIP, "gg_all_score: %s", hipGetErrorString(e));
+    return GG_OK;
+}
+
+// gg_all_score_reduce: see include/graphgan_hip.h.
+extern "C" int gg_all_score_reduce(gg_ctx *ctx, const int32_t *rows, int32_t n_rows, int32_t precision, int32_t want_lse, float *row_max,
+                                   int32_t *row_argmax, float *row_lse, double *kernel_ms_out) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    GG_CHECK(ctx, n_rows >= 0 && row_max && row_argmax && (row_lse || !want_lse), GG_EINVAL, "gg_all_score_reduce: bad argument");
+    GG_CHECK(ctx, precision == 0 || precision == 1, GG_EINVAL, "gg_all_score_reduce: precision must be 0 (fp32) or 1 (bf16)");
+    if (!rows) n_rows = ctx->n_node;
+    if (n_rows == 0) return GG_OK;
+    const int n = ctx->n_node, ld = ctx->ld;
+    if (rows)
+        for (int i = 0; i < n_rows; ++i) GG_CHECK(ctx, rows[i] >= 0 && rows[i] < n, GG_EINVAL, "gg_all_score_reduce: row id %d out of range", rows[i]);
+    GG_HIP(ctx, hipSetDevice(ctx->device));
+    // k-steps of 16 bf16 elements; the kernel is instantiated for 4 / 8 / 16 / 32 of them: the copy is zero padded to that
+    const int ks_need = (ctx->n_emb + 15) / 16;
+    const int KS = ks_need <= 4 ? 4 : ks_need <= 8 ? 8 : ks_need <= 16 ? 16 : 32;
+    const int ld16 = 16 * KS;
+    const int RB = (precision == 1 && KS <= 8) ? 2 : 1;
+    const int tile_rows = 32 * RB;
+    const int row_tiles = cdiv(n_rows, tile_rows);
+    // enough workgroups for the chip: split the columns when there are few row tiles (multiples of 128 columns)
+    int splits = std::max(1, std::min(cdiv(n, 128), cdiv(2048, row_tiles)));
+    int cps = cdiv(cdiv(n, splits), 128) * 128;
+    splits = cdiv(n, cps);
+    DevBuf d_rows, d_pm, d_pa, d_ps, d_bf;
+    auto rel = [&]() { d_rows.release(); d_pm.release(); d_pa.release(); d_ps.release(); d_bf.release(); };
+    const size_t np = (size_t)n_rows * splits;
+    hipError_t e = d_pm.reserve(sizeof(float) * np);
+    if (e == hipSuccess) e = d_pa.reserve(sizeof(int32_t) * np);
+    if (e == hipSuccess) e = d_ps.reserve(sizeof(float) * np);
+    if (e == hipSuccess && rows) e = d_rows.reserve(sizeof(int32_t) * n_rows);
+    if (e == hipSuccess && precision == 1) e = d_bf.reserve(sizeof(uint16_t) * (size_t)n * ld16);
+    if (e != hipSuccess) { rel(); return fail(ctx, GG_ENOMEM, "gg_all_score_reduce: %s", hipGetErrorString(e)); }
+    if (rows) (void)hipMemcpyAsync(d_rows.p, rows, sizeof(int32_t) * n_rows, hipMemcpyHostToDevice, ctx->stream);
+    const Model &G = ctx->model[0];
+    const int32_t *dr = rows ? d_rows.as<int32_t>() : nullptr;
+    const dim3 grid(splits, row_tiles);
+    if (precision == 1) {
+        const int64_t tot = (int64_t)n * ld16;
+        hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, G.E, (int64_t)n, ld, ld16, (__bf16 *)d_bf.p);
+    }
+    (void)hipEventRecord(ctx->ev0, ctx->stream);
+    if (precision == 0) {
+        const size_t dyn = sizeof(float) * 32 * (size_t)(ld + 1);
+        if (dyn > 48 * 1024) (void)hipFuncSetAttribute((const void *)all_score_reduce_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        hipLaunchKernelGGL(all_score_reduce_f32_kernel, grid, dim3(256), dyn, ctx->stream, G.E, G.b, n, ld, dr, n_rows, cps, want_lse,
+                           d_pm.as<float>(), d_pa.as<int32_t>(), d_ps.as<float>());
+    } else {
+        const uint4 *Eb = (const uint4 *)d_bf.p;
+#define GG_BF16_LAUNCH(KSV, RBV)                                                                                                    \
+    hipLaunchKernelGGL((all_score_reduce_bf16_kernel<KSV, RBV>), grid, dim3(256), 0, ctx->stream, Eb, G.b, n, dr, n_rows, cps, want_lse, \
+                       d_pm.as<float>(), d_pa.as<int32_t>(), d_ps.as<float>())
+        if (KS <= 4) { GG_BF16_LAUNCH(4, 2); }
+        else if (KS <= 8) { GG_BF16_LAUNCH(8, 2); }
+        else if (KS <= 16) { GG_BF16_LAUNCH(16, 1); }
+        else { GG_BF16_LAUNCH(32, 1); }
+#undef GG_BF16_LAUNCH
+    }
+    (void)hipEventRecord(ctx->ev1, ctx->stream);
+    std::vector<float> pm(np), ps(np);
+    std::vector<int32_t> pa(np);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(pm.data(), d_pm.p, sizeof(float) * np, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(pa.data(), d_pa.p, sizeof(int32_t) * np, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ps.data(), d_ps.p, sizeof(float) * np, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    float ms = 0.f;
+    if (e == hipSuccess) (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    rel();
+    if (e != hipSuccess) return fail(ctx, GG_EHIP, "gg_all_score_reduce: %s", hipGetErrorString(e));
+    if (kernel_ms_out) *kernel_ms_out = ms;
+    for (int r = 0; r < n_rows; ++r) {  // merge the column splits (ascending columns: the first maximum wins, like numpy argmax)
+        float M = -INFINITY;
+        int arg = 0x7fffffff;
+        for (int sp = 0; sp < splits; ++sp) {
+            const size_t o = (size_t)r * splits + sp;
+            if (pm[o] > M || (pm[o] == M && pa[o] < arg)) { M = pm[o]; arg = pa[o]; }
+        }
+        double S = 0.0;
+        if (want_lse)
+            for (int sp = 0; sp < splits; ++sp) {
+                const size_t o = (size_t)r * splits + sp;
+                if (pm[o] > -INFINITY) S += (double)ps[o] * exp((double)pm[o] - (double)M);
+            }
+        row_max[r] = M;
+        row_argmax[r] = arg;
+        if (want_lse) row_lse[r] = (float)((double)M + log(S));
+    }
     return GG_OK;
 }

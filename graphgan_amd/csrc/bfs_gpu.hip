@@ -400,8 +400,10 @@ extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t 
     const size_t lds_total = 160 * 1024;
     const bool lds_bm = !getenv("GG_BFS_GLOBAL_BITMAP") && fa.sharedSizeBytes + (size_t)bm_words * 4 <= lds_total;
 
-    DevBuf gkey, gbm, misc;
-    auto cleanup = [&]() { gkey.release(); gbm.release(); misc.release(); };
+    // scratch kept in the context: an epoch over non-resident roots calls this once per root batch
+    DevBuf &gkey = ctx->bfs_key, &gbm = ctx->bfs_bm, &misc = ctx->bfs_misc;
+    auto cleanup = [&]() {};
+    const size_t key_bytes_before = gkey.bytes;
     hipError_t e = gkey.reserve(sizeof(uint32_t) * (size_t)grid * n);
     if (e == hipSuccess && !lds_bm) e = gbm.reserve(sizeof(uint32_t) * (size_t)grid * bm_words);
     if (e == hipSuccess) e = misc.reserve(sizeof(int32_t) * 8 + sizeof(unsigned long long) * 16);
@@ -424,7 +426,8 @@ extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t 
     a.exp = getenv("GG_BFS_EXPERIMENT") ? atoi(getenv("GG_BFS_EXPERIMENT")) : 0;
     a.prof = prof ? (unsigned long long *)(misc.as<int32_t>() + 8) : nullptr;
     (void)hipMemsetAsync(misc.p, 0, sizeof(int32_t) * 8 + sizeof(unsigned long long) * 16, ctx->stream);
-    (void)hipMemsetAsync(gkey.p, 0xFF, sizeof(uint32_t) * (size_t)grid * n, ctx->stream);
+    if (gkey.bytes != key_bytes_before)  // new allocation: all-ones; the kernel restores every word it uses
+        (void)hipMemsetAsync(gkey.p, 0xFF, sizeof(uint32_t) * (size_t)grid * n, ctx->stream);
     (void)hipEventRecord(ctx->ev0, ctx->stream);
     if (lds_bm) {
         const size_t dyn = (size_t)bm_words * 4;

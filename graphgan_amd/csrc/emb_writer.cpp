@@ -138,3 +138,25 @@ extern "C" int gg_write_embeddings(gg_ctx *ctx, int32_t which, const char *path,
     if (rc != GG_OK) return rc;
     return write_embedding_file(ctx, host.data(), ctx->n_node, ctx->n_emb, path, n_threads);
 }
+
+// Binary side-car of the .emb text: at N = 10^7, d = 256 the reference's text is ~50 GB per
+// model and write; the side-car holds the same fp32 numbers in 10 GB.  Layout: {magic "GGEB", version 1, n_emb i32,
+// n_node i64} then n_node * n_emb fp32, row-major, little endian (numpy: np.fromfile(f, "<f4", offset=20)).
+extern "C" int gg_write_embeddings_bin(gg_ctx *ctx, int32_t which, const char *path) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    GG_CHECK(ctx, (which == 0 || which == 1) && path, GG_EINVAL, "gg_write_embeddings_bin: bad argument");
+    std::vector<float> host((size_t)ctx->n_node * ctx->n_emb);
+    int rc = gg_get_embeddings(ctx, which, host.data());
+    if (rc != GG_OK) return rc;
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return fail(ctx, GG_EIO, "gg_write_embeddings_bin: cannot open %s", tmp.c_str());
+    struct { char magic[4]; int32_t version, n_emb; int64_t n_node; } __attribute__((packed)) h = {{'G', 'G', 'E', 'B'}, 1, ctx->n_emb, ctx->n_node};
+    const bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(host.data(), sizeof(float), host.size(), f) == host.size() && fflush(f) == 0;
+    fclose(f);
+    if (!ok || rename(tmp.c_str(), path) != 0) {
+        (void)remove(tmp.c_str());
+        return fail(ctx, GG_EIO, "gg_write_embeddings_bin: cannot write %s", path);
+    }
+    return GG_OK;
+}

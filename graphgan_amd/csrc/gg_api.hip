@@ -35,6 +35,7 @@ static void free_trees(gg_ctx *ctx) {
     ctx->t_root = ctx->t_order = ctx->t_cstart = nullptr;
     ctx->t_base = ctx->t_q3off = nullptr;
     ctx->t_q3 = nullptr;
+    ctx->t_cap_nodes = ctx->t_cap_roots = ctx->t_cap_q3 = 0;
     ctx->n_tree_roots = 0;
     ctx->tree_nodes = ctx->tree_entries = 0;
     ctx->tree_max_depth = ctx->tree_max_list = 0;
@@ -47,7 +48,6 @@ static void free_trees(gg_ctx *ctx) {
 // the graph), Q3 bit rows sized by the roots' child counts (NULL: their degrees, an upper bound), zero-initialised.
 int alloc_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int64_t *node_counts, const int64_t *root_children) {
     (void)hipDeviceSynchronize();  // walks of calls that returned early may still read the old trees
-    free_trees(ctx);
     const int n = ctx->n_node;
     if (!node_counts && ctx->h_comp_size.empty()) component_sizes(n, ctx->h_rowptr.data(), ctx->h_col.data(), ctx->h_comp_size);
     ctx->h_tbase.assign(n_roots + 1, 0);
@@ -59,12 +59,30 @@ int alloc_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int64_
     }
     const int64_t nodes = ctx->h_tbase[n_roots], q3w = ctx->h_q3off[n_roots];
     const int nr = std::max(n_roots, 1);
-    GG_HIP(ctx, hipMalloc((void **)&ctx->t_root, sizeof(int32_t) * nr));
-    GG_HIP(ctx, hipMalloc((void **)&ctx->t_order, sizeof(int32_t) * (size_t)std::max<int64_t>(nodes, 1)));
-    GG_HIP(ctx, hipMalloc((void **)&ctx->t_cstart, sizeof(int32_t) * (size_t)(nodes + nr)));
-    GG_HIP(ctx, hipMalloc((void **)&ctx->t_base, sizeof(int64_t) * (n_roots + 1)));
-    GG_HIP(ctx, hipMalloc((void **)&ctx->t_q3, sizeof(uint32_t) * (size_t)std::max<int64_t>(q3w, 1)));
-    GG_HIP(ctx, hipMalloc((void **)&ctx->t_q3off, sizeof(int64_t) * (n_roots + 1)));
+    // Trees are rebuilt per root batch when they cannot all stay resident (an epoch over 10^6 roots): keep the arrays
+    // of the previous batch when they are large enough instead of returning 64 GB to the driver and asking for it again.
+    auto regrow = [&](void **p, size_t bytes) -> hipError_t {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+        return hipMalloc(p, bytes);
+    };
+    if (nodes > ctx->t_cap_nodes || (ctx->t_cap_nodes > (64 << 20) && nodes < ctx->t_cap_nodes / 4) || nr > ctx->t_cap_roots) {
+        // cstart holds nodes + roots entries: both capacities are tied to the same allocation
+        const int64_t cn = std::max<int64_t>(nodes, 1), cr = std::max<int64_t>(nr, ctx->t_cap_roots);
+        GG_HIP(ctx, regrow((void **)&ctx->t_order, sizeof(int32_t) * (size_t)cn));
+        GG_HIP(ctx, regrow((void **)&ctx->t_cstart, sizeof(int32_t) * (size_t)(cn + cr)));
+        GG_HIP(ctx, regrow((void **)&ctx->t_root, sizeof(int32_t) * (size_t)cr));
+        GG_HIP(ctx, regrow((void **)&ctx->t_base, sizeof(int64_t) * (size_t)(cr + 1)));
+        GG_HIP(ctx, regrow((void **)&ctx->t_q3off, sizeof(int64_t) * (size_t)(cr + 1)));
+        ctx->t_cap_nodes = cn;
+        ctx->t_cap_roots = cr;
+    }
+    if (q3w > ctx->t_cap_q3 || !ctx->t_q3) {  // the Q3 rows depend on the roots' degrees: leave room for the next batch
+        const int64_t cq = std::max<int64_t>(q3w + q3w / 2, 1);
+        GG_HIP(ctx, regrow((void **)&ctx->t_q3, sizeof(uint32_t) * (size_t)cq));
+        ctx->t_cap_q3 = cq;
+    }
+    ctx->tree_max_depth = ctx->tree_max_list = 0;
     GG_HIP(ctx, hipMemcpyAsync(ctx->t_root, roots, sizeof(int32_t) * n_roots, hipMemcpyHostToDevice, ctx->stream));
     GG_HIP(ctx, hipMemcpyAsync(ctx->t_base, ctx->h_tbase.data(), sizeof(int64_t) * (n_roots + 1), hipMemcpyHostToDevice, ctx->stream));
     GG_HIP(ctx, hipMemcpyAsync(ctx->t_q3off, ctx->h_q3off.data(), sizeof(int64_t) * (n_roots + 1), hipMemcpyHostToDevice, ctx->stream));
@@ -347,7 +365,7 @@ int gg_destroy(gg_ctx *ctx) {
                       &ctx->d_ptr, &ctx->g_node1, &ctx->g_node2, &ctx->g_reward, &ctx->g_cnt, &ctx->g_ptr, &ctx->scan_tmp,
                       &ctx->step_u, &ctx->step_v, &ctx->step_x, &ctx->touched_ptr, &ctx->x_cnt, &ctx->x_send_ids, &ctx->x_send_rows,
                       &ctx->x_recv_ids, &ctx->x_recv_rows, &ctx->x_nglob, &ctx->st_item, &ctx->st_cur, &ctx->st_prev, &ctx->st_len,
-                      &ctx->st_alive, &ctx->st_rank, &ctx->lv_beg, &ctx->lv_k, &ctx->lv_chunks, &ctx->lv_coff, &ctx->lv_scores, &ctx->lv_chunk_owner, &ctx->lv_prefix, &ctx->lv_big};
+                      &ctx->st_alive, &ctx->st_rank, &ctx->bfs_key, &ctx->bfs_bm, &ctx->bfs_misc, &ctx->lv_beg, &ctx->lv_k, &ctx->lv_chunks, &ctx->lv_coff, &ctx->lv_scores, &ctx->lv_chunk_owner, &ctx->lv_prefix, &ctx->lv_big};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : ctx->lv_ev)
         if (e) (void)hipEventDestroy(e);

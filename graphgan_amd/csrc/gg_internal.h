@@ -95,6 +95,7 @@ struct gg_ctx {
     // (root, child of the root), t_q3[t_q3off[r] * 32 + (rank - 1)].
     int32_t n_tree_roots = 0, tree_max_depth = 0, tree_max_list = 0;
     int64_t tree_nodes = 0;      // sum of C_r
+    int64_t t_cap_nodes = 0, t_cap_roots = 0, t_cap_q3 = 0;  // allocated capacity of the tree arrays (kept across rebuilds)
     int64_t tree_entries = 0;    // entries of the reference-shaped lists: sum of 2 C_r - 1 (gg_tree_info / gg_get_trees)
     int32_t *t_root = nullptr;   // [R] root node id of each slot
     int32_t *t_order = nullptr;  // [tree_nodes]
@@ -145,6 +146,7 @@ struct gg_ctx {
     int64_t g_pairs = 0;
     bool g_paths_valid = false;  // w_paths / g_ptr still describe the resident prepare_g data
     gg::DevBuf touched_ptr;
+    gg::DevBuf bfs_key, bfs_bm, bfs_misc;  // scratch of gg_build_trees_device (bfs_gpu.hip)
     gg::DevBuf scan_tmp, step_u, step_v, step_x;
 
     // device-side counters of the walk launch in flight (zeroed at its start): [0]=hops [1]=nbr_reads [3]=error flag

@@ -4,6 +4,8 @@
 //   D rows [pos..., neg...]    (graph_gan.py:193-201)
 // so that prepare_data_for_g / prepare_data_for_d (graph_gan.py:182-223) never round-trip
 // node lists through the host between the walk kernel and the update passes.
+#include <algorithm>
+
 #include "gg_internal.h"
 
 namespace gg {
@@ -162,6 +164,23 @@ __global__ __launch_bounds__(256) void pair_reward_kernel(const float *E, const 
             s = fminf(fmaxf(s, -10.0f), 10.0f);
             out[p] = logf(1.0f + expf(s));  // tf.log(1 + tf.exp(score)), fp32
         }
+    }
+}
+
+// Evaluator scores (reference src/evaluation/link_prediction.py:26-27): np.dot of two embedding rows, in float64 like the
+// reference computes them (its embeddings are float64 arrays holding the fp32 values): one 16-lane group per edge.
+__global__ __launch_bounds__(256) void edge_dot_f64_kernel(const float *E, int ld, const int32_t *u, const int32_t *v, int64_t n, double *out) {
+    const int t = threadIdx.x & 15;
+    const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4, ng = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    for (int64_t p = g0; p < n; p += ng) {
+        const float *ra = E + (int64_t)u[p] * ld, *rb = E + (int64_t)v[p] * ld;
+        double acc = 0.0;
+        for (int k = t; k < ld; k += 16) acc = fma((double)ra[k], (double)rb[k], acc);
+        acc += __shfl_xor(acc, 8, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 1, 64);
+        if (t == 0) out[p] = acc;
     }
 }
 
@@ -377,3 +396,25 @@ int gg_pair_reward(gg_ctx *ctx, const int32_t *u, const int32_t *v, int64_t n, f
 }
 
 }  // extern "C"
+
+// gg_edge_scores: see include/graphgan_hip.h.
+extern "C" int gg_edge_scores(gg_ctx *ctx, int32_t which, const int32_t *u, const int32_t *v, int64_t n, double *out) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    GG_CHECK(ctx, (which == 0 || which == 1) && n >= 0 && (n == 0 || (u && v && out)), GG_EINVAL, "gg_edge_scores: bad argument");
+    if (n == 0) return GG_OK;
+    for (int64_t i = 0; i < n; ++i)
+        GG_CHECK(ctx, u[i] >= 0 && u[i] < ctx->n_node && v[i] >= 0 && v[i] < ctx->n_node, GG_EINVAL, "gg_edge_scores: id out of range at %lld", (long long)i);
+    GG_HIP(ctx, hipSetDevice(ctx->device));
+    GG_HIP(ctx, ctx->step_u.reserve(sizeof(int32_t) * n));
+    GG_HIP(ctx, ctx->step_v.reserve(sizeof(int32_t) * n));
+    GG_HIP(ctx, ctx->step_x.reserve(sizeof(double) * n));
+    GG_HIP(ctx, hipMemcpyAsync(ctx->step_u.p, u, sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    GG_HIP(ctx, hipMemcpyAsync(ctx->step_v.p, v, sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    int64_t blocks = std::min<int64_t>((n * 16 + 255) / 256, 4096);
+    hipLaunchKernelGGL(edge_dot_f64_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->model[which].E, ctx->ld,
+                       ctx->step_u.as<int32_t>(), ctx->step_v.as<int32_t>(), n, ctx->step_x.as<double>());
+    GG_HIP(ctx, hipGetLastError());
+    GG_HIP(ctx, hipMemcpyAsync(out, ctx->step_x.p, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GG_OK;
+}

@@ -302,6 +302,20 @@ class Engine:
         self._ck(lib.gg_all_score(self._ctx, _ptr(rows), len(rows), _ptr(out)))
         return out
 
+    def all_score_reduce(self, rows=None, precision="fp32", logsumexp=True):
+        """Rows of ``generator.all_score`` (generator.py:21) streamed through a fused consumer: per row the maximum, its
+        column and log-sum-exp over ALL nodes; nothing of size rows x N is materialised.  precision "fp32" (exact) or
+        "bf16" (bf16 inputs on the matrix cores, fp32 accumulate).  Returns dict(max, argmax, logsumexp, kernel_ms)."""
+        n_rows = self.n_node if rows is None else len(rows)
+        rows_a = None if rows is None else _i32(rows)
+        mx = np.zeros(n_rows, dtype=np.float32)
+        am = np.zeros(n_rows, dtype=np.int32)
+        lse = np.zeros(n_rows, dtype=np.float32) if logsumexp else None
+        ms = ctypes.c_double()
+        self._ck(lib.gg_all_score_reduce(self._ctx, _ptr(rows_a), n_rows, {"fp32": 0, "bf16": 1}[precision], int(bool(logsumexp)),
+                                         _ptr(mx), _ptr(am), _ptr(lse), ctypes.byref(ms)))
+        return dict(max=mx, argmax=am, logsumexp=lse, kernel_ms=ms.value)
+
     def get_embeddings(self, which):
         """sess.run(embedding_matrix) (graph_gan.py:298); which: 0 = gen, 1 = dis."""
         out = np.zeros((self.n_node, self.n_emb), dtype=np.float32)
@@ -311,6 +325,17 @@ class Engine:
     def write_embeddings(self, which, path, n_threads=0):
         """write_embeddings_to_file (graph_gan.py:293-306) for one model, natively."""
         self._ck(lib.gg_write_embeddings(self._ctx, which, str(path).encode(), n_threads))
+
+    def write_embeddings_bin(self, which, path):
+        """Binary side-car of the ``.emb`` text (same fp32 numbers; header "GGEB", version, n_emb, n_node)."""
+        self._ck(lib.gg_write_embeddings_bin(self._ctx, which, str(path).encode()))
+
+    def edge_scores(self, which, u, v):
+        """Evaluator scores np.dot(emd[u], emd[v]) (link_prediction.py:26-27) from the resident table, float64."""
+        u, v = _i32(u), _i32(v)
+        out = np.zeros(len(u), dtype=np.float64)
+        self._ck(lib.gg_edge_scores(self._ctx, which, _ptr(u), _ptr(v), len(u), _ptr(out)))
+        return out
 
     def get_bias(self, which):
         out = np.zeros(self.n_node, dtype=np.float32)

@@ -8,7 +8,7 @@ from .. import utils
 
 
 class LinkPredictEval(object):
-    def __init__(self, embed_filename, test_filename, test_neg_filename, n_node, n_embed, emd=None):
+    def __init__(self, embed_filename, test_filename, test_neg_filename, n_node, n_embed, emd=None, engine=None, which=0):
         self.embed_filename = embed_filename
         self.test_filename = test_filename
         self.test_neg_filename = test_neg_filename
@@ -16,13 +16,23 @@ class LinkPredictEval(object):
         self.n_embed = n_embed
         # ``emd`` (float64 [n_node, n_embed]) skips re-parsing the text that was just written: the file holds
         # repr(float64(fp32)) of exactly these numbers, so parsing it back gives the same matrix
-        self.emd = emd if emd is not None else utils.read_embeddings(embed_filename, n_node=n_node, n_embed=n_embed)
+        # ``engine`` (+ ``which``: 0 = generator, 1 = discriminator): the per-edge dots are computed on the device from
+        # the resident table (gg_edge_scores, float64 like np.dot on the reference's float64 arrays); no N x d matrix
+        # is fetched or parsed at all
+        self.engine, self.which = engine, which
+        if engine is not None:
+            self.emd = None
+        else:
+            self.emd = emd if emd is not None else utils.read_embeddings(embed_filename, n_node=n_node, n_embed=n_embed)
 
     def eval_link_prediction(self):
         edges = np.array(utils.read_edges_from_file(self.test_filename) +
                          utils.read_edges_from_file(self.test_neg_filename), dtype=np.int64)
         # per-edge np.dot like the reference (link_prediction.py:26-27): identical fp64 rounding
-        score = np.array([np.dot(self.emd[a], self.emd[b]) for a, b in edges])
+        if self.engine is not None:
+            score = self.engine.edge_scores(self.which, edges[:, 0], edges[:, 1])
+        else:
+            score = np.array([np.dot(self.emd[a], self.emd[b]) for a, b in edges])
         predicted = score >= np.median(score)
         truth = np.arange(len(edges)) < len(edges) // 2
         return float(np.mean(predicted == truth))

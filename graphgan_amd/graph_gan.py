@@ -280,7 +280,10 @@ class GraphGAN(object):
         cfg = self.config
         for i in range(2):
             os.makedirs(os.path.dirname(cfg.emb_filenames[i]) or ".", exist_ok=True)
-            self.engine.write_embeddings(i, cfg.emb_filenames[i])  # native formatter, byte-identical text
+            if _cfg(cfg, "engine_emb_text", True):
+                self.engine.write_embeddings(i, cfg.emb_filenames[i])  # native formatter, byte-identical text
+            if _cfg(cfg, "engine_emb_sidecar", False):
+                self.engine.write_embeddings_bin(i, cfg.emb_filenames[i] + ".bin")  # same numbers, 4 B each
 
     @staticmethod
     def evaluation(self):
@@ -288,8 +291,9 @@ class GraphGAN(object):
         results = []
         if cfg.app == "link_prediction":
             for i in range(2):
+                # the per-edge dots run on the device (gg_edge_scores) instead of re-reading the text just written
                 lpe = lp.LinkPredictEval(cfg.emb_filenames[i], cfg.test_filename, cfg.test_neg_filename, self.n_node, cfg.n_emb,
-                                         emd=self.engine.get_embeddings(i).astype(np.float64))
+                                         engine=self.engine, which=i)
                 result = lpe.eval_link_prediction()
                 results.append(cfg.modes[i] + ":" + str(result) + "\n")
         os.makedirs(os.path.dirname(cfg.result_filename) or ".", exist_ok=True)

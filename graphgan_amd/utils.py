@@ -42,3 +42,14 @@ def read_embeddings(filename, n_node, n_embed):
             if tok:
                 emb[int(tok[0]), :] = [float(x) for x in tok[1:]]
     return emb
+
+
+def read_embeddings_bin(filename):
+    """Binary side-car written next to the ``.emb`` text (``Engine.write_embeddings_bin``) -> float32 [n_node, n_emb]."""
+    with open(filename, "rb") as f:
+        head = f.read(20)
+        if head[:4] != b"GGEB" or np.frombuffer(head, "<i4", 1, 4)[0] != 1:
+            raise ValueError("%s is not a GGEB v1 file" % filename)
+        n_emb = int(np.frombuffer(head, "<i4", 1, 8)[0])
+        n_node = int(np.frombuffer(head, "<i8", 1, 12)[0])
+        return np.fromfile(f, dtype="<f4", count=n_node * n_emb).reshape(n_node, n_emb)

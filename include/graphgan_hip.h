@@ -210,6 +210,16 @@ int gg_g_step(gg_ctx *ctx, const int32_t *u, const int32_t *v, const float *rewa
  * callers that still want score rows. */
 int gg_all_score(gg_ctx *ctx, const int32_t *rows, int32_t n_rows, float *out);
 
+/* gg_all_score_reduce: the same score rows STREAMED through a fused consumer instead of being materialised: for each
+ * requested row i (rows == NULL: every node) the maximum of S[i, :], its column (first maximum, like numpy argmax) and
+ * log sum_j exp(S[i, j]) -- the normaliser of the full softmax over all nodes (row_lse may be NULL with want_lse = 0).
+ * Nothing of size n_rows x n_node exists at any time.  precision 0: exact fp32 scores on v_mfma_f32_32x32x2_f32;
+ * precision 1: a bf16 copy of the table (round to nearest even) on v_mfma_f32_32x32x16_bf16, fp32 accumulate.
+ * kernel_ms_out (may be NULL): HIP-event time of the tile stream.  Replaces what a caller of generator.all_score
+ * (generator.py:21) would do with the N x N matrix at sizes where it cannot exist (BASELINE.json configs[4]). */
+int gg_all_score_reduce(gg_ctx *ctx, const int32_t *rows, int32_t n_rows, int32_t precision, int32_t want_lse, float *row_max,
+                        int32_t *row_argmax, float *row_lse, double *kernel_ms_out);
+
 /* sess.run(embedding_matrix) (graph_gan.py:298); which: 0 = generator, 1 = discriminator
  * (config.modes order, config.py:1).  out is [n_node, n_emb] fp32, unpadded. */
 int gg_get_embeddings(gg_ctx *ctx, int32_t which, float *out);
@@ -219,6 +229,11 @@ int gg_get_bias(gg_ctx *ctx, int32_t which, float *out);
  * host threads.  gg_host_write_embeddings: the same for a caller-supplied [n_node, n_emb] fp32 matrix. */
 int gg_write_embeddings(gg_ctx *ctx, int32_t which, const char *path, int32_t n_threads);
 int gg_host_write_embeddings(const float *emb, int64_t n_node, int32_t n_emb, const char *path, int32_t n_threads);
+/* gg_write_embeddings_bin: binary side-car of that text for large N: {"GGEB", version 1 i32, n_emb i32, n_node i64} + fp32 rows. */
+int gg_write_embeddings_bin(gg_ctx *ctx, int32_t which, const char *path);
+/* gg_edge_scores: the evaluator's scores (src/evaluation/link_prediction.py:26-27: np.dot(emd[u], emd[v]) per test /
+ * negative edge) computed on the device from the resident table of model `which`, in float64 like the reference. */
+int gg_edge_scores(gg_ctx *ctx, int32_t which, const int32_t *u, const int32_t *v, int64_t n, double *out);
 int gg_set_embeddings(gg_ctx *ctx, int32_t which, const float *emb);
 int gg_set_bias(gg_ctx *ctx, int32_t which, const float *bias);
 

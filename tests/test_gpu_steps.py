@@ -468,3 +468,75 @@ def test_sampled_profiling_and_early_returning_passes(ga, every, monkeypatch):
         eng.set_profiling(-1)
     eng.close()
     ref.close()
+
+
+def _bf16_round(x):
+    """fp32 -> bf16 (round to nearest even) -> fp32, like v_cvt_pk_bf16_f32"""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32)
+
+
+@pytest.mark.parametrize("n,d", [(700, 50), (3000, 128), (1029, 256), (300, 8)])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_all_score_streamed_consumer(ga, n, d, precision):
+    """generator.all_score (generator.py:21) streamed through the fused consumer (max, argmax, log-sum-exp per row; nothing
+    of size rows x N materialised) against numpy on the materialised rows.  fp32: the matrix-core scores are exact fp32
+    (max equal to the oracle's k-ordered chain, argmax identical, lse to 1e-5); bf16: against numpy on the bf16-rounded
+    table (fp32 accumulation order differs: 2e-3 abs on scores of magnitude ~10)."""
+    Eg, Ed, bg, bd = make_models(n, d, n + d)
+    Eg = Eg * np.float32(1.5)
+    eng = engine_with(ga, Eg, Ed, bg, bd)
+    rows = np.unique(np.random.RandomState(3).randint(0, n, 150)).astype(np.int32)
+    res = eng.all_score_reduce(rows, precision=precision)
+    ref = _bf16_round(Eg) if precision == "bf16" else Eg
+    S = (ref[rows].astype(np.float64) @ ref.T.astype(np.float64)) + bg.astype(np.float64)[None, :]
+    tol = 2e-3 if precision == "bf16" else 2e-5
+    assert np.max(np.abs(res["max"] - S.max(1))) <= tol * max(1.0, np.abs(S).max())
+    lse = S.max(1) + np.log(np.exp(S - S.max(1, keepdims=True)).sum(1))
+    assert np.max(np.abs(res["logsumexp"] - lse)) <= tol * max(1.0, np.abs(S).max())
+    # argmax: identical unless two scores are closer than the tolerance
+    am = S.argmax(1)
+    close = np.abs(S[np.arange(len(rows)), res["argmax"]] - S.max(1)) <= tol * max(1.0, np.abs(S).max())
+    assert close.all() and (res["argmax"] == am).mean() > (0.97 if precision == "bf16" else 0.999)
+    if precision == "fp32":
+        want = orc.c_all_score_rows(orc.pad_rows(Eg), bg, rows)  # the oracle's exact fp32 rows
+        assert np.array_equal(res["max"], want.max(1)) and np.array_equal(res["argmax"], want.argmax(1))
+    all_rows = eng.all_score_reduce(None, precision=precision, logsumexp=False)
+    assert np.array_equal(all_rows["argmax"][rows], res["argmax"]) and all_rows["logsumexp"] is None
+    assert res["kernel_ms"] > 0
+    eng.close()
+
+
+def test_evaluator_scores_on_the_device_and_binary_sidecar(ga, tmp_path):
+    """src/evaluation/link_prediction.py:19-38 with the per-edge dots computed by gg_edge_scores: the accuracy of the shipped
+    pre-trained embeddings is the reference's 0.7598343685300207 to the digit, scores equal np.dot to 1e-12, and the
+    binary side-car holds exactly the numbers of the text file."""
+    from graphgan_amd.evaluation import link_prediction as lp
+    from graphgan_amd import utils
+    d, n, graph = load_ca_grqc()
+    emb = ca_grqc_init_embeddings(d, n).astype(np.float32)
+    eng = ga.Engine(emb, emb * np.float32(0.5))
+    te, neg = str(tmp_path / "test.txt"), str(tmp_path / "neg.txt")
+    for path, key in ((te, "test"), (neg, "test_neg")):
+        with open(path, "w") as f:
+            f.writelines("%d\t%d\n" % (a, b) for a, b in d[key].tolist())
+    acc_dev = lp.LinkPredictEval("unused", te, neg, n, 50, engine=eng, which=0).eval_link_prediction()
+    acc_ref = lp.LinkPredictEval("unused", te, neg, n, 50, emd=emb.astype(np.float64)).eval_link_prediction()
+    assert acc_dev == acc_ref == 0.7598343685300207
+    edges = np.array(d["test"].tolist() + d["test_neg"].tolist())
+    got = eng.edge_scores(1, edges[:, 0], edges[:, 1])
+    e64 = (emb * np.float32(0.5)).astype(np.float64)
+    want = np.array([np.dot(e64[a], e64[b]) for a, b in edges])
+    assert np.max(np.abs(got - want)) <= 1e-12 * max(1.0, np.abs(want).max())
+    with pytest.raises(ga.GraphGANHipError):
+        eng.edge_scores(0, [0], [n])
+    txt, bn = str(tmp_path / "gen.emb"), str(tmp_path / "gen.emb.bin")
+    eng.write_embeddings(0, txt)
+    eng.write_embeddings_bin(0, bn)
+    assert os.path.getsize(bn) == 20 + 4 * n * 50 and os.path.getsize(txt) > 3 * os.path.getsize(bn)
+    back = utils.read_embeddings_bin(bn)
+    assert back.dtype == np.float32 and np.array_equal(back, emb)
+    np.random.seed(0)
+    assert np.array_equal(utils.read_embeddings(txt, n, 50), emb.astype(np.float64))
+    eng.close()

@@ -113,6 +113,9 @@ class _FakeEngine(object):
     def d_pass(self, starts, batch): self.calls.append(("d_pass", list(starts), batch))
     def g_pass(self, starts, batch): self.calls.append(("g_pass", list(starts), batch))
     def get_embeddings(self, which): return self.E[which]
+    def edge_scores(self, which, u, v):
+        e = self.E[which].astype(np.float64)
+        return np.array([np.dot(e[a], e[b]) for a, b in zip(u, v)])
     def get_bias(self, which): return np.zeros(self.n_node, np.float32)
     def write_embeddings(self, which, path):
         from graphgan_amd import engine
