@@ -103,6 +103,7 @@ SIGNATURES = {
     "gg_comm_unique_id": (ctypes.c_int, [_P]),
     "gg_comm_init": (ctypes.c_int, [_P, _P, _i32, _i32]),
     "gg_comm_barrier": (ctypes.c_int, [_P]),
+    "gg_comm_stats": (ctypes.c_int, [_P, _P]),
     "gg_synth_powerlaw": (_i64, [_i32, _i32, _u64, _u64, _P, _i64]),
     "gg_host_read_edges": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(GGGraph)]),
     "gg_host_free_graph": (None, [ctypes.POINTER(GGGraph)]),

@@ -21,6 +21,7 @@ typedef int (*fn_CommInitRank)(void **, int, RcclUniqueId, int);
 typedef int (*fn_CommDestroy)(void *);
 typedef int (*fn_AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t);
 typedef int (*fn_AllGather)(const void *, void *, size_t, int, void *, hipStream_t);
+typedef int (*fn_ReduceScatter)(const void *, void *, size_t, int, int, void *, hipStream_t);
 typedef const char *(*fn_GetErrorString)(int);
 
 struct RcclApi {
@@ -30,12 +31,14 @@ struct RcclApi {
     fn_CommDestroy CommDestroy = nullptr;
     fn_AllReduce AllReduce = nullptr;
     fn_AllGather AllGather = nullptr;
+    fn_ReduceScatter ReduceScatter = nullptr;
     fn_GetErrorString GetErrorString = nullptr;
 };
 
 static RcclApi g_rccl;
 constexpr int NCCL_FLOAT32 = 7;  // ncclFloat32
 constexpr int NCCL_SUM = 0;      // ncclSum
+constexpr int NCCL_MAX = 2;      // ncclMax
 constexpr int NCCL_INT32 = 2;    // ncclInt32
 constexpr int NCCL_INT64 = 4;    // ncclInt64
 
@@ -55,8 +58,9 @@ static int load_rccl(gg_ctx *ctx) {
     api.CommDestroy = (fn_CommDestroy)dlsym(h, "ncclCommDestroy");
     api.AllReduce = (fn_AllReduce)dlsym(h, "ncclAllReduce");
     api.AllGather = (fn_AllGather)dlsym(h, "ncclAllGather");
+    api.ReduceScatter = (fn_ReduceScatter)dlsym(h, "ncclReduceScatter");
     api.GetErrorString = (fn_GetErrorString)dlsym(h, "ncclGetErrorString");
-    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.AllGather || !api.GetErrorString)
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.AllGather || !api.ReduceScatter || !api.GetErrorString)
         return fail(ctx, GG_ECOMM, "librccl is missing a required symbol");
     g_rccl = api;
     return GG_OK;
@@ -68,12 +72,37 @@ static int load_rccl(gg_ctx *ctx) {
         if (r__ != 0) return fail(ctx, GG_ECOMM, "%s -> %s", #call, g_rccl.GetErrorString(r__));        \
     } while (0)
 
-// dense exchange (GG_OPT_ADAM_DENSE): sum the whole accumulators
+// Dense exchange (GG_OPT_ADAM_DENSE, and the scale modes when the replicas together touch most of the table): the sum of
+// the whole accumulators.  xGMI is point to point (7 links per GPU): the sum is issued as an in-place REDUCE-SCATTER --
+// every rank ends up owning the sum of one 1/world slice, each slice arriving over its own link -- followed by an in-place
+// ALL-GATHER of the slices, instead of one ring all-reduce that is bound by a single link.  The
+// accumulator is padded to a multiple of the world size (gg_comm_init).  GG_COMM_DENSE=allreduce selects the plain call.
 int comm_allreduce_grads(gg_ctx *ctx) {
     if (!ctx->comm) return GG_OK;
     const size_t ne = (size_t)ctx->n_node * ctx->ld;
-    GG_NCCL(ctx, g_rccl.AllReduce(ctx->gradE, ctx->gradE, ne, NCCL_FLOAT32, NCCL_SUM, ctx->comm, ctx->stream));
+    if (ctx->comm_rsag && ctx->world > 1) {
+        const size_t chunk = ctx->grad_elems_padded / (size_t)ctx->world;
+        float *mine = ctx->gradE + chunk * (size_t)ctx->rank;
+        GG_NCCL(ctx, g_rccl.ReduceScatter(ctx->gradE, mine, chunk, NCCL_FLOAT32, NCCL_SUM, ctx->comm, ctx->stream));
+        GG_NCCL(ctx, g_rccl.AllGather(mine, ctx->gradE, chunk, NCCL_FLOAT32, ctx->comm, ctx->stream));
+    } else {
+        GG_NCCL(ctx, g_rccl.AllReduce(ctx->gradE, ctx->gradE, ne, NCCL_FLOAT32, NCCL_SUM, ctx->comm, ctx->stream));
+    }
     GG_NCCL(ctx, g_rccl.AllReduce(ctx->gradb, ctx->gradb, (size_t)ctx->n_node, NCCL_FLOAT32, NCCL_SUM, ctx->comm, ctx->stream));
+    return GG_OK;
+}
+
+// bytes a rank sends for one dense exchange (statistics: gg_comm_stats)
+size_t comm_dense_bytes(const gg_ctx *ctx) {
+    if (!ctx->comm || ctx->world <= 1) return 0;
+    const double f = (double)(ctx->world - 1) / (double)ctx->world;
+    return (size_t)(2.0 * f * 4.0 * ((double)ctx->grad_elems_padded + (double)ctx->n_node));
+}
+
+// max of `count` int64 words over ranks (row / pair counts of a prepare call)
+int comm_allreduce_max_i64(gg_ctx *ctx, int64_t *buf, size_t count) {
+    if (!ctx->comm) return GG_OK;
+    GG_NCCL(ctx, g_rccl.AllReduce(buf, buf, count, NCCL_INT64, NCCL_MAX, ctx->comm, ctx->stream));
     return GG_OK;
 }
 
@@ -144,6 +173,18 @@ int gg_comm_init(gg_ctx *ctx, const void *id128, int32_t rank, int32_t world) {
     ctx->comm = comm;
     ctx->rank = rank;
     ctx->world = world;
+    if (const char *m = getenv("GG_COMM_DENSE")) ctx->comm_rsag = strcmp(m, "allreduce") != 0;
+    // the reduce-scatter needs equal slices: pad the gradient accumulator to a multiple of the world size
+    const size_t ne = (size_t)ctx->n_node * ctx->ld;
+    const size_t padded = (ne + (size_t)world - 1) / (size_t)world * (size_t)world;
+    if (padded != ctx->grad_elems_padded) {
+        GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->gradE) (void)hipFree(ctx->gradE);
+        ctx->gradE = nullptr;
+        GG_HIP(ctx, hipMalloc((void **)&ctx->gradE, sizeof(float) * padded));
+        GG_HIP(ctx, hipMemset(ctx->gradE, 0, sizeof(float) * padded));
+        ctx->grad_elems_padded = padded;
+    }
     return GG_OK;
 }
 
@@ -157,7 +198,17 @@ int gg_comm_barrier(gg_ctx *ctx) {
     }
     GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     harvest_timings(ctx);
-    return GG_OK;
+    return check_exchange_flag(ctx);
 }
 
 }  // extern "C"
+
+// gg_comm_stats: see include/graphgan_hip.h.
+extern "C" int gg_comm_stats(gg_ctx *ctx, int64_t *out4) {
+    if (!ctx || !out4) return fail(ctx, GG_EINVAL, "gg_comm_stats: NULL argument");
+    out4[0] = ctx->comm_steps_sparse;
+    out4[1] = ctx->comm_steps_dense;
+    out4[2] = ctx->comm_bytes_sent;
+    out4[3] = ctx->world;
+    return GG_OK;
+}

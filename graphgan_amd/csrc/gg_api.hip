@@ -328,6 +328,7 @@ int gg_create(int32_t n_node, int32_t n_emb, const float *emb_gen, const float *
         GG_HIP(ctx, hipMalloc((void **)&ctx->gradE, tb));
         GG_HIP(ctx, hipMalloc((void **)&ctx->gradb, vb));
         GG_HIP(ctx, hipMemset(ctx->gradE, 0, tb));
+        ctx->grad_elems_padded = (size_t)n_node * ctx->ld;
         GG_HIP(ctx, hipMemset(ctx->gradb, 0, vb));
         GG_HIP(ctx, hipMalloc((void **)&ctx->touched, sizeof(int32_t) * n_node));
         GG_HIP(ctx, hipMalloc((void **)&ctx->touched_list, sizeof(int32_t) * n_node));
@@ -750,10 +751,20 @@ int gg_synchronize(gg_ctx *ctx) {
     GG_HIP(ctx, hipSetDevice(ctx->device));
     GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     harvest_timings(ctx);
-    return GG_OK;
+    return check_exchange_flag(ctx);
 }
 
 }  // extern "C"
+
+// A row pack of the replica exchange did not fit its capacity (steps.hip: the capacity rule was violated, e.g. ranks
+// passed inconsistent batch sizes): the step's gradients were truncated -- report it instead of training on.
+int gg::check_exchange_flag(gg_ctx *ctx) {
+    if (!ctx->comm && ctx->fake_world <= 1) return GG_OK;
+    int32_t flag = 0;
+    GG_HIP(ctx, hipMemcpy(&flag, ctx->touched_cnt + 2, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (flag) return fail(ctx, GG_ECOMM, "replica exchange: a rank touched more rows than the pack capacity of its step");
+    return GG_OK;
+}
 
 // Event triples {before the gradient / reward kernel, between gradient and optimizer, after} recorded by profiled
 // prepare / pass calls; folded into the counters once the stream has passed them (called after host synchronisations).

@@ -156,6 +156,11 @@ struct gg_ctx {
 
     // multi-GPU
     void *comm = nullptr;  // ncclComm_t
+    bool comm_rsag = true;             // dense exchange as reduce-scatter + all-gather (GG_COMM_DENSE=allreduce: one all-reduce)
+    size_t grad_elems_padded = 0;      // length of gradE (n_node * ld rounded up to a multiple of the world size)
+    int64_t d_rows_max = 0, g_pairs_max = 0;  // max over ranks of the prepared rows / pairs (exchanged inside gg_prepare_*)
+    int64_t step_bound = 0;            // pairs any rank can contribute to the step being enqueued -> capacity of its row packs
+    int64_t comm_steps_sparse = 0, comm_steps_dense = 0, comm_bytes_sent = 0;  // gg_comm_stats
     int32_t rank = 0, world = 1;
     bool deterministic = false;  // GG_DETERMINISTIC=1: atomic-free gradient kernel for batches <= 256 pairs
     float dense_exchange_ratio = 1.5f;  // sparse exchange only while (rows touched over all ranks) < ratio * n_node (GG_COMM_DENSE_RATIO)
@@ -205,6 +210,7 @@ int walk_launch_async(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks,
                       int32_t for_d, uint64_t seed, uint32_t stream, int32_t stride, bool side_stream = false);
 int walk_finalize(gg_ctx *ctx, bool *retried);
 int timing_slot(gg_ctx *ctx);
+int check_exchange_flag(gg_ctx *ctx);
 void harvest_timings(gg_ctx *ctx);  // after a synchronisation of ctx->stream: fold finished event triples into the counters
 int walk_resident(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, int32_t uniform_walks, int32_t n_slots,
                   int32_t for_d, uint64_t seed, uint32_t stream, int32_t stride);
@@ -214,6 +220,9 @@ int run_step(gg_ctx *ctx, int which, const int32_t *d_u, const int32_t *d_v, con
 int comm_allreduce_grads(gg_ctx *ctx);
 int comm_allreduce_flags(gg_ctx *ctx);
 int comm_allreduce_i64(gg_ctx *ctx, int64_t *buf, size_t count);
+int comm_allreduce_max_i64(gg_ctx *ctx, int64_t *buf, size_t count);
+size_t comm_dense_bytes(const gg_ctx *ctx);
+int exchange_count_max(gg_ctx *ctx, int64_t local, int64_t *max_out);  // steps.hip: max over ranks of a prepared row / pair count
 int comm_allgather(gg_ctx *ctx, const void *send, void *recv, size_t count, int elem_bytes);
 void comm_destroy(gg_ctx *ctx);
 

@@ -280,6 +280,8 @@ int gg_prepare_d(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, uint64_t se
         ctx->d_rows = (int64_t)ctx->h_pin[gg_ctx::H_TOTAL];
         if (root_status) GG_HIP(ctx, hipMemcpy(root_status, ctx->w_status.p, sizeof(int32_t) * n_slots, hipMemcpyDeviceToHost));
     }
+    rc = exchange_count_max(ctx, ctx->d_rows, &ctx->d_rows_max);  // replicas: capacity rule of the passes' row packs
+    if (rc != GG_OK) return rc;
     if (n_rows_out) *n_rows_out = ctx->d_rows;
     return GG_OK;
 }
@@ -360,6 +362,8 @@ int gg_prepare_g(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, int32_t n_s
         ctx->g_paths_valid = true;
     }
     if (root_status && n_slots) GG_HIP(ctx, hipMemcpy(root_status, ctx->w_status.p, sizeof(int32_t) * n_slots, hipMemcpyDeviceToHost));
+    rc = exchange_count_max(ctx, ctx->g_pairs, &ctx->g_pairs_max);
+    if (rc != GG_OK) return rc;
     if (n_pairs_out) *n_pairs_out = ctx->g_pairs;
     return GG_OK;
 }

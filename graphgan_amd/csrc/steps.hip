@@ -428,12 +428,21 @@ __global__ __launch_bounds__(256) void sparse_opt_kernel(const OptArgs a) {
 // {row id, gradient row, bias gradient}, the packs are all-gathered, and every rank adds the packs
 // in RANK ORDER with one launch per source rank (ids are unique inside a pack -> plain adds, no
 // atomics): all replicas compute bit-identical sums, so they stay bit-identical.
+// The pack has a fixed CAPACITY known to every rank's host before the step (2 * the most pairs any rank can bring:
+// every pair touches at most two rows), so the collectives that move it need no row count from the device: entries
+// behind this rank's rows carry id -1 and are skipped by the receivers.  `err` is raised if the rows do not fit
+// (impossible while the capacity rule holds; checked at the next host synchronisation).
 __global__ __launch_bounds__(256) void pack_rows_kernel(float *gE, float *gb, int32_t *touched, const int32_t *list, const int64_t *cnt_ptr,
-                                                        int ld, int32_t *out_ids, float *out_rows) {
+                                                        int64_t cap, int ld, int32_t *out_ids, float *out_rows, int32_t *err) {
     const int t = threadIdx.x & 15;
     const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4, ng = ((int64_t)gridDim.x * blockDim.x) >> 4;
     const int64_t cnt = *cnt_ptr;
-    for (int64_t r = g0; r < cnt; r += ng) {
+    if (cnt > cap && blockIdx.x == 0 && threadIdx.x == 0) *err = 1;
+    for (int64_t r = g0; r < cap; r += ng) {
+        if (r >= cnt) {
+            if (t == 0) out_ids[r] = -1;
+            continue;
+        }
         const int row = list[r];
         float *src = gE + (int64_t)row * ld, *dst = out_rows + r * (ld + 1);
         for (int f = t; f < ld; f += 16) { dst[f] = src[f]; src[f] = 0.f; }
@@ -447,6 +456,7 @@ __global__ __launch_bounds__(256) void add_rows_kernel(float *gE, float *gb, int
     const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4, ng = ((int64_t)gridDim.x * blockDim.x) >> 4;
     for (int64_t r = g0; r < cnt; r += ng) {
         const int row = ids[r];
+        if (row < 0) continue;  // padding behind the source rank's rows
         float *dst = gE + (int64_t)row * ld;
         const float *src = rows + r * (ld + 1);
         for (int f = t; f < ld; f += 16) dst[f] += src[f];
@@ -566,61 +576,72 @@ __global__ void scale_grads_kernel(float *gE, float *gb, int64_t nE, int n, floa
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) gb[i] *= k;
 }
 
-// Sparse exchange: see pack_rows_kernel.  One host read-back (the per-rank row counts) per step.
-static int exchange_sparse(gg_ctx *ctx, OptArgs &o, int world) {
+// Replica exchange of the lazy / sgd modes, WITHOUT host synchronisation.  `bound` = the most pairs any rank brings to
+// this step (known on every host: the batch size of a minibatch step, or the max over ranks of the prepared rows that
+// gg_prepare_* exchanged inside its own synchronisation), so cap = min(N, 2 * bound) rows bound every rank's pack.
+//   world * cap <  ratio * N : fixed-capacity row packs {id, gradient row, bias gradient}, all-gathered (every rank's
+//                              pack travels over its own xGMI link) and added in RANK ORDER with plain adds -- replicas
+//                              compute bit-identical sums;
+//   otherwise                : the replicas together may touch most of the table: dense reduce-scatter + all-gather of
+//                              the accumulators and the union of the row flags.
+// The choice depends on host-side numbers that are identical on every rank, so all ranks take the same branch.
+static int exchange_sparse(gg_ctx *ctx, OptArgs &o, int world, int64_t bound) {
     const int n = ctx->n_node, ld = ctx->ld;
-    int rc = device_exclusive_scan(ctx, ctx->touched, ctx->touched_ptr.as<int64_t>(), n);
-    if (rc != GG_OK) return rc;
-    hipLaunchKernelGGL(compact_touched_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, o);
-    GG_HIP(ctx, ctx->x_cnt.reserve(sizeof(int64_t) * (world + 1)));
-    rc = comm_allgather(ctx, o.touched_total, ctx->x_cnt.as<int64_t>(), 1, 8);
-    if (rc != GG_OK) return rc;
-    std::vector<int64_t> cnt(world);
-    GG_HIP(ctx, hipMemcpyAsync(cnt.data(), ctx->x_cnt.p, sizeof(int64_t) * world, hipMemcpyDeviceToHost, ctx->stream));
-    GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    int64_t maxc = 0;
-    for (int r = 0; r < world; ++r) {
-        GG_CHECK(ctx, cnt[r] >= 0 && cnt[r] <= n, GG_ECOMM, "sparse exchange: rank %d reports %lld rows", r, (long long)cnt[r]);
-        maxc = std::max(maxc, cnt[r]);
-    }
-    if (maxc == 0) return GG_OK;
-    // Packs pay off while few rows are touched: a rank receives (sum of the other ranks' rows) * row bytes,
-    // a ring all-reduce moves ~2 * n_node * row bytes.  When the replicas together touch most of the table
-    // (many roots per step), fall back to the dense all-reduce of the accumulators + the flag union.
-    // cnt[] is identical on every rank, so all ranks take the same branch.
-    int64_t total = 0;
-    for (int r = 0; r < world; ++r) total += cnt[r];
-    if ((double)total >= (double)ctx->dense_exchange_ratio * n) {
+    const int64_t cap = std::min<int64_t>(n, 2 * std::max<int64_t>(bound, 0));
+    if (cap == 0) return GG_OK;  // no rank has a pair in this step
+    if ((double)world * (double)cap >= (double)ctx->dense_exchange_ratio * n) {
         if (ctx->comm) {
-            rc = comm_allreduce_grads(ctx);
+            int rc = comm_allreduce_grads(ctx);
             if (rc == GG_OK) rc = comm_allreduce_flags(ctx);
             if (rc != GG_OK) return rc;
+            ctx->comm_bytes_sent += (int64_t)comm_dense_bytes(ctx) + (int64_t)(2.0 * 4.0 * n * (world - 1) / world);
         } else {  // GG_COMM_FAKE_WORLD: every simulated rank holds this rank's gradient
             hipLaunchKernelGGL(scale_grads_kernel, dim3(2048), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, (int64_t)n * ld, n, (float)world);
         }
         hipLaunchKernelGGL(normalize_flags_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, ctx->touched, n);
         GG_HIP(ctx, hipGetLastError());
+        ctx->comm_steps_dense += 1;
         return GG_OK;
     }
+    int rc = device_exclusive_scan(ctx, ctx->touched, ctx->touched_ptr.as<int64_t>(), n);
+    if (rc != GG_OK) return rc;
+    hipLaunchKernelGGL(compact_touched_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, o);
     const size_t row_f = (size_t)ld + 1;
-    GG_HIP(ctx, ctx->x_send_ids.reserve(sizeof(int32_t) * maxc));
-    GG_HIP(ctx, ctx->x_send_rows.reserve(sizeof(float) * maxc * row_f));
-    GG_HIP(ctx, ctx->x_recv_ids.reserve(sizeof(int32_t) * maxc * world));
-    GG_HIP(ctx, ctx->x_recv_rows.reserve(sizeof(float) * maxc * row_f * world));
-    int nb = cdiv(maxc * 16, 256);
+    GG_HIP(ctx, ctx->x_send_ids.reserve(sizeof(int32_t) * cap));
+    GG_HIP(ctx, ctx->x_send_rows.reserve(sizeof(float) * cap * row_f));
+    GG_HIP(ctx, ctx->x_recv_ids.reserve(sizeof(int32_t) * cap * world));
+    GG_HIP(ctx, ctx->x_recv_rows.reserve(sizeof(float) * cap * row_f * world));
+    int nb = cdiv(cap * 16, 256);
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(pack_rows_kernel, dim3(nb), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, ctx->touched, ctx->touched_list,
-                       o.touched_total, ld, ctx->x_send_ids.as<int32_t>(), ctx->x_send_rows.as<float>());
-    rc = comm_allgather(ctx, ctx->x_send_ids.p, ctx->x_recv_ids.p, (size_t)maxc, 4);
+                       o.touched_total, cap, ld, ctx->x_send_ids.as<int32_t>(), ctx->x_send_rows.as<float>(), ctx->touched_cnt + 2);
+    rc = comm_allgather(ctx, ctx->x_send_ids.p, ctx->x_recv_ids.p, (size_t)cap, 4);
     if (rc != GG_OK) return rc;
-    rc = comm_allgather(ctx, ctx->x_send_rows.p, ctx->x_recv_rows.p, (size_t)maxc * row_f, 4);
+    rc = comm_allgather(ctx, ctx->x_send_rows.p, ctx->x_recv_rows.p, (size_t)cap * row_f, 4);
     if (rc != GG_OK) return rc;
-    for (int r = 0; r < world; ++r) {
-        if (cnt[r] == 0) continue;
+    for (int r = 0; r < world; ++r)
         hipLaunchKernelGGL(add_rows_kernel, dim3(nb), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, ctx->touched,
-                           ctx->x_recv_ids.as<int32_t>() + (size_t)r * maxc, ctx->x_recv_rows.as<float>() + (size_t)r * maxc * row_f, cnt[r], ld);
-    }
+                           ctx->x_recv_ids.as<int32_t>() + (size_t)r * cap, ctx->x_recv_rows.as<float>() + (size_t)r * cap * row_f, cap, ld);
     GG_HIP(ctx, hipGetLastError());
+    ctx->comm_steps_sparse += 1;
+    if (ctx->comm) ctx->comm_bytes_sent += (int64_t)((world - 1) * cap * (row_f + 1) * 4);
+    return GG_OK;
+}
+
+// Max over ranks of the rows / pairs a prepare call produced (one 8-byte all-reduce and one synchronisation per PREPARE
+// call on replicas -- not per step): the capacity rule of the steps' row packs.
+int exchange_count_max(gg_ctx *ctx, int64_t local, int64_t *max_out) {
+    *max_out = local;
+    if (!ctx->comm || ctx->world <= 1) return GG_OK;
+    GG_HIP(ctx, ctx->x_nglob.reserve(sizeof(int64_t) * 4));
+    int64_t *w = ctx->x_nglob.as<int64_t>() + 2;
+    ctx->h_pin[gg_ctx::H_TOTAL + 2] = (unsigned long long)local;
+    GG_HIP(ctx, hipMemcpyAsync(w, ctx->h_pin + gg_ctx::H_TOTAL + 2, sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    int rc = comm_allreduce_max_i64(ctx, w, 1);
+    if (rc != GG_OK) return rc;
+    GG_HIP(ctx, hipMemcpyAsync(ctx->h_pin + gg_ctx::H_TOTAL + 1, w, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *max_out = (int64_t)ctx->h_pin[gg_ctx::H_TOTAL + 1];
     return GG_OK;
 }
 
@@ -629,7 +650,10 @@ int apply_optimizer(gg_ctx *ctx, int which, int64_t n) {
     Model &M = ctx->model[which];
     const int opt = ctx->cfg.optimizer;
     int rc = GG_OK;
-    if (opt == GG_OPT_ADAM_DENSE) rc = comm_allreduce_grads(ctx);
+    if (opt == GG_OPT_ADAM_DENSE) {
+        rc = comm_allreduce_grads(ctx);
+        if (ctx->comm && ctx->world > 1) { ctx->comm_steps_dense += 1; ctx->comm_bytes_sent += (int64_t)comm_dense_bytes(ctx); }
+    }
     if (rc != GG_OK) return rc;
 
     OptArgs o{};
@@ -653,7 +677,7 @@ int apply_optimizer(gg_ctx *ctx, int which, int64_t n) {
         o.touched_total = o.touched_ptr + ctx->n_node;
         const int world = ctx->comm ? ctx->world : ctx->fake_world;
         if (world > 1 || (ctx->comm && ctx->world == 1)) {
-            rc = exchange_sparse(ctx, o, world < 1 ? 1 : world);
+            rc = exchange_sparse(ctx, o, world < 1 ? 1 : world, ctx->step_bound > 0 ? ctx->step_bound : n);
             if (rc != GG_OK) return rc;
         }
         rc = device_exclusive_scan(ctx, ctx->touched, ctx->touched_ptr.as<int64_t>(), ctx->n_node);
@@ -692,6 +716,20 @@ static int host_step(gg_ctx *ctx, int which, const int32_t *u, const int32_t *v,
     GG_HIP(ctx, hipMemcpyAsync(ctx->step_u.p, u, sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
     GG_HIP(ctx, hipMemcpyAsync(ctx->step_v.p, v, sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
     GG_HIP(ctx, hipMemcpyAsync(ctx->step_x.p, x, sizeof(float) * n, hipMemcpyHostToDevice, ctx->stream));
+    ctx->step_bound = n;
+    if (ctx->comm && ctx->world > 1 && ctx->cfg.optimizer != GG_OPT_ADAM_DENSE) {
+        // ranks may pass batches of different sizes: the pack capacity is the largest of them (this call is synchronous anyway)
+        GG_HIP(ctx, ctx->x_nglob.reserve(sizeof(int64_t) * 4));
+        int64_t *w = ctx->x_nglob.as<int64_t>() + 3;
+        const int64_t mine = n;
+        GG_HIP(ctx, hipMemcpyAsync(w, &mine, sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+        int rc0 = comm_allreduce_max_i64(ctx, w, 1);
+        if (rc0 != GG_OK) return rc0;
+        int64_t mx = n;
+        GG_HIP(ctx, hipMemcpyAsync(&mx, w, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->step_bound = mx;
+    }
     int rc = run_step(ctx, which, ctx->step_u.as<int32_t>(), ctx->step_v.as<int32_t>(), ctx->step_x.as<float>(), n);
     if (rc != GG_OK) return rc;
     GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -706,20 +744,25 @@ static int run_pass(gg_ctx *ctx, int which, const int64_t *starts, int64_t n_bat
     const int32_t *v = which == 1 ? ctx->d_neighbor.as<int32_t>() : ctx->g_node2.as<int32_t>();
     const float *x = which == 1 ? ctx->d_label.as<float>() : ctx->g_reward.as<float>();
     GG_HIP(ctx, hipSetDevice(ctx->device));
-    if (rows == 0) {
-        // nothing prepared on this rank; with replicas it still has to take part in the step's
-        // gradient exchange (the other ranks are waiting in the collective)
-        if (ctx->comm && n_batches > 0) {
-            int rc = GG_OK;
-            if (which == 0) {  // the generator's steps open with the all-reduce of the ranks' pair counts
-                const int64_t *unused = nullptr;
-                rc = global_pair_count(ctx, 0, &unused);
-                if (rc != GG_OK) return rc;
-            }
-            rc = apply_optimizer(ctx, which, 0);
+    const int64_t rows_max = std::max(rows, which == 1 ? ctx->d_rows_max : ctx->g_pairs_max);
+    // A step this rank has no rows for (start < 0, or nothing prepared at all): with replicas it still takes part in the
+    // step's collectives -- the other ranks are waiting in them -- and applies the summed update of the others.
+    auto empty_step = [&]() -> int {
+        if (!ctx->comm) return GG_OK;
+        if (which == 0) {  // the generator's steps open with the all-reduce of the ranks' pair counts
+            const int64_t *unused = nullptr;
+            int rc = global_pair_count(ctx, 0, &unused);
             if (rc != GG_OK) return rc;
-            GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
+        return apply_optimizer(ctx, which, 0);
+    };
+    if (rows == 0) {
+        ctx->step_bound = std::min<int64_t>(batch_size, rows_max);
+        for (int64_t k = 0; k < n_batches; ++k) {
+            int rc = empty_step();
+            if (rc != GG_OK) return rc;
+        }
+        if (ctx->comm && n_batches > 0) GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return GG_OK;
     }
     const bool timed = ctx->profile_every == 1;  // gg_set_profiling: otherwise no events and no wait
@@ -732,13 +775,19 @@ static int run_pass(gg_ctx *ctx, int which, const int64_t *starts, int64_t n_bat
         ctx->tm_cur = timing_slot(ctx);
         if (ctx->tm_cur >= 0) GG_HIP(ctx, hipEventRecord(ctx->tm_ev[ctx->tm_cur][0], ctx->stream));
     }
+    ctx->step_bound = std::min<int64_t>(batch_size, rows_max);
     if (which == 0 && whole && ctx->g_paths_valid && ctx->cfg.window_size <= 2 && ctx->ld <= 256 && !getenv("GG_NO_PATH_GRAD")) {
         int rc = run_path_step(ctx);
         if (rc != GG_OK) { ctx->tm_cur = -1; return rc; }
     } else {
         for (int64_t k = 0; k < n_batches; ++k) {
             const int64_t s = starts[k];
-            GG_CHECK(ctx, s >= 0 && s < rows, GG_EINVAL, "pass: start %lld outside the %lld prepared rows", (long long)s, (long long)rows);
+            if (s < 0) {  // this rank's share of the step is empty (the replicas' batch lists have different lengths)
+                int rc = empty_step();
+                if (rc != GG_OK) return rc;
+                continue;
+            }
+            GG_CHECK(ctx, s < rows, GG_EINVAL, "pass: start %lld outside the %lld prepared rows", (long long)s, (long long)rows);
             const int32_t n = (int32_t)std::min<int64_t>(batch_size, rows - s);
             int rc = run_step(ctx, which, u + s, v + s, x + s, n);
             if (rc != GG_OK) return rc;

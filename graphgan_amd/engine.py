@@ -386,5 +386,11 @@ class Engine:
         buf = (ctypes.c_char * 128).from_buffer_copy(unique_id)
         self._ck(lib.gg_comm_init(self._ctx, buf, rank, world))
 
+    def comm_stats(self):
+        """Gradient-exchange statistics of this rank: dict(sparse_steps, dense_steps, bytes_sent, world)."""
+        out = np.zeros(4, dtype=np.int64)
+        self._ck(lib.gg_comm_stats(self._ctx, _ptr(out)))
+        return dict(sparse_steps=int(out[0]), dense_steps=int(out[1]), bytes_sent=int(out[2]), world=int(out[3]))
+
     def comm_barrier(self):
         self._ck(lib.gg_comm_barrier(self._ctx))

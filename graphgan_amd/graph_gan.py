@@ -40,7 +40,7 @@ try:  # the user's flag module in the working directory wins, as with the refere
 except ImportError:
     from graphgan_amd import config  # noqa: E402
 
-from graphgan_amd import _lib, engine as _engine, utils  # noqa: E402
+from graphgan_amd import _lib, engine as _engine, parallel, utils  # noqa: E402
 from graphgan_amd.evaluation import link_prediction as lp  # noqa: E402
 
 _OPTIMIZERS = {"adam_dense": _lib.GG_OPT_ADAM_DENSE, "adam_lazy": _lib.GG_OPT_ADAM_LAZY, "sgd": _lib.GG_OPT_SGD}
@@ -58,7 +58,18 @@ class GraphGAN(object):
         # native ingest (same adjacency as utils.read_edges, utils.py:12-47); self.graph[i] still lists i's neighbours
         self.n_node, self._rowptr, self._col = _engine.read_edges_csr(cfg.train_filename, cfg.test_filename)
         self.graph = _engine.CSRGraph(self._rowptr, self._col)
-        self.root_nodes = [i for i in range(self.n_node)]
+        # One process per GPU (torch.distributed.run exports RANK / WORLD_SIZE / LOCAL_RANK; a plain `python graph_gan.py`
+        # is world 1).  The reference is a single tf.Session (:57-61): every rank here holds full replicas of both models,
+        # walks ITS share of the roots (:188, :208 -- the walk RNG is keyed by root id, so the share does not change a
+        # walk) and the replicas sum their gradients inside every optimizer step (:154, :173; RCCL inside the engine).
+        self.ctl = parallel.Control()
+        self.rank, self.world = self.ctl.rank, self.ctl.world
+        self.all_root_nodes = [i for i in range(self.n_node)]
+        deg = (self._rowptr[1:] - self._rowptr[:-1]).astype(np.int64)
+        # degree-balanced shares (D-mode walks per root = its degree); world 1: all roots, in id order like the reference
+        self.root_nodes = [int(r) for r in parallel.shard_roots(np.arange(self.n_node), self.rank, self.world,
+                                                                weights=deg if self.world > 1 else None)]
+        self._prepare_no = 0
 
         self.seed = int(_cfg(cfg, "engine_seed", 0))
         # rows missing from the pre-trained file are drawn from the global numpy RNG (utils.py:63); the
@@ -70,7 +81,7 @@ class GraphGAN(object):
         self.node_embed_init_g = utils.read_embeddings(filename=cfg.pretrain_emb_filename_g, n_node=self.n_node,
                                                        n_embed=cfg.n_emb)
 
-        self.host_rng = np.random.RandomState(self.seed)
+        self.host_rng = np.random.RandomState(self.seed if self.world == 1 else [self.seed, self.rank])
 
         print("building GAN model...")
         self.engine = None
@@ -92,6 +103,8 @@ class GraphGAN(object):
         if cfg.update_ratio >= 1 or self.engine.tree_bytes_estimate(len(self.root_nodes)) <= budget:
             # construct or read BFS-trees (reference :31-46; the cache is a flat GGTR file instead of a pickle)
             cache = _cfg(cfg, "cache_filename", None)
+            if cache and self.world > 1:
+                cache = "%s.rank%dof%d" % (cache, self.rank, self.world)  # every rank caches the trees of its own roots
             if cache and os.path.isfile(cache) and self._load_tree_cache(cache):
                 print("reading BFS-trees from cache...")
             else:
@@ -109,10 +122,12 @@ class GraphGAN(object):
             self.engine = _engine.Engine(
                 self.node_embed_init_g, self.node_embed_init_d, lr_gen=cfg.lr_gen, lr_dis=cfg.lr_dis,
                 lambda_gen=cfg.lambda_gen, lambda_dis=cfg.lambda_dis, window_size=cfg.window_size,
-                optimizer=_OPTIMIZERS[_cfg(cfg, "engine_optimizer", "adam_dense")], device=int(_cfg(cfg, "engine_device", 0)))
+                optimizer=_OPTIMIZERS[_cfg(cfg, "engine_optimizer", "adam_dense")],
+                device=int(_cfg(cfg, "engine_device", 0)) if self.world == 1 else self.ctl.local_rank)
             if int(_cfg(cfg, "engine_profile_every", 1)) != 1:
                 self.engine.set_profiling(int(_cfg(cfg, "engine_profile_every", 1)))
             self.engine.set_graph_csr(self._rowptr, self._col)
+            self.ctl.connect_engine(self.engine)  # world > 1: RCCL communicator (unique id over the gloo control plane)
         return self.engine
 
     def build_generator(self):
@@ -165,14 +180,15 @@ class GraphGAN(object):
             print("loading the checkpoint: %s" % self.latest_checkpoint)
             self.engine.load_state(self.latest_checkpoint)
 
-        self.write_embeddings_to_file()
-        self.evaluation(self)
+        if self.rank == 0:  # the replicas are identical: one of them writes
+            self.write_embeddings_to_file()
+            self.evaluation(self)
 
         print("start training...")
         for epoch in range(cfg.n_epochs):
             print("epoch %d" % epoch)
 
-            if epoch > 0 and epoch % cfg.save_steps == 0:
+            if epoch > 0 and epoch % cfg.save_steps == 0 and self.rank == 0:
                 os.makedirs(cfg.model_log, exist_ok=True)
                 self.engine.save_state(self.latest_checkpoint)
 
@@ -182,9 +198,7 @@ class GraphGAN(object):
                 if d_epoch % cfg.dis_interval == 0:
                     self._stream = self.stream_id(epoch, d_epoch, cfg.n_epochs_dis, True)
                     train_size = self._prepare_d_resident()
-                start_list = list(range(0, train_size, cfg.batch_size_dis))
-                self.host_rng.shuffle(start_list)
-                self.engine.d_pass(start_list, cfg.batch_size_dis)
+                self.engine.d_pass(self._batch_starts(train_size, cfg.batch_size_dis), cfg.batch_size_dis)
 
             # G-steps
             train_size = 0
@@ -192,13 +206,25 @@ class GraphGAN(object):
                 if g_epoch % cfg.gen_interval == 0:
                     self._stream = self.stream_id(epoch, g_epoch, cfg.n_epochs_gen, False)
                     train_size = self._prepare_g_resident()
-                start_list = list(range(0, train_size, cfg.batch_size_gen))
-                self.host_rng.shuffle(start_list)
-                self.engine.g_pass(start_list, cfg.batch_size_gen)
+                self.engine.g_pass(self._batch_starts(train_size, cfg.batch_size_gen), cfg.batch_size_gen)
 
-            self.write_embeddings_to_file()
-            self.evaluation(self)
+            if self.rank == 0:
+                self.write_embeddings_to_file()
+                self.evaluation(self)
         print("training completes")
+
+    def _batch_starts(self, train_size, batch_size):
+        """One inner epoch's minibatches (reference :149-152, :168-171): the shuffled list of contiguous batch starts over
+        THIS rank's prepared rows.  With replicas, step k of the pass is the union of every rank's k-th batch (a global
+        batch of up to world * batch_size rows whose gradients the engine sums); ranks with fewer batches pad their list
+        with -1 = "nothing from me in this step", so that all ranks issue the same number of steps (each step is a
+        collective)."""
+        start_list = list(range(0, train_size, batch_size))
+        self.host_rng.shuffle(start_list)
+        if self.world > 1:
+            n_steps = int(self.ctl.max(len(start_list)))
+            start_list += [-1] * (n_steps - len(start_list))
+        return start_list
 
     # ------------------------------------------------------------------ sample preparation
     def _select_slots(self):
@@ -207,7 +233,12 @@ class GraphGAN(object):
         cfg = self.config
         if cfg.update_ratio >= 1:
             return np.arange(len(self.root_nodes), dtype=np.int32)
-        take = np.flatnonzero(self.host_rng.rand(len(self.root_nodes)) < cfg.update_ratio)
+        self._prepare_no += 1
+        if self.world == 1:
+            take = np.flatnonzero(self.host_rng.rand(len(self.root_nodes)) < cfg.update_ratio)
+        else:  # one draw per ROOT of the whole graph, keyed by the prepare call: the selection does not depend on the sharding
+            draws = np.random.RandomState([self.seed, self._prepare_no]).rand(self.n_node)
+            take = np.flatnonzero(draws[np.asarray(self.root_nodes, dtype=np.int64)] < cfg.update_ratio)
         if self._all_resident:
             return take.astype(np.int32)  # slot i holds root_nodes[i]
         if len(take) == 0:

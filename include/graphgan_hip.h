@@ -265,6 +265,9 @@ int gg_synchronize(gg_ctx *ctx);
 int gg_comm_unique_id(void *id128);
 int gg_comm_init(gg_ctx *ctx, const void *id128, int32_t rank, int32_t world);
 int gg_comm_barrier(gg_ctx *ctx);
+/* gg_comm_stats: out4 = {optimizer steps that exchanged row packs (sparse), steps that exchanged the whole accumulators
+ * (dense: reduce-scatter + all-gather), bytes this rank has sent for gradient exchanges so far, world size}. */
+int gg_comm_stats(gg_ctx *ctx, int64_t *out4);
 
 /* ---- edge-list ingest: utils.read_edges (utils.py:12-54) natively -- adjacency CSR in the reference's
  * list order from the train file (+ node ids of the test file); buffers are malloc'ed by the library and

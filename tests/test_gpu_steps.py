@@ -364,9 +364,11 @@ def test_sparse_exchange_with_simulated_ranks(ga, mode, monkeypatch):
     3-rank code path with three copies of the local pack: the applied gradient must be exactly
     3x the local one (offsets, counts, per-rank launches, flag union all exercised)."""
     monkeypatch.setenv("GG_COMM_FAKE_WORLD", "3")
-    if mode.endswith("dense-fallback"):  # force the "replicas touch most of the table" branch
+    if mode.endswith("dense-fallback"):  # force the "replicas may touch most of the table" branch
         monkeypatch.setenv("GG_COMM_DENSE_RATIO", "0")
         mode = "sgd"
+    else:  # fixed-capacity row packs (capacity min(N, 2 * batch) = 400 rows, 200 of them used: the rest is -1 padding)
+        monkeypatch.setenv("GG_COMM_DENSE_RATIO", "100")
     n, d = 400, 64
     Eg, Ed, bg, bd = make_models(n, d, 21)
     opt = ga.GG_OPT_SGD if mode == "sgd" else ga.GG_OPT_ADAM_LAZY

@@ -116,3 +116,111 @@ def test_shard_roots_properties():
         assert sorted(np.concatenate(parts).tolist()) == roots.tolist()
         loads = [w[np.isin(roots, p)].sum() for p in parts]
         assert max(loads) <= min(loads) + w.max() + 1e-6
+
+
+class _ReplicaEngine(object):
+    """Stand-in for the HIP engine on one rank of a 2-rank GraphGAN.train(): it owns a small "model" vector, every
+    optimizer step all-reduces a deterministic gradient of the rows this rank contributes (over gloo, like the engine
+    does over RCCL) and applies the sum -- a step count mismatch between the ranks hangs the collective, a rank that
+    skips its empty steps ends with a different replica."""
+
+    def __init__(self, emb_g, emb_d, **kw):
+        import torch.distributed as dist
+        self.dist = dist
+        self.kw = kw
+        self.E = [np.array(emb_g, np.float32), np.array(emb_d, np.float32)]
+        self.n_node, self.n_emb = self.E[0].shape
+        self.model = [np.zeros(64), np.zeros(64)]
+        self.steps = [0, 0]
+        self.calls = []
+        self.tree_roots = None
+        self.rows = [0, 0]
+
+    def tree_bytes_estimate(self, n_roots): return 8.0 * n_roots * (self.n_node + 1)
+    def set_profiling(self, k): pass
+    def set_graph_csr(self, rowptr, col): self.deg = np.diff(rowptr)
+    def comm_unique_id(self): return b"x" * 128
+    def comm_init(self, uid, rank, world): self.calls.append(("comm_init", uid, rank, world)); self.rank, self.world = rank, world
+    def build_trees(self, roots, **kw): self.tree_roots = [int(r) for r in roots]
+    def save_trees(self, path): pass
+    def load_state(self, path): pass
+    def save_state(self, path): open(path, "w").write("x")
+
+    def prepare_d(self, slots, seed, stream, fetch=True):
+        self.rows[1] = int(2 * self.deg[np.asarray(self.tree_roots)[np.asarray(slots)]].sum())  # 2 * deg rows per root
+        return self.rows[1]
+
+    def prepare_g(self, slots, n_sample, seed, stream, fetch=True):
+        self.rows[0] = 37 * len(slots) + 5 * self.rank
+        return self.rows[0]
+
+    def _pass(self, which, starts, batch):
+        import torch
+        for s in starts:
+            g = np.zeros(64)
+            if s >= 0:
+                n = min(batch, self.rows[which] - s)
+                assert n > 0
+                g[(s // batch) % 64] += n * (1 + self.rank)
+            t = torch.from_numpy(g)
+            self.dist.all_reduce(t)
+            self.model[which] = self.model[which] * 0.9 + t.numpy()
+            self.steps[which] += 1
+
+    def d_pass(self, starts, batch): self._pass(1, starts, batch)
+    def g_pass(self, starts, batch): self._pass(0, starts, batch)
+    def get_embeddings(self, which): return self.E[which]
+    def get_bias(self, which): return np.zeros(self.n_node, np.float32)
+    def edge_scores(self, which, u, v): return np.arange(len(u), dtype=np.float64)
+
+    def write_embeddings(self, which, path):
+        self.calls.append(("write_embeddings", which))
+        open(path, "w").write("%d\t%d\n" % (self.n_node, self.n_emb))
+
+
+def _trainer_worker(rank, world, port, base, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch
+    import torch.distributed as dist
+    from graphgan_amd import engine as eng_mod, graph_gan
+    from tests.test_gpu_e2e import make_cfg
+    eng_mod.Engine = _ReplicaEngine
+    cfg = make_cfg(base, n_epochs=2, n_epochs_dis=2, n_epochs_gen=2, dis_interval=1, gen_interval=2, engine_seed=3, update_ratio=0.3,
+                   batch_size_dis=64, batch_size_gen=64)
+    g = graph_gan.GraphGAN(cfg)
+    assert (g.rank, g.world) == (rank, world) and g.engine.calls[0][0] == "comm_init" and g.engine.calls[0][2:] == (rank, world)
+    g.train()
+    e = g.engine
+    # gather what the other rank ended with
+    state = torch.from_numpy(np.concatenate([e.model[0], e.model[1], np.array(e.steps, dtype=np.float64)]))
+    both = [torch.zeros_like(state) for _ in range(world)]
+    dist.all_gather(both, state)
+    own = np.zeros(g.n_node)
+    own[g.root_nodes] = 1
+    t = torch.from_numpy(own)
+    dist.all_reduce(t)
+    wrote = len([c for c in e.calls if c[0] == "write_embeddings"])
+    np.savez(out % rank, a=both[0].numpy(), b=both[1].numpy(), cover=t.numpy(), wrote=wrote, n_roots=len(g.root_nodes),
+             deg_load=float(e.deg[g.root_nodes].sum()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_trainer_keeps_replicas_identical(tmp_path):
+    """GraphGAN.train() on two ranks (gloo) against an engine stand-in whose optimizer steps are collectives: the roots are
+    partitioned (degree balanced), both ranks issue the same number of steps in every pass although their batch lists
+    differ in length (padding with empty steps), the replicas end identical, only rank 0 writes files, and
+    update_ratio < 1 selects roots independently of the sharding."""
+    import torch.multiprocessing as mp
+    from tests.test_gpu_e2e import write_reference_layout
+    base = str(tmp_path)
+    d, n, graph = write_reference_layout(base)
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_trainer_worker, args=(2, _free_port(), base, out), nprocs=2, join=True)
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    assert np.array_equal(r0["cover"], np.ones(n))                        # a partition of the roots
+    assert r0["n_roots"] + r1["n_roots"] == n and abs(r0["deg_load"] - r1["deg_load"]) <= 80  # balanced by degree (max degree 74)
+    for r in (r0, r1):
+        assert np.array_equal(r["a"], r["b"])                             # identical replicas, identical step counts
+    assert np.array_equal(r0["a"], r1["a"]) and r0["a"][-1] > 10 and r0["a"][-2] > 10
+    assert r0["wrote"] == 2 * 3 and r1["wrote"] == 0                       # before training + after each of the 2 epochs, rank 0 only
