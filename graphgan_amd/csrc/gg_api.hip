@@ -172,6 +172,7 @@ int gg::walk_launch_async(gg_ctx *ctx, const int32_t *slots, const int32_t *n_wa
     ctx->w_total = total;
     ctx->w_stride = stride;
     ctx->w_nslots = n_slots;
+    ctx->w_uniform = (!n_walks && uniform_walks >= 0) ? uniform_walks : -1;
     ctx->w_args = {for_d, seed, stream};
     ctx->g_paths_valid = false;
     if (n_slots == 0) {

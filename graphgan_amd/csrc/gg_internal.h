@@ -118,6 +118,7 @@ struct gg_ctx {
     int32_t walk_levels = 64;  // hops handled by the streaming level kernels before the per-walk finisher (GG_WALK_LEVELS)
     int64_t w_total = 0;
     int32_t w_stride = 0, w_nslots = 0;
+    int32_t w_uniform = -1;  // walks per root of the resident launch when every root has the same number (prepare_g), else -1
     struct { int32_t for_d; uint64_t seed; uint32_t stream; } w_args{};
     std::vector<int64_t> h_walk_ptr;
     // pinned host mirror: [0, 456) the launch's device counters, [H_TOTAL] the row / pair count of a prepare call --

@@ -376,17 +376,11 @@ __global__ __launch_bounds__(256) void adam_dense_kernel(const OptArgs a) {
     }
 }
 
-// Lazy Adam / SGD over the rows touched by this step: one 16-lane group per row.
+// Lazy Adam / SGD on one touched row by one 16-lane group (clears the row's gradient and flag).
 template <int SGD>
-__global__ __launch_bounds__(256) void sparse_opt_kernel(const OptArgs a) {
-    const int t = threadIdx.x & 15;
-    const int g0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const int ng = (gridDim.x * blockDim.x) >> 4;
-    const int cnt = (int)*a.touched_total;
-    const int nchunk = a.ld >> 2;
+__device__ __forceinline__ void opt_row(const OptArgs &a, int row, int t, int nchunk) {
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int r = g0; r < cnt; r += ng) {
-        const int row = a.touched_list[r];
+    {
         const int64_t o = ((int64_t)row * a.ld) >> 2;
         for (int c = t; c < nchunk; c += 16) {
             float4 var = ((float4 *)a.E)[o + c];
@@ -421,6 +415,20 @@ __global__ __launch_bounds__(256) void sparse_opt_kernel(const OptArgs a) {
             a.touched[row] = 0;
         }
     }
+}
+
+// ... over the compacted row list (flag array -> scan -> list: deterministic row order; the replica exchange packs the same list).
+// (Measured and not kept: updating straight from the flags without the scan / compaction launches -- 30 us SLOWER per call:
+// the list gives every group exactly one row; and summing one root's walk gradients in LDS before the global atomics --
+// 80 us slower per G pass: the 20 walks of a root share too few rows below its first level.)
+template <int SGD>
+__global__ __launch_bounds__(256) void sparse_opt_kernel(const OptArgs a) {
+    const int t = threadIdx.x & 15;
+    const int g0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int ng = (gridDim.x * blockDim.x) >> 4;
+    const int cnt = (int)*a.touched_total;
+    const int nchunk = a.ld >> 2;
+    for (int r = g0; r < cnt; r += ng) opt_row<SGD>(a, a.touched_list[r], t, nchunk);
 }
 
 // ---- sparse gradient exchange between replicas (lazy / sgd modes).  A step touches a small part of
