@@ -390,9 +390,7 @@ extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t 
     if (rc != GG_OK) return rc;
     if (n_roots == 0) return GG_OK;
 
-    hipDeviceProp_t prop;
-    GG_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
-    const int grid = std::min<int>(n_roots, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+    const int grid = std::min<int>(n_roots, ctx->n_cus);
     const int bm_words = (n + 31) / 32;
     // static LDS of the kernel (eoff, e0s, duplicate list, mask, counters) ~ 21.5 KB; the CU has 160 KB
     hipFuncAttributes fa;

@@ -278,6 +278,7 @@ int gg_create(int32_t n_node, int32_t n_emb, const float *emb_gen, const float *
     ctx->ld = (n_emb + 3) / 4 * 4;
     ctx->cfg = *cfg;
     ctx->device = cfg->device;
+    ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char *lv = getenv("GG_WALK_LEVELS")) ctx->walk_levels = atoi(lv);
     if (const char *pe = getenv("GG_PROFILE_EVERY")) ctx->profile_every = std::max(0, atoi(pe));
     if (const char *fw = getenv("GG_COMM_FAKE_WORLD")) ctx->fake_world = atoi(fw);

@@ -148,6 +148,7 @@ struct gg_ctx {
     bool g_paths_valid = false;  // w_paths / g_ptr still describe the resident prepare_g data
     gg::DevBuf touched_ptr;
     gg::DevBuf bfs_key, bfs_bm, bfs_misc;  // scratch of gg_build_trees_device (bfs_gpu.hip)
+    int n_cus = 256;                       // compute units of the device (gg_create; hipGetDeviceProperties costs milliseconds)
     gg::DevBuf scan_tmp, step_u, step_v, step_x;
 
     // device-side counters of the walk launch in flight (zeroed at its start): [0]=hops [1]=nbr_reads [3]=error flag

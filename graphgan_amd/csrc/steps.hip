@@ -504,6 +504,13 @@ static int global_pair_count(gg_ctx *ctx, int64_t n_local, const int64_t **out) 
 }
 
 // One optimizer step of model `which` on n device-resident rows.
+// Strict mode (batch 64, dense TF1-Adam, the reference's default schedule) is two launches per step: the gradient kernel
+// and the dense sweep, ~8.8 us together on CA-GrQc -- the cost of two dependent kernel boundaries.  Measured on the
+// MI355X and NOT kept: (a) a persistent kernel per pass with the model resident in LDS over 64 workgroups and one grid
+// barrier per step (agent-scope counter, next minibatch's rows published through memory): correct, 75 us per step --
+// cross-XCD arrive-and-poll is an order of magnitude dearer than a kernel boundary; (b) one fused launch per step (every
+// workgroup recomputes the 64 pair coefficients, variables double-buffered): correct, no faster (the chain ids -> rows ->
+// update is as long as the boundary it saves); (c) hipGraph replay of the two launches (round 1): no gain.
 int run_step(gg_ctx *ctx, int which, const int32_t *d_u, const int32_t *d_v, const float *d_x, int32_t n) {
     if (n <= 0) return GG_OK;
     Model &M = ctx->model[which];
