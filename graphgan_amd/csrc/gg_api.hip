@@ -48,6 +48,7 @@ static void free_trees(gg_ctx *ctx) {
 // the graph), Q3 bit rows sized by the roots' child counts (NULL: their degrees, an upper bound), zero-initialised.
 int alloc_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int64_t *node_counts, const int64_t *root_children) {
     (void)hipDeviceSynchronize();  // walks of calls that returned early may still read the old trees
+    ctx->dc_valid = false;
     const int n = ctx->n_node;
     if (!node_counts && ctx->h_comp_size.empty()) component_sizes(n, ctx->h_rowptr.data(), ctx->h_col.data(), ctx->h_comp_size);
     ctx->h_tbase.assign(n_roots + 1, 0);
@@ -283,6 +284,7 @@ int gg_create(int32_t n_node, int32_t n_emb, const float *emb_gen, const float *
     if (const char *pe = getenv("GG_PROFILE_EVERY")) ctx->profile_every = std::max(0, atoi(pe));
     if (const char *fw = getenv("GG_COMM_FAKE_WORLD")) ctx->fake_world = atoi(fw);
     if (const char *dt = getenv("GG_DETERMINISTIC")) ctx->deterministic = atoi(dt) != 0;
+    if (const char *nc = getenv("GG_NO_DIST_CACHE")) ctx->dc_enabled = atoi(nc) == 0;
     if (const char *dr = getenv("GG_COMM_DENSE_RATIO")) ctx->dense_exchange_ratio = (float)atof(dr);
 #define GG_TRY(call)                        \
     do {                                    \
@@ -368,7 +370,7 @@ int gg_destroy(gg_ctx *ctx) {
                       &ctx->d_ptr, &ctx->g_node1, &ctx->g_node2, &ctx->g_reward, &ctx->g_cnt, &ctx->g_ptr, &ctx->scan_tmp,
                       &ctx->step_u, &ctx->step_v, &ctx->step_x, &ctx->touched_ptr, &ctx->x_cnt, &ctx->x_send_ids, &ctx->x_send_rows,
                       &ctx->x_recv_ids, &ctx->x_recv_rows, &ctx->x_nglob, &ctx->st_item, &ctx->st_cur, &ctx->st_prev, &ctx->st_len,
-                      &ctx->st_alive, &ctx->st_rank, &ctx->bfs_key, &ctx->bfs_bm, &ctx->bfs_misc, &ctx->lv_beg, &ctx->lv_k, &ctx->lv_chunks, &ctx->lv_coff, &ctx->lv_scores, &ctx->lv_chunk_owner, &ctx->lv_prefix, &ctx->lv_big};
+                      &ctx->st_alive, &ctx->st_rank, &ctx->bfs_key, &ctx->bfs_bm, &ctx->bfs_misc, &ctx->lv_pfx, &ctx->dc_keys, &ctx->dc_vals, &ctx->dc_words, &ctx->lv_beg, &ctx->lv_k, &ctx->lv_chunks, &ctx->lv_coff, &ctx->lv_scores, &ctx->lv_chunk_owner, &ctx->lv_prefix, &ctx->lv_big};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : ctx->lv_ev)
         if (e) (void)hipEventDestroy(e);
@@ -669,6 +671,8 @@ int gg_walk_sample(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, in
                    int32_t *root_status) {
     if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
     GG_CHECK(ctx, n_walks || n_slots == 0, GG_EINVAL, "gg_walk_sample: n_walks is NULL");
+    ctx->dc_request = 0;
+    ctx->dc_valid = false;  // this launch reuses the prefix buffer from offset 0
     int rc = walk_resident(ctx, slots, n_walks, -1, n_slots, for_d ? 1 : 0, seed, stream, stride);
     if (rc != GG_OK) return rc;
     const int64_t total = ctx->w_total;
@@ -707,6 +711,7 @@ static int table_io(gg_ctx *ctx, int32_t which, float *out, const float *in, boo
     GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     Model &M = ctx->model[which];
     const int n = ctx->n_node, d = ctx->n_emb, ld = ctx->ld;
+    if (in && which == 0) ctx->dc_valid = false;
     if (bias) {
         if (out) GG_HIP(ctx, hipMemcpy(out, M.b, sizeof(float) * n, hipMemcpyDeviceToHost));
         else GG_HIP(ctx, hipMemcpy(M.b, in, sizeof(float) * n, hipMemcpyHostToDevice));
@@ -892,6 +897,7 @@ int state_io(gg_ctx *ctx, const char *path, bool save) {
         return rc;
     }
     fclose(f);
+    ctx->dc_valid = false;
     if (rc == GG_OK)  // step counts / beta powers only once every table arrived
         for (int m = 0; m < 2; ++m) { ctx->model[m].t = loaded[m].t; ctx->model[m].b1p = loaded[m].b1p; ctx->model[m].b2p = loaded[m].b2p; }
     return rc;

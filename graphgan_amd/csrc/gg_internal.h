@@ -111,6 +111,12 @@ struct gg_ctx {
     gg::DevBuf w_slots, w_ptr, w_samples, w_paths, w_len, w_status, w_first, w_abort, w_scratch;
     // level-synchronous front end of the walk sampler (walk_sample.hip): per-walk state + per-level tasks
     gg::DevBuf st_cur, st_prev, st_len, st_alive, st_rank, st_item, lv_beg, lv_k, lv_chunks, lv_coff, lv_scores, lv_chunk_owner, lv_prefix, lv_big;
+    gg::DevBuf lv_pfx, dc_keys, dc_vals, dc_words;  // distribution cache (walk_sample.hip): prefix offsets per walk, hash table, base words
+    size_t dc_size = 0;                // hash table entries (power of two)
+    int32_t dc_request = 0;            // mode of the NEXT walk launch: 0 off, 1 register (gg_prepare_d), 2 look up (gg_prepare_g)
+    bool dc_valid = false;             // the D launch's distributions match the generator's current tables and the resident trees
+    bool dc_enabled = true;            // GG_NO_DIST_CACHE=1 switches it off
+    int64_t lv_cap_total = 0;          // learned capacity (chunks over all hops, D + G launch) of the prefix buffer
     int32_t lv_levels_learned = 0;     // hops earlier (sized) launches needed until every walk had finished
     int64_t lv_cap_chunks = 0;         // learned capacity (chunks per level) for the sync-free launches
     bool walk_force_sized = false;     // retry path after a speculative overflow

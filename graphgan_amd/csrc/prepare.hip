@@ -256,8 +256,11 @@ int gg_prepare_d(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, uint64_t se
     // a D path never exceeds tree depth + 2 entries
     const int stride = ctx->tree_max_depth + 3;
     ctx->d_rows = 0;
+    // the distributions these walks evaluate are registered for the G-mode walks of the same step (walk_sample.hip)
+    ctx->dc_valid = false;
+    ctx->dc_request = ctx->dc_enabled ? 1 : 0;
     int rc = walk_launch_async(ctx, slots, nullptr, -1, n_slots, 1, seed, stream, stride);
-    if (rc != GG_OK) return rc;
+    if (rc != GG_OK) { ctx->dc_request = 0; return rc; }
     if (n_slots > 0) {
         const int64_t cap = 2 * ctx->w_total;  // every root contributes at most 2 * deg rows
         GG_HIP(ctx, ctx->d_cnt.reserve(sizeof(int32_t) * n_slots));
@@ -269,7 +272,8 @@ int gg_prepare_d(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, uint64_t se
         if (rc != GG_OK) return rc;
     }
     bool retried = false;
-    rc = walk_finalize(ctx, &retried);  // the only host synchronisation of the call
+    rc = walk_finalize(ctx, &retried);  // the only host synchronisation of the call (a rerun keeps the launch's cache mode)
+    ctx->dc_request = 0;
     if (rc != GG_OK) return rc;
     if (n_slots > 0) {
         if (retried) {
@@ -278,6 +282,7 @@ int gg_prepare_d(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, uint64_t se
             GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
         ctx->d_rows = (int64_t)ctx->h_pin[gg_ctx::H_TOTAL];
+        ctx->dc_valid = ctx->dc_enabled && ctx->walk_levels > 0;
         if (root_status) GG_HIP(ctx, hipMemcpy(root_status, ctx->w_status.p, sizeof(int32_t) * n_slots, hipMemcpyDeviceToHost));
     }
     rc = exchange_count_max(ctx, ctx->d_rows, &ctx->d_rows_max);  // replicas: capacity rule of the passes' row packs
@@ -333,8 +338,9 @@ int gg_prepare_g(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, int32_t n_s
     const int stride = ctx->tree_max_depth + 3;
     ctx->g_pairs = 0;
     // G walks read the generator's tables and the trees only: beside the discriminator update still in flight
+    ctx->dc_request = ctx->dc_valid ? 2 : 0;  // G-mode walks look their distributions up in what the D launch of the step left
     int rc = walk_launch_async(ctx, slots, nullptr, n_sample, n_slots, 0, seed, stream, stride, /*side_stream=*/true);
-    if (rc != GG_OK) return rc;
+    if (rc != GG_OK) { ctx->dc_request = 0; return rc; }
     const int64_t nw = ctx->w_total;
     // a path of L = len - 1 <= stride - 1 nodes gives at most 2 * window * L pairs
     const int64_t cap = nw * 2 * ctx->cfg.window_size * (stride - 1);
@@ -349,6 +355,7 @@ int gg_prepare_g(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, int32_t n_s
     }
     bool retried = false;
     rc = walk_finalize(ctx, &retried);  // the only host synchronisation of the call
+    ctx->dc_request = 0;
     if (rc != GG_OK) return rc;
     if (nw > 0) {
         if (retried) {

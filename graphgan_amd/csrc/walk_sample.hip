@@ -68,7 +68,17 @@ struct WalkArgs {
     int64_t *lv_coff;      // first chunk of the score / prefix region this walk samples from (its owner's)
     float *lv_scores;      // [CHUNK * total chunks]
     int4 *lv_chunk_desc;   // [total chunks] {cur node, rows | flags | offset bits 32..47, offset bits 0..31, father id} of chunk c
-    uint64_t *lv_prefix;   // [CHUNK * total chunks] inclusive prefix sums of the fixed-point weights
+    uint64_t *lv_prefix;   // [CHUNK * chunks of the launch(es)] inclusive prefix sums of the fixed-point weights; regions are addressed
+                           // by GLOBAL chunk offsets: launch base + chunks of the earlier levels + offset inside the level
+    int64_t *lv_pfx;       // [total_walks] global chunk offset of the prefix sums this walk samples from
+    int64_t cap_total;     // chunks the prefix buffer holds
+    // Distribution cache: the generator's tables do not change between the D-mode and the G-mode walks
+    // of a step, so a (root slot, node rank, father flag) distribution the D launch evaluated is NOT evaluated again by
+    // the G launch: D owners register {key -> global prefix offset, k} in a hash table, G walks look their node up.
+    int32_t dc_mode;       // 0 = off, 1 = register (D launch), 2 = look up (G launch)
+    unsigned long long *dc_keys, *dc_vals;
+    uint32_t dc_mask;      // table size - 1 (power of two)
+    const int64_t *dc_words;  // [0] global chunk offset this launch starts at, [1] chunks in the buffer after the D launch
     int32_t *lv_big;       // [total_walks] owner walks with k > BIG_TASK, appended per level
 };
 
@@ -216,6 +226,17 @@ constexpr int CTR_DISTS = 392;   // ctr[CTR_DISTS + (block & 63)]: (root, node) 
 constexpr int CTR_WORDS = 456;
 constexpr int MAX_LEVELS = 64;
 
+// Global chunk offset of the first chunk of hop a.level: the launch's base + the chunks of its earlier hops.
+__device__ __forceinline__ int64_t level_chunk_base(const WalkArgs &a) {
+    int64_t b = a.dc_words[0];
+    for (int l = 0; l < a.level; ++l) b += (int64_t)a.ctr[CTR_CHUNKS + l];
+    return b;
+}
+
+__device__ __forceinline__ unsigned long long dc_key(int slot, int rank, int hf) {
+    return ((unsigned long long)(unsigned)slot << 32) | ((unsigned long long)(unsigned)rank << 1) | (unsigned long long)hf;
+}
+
 // Descriptor of chunk i of a k-candidate distribution: {cur, rows | flags | offset bits 32..47, offset bits 0..31, father id}.
 // Candidate c of the distribution is the father (c == 0, only if hf) or the child order[beg_abs + c - hf]; `offset` is the
 // t_order index of the chunk's candidate 0 (for the first chunk of a list with a father entry that is ONE BEFORE the first
@@ -250,7 +271,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     const int lane = threadIdx.x & 63;
     const bool in_range = w < a.total_walks;
     bool alive = false, sampled = false;
-    int item = 0, cur = -1, k = 0, hf = 0, father = -1;
+    int item = 0, cur = -1, k = 0, hf = 0, father = -1, slot_w = 0, rank_w = 0;
     unsigned long long my_k = 0;
     int64_t beg_abs = 0;
     // finished walks (the majority at the deeper hops) leave after ONE load
@@ -283,7 +304,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
                 const int kraw = a.lv_k[w];
                 const int kk = kraw & 0x7fffffff, hf0 = (int)((unsigned)kraw >> 31);
                 my_k = (unsigned long long)kk;
-                const uint64_t *const pf = a.lv_prefix + a.lv_coff[w] * CHUNK;
+                const uint64_t *const pf = a.lv_prefix + a.lv_pfx[w] * CHUNK;
                 const int64_t beg0 = a.lv_beg[w];
                 const int len = a.st_len[w];
                 const int cur0 = a.st_cur[w], prev0 = a.st_prev[w];
@@ -384,6 +405,8 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
             a.st_cur[w] = cur;
             a.st_rank[w] = rank;  // also behind the last streamed level: the finisher resumes from it
         }
+        slot_w = slot;
+        rank_w = rank;
         a.st_alive[w] = alive ? 1 : 0;
         // the sync-free launch ran only as many levels as earlier launches needed: a walk that is
         // still going after the last one sends the launch to the sized rerun
@@ -399,23 +422,43 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         }
     }
     if (!do_setup) return;
+    // G launch: was this very distribution evaluated by the D launch of the step?  (Same slot, same node, same
+    // father flag => same candidate list; same generator tables => same prefix sums, bit for bit.)
+    bool cached = false;
+    int64_t cached_off = 0;
+    if (alive && a.dc_mode == 2) {
+        const unsigned long long key = dc_key(slot_w, rank_w, hf);
+        uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & a.dc_mask;
+        for (int tries = 0; tries < 64; ++tries) {
+            const unsigned long long kk = a.dc_keys[h];
+            if (kk == key) {
+                const unsigned long long v = a.dc_vals[h];
+                if ((int)(v & 0xffffffffull) == k) { cached = true; cached_off = (int64_t)(v >> 32); }
+                break;
+            }
+            if (kk == ~0ull) break;
+            h = (h + 1) & a.dc_mask;
+        }
+    }
     // dedup inside the workgroup (256 consecutive walks): the first walk with the same (item, cur) owns the
     // distribution.  Walks of one root are consecutive, so a walk scans backwards over its root's walks only
     // (finished walks are skipped, the first live walk of another root ends the scan).
     __shared__ long long blk_keys[256];
     __shared__ long long blk_coff[256];
-    const long long key = alive ? (((long long)item << 32) | (unsigned)cur) : -1ll;
+    __shared__ long long blk_lbase;
+    if (threadIdx.x == 0) blk_lbase = level_chunk_base(a);
+    const long long key = (alive && !cached) ? (((long long)item << 32) | (unsigned)cur) : -1ll;
     blk_keys[threadIdx.x] = key;
     __syncthreads();
     int owner = (int)threadIdx.x;
-    if (alive) {
+    if (alive && !cached) {
         for (int jj = (int)threadIdx.x - 1; jj >= 0; --jj) {
             const long long kj = blk_keys[jj];
             if (kj == key) owner = jj;
             else if (kj >= 0 && (int)(kj >> 32) != item) break;
         }
     }
-    const bool owns = alive && owner == (int)threadIdx.x;
+    const bool owns = alive && !cached && owner == (int)threadIdx.x;
     const int chunks = owns ? (k + CHUNK - 1) / CHUNK : 0;
     const bool big = owns && k > BIG_TASK;
     // chunk offsets and big-task slots: in-wave exclusive scans, per-block totals through LDS, and ONE
@@ -455,13 +498,25 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     blk_coff[threadIdx.x] = coff_own;
     __syncthreads();
     const int64_t coff = blk_coff[owner];  // non-owners sample from their owner's region
-    const bool fits = (int64_t)blk_base[0] + blk_chunks <= cap_chunks;
+    const int64_t lbase = blk_lbase;
+    const bool fits = (int64_t)blk_base[0] + blk_chunks <= cap_chunks && lbase + (int64_t)blk_base[0] + blk_chunks <= a.cap_total;
     if (write_desc == 1 && !fits && threadIdx.x == 0) a.ctr[3] = 2ull;  // speculative capacity exceeded: the host reruns in sized mode
     if (in_range) {
         a.lv_beg[w] = beg_abs;
         a.lv_k[w] = k | (hf << 31);
         a.lv_chunks[w] = chunks;
         a.lv_coff[w] = coff;
+        a.lv_pfx[w] = cached ? cached_off : lbase + coff;
+        if (owns && a.dc_mode == 1 && (fits || write_desc == 0)) {  // D launch: register the distribution for the G launch of the step (sized mode: the buffers are sized after this kernel)
+            const unsigned long long key2 = dc_key(slot_w, rank_w, hf);
+            uint32_t h = (uint32_t)((key2 * 0x9E3779B97F4A7C15ull) >> 40) & a.dc_mask;
+            for (int tries = 0; tries < 64; ++tries) {
+                const unsigned long long old = atomicCAS(&a.dc_keys[h], ~0ull, key2);
+                if (old == ~0ull) { a.dc_vals[h] = ((unsigned long long)(lbase + coff) << 32) | (unsigned long long)(unsigned)k; break; }
+                if (old == key2) break;  // another workgroup registered the same distribution: one copy is enough
+                h = (h + 1) & a.dc_mask;
+            }
+        }
         if (big) a.lv_big[blk_base[1] + big_before + __popcll(big_bal & ((1ull << lane) - 1ull))] = (int32_t)w;
         if (write_desc == 1 && fits)
             for (int i = 0; i < chunks; ++i) a.lv_chunk_desc[coff + i] = chunk_desc(cur, k, hf, father, beg_abs, i);
@@ -513,7 +568,8 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const
     if (threadIdx.x == 0) blk_rows = 0;
     __syncthreads();
     const int64_t total_chunks = (int64_t)a.ctr[CTR_CHUNKS + a.level];
-    if (total_chunks > cap_chunks) return;
+    const int64_t lbase = level_chunk_base(a);
+    if (total_chunks > cap_chunks || lbase + total_chunks > a.cap_total) return;
     const int t = threadIdx.x & 15;
     const int nblk = gridDim.x;
     // consecutive chunks (same task / same root) -> consecutive logical blocks -> one XCD's L2.  (Giving every XCD
@@ -577,7 +633,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const
             for (int off = 8; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 16));
             const uint64_t wgt = (t < nblock) ? weight_fix40(exp_spec(mysc - mx)) : 0ull;
             const uint64_t C = group16_incl_scan_u64(wgt, t);
-            if (t < nblock) a.lv_prefix[c * CHUNK + t] = C;
+            if (t < nblock) a.lv_prefix[(lbase + c) * CHUNK + t] = C;
         } else if (t < nblock) {
             out[t] = mysc;  // one coalesced 64-byte store per chunk
         }
@@ -600,9 +656,8 @@ __device__ __forceinline__ void weights_small_block(const WalkArgs &a, const int
     if (w >= a.total_walks || a.lv_chunks[w] <= 1) return;  // non-owners, and single-chunk tasks (done by the score kernel)
     const int k = a.lv_k[w] & 0x7fffffff;
     if (k > BIG_TASK) return;
-    const int64_t base = a.lv_coff[w] * CHUNK;
-    const float *const sc = a.lv_scores + base;
-    uint64_t *const pf = a.lv_prefix + base;
+    const float *const sc = a.lv_scores + a.lv_coff[w] * CHUNK;
+    uint64_t *const pf = a.lv_prefix + a.lv_pfx[w] * CHUNK;  // (an owner's prefix region = level base + its score region)
     constexpr int PER_LANE = BIG_TASK / 16;
     float v[PER_LANE];
 #pragma unroll
@@ -641,9 +696,8 @@ __device__ __forceinline__ void weights_big_blocks(const WalkArgs &a) {
     for (int b = blockIdx.x; b < n_big; b += BIG_BLOCKS) {
         const int64_t w = a.lv_big[b];
         const int k = a.lv_k[w] & 0x7fffffff;
-        const int64_t base = a.lv_coff[w] * CHUNK;
-        const float *const sc = a.lv_scores + base;
-        uint64_t *const pf = a.lv_prefix + base;
+        const float *const sc = a.lv_scores + a.lv_coff[w] * CHUNK;
+        uint64_t *const pf = a.lv_prefix + a.lv_pfx[w] * CHUNK;
         constexpr int PER_THREAD = BIG_REG / 256;
         const bool in_regs = k <= BIG_REG;  // uniform in the workgroup
         float v[PER_THREAD];
@@ -696,7 +750,7 @@ __device__ __forceinline__ void weights_big_blocks(const WalkArgs &a) {
 // classes cost the sum of their latency-bound run times; together, the longer of the two.
 __global__ __launch_bounds__(256) void level_weights_kernel(const WalkArgs a, const int64_t cap_chunks) {
     const unsigned long long total_chunks = a.ctr[CTR_CHUNKS + a.level];
-    if ((int64_t)total_chunks > cap_chunks || total_chunks == 0ull) return;
+    if ((int64_t)total_chunks > cap_chunks || total_chunks == 0ull || level_chunk_base(a) + (int64_t)total_chunks > a.cap_total) return;
     if (blockIdx.x < BIG_BLOCKS) weights_big_blocks(a);
     else weights_small_block(a, (int64_t)blockIdx.x - BIG_BLOCKS);
 }
@@ -875,11 +929,39 @@ __global__ void walk_init_status_kernel(const WalkArgs a) {
 static int reserve_level_buffers(gg_ctx *ctx, WalkArgs &a, int64_t chunks) {
     GG_HIP(ctx, ctx->lv_scores.reserve(sizeof(float) * CHUNK * (size_t)chunks + 256));
     GG_HIP(ctx, ctx->lv_chunk_owner.reserve(sizeof(int4) * (size_t)chunks + 256));
-    GG_HIP(ctx, ctx->lv_prefix.reserve(sizeof(uint64_t) * CHUNK * (size_t)chunks + 256));
     a.lv_scores = ctx->lv_scores.as<float>();
     a.lv_chunk_desc = ctx->lv_chunk_owner.as<int4>();
-    a.lv_prefix = ctx->lv_prefix.as<uint64_t>();
     return GG_OK;
+}
+
+// The prefix sums of ALL hops of a launch (and, for the distribution cache, of the D launch before it) live in one
+// buffer addressed by global chunk offsets.  Growing it keeps what is there (`keep`): the G launch samples from the
+// D launch's regions.
+static int reserve_prefix(gg_ctx *ctx, WalkArgs &a, int64_t chunks, bool keep) {
+    const size_t need = sizeof(uint64_t) * CHUNK * (size_t)chunks + 256;
+    if (need > ctx->lv_prefix.bytes) {
+        if (keep && ctx->lv_prefix.p) {
+            DevBuf bigger;
+            GG_HIP(ctx, bigger.reserve(need));
+            GG_HIP(ctx, hipMemcpyAsync(bigger.p, ctx->lv_prefix.p, ctx->lv_prefix.bytes, hipMemcpyDeviceToDevice, ctx->walk_stream));
+            GG_HIP(ctx, hipStreamSynchronize(ctx->walk_stream));
+            ctx->lv_prefix.release();
+            ctx->lv_prefix = bigger;
+        } else {
+            GG_HIP(ctx, ctx->lv_prefix.reserve(need));
+        }
+    }
+    a.lv_prefix = ctx->lv_prefix.as<uint64_t>();
+    a.cap_total = (int64_t)((ctx->lv_prefix.bytes - 256) / (sizeof(uint64_t) * CHUNK));
+    return GG_OK;
+}
+
+// end of a D launch that registered its distributions: chunks now in the prefix buffer = where the G launch appends
+__global__ void dc_finish_kernel(const WalkArgs a, int64_t *words, int n_levels) {
+    if (a.ctr[3] == 2ull) { words[1] = 0; return; }  // the launch is being rerun
+    int64_t b = words[0];
+    for (int l = 0; l < n_levels; ++l) b += (int64_t)a.ctr[CTR_CHUNKS + l];
+    words[1] = b;
 }
 
 // Levels 0 .. n_levels-1 through the streaming kernels.  sized == true: one 16-byte read-back
@@ -890,8 +972,18 @@ template <int NCH>
 static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_levels, bool sized, bool *any_alive) {
     const dim3 blk(WAVES_PER_BLOCK * 64);
     int64_t cap = sized ? 0 : ctx->lv_cap_chunks;
+    const bool keep = a.dc_mode != 0;  // cached prefix regions must survive a growing buffer
+    int64_t base_host = 0, cum = 0;    // sized mode: global chunk offset of the launch / chunks of its hops so far
     if (!sized) {
         int rc = reserve_level_buffers(ctx, a, cap);
+        if (rc == GG_OK) rc = reserve_prefix(ctx, a, std::max<int64_t>(ctx->lv_cap_total, cap), keep);
+        if (rc != GG_OK) return rc;
+    } else {
+        if (a.dc_mode == 2) {  // where the D launch of the step stopped
+            GG_HIP(ctx, hipMemcpyAsync(&base_host, a.dc_words, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->walk_stream));
+            GG_HIP(ctx, hipStreamSynchronize(ctx->walk_stream));
+        }
+        int rc = reserve_prefix(ctx, a, std::max<int64_t>(base_host, 1), keep);
         if (rc != GG_OK) return rc;
     }
     const unsigned wblocks = (unsigned)cdiv(total_walks, 256);
@@ -908,12 +1000,19 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
             GG_HIP(ctx, hipMemcpyAsync(&total_chunks, ctx->dev_ctr + CTR_CHUNKS + level, sizeof(total_chunks), hipMemcpyDeviceToHost, ctx->walk_stream));
             GG_HIP(ctx, hipMemcpyAsync(&alive, ctx->dev_ctr + CTR_ALIVE + level, sizeof(alive), hipMemcpyDeviceToHost, ctx->walk_stream));
             GG_HIP(ctx, hipStreamSynchronize(ctx->walk_stream));
-            if (alive == 0) { *any_alive = false; return GG_OK; }
+            if (alive == 0) {  // every walk has finished
+                *any_alive = false;
+                if (a.dc_mode == 1) hipLaunchKernelGGL(dc_finish_kernel, dim3(1), dim3(1), 0, ctx->walk_stream, a, ctx->dc_words.as<int64_t>(), level + 1);
+                return GG_OK;
+            }
             if (level + 1 > ctx->lv_levels_learned) ctx->lv_levels_learned = level + 1;
             cap = (int64_t)total_chunks;
             if (cap + cap / 4 + 4096 > ctx->lv_cap_chunks) ctx->lv_cap_chunks = cap + cap / 4 + 4096;
             int rc = reserve_level_buffers(ctx, a, cap);
+            if (rc == GG_OK) rc = reserve_prefix(ctx, a, base_host + cum + cap, true);
             if (rc != GG_OK) return rc;
+            cum += cap;
+            if (base_host + cum + (base_host + cum) / 4 + 4096 > ctx->lv_cap_total) ctx->lv_cap_total = base_host + cum + (base_host + cum) / 4 + 4096;
             hipLaunchKernelGGL(level_expand_kernel, dim3(wblocks), dim3(256), 0, ctx->walk_stream, a);
         }
         int64_t blocks = sized ? (cap + WAVES_PER_BLOCK * 4 - 1) / (WAVES_PER_BLOCK * 4) : score_blocks();
@@ -937,6 +1036,7 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
     // finish the last prepared hop
     a.level = level;
     hipLaunchKernelGGL(level_advance_kernel, dim3(wblocks), dim3(256), 0, ctx->walk_stream, a, 1, 0, (!sized && all_levels) ? 2 : 0, 0);
+    if (a.dc_mode == 1) hipLaunchKernelGGL(dc_finish_kernel, dim3(1), dim3(1), 0, ctx->walk_stream, a, ctx->dc_words.as<int64_t>(), level);
     GG_HIP(ctx, hipGetLastError());
     return GG_OK;
 }
@@ -962,6 +1062,7 @@ static int run_levels_and_finish(gg_ctx *ctx, WalkArgs &a, int64_t total_walks) 
         GG_HIP(ctx, ctx->lv_chunks.reserve(sizeof(int32_t) * total_walks));
         GG_HIP(ctx, ctx->lv_big.reserve(sizeof(int32_t) * total_walks));
         GG_HIP(ctx, ctx->lv_coff.reserve(sizeof(int64_t) * (total_walks + 1)));
+        GG_HIP(ctx, ctx->lv_pfx.reserve(sizeof(int64_t) * (total_walks + 1)));
         GG_HIP(ctx, ctx->st_item.reserve(sizeof(int4) * total_walks));
         a.st_cur = ctx->st_cur.as<int32_t>();
         a.st_prev = ctx->st_prev.as<int32_t>();
@@ -974,6 +1075,7 @@ static int run_levels_and_finish(gg_ctx *ctx, WalkArgs &a, int64_t total_walks) 
         a.lv_chunks = ctx->lv_chunks.as<int32_t>();
         a.lv_big = ctx->lv_big.as<int32_t>();
         a.lv_coff = ctx->lv_coff.as<int64_t>();
+        a.lv_pfx = ctx->lv_pfx.as<int64_t>();
         const bool sized = ctx->lv_cap_chunks == 0 || ctx->walk_force_sized;
         int rc = run_levels<NCH>(ctx, a, total_walks, n_levels, sized, &any_alive);
         if (rc != GG_OK) return rc;
@@ -1025,6 +1127,27 @@ int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int fo
     a.first_child = ctx->w_first.as<int32_t>();
     a.abort_walk = ctx->w_abort.as<int32_t>();
     a.ctr = ctx->dev_ctr;
+    // distribution cache: mode requested by gg_prepare_d (register) / gg_prepare_g (look up); anything else runs without it
+    GG_HIP(ctx, ctx->dc_words.reserve(sizeof(int64_t) * 4));
+    a.dc_words = ctx->dc_words.as<int64_t>();
+    a.dc_mode = (ctx->walk_levels > 0 && total_walks > 0) ? ctx->dc_request : 0;
+    if (a.dc_mode == 1) {
+        size_t want = 1u << 16;
+        while (want < (size_t)total_walks * 8 && want < (1u << 24)) want <<= 1;  // distributions of a launch <= a few per walk
+        if (want > ctx->dc_size) {
+            GG_HIP(ctx, ctx->dc_keys.reserve(sizeof(unsigned long long) * want));
+            GG_HIP(ctx, ctx->dc_vals.reserve(sizeof(unsigned long long) * want));
+            ctx->dc_size = want;
+        }
+        GG_HIP(ctx, hipMemsetAsync(ctx->dc_keys.p, 0xFF, sizeof(unsigned long long) * ctx->dc_size, ctx->walk_stream));
+    }
+    a.dc_keys = ctx->dc_keys.as<unsigned long long>();
+    a.dc_vals = ctx->dc_vals.as<unsigned long long>();
+    a.dc_mask = (uint32_t)(ctx->dc_size ? ctx->dc_size - 1 : 0);
+    if (a.dc_mode == 2)  // append behind the D launch's regions
+        GG_HIP(ctx, hipMemcpyAsync(ctx->dc_words.as<int64_t>(), ctx->dc_words.as<int64_t>() + 1, sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->walk_stream));
+    else
+        GG_HIP(ctx, hipMemsetAsync(ctx->dc_words.p, 0, sizeof(int64_t), ctx->walk_stream));
 
     // every counter word belongs to ONE launch (the host accumulates, walk_finalize): hops / reads / rows, error
     // flag [3], ticket [4], per-level counters and the spread words
