@@ -92,13 +92,15 @@ struct Running {
 };
 
 __device__ __forceinline__ void run_update(Running &r, float x, int col, bool lse) {
-    if (x > r.m) {
-        if (lse) r.s = r.s * __expf(r.m - x) + 1.0f;
-        r.m = x;
-        r.arg = col;
-    } else if (lse) {
-        r.s += __expf(x - r.m);
+    // branch-free: one exponential per score (exp of minus the distance to the new maximum), selects instead of branches
+    const bool up = x > r.m;
+    const float nm = up ? x : r.m;
+    if (lse) {
+        const float e = __expf((up ? r.m : x) - nm);  // exp(-inf) = 0 covers the first score of a cell
+        r.s = up ? r.s * e + 1.0f : r.s + e;
     }
+    r.arg = up ? col : r.arg;
+    r.m = nm;
 }
 
 __device__ __forceinline__ void run_merge(Running &a, float m, float s, int arg, bool lse) {
@@ -239,10 +241,20 @@ __global__ __launch_bounds__(256) void all_score_reduce_bf16_kernel(const uint4 
 #pragma unroll
     for (int i = 0; i < 16 * RB; ++i) run[i] = Running{-INFINITY, 0.f, 0x7fffffff};
     const int cbeg = split * cols_per_split, cend = min(n_node, cbeg + cols_per_split);
+    // B fragments are double buffered in registers: the KS loads of the NEXT 32-column tile are issued before the matrix
+    // instructions and the consumer of the current one, so that memory latency hides behind them (two waves per SIMD).
+    Frag bcur[KS], bnxt[KS];
+    auto load_tile = [&](Frag (&dst)[KS], int c0t) {
+        const int colt = c0t + (lane & 31);
+        const uint4 *brow = Eb + (int64_t)((c0t < cend && colt < cend) ? colt : cbeg) * (2 * KS) + half;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) dst[s].u = brow[2 * s];
+    };
+    load_tile(bcur, cbeg + wv * 32);
     for (int c0 = cbeg + wv * 32; c0 < cend; c0 += 128) {
         const int col = c0 + (lane & 31);
         const bool ok = col < cend;
-        const uint4 *brow = Eb + (int64_t)(ok ? col : cbeg) * (2 * KS) + half;
+        load_tile(bnxt, c0 + 128);
         f32x16 acc[RB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
@@ -250,11 +262,11 @@ __global__ __launch_bounds__(256) void all_score_reduce_bf16_kernel(const uint4 
             for (int i = 0; i < 16; ++i) acc[rb][i] = 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            Frag b;
-            b.u = brow[2 * s];
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[rb][s].v, b.v, acc[rb], 0, 0, 0);
+            for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[rb][s].v, bcur[s].v, acc[rb], 0, 0, 0);
         }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) bcur[s] = bnxt[s];
         if (ok) {
             const float bj = bias[col];
 #pragma unroll
