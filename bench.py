@@ -95,6 +95,40 @@ def cpu_baseline(args, n, rowptr, col, emb, bias, roots, seconds):
         args.n_sample_gen, len(rts), stream // 2, hops, t)
 
 
+def cpu_baseline_faithful(n_roots=24):
+    """The 'faithful' flavour of SURVEY.md section 8d on BASELINE configs[0..1] (CA-GrQc, n_emb = 50): like the reference,
+    EVERY sample() call first recomputes the full N x N score matrix (graph_gan.py:238, generator.py:21: E.E^T + b, numpy on
+    the host's BLAS threads) and then walks (C oracle, one core).  Timed on a bounded sample of roots; the N x N matrix
+    cannot exist for the 1M-node workload, so this flavour is only reported here."""
+    from oracle import graphgan_oracle as orc
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ca_grqc.npz"))
+    n = int(g["n_node"])
+    import graphgan_amd as ga
+    rowptr, col = ga.edges_to_csr(n, g["train"])
+    emb = np.random.RandomState(5).rand(n, g["emb_rows"].shape[1])
+    emb[g["emb_ids"]] = g["emb_rows"]
+    emb = emb.astype(np.float32)
+    bias = np.zeros(n, np.float32)
+    deg = rowptr[1:] - rowptr[:-1]
+    roots = np.flatnonzero(deg > 0)[:: max(1, int((deg > 0).sum()) // n_roots)][:n_roots].astype(np.int32)
+    off, nbr, base, dmax = orc.c_build_trees(n, rowptr, col, roots)
+    Ep = orc.pad_rows(emb)
+    t_mm = 0.0
+    for _ in roots:  # one all_score per sample() call
+        t0 = time.perf_counter()
+        S = emb @ emb.T + bias[None, :]
+        t_mm += time.perf_counter() - t0
+    assert S.shape == (n, n)
+    t0 = time.perf_counter()
+    res = orc.c_walk_sample(Ep, bias, off, nbr, base, roots, np.arange(len(roots), dtype=np.int32), np.full(len(roots), 20, np.int32), False, 6, 1, dmax + 3)
+    t_walk = time.perf_counter() - t0
+    hops = int(res["hops"])
+    return {"value": hops / (t_mm + t_walk), "unit": "edges/s", "kind": "port", "flavour": "faithful: all_score (N x N) recomputed per sample() call",
+            "cores": os.cpu_count(), "workload": "CA-GrQc (5242 nodes), n_emb=50, G-mode walks (20 per root)",
+            "sample": "%d roots: %d hops, %.2f s in %d matmuls of %.0f MFLOP (numpy BLAS threads), %.3f s walking (one core)" % (
+                len(roots), hops, t_mm, len(roots), 2e-6 * n * n * emb.shape[1], t_walk)}
+
+
 def pmc_traffic(kernel_substr):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
     (profiles/summarize.py; FETCH_SIZE / WRITE_SIZE collected in separate passes of this same
@@ -357,6 +391,7 @@ def main():
         v, sample = cpu_baseline(args, n, rowptr, col, embg, bias, roots, args.cpu_baseline_seconds)
         out["cpu_baseline"] = {"value": v, "unit": "edges/s", "cores": 1, "host_cores_on_box": os.cpu_count(), "kind": "port", "sample": sample}
         out["walk_kernel_vs_cpu"] = out["walk_kernel_edges_per_sec"] / v if v > 0 and out["walk_kernel_edges_per_sec"] else None
+        out["cpu_baseline_faithful"] = cpu_baseline_faithful()
     eng.close()
     print(json.dumps(out))
 
