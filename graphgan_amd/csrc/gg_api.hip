@@ -228,7 +228,7 @@ int gg::walk_finalize(gg_ctx *ctx, bool *retried) {
             ctx->ctr.score_chunks += (int64_t)c[136 + i];
             if (getenv("GG_WALK_DEBUG"))
                 fprintf(stderr, "[walk] for_d=%d level %d alive %llu chunks %llu big %llu score %.1f us\n", ctx->w_args.for_d, i,
-                        c[8 + i], c[136 + i], c[72 + i], lms * 1e3);
+                        c[8 + i], c[136 + i], c[72 + i] & 0xffffffffull, lms * 1e3);
         }
         if (ctx->lv_ev_used) {
             ctx->ctr.score_rows += (int64_t)(rows - c[5]);  // rows of the timed score launches

@@ -217,7 +217,8 @@ static int score_blocks() {
 constexpr int BIG_TASK = 256;   // owner tasks with more candidates get a whole workgroup for their prefix sums
 constexpr int CTR_NONFINITE = 6; // ctr[6]: a distribution had total weight 0 (non-finite generator scores) -> GG_EINVAL
 constexpr int CTR_ALIVE = 8;    // ctr[CTR_ALIVE + level]: walks alive when hop `level` was set up
-constexpr int CTR_BIG = 72;     // ctr[CTR_BIG + level]:   big owner tasks of hop `level`
+constexpr int CTR_BIG = 72;     // ctr[CTR_BIG + level]:   owner tasks of hop `level` that need the weights kernel: big ones (k > BIG_TASK) in
+                                //                         the low 32 bits, small multi-chunk ones in the high 32 bits (one atomic hands out both)
 constexpr int CTR_CHUNKS = 136; // ctr[CTR_CHUNKS + level]: chunks of hop `level` (chunk offsets are handed out per wave)
 constexpr int CTR_ROWS = 200;   // ctr[CTR_ROWS + (block & 63)]: candidate rows scored by this launch (spread words, folded by the host)
 constexpr int CTR_HOPS_V = 264;  // ctr[CTR_HOPS_V + (block & 63)]: hop counts of the level pipeline, spread over 64 words
@@ -461,10 +462,11 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     const bool owns = alive && !cached && owner == (int)threadIdx.x;
     const int chunks = owns ? (k + CHUNK - 1) / CHUNK : 0;
     const bool big = owns && k > BIG_TASK;
+    const bool small = owns && chunks > 1 && !big;  // 16 < k <= BIG_TASK: a 16-lane group of the weights kernel
     // chunk offsets and big-task slots: in-wave exclusive scans, per-block totals through LDS, and ONE
     // returning atomic per block and counter (a single word serves only ~88 returning atomics per us);
     // the order of the blocks' regions in the score buffer is irrelevant
-    __shared__ int wv_chunks[4], wv_big[4], wv_own[4];
+    __shared__ int wv_chunks[4], wv_big[4], wv_own[4], wv_small[4];
     __shared__ unsigned long long blk_base[2];
     int inc = chunks;
 #pragma unroll
@@ -476,6 +478,8 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     const int wv = threadIdx.x >> 6;
     if (lane == 63) wv_chunks[wv] = inc;
     if (lane == 0) wv_big[wv] = __popcll(big_bal);
+    const unsigned long long small_bal = __ballot(small);
+    if (lane == 0) wv_small[wv] = __popcll(small_bal);
     const unsigned long long own_bal = __ballot(owns);
     if (lane == 0) wv_own[wv] = __popcll(own_bal);
     __syncthreads();
@@ -483,15 +487,16 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         const int tc = wv_chunks[0] + wv_chunks[1] + wv_chunks[2] + wv_chunks[3];
         const int tb = wv_big[0] + wv_big[1] + wv_big[2] + wv_big[3];
         blk_base[0] = tc ? atomicAdd(&a.ctr[CTR_CHUNKS + a.level], (unsigned long long)tc) : 0ull;
-        blk_base[1] = tb ? atomicAdd(&a.ctr[CTR_BIG + a.level], (unsigned long long)tb) : 0ull;
+        const int ts = wv_small[0] + wv_small[1] + wv_small[2] + wv_small[3];
+        blk_base[1] = (tb | ts) ? atomicAdd(&a.ctr[CTR_BIG + a.level], (unsigned long long)tb | ((unsigned long long)ts << 32)) : 0ull;
         const int to = wv_own[0] + wv_own[1] + wv_own[2] + wv_own[3];
         if (to) atomicAdd(&a.ctr[CTR_DISTS + (blockIdx.x & 63)], (unsigned long long)to);
     }
     __syncthreads();
-    int chunks_before = 0, big_before = 0, blk_chunks = 0;
+    int chunks_before = 0, big_before = 0, small_before = 0, blk_chunks = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        if (i < wv) { chunks_before += wv_chunks[i]; big_before += wv_big[i]; }
+        if (i < wv) { chunks_before += wv_chunks[i]; big_before += wv_big[i]; small_before += wv_small[i]; }
         blk_chunks += wv_chunks[i];
     }
     const int64_t coff_own = (int64_t)blk_base[0] + chunks_before + inc - chunks;
@@ -517,7 +522,9 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
                 h = (h + 1) & a.dc_mask;
             }
         }
-        if (big) a.lv_big[blk_base[1] + big_before + __popcll(big_bal & ((1ull << lane) - 1ull))] = (int32_t)w;
+        // the two task lists of the weights kernel share one array: big tasks from the front, small ones from the back
+        if (big) a.lv_big[(blk_base[1] & 0xffffffffull) + big_before + __popcll(big_bal & ((1ull << lane) - 1ull))] = (int32_t)w;
+        if (small) a.lv_big[a.total_walks - 1 - (int64_t)((blk_base[1] >> 32) + small_before + __popcll(small_bal & ((1ull << lane) - 1ull)))] = (int32_t)w;
         if (write_desc == 1 && fits)
             for (int i = 0; i < chunks; ++i) a.lv_chunk_desc[coff + i] = chunk_desc(cur, k, hf, father, beg_abs, i);
     }
@@ -650,12 +657,8 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const
 // (spec S2, S3) and their inclusive prefix sums, computed once per (root, node).  All of the task's
 // scores are fetched with independent loads up front (<= 16 per lane): the kernel used to be two
 // dependent passes of k/16 load -> use steps each.
-__device__ __forceinline__ void weights_small_block(const WalkArgs &a, const int64_t block) {
-    const int t = threadIdx.x & 15;
-    const int64_t w = (block * 256 + threadIdx.x) >> 4;
-    if (w >= a.total_walks || a.lv_chunks[w] <= 1) return;  // non-owners, and single-chunk tasks (done by the score kernel)
+__device__ __forceinline__ void weights_small_task(const WalkArgs &a, const int64_t w, const int t) {
     const int k = a.lv_k[w] & 0x7fffffff;
-    if (k > BIG_TASK) return;
     const float *const sc = a.lv_scores + a.lv_coff[w] * CHUNK;
     uint64_t *const pf = a.lv_prefix + a.lv_pfx[w] * CHUNK;  // (an owner's prefix region = level base + its score region)
     constexpr int PER_LANE = BIG_TASK / 16;
@@ -683,6 +686,13 @@ __device__ __forceinline__ void weights_small_block(const WalkArgs &a, const int
     }
 }
 
+constexpr int SMALL_BLOCKS = 2048;  // workgroups of the weights launch that serve the small-task list (16 tasks each per round)
+__device__ __forceinline__ void weights_small_blocks(const WalkArgs &a, const int block) {
+    const int t = threadIdx.x & 15;
+    const int64_t n_small = (int64_t)(a.ctr[CTR_BIG + a.level] >> 32);
+    for (int64_t i = (int64_t)block * 16 + (threadIdx.x >> 4); i < n_small; i += (int64_t)SMALL_BLOCKS * 16) weights_small_task(a, a.lv_big[a.total_walks - 1 - i], t);
+}
+
 // Big owner tasks (hubs): one 256-thread workgroup per task, from the level's big-task list.  Tasks of up to
 // BIG_REG candidates keep their scores in registers between the max and the scan pass (one round of
 // independent loads); larger ones re-read them.
@@ -692,7 +702,7 @@ __device__ __forceinline__ void weights_big_blocks(const WalkArgs &a) {
     __shared__ float red[4];
     __shared__ uint64_t wave_tot[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int n_big = (int)a.ctr[CTR_BIG + a.level];
+    const int n_big = (int)(a.ctr[CTR_BIG + a.level] & 0xffffffffull);
     for (int b = blockIdx.x; b < n_big; b += BIG_BLOCKS) {
         const int64_t w = a.lv_big[b];
         const int k = a.lv_k[w] & 0x7fffffff;
@@ -752,7 +762,7 @@ __global__ __launch_bounds__(256) void level_weights_kernel(const WalkArgs a, co
     const unsigned long long total_chunks = a.ctr[CTR_CHUNKS + a.level];
     if ((int64_t)total_chunks > cap_chunks || total_chunks == 0ull || level_chunk_base(a) + (int64_t)total_chunks > a.cap_total) return;
     if (blockIdx.x < BIG_BLOCKS) weights_big_blocks(a);
-    else weights_small_block(a, (int64_t)blockIdx.x - BIG_BLOCKS);
+    else weights_small_blocks(a, (int)blockIdx.x - BIG_BLOCKS);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1031,7 +1041,7 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
             GG_HIP(ctx, hipEventRecord(ctx->lv_ev[2 * level + 1], ctx->walk_stream));
             ctx->lv_ev_used = level + 1;
         }
-        hipLaunchKernelGGL(level_weights_kernel, dim3((unsigned)(BIG_BLOCKS + cdiv(total_walks * 16, 256))), dim3(256), 0, ctx->walk_stream, a, cap);
+        hipLaunchKernelGGL(level_weights_kernel, dim3((unsigned)(BIG_BLOCKS + std::min<int64_t>(SMALL_BLOCKS, cdiv(total_walks * 16, 256)))), dim3(256), 0, ctx->walk_stream, a, cap);
     }
     // finish the last prepared hop
     a.level = level;
