@@ -309,12 +309,22 @@ def main():
     # The reference evaluates every hop's distribution from scratch (4k(d+2) + 4d + 12 per hop);
     # the engine evaluates each distinct (root, node) distribution of a launch once.
     ref_bytes = 4.0 * (d + 2) * reads + (4.0 * d + 12.0) * hops
-    traffic, traffic_src = pmc_traffic("level_score_kernel") if args.workload == "powerlaw" and args.nodes == 1_000_000 else (None, None)
+    big_default = args.workload == "powerlaw" and args.nodes == 1_000_000 and args.emb == 128 and args.roots == 8192  # what the committed PMC passes ran
+    traffic, traffic_src = pmc_traffic("level_score_kernel") if big_default else (None, None)
     # K2 pair_reward: 8d + 16 per pair.  K3 / K4 (fast mode, lazy Adam) per section 8d: gradient kernel 16d + 20 per pair
     # (two rows read, two rows of gradient added), whole step 48d + 36 per pair; K5 optimizer kernel per touched row:
     # E, m, v read + written, gradient read + cleared = 32d, plus 32 for the bias and its slots.
     row_b = 32.0 * d + 32.0 if args.optimizer != "sgd" else 16.0 * d + 16.0
-    k2 = gbs((8.0 * d + 16.0) * c["reward_pairs_timed"], c["reward_kernel_ms"])
+    k2_pair_model = gbs((8.0 * d + 16.0) * c["reward_pairs_timed"], c["reward_kernel_ms"])
+    # path_reward_kernel reads every path node's row once per walk (row + id + bias) and writes one reward per pair
+    k2 = gbs((4.0 * d + 8.0) * c["g_walk_nodes_timed"] + 4.0 * c["reward_pairs_timed"], c["reward_kernel_ms"])
+
+    def by_traffic(kernel, ms, launches):
+        t, src = pmc_traffic(kernel) if big_default else (None, None)
+        if not t or not launches or ms <= 0:
+            return {"traffic": None}
+        v = gbs(t * launches, ms)
+        return {"traffic": t, "traffic_source": src, "traffic_GBs": v, "traffic_frac": frac(v)}
     kd_g, kd_o = gbs((16.0 * d + 20.0) * c["d_pairs_timed"], c["d_grad_ms"]), gbs(row_b * c["d_rows_timed"], c["d_opt_ms"])
     kg_g, kg_o = gbs((16.0 * d + 20.0) * c["g_pairs_timed"], c["g_grad_ms"]), gbs(row_b * c["g_rows_timed"], c["g_opt_ms"])
     kd_s = gbs((48.0 * d + 36.0) * c["d_pairs_timed"], c["d_grad_ms"] + c["d_opt_ms"])
@@ -360,14 +370,21 @@ def main():
                      "overlapped": {"achieved": achieved_ovl, "frac": frac(achieved_ovl), "launches": int(co["score_launches"]),
                                     "what": "%d further steps with the profiled G-mode launches left beside the discriminator update" % args.overlap_steps},
                      "microbenchmarks": "profiles/r1_gather_bw2.txt, profiles/r1_gather_bw3.txt (tools/gather_bw*.hip on the same chip)"},
-        "roofline_k2": {"kernel": "pair_reward_kernel", "bound": "hbm", "achieved": k2, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac(k2),
-                        "bytes_model": "8d + 16 per pair", "pairs": int(c["reward_pairs_timed"]), "ms": c["reward_kernel_ms"]},
+        "roofline_k2": {"kernel": "path_reward_kernel", "bound": "hbm", "achieved": k2, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac(k2),
+                        "bytes_model": "(4d + 8) per path node + 4 per pair: the whole-walk kernel reads every row once per walk",
+                        "per_pair_model": {"bytes_model": "SURVEY 8d: 8d + 16 per pair", "achieved": k2_pair_model,
+                                           "note": "above the HBM peak by construction: the 2-8 uses of a row by the window pairs of its walk come from registers"},
+                        "pairs": int(c["reward_pairs_timed"]), "path_nodes": int(c["g_walk_nodes_timed"]), "ms": c["reward_kernel_ms"]},
         "roofline_k34": {"bound": "hbm (fp32 atomics in L2)", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "bytes_model": "gradient kernel 16d + 20 per pair; whole step (gradient + optimizer) 48d + 36 per pair (SURVEY 8d, lazy Adam)",
-                         "d": {"kernel": "pair_grad_kernel", "achieved": kd_g, "frac": frac(kd_g), "step_achieved": kd_s, "step_frac": frac(kd_s),
-                               "pairs": int(c["d_pairs_timed"]), "grad_ms": c["d_grad_ms"], "passes": int(c["d_passes_timed"])},
-                         "g": {"kernel": "path_grad_kernel (reads every path node once: its traffic is below the per-pair model)", "achieved": kg_g, "frac": frac(kg_g),
-                               "step_achieved": kg_s, "step_frac": frac(kg_s), "pairs": int(c["g_pairs_timed"]), "grad_ms": c["g_grad_ms"], "passes": int(c["g_passes_timed"])}},
+                         "bytes_model": "gradient kernel 16d + 20 per pair; whole step (gradient + optimizer) 48d + 36 per pair (SURVEY 8d, lazy Adam); "
+                                        "traffic_* = HBM bytes of the PMC passes / the same event time: what the atomics really move",
+                         "d": dict({"kernel": "pair_grad_kernel", "achieved": kd_g, "frac": frac(kd_g), "step_achieved": kd_s, "step_frac": frac(kd_s),
+                                    "pairs": int(c["d_pairs_timed"]), "grad_ms": c["d_grad_ms"], "passes": int(c["d_passes_timed"])},
+                                   **by_traffic("pair_grad_kernel", c["d_grad_ms"], c["d_passes_timed"])),
+                         "g": dict({"kernel": "path_grad_kernel (reads every path node once and adds one gradient row per node: its traffic is below the per-pair model)",
+                                    "achieved": kg_g, "frac": frac(kg_g), "step_achieved": kg_s, "step_frac": frac(kg_s), "pairs": int(c["g_pairs_timed"]),
+                                    "grad_ms": c["g_grad_ms"], "passes": int(c["g_passes_timed"])},
+                                   **by_traffic("path_grad_kernel", c["g_grad_ms"], c["g_passes_timed"]))},
         "roofline_opt": {"kernel": "sparse_opt_kernel (+ flag scan / compaction%s)" % (", replica exchange" if world > 1 else ""), "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "bytes_model": "%s per touched row" % ("32d + 32 (E, m, v read + written, gradient read + cleared)" if args.optimizer != "sgd" else "16d + 16"),
                          "d": {"achieved": kd_o, "frac": frac(kd_o), "rows": int(c["d_rows_timed"]), "ms": c["d_opt_ms"]},

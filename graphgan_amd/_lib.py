@@ -39,7 +39,8 @@ class GGCounters(ctypes.Structure):
                 ("reward_kernel_ms", ctypes.c_double), ("reward_pairs_timed", ctypes.c_int64),
                 ("d_grad_ms", ctypes.c_double), ("d_opt_ms", ctypes.c_double), ("d_pairs_timed", ctypes.c_int64), ("d_rows_timed", ctypes.c_int64),
                 ("g_grad_ms", ctypes.c_double), ("g_opt_ms", ctypes.c_double), ("g_pairs_timed", ctypes.c_int64), ("g_rows_timed", ctypes.c_int64),
-                ("d_passes_timed", ctypes.c_int64), ("g_passes_timed", ctypes.c_int64)]
+                ("d_passes_timed", ctypes.c_int64), ("g_passes_timed", ctypes.c_int64),
+                ("g_walk_nodes_timed", ctypes.c_int64)]
 
 
 class GGGraph(ctypes.Structure):

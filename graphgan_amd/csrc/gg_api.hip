@@ -134,7 +134,7 @@ int gg::walk_launch_async(gg_ctx *ctx, const int32_t *slots, const int32_t *n_wa
     GG_CHECK(ctx, ctx->n_tree_roots > 0, GG_EINVAL, "walk: no trees loaded (gg_build_trees / gg_set_trees)");
     GG_CHECK(ctx, n_slots >= 0 && (slots || n_slots == 0), GG_EINVAL, "walk: bad slots");
     GG_CHECK(ctx, stride >= 2, GG_ECAPACITY, "walk: stride %d < 2", stride);
-    std::vector<int64_t> &ptr = ctx->h_walk_ptr;
+    std::vector<int64_t> &ptr = ctx->h_ptr_new;
     ptr.assign(n_slots + 1, 0);
     for (int i = 0; i < n_slots; ++i) {
         GG_CHECK(ctx, slots[i] >= 0 && slots[i] < ctx->n_tree_roots, GG_EINVAL, "walk: slot %d out of range", slots[i]);
@@ -151,8 +151,10 @@ int gg::walk_launch_async(gg_ctx *ctx, const int32_t *slots, const int32_t *n_wa
     }
     const int64_t total = ptr[n_slots];
     GG_HIP(ctx, hipSetDevice(ctx->device));
-    GG_HIP(ctx, ctx->w_slots.reserve(sizeof(int32_t) * (n_slots + 1)));
-    GG_HIP(ctx, ctx->w_ptr.reserve(sizeof(int64_t) * (n_slots + 1)));
+    const int mode = for_d ? 1 : 0;
+    ctx->w_mode = mode;
+    GG_HIP(ctx, ctx->w_slots_m[mode].reserve(sizeof(int32_t) * (n_slots + 1)));
+    GG_HIP(ctx, ctx->w_ptr_m[mode].reserve(sizeof(int64_t) * (n_slots + 1)));
     GG_HIP(ctx, ctx->w_status.reserve(sizeof(int32_t) * (n_slots + 1)));
     GG_HIP(ctx, ctx->w_abort.reserve(sizeof(int32_t) * (n_slots + 1)));
     GG_HIP(ctx, ctx->w_samples.reserve(sizeof(int32_t) * (total + 1)));
@@ -167,9 +169,17 @@ int gg::walk_launch_async(gg_ctx *ctx, const int32_t *slots, const int32_t *n_wa
     } else if (side_stream && ctx->gen_pass_recorded) {
         GG_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_gen_pass, 0));
     }
-    // h_walk_ptr and the caller's slots outlive the enqueued copies: every public call ends with a stream sync
-    if (n_slots) GG_HIP(ctx, hipMemcpyAsync(ctx->w_slots.p, slots, sizeof(int32_t) * n_slots, hipMemcpyHostToDevice, ctx->walk_stream));
-    GG_HIP(ctx, hipMemcpyAsync(ctx->w_ptr.p, ptr.data(), sizeof(int64_t) * (n_slots + 1), hipMemcpyHostToDevice, ctx->walk_stream));
+    // the lists of this mode's previous call are still resident: upload only what changed (the host shadows outlive the
+    // enqueued copies: every public call ends with a stream sync)
+    std::vector<int32_t> &hs = ctx->h_slots_m[mode];
+    if (hs.size() != (size_t)n_slots || (n_slots && memcmp(hs.data(), slots, sizeof(int32_t) * n_slots) != 0)) {
+        hs.assign(slots, slots + n_slots);
+        if (n_slots) GG_HIP(ctx, hipMemcpyAsync(ctx->w_slots_m[mode].p, hs.data(), sizeof(int32_t) * n_slots, hipMemcpyHostToDevice, ctx->walk_stream));
+    }
+    if (ctx->h_ptr_m[mode] != ptr) {
+        ctx->h_ptr_m[mode].swap(ptr);
+        GG_HIP(ctx, hipMemcpyAsync(ctx->w_ptr_m[mode].p, ctx->h_ptr_m[mode].data(), sizeof(int64_t) * (n_slots + 1), hipMemcpyHostToDevice, ctx->walk_stream));
+    }
     ctx->w_total = total;
     ctx->w_stride = stride;
     ctx->w_nslots = n_slots;
@@ -206,6 +216,12 @@ int gg::walk_finalize(gg_ctx *ctx, bool *retried) {
         GG_HIP(ctx, hipMemcpyAsync(c, ctx->dev_ctr, sizeof(unsigned long long) * 456, hipMemcpyDeviceToHost, ctx->stream));
         GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (retried) *retried = true;
+    }
+    {   // walks alive per streamed level, and behind the last one: where the next launch of this mode hands over to the finisher
+        int64_t *prof = ctx->alive_prof[ctx->w_args.for_d ? 1 : 0];
+        const int run = ctx->w_levels_run;
+        for (int i = 0; i < 64; ++i) prof[i] = i < run ? (int64_t)c[8 + i] : -1;
+        if (run > 0 && run < 64 && ctx->w_fin_follows) prof[run] = (int64_t)c[7];
     }
     // c[0], c[1], c[5]: counts of the per-walk finisher; the level pipeline's counts sit in 64 spread words each
     unsigned long long hops = c[0], reads = c[1], rows = c[5];
@@ -285,6 +301,8 @@ int gg_create(int32_t n_node, int32_t n_emb, const float *emb_gen, const float *
     if (const char *fw = getenv("GG_COMM_FAKE_WORLD")) ctx->fake_world = atoi(fw);
     if (const char *dt = getenv("GG_DETERMINISTIC")) ctx->deterministic = atoi(dt) != 0;
     if (const char *nc = getenv("GG_NO_DIST_CACHE")) ctx->dc_enabled = atoi(nc) == 0;
+    if (const char *ft = getenv("GG_FIN_THRESHOLD")) ctx->fin_threshold = std::max(0, atoi(ft));
+    for (auto &m : ctx->alive_prof) for (auto &v : m) v = -1;
     if (const char *dr = getenv("GG_COMM_DENSE_RATIO")) ctx->dense_exchange_ratio = (float)atof(dr);
 #define GG_TRY(call)                        \
     do {                                    \
@@ -365,7 +383,7 @@ int gg_destroy(gg_ctx *ctx) {
     for (void *p : ps)
         if (p) (void)hipFree(p);
     free_trees(ctx);
-    DevBuf *bufs[] = {&ctx->w_slots, &ctx->w_ptr, &ctx->w_samples, &ctx->w_paths, &ctx->w_len, &ctx->w_status,
+    DevBuf *bufs[] = {&ctx->w_slots_m[0], &ctx->w_slots_m[1], &ctx->w_ptr_m[0], &ctx->w_ptr_m[1], &ctx->w_samples, &ctx->w_paths, &ctx->w_len, &ctx->w_status,
                       &ctx->w_first, &ctx->w_abort, &ctx->w_scratch, &ctx->d_center, &ctx->d_neighbor, &ctx->d_label, &ctx->d_cnt,
                       &ctx->d_ptr, &ctx->g_node1, &ctx->g_node2, &ctx->g_reward, &ctx->g_cnt, &ctx->g_ptr, &ctx->scan_tmp,
                       &ctx->step_u, &ctx->step_v, &ctx->step_x, &ctx->touched_ptr, &ctx->x_cnt, &ctx->x_send_ids, &ctx->x_send_rows,

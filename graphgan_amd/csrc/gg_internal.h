@@ -108,7 +108,22 @@ struct gg_ctx {
     std::vector<int32_t> h_comp_size;  // |component| of every node (one host sweep per graph, cached): C_r before any BFS runs
 
     // walk outputs (device resident)
-    gg::DevBuf w_slots, w_ptr, w_samples, w_paths, w_len, w_status, w_first, w_abort, w_scratch;
+    // walk inputs (slot list, walk offsets): one resident copy per mode (index 1 = D-mode, 0 = anything else) with the host
+    // shadow that tells whether the next call brings the same lists -- the trainer alternates D and G calls over the same
+    // roots, and two staged pageable H2D copies at the head of every call were ~40 us of its critical path
+    gg::DevBuf w_slots_m[2], w_ptr_m[2];
+    std::vector<int32_t> h_slots_m[2];
+    std::vector<int64_t> h_ptr_m[2], h_ptr_new;
+    int w_mode = 0;                       // the mode of the current call
+    // walks alive per streamed level in the previous launch of each mode (-1 = unknown): where the next launch hands over
+    // to the finisher (walk_sample.hip, run_levels_and_finish); GG_FIN_THRESHOLD, 0 = stream every level
+    int64_t alive_prof[2][64];
+    int64_t fin_threshold = 0;
+    int w_levels_run = 0;
+    bool w_fin_follows = false;
+    const gg::DevBuf &w_slots_buf() const { return w_slots_m[w_mode]; }
+    const gg::DevBuf &w_ptr_buf() const { return w_ptr_m[w_mode]; }
+    gg::DevBuf w_samples, w_paths, w_len, w_status, w_first, w_abort, w_scratch;
     // level-synchronous front end of the walk sampler (walk_sample.hip): per-walk state + per-level tasks
     gg::DevBuf st_cur, st_prev, st_len, st_alive, st_rank, st_item, lv_beg, lv_k, lv_chunks, lv_coff, lv_scores, lv_chunk_owner, lv_prefix, lv_big;
     gg::DevBuf lv_pfx, dc_keys, dc_vals, dc_words;  // distribution cache (walk_sample.hip): prefix offsets per walk, hash table, base words
@@ -126,7 +141,7 @@ struct gg_ctx {
     int32_t w_stride = 0, w_nslots = 0;
     int32_t w_uniform = -1;  // walks per root of the resident launch when every root has the same number (prepare_g), else -1
     struct { int32_t for_d; uint64_t seed; uint32_t stream; } w_args{};
-    std::vector<int64_t> h_walk_ptr;
+
     // pinned host mirror: [0, 456) the launch's device counters, [H_TOTAL] the row / pair count of a prepare call --
     // both arrive with asynchronous copies behind the kernels and ONE stream synchronisation (pageable destinations
     // would make every copy its own host round trip)
@@ -200,6 +215,7 @@ int fail(gg_ctx *ctx, int code, const char *fmt, ...);
 
 // exclusive scan of n int32 counts into n+1 int64 offsets (prepare.hip)
 int device_exclusive_scan(gg_ctx *ctx, const int32_t *cnt, int64_t *ptr, int64_t n);
+int device_compact_flags(gg_ctx *ctx, const int32_t *flag, int64_t n, int32_t *list, int64_t *total_out);  // prepare.hip
 
 // trees (gg_api.hip / tree_builder.cpp)
 int alloc_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int64_t *node_counts, const int64_t *root_children);

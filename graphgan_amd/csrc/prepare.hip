@@ -96,6 +96,53 @@ int device_exclusive_scan(gg_ctx *ctx, const int32_t *cnt, int64_t *ptr, int64_t
     return GG_OK;
 }
 
+// Flags -> ascending list of the set positions (the optimizer's touched rows, deterministic order) in the scan's own third
+// pass: the tile offsets are all the compaction needs, so the [n + 1] offset array (8 B per node written, then read again by
+// a separate compaction kernel) is never materialised.  *total_out = number of set flags.
+__global__ __launch_bounds__(SCAN_THREADS) void flag_tile_sums(const int32_t *flag, int64_t n, int64_t *tile_sum) {
+    __shared__ int64_t sh[SCAN_THREADS / 64];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i)
+        if (base + i < n) s += flag[base + i] > 0 ? 1 : 0;
+    int64_t tot;
+    (void)block_excl_scan(s, &tot, sh);
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void flag_compact(const int32_t *flag, int64_t n, const int64_t *tile_off, int32_t *list) {
+    __shared__ int64_t sh[SCAN_THREADS / 64];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    bool v[SCAN_ITEMS];
+    int64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        v[i] = base + i < n && flag[base + i] > 0;
+        s += v[i] ? 1 : 0;
+    }
+    int64_t tot;
+    int64_t run = tile_off[blockIdx.x] + block_excl_scan(s, &tot, sh);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i)
+        if (v[i]) list[run++] = (int32_t)(base + i);
+}
+
+int device_compact_flags(gg_ctx *ctx, const int32_t *flag, int64_t n, int32_t *list, int64_t *total_out) {
+    const int64_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    GG_HIP(ctx, ctx->scan_tmp.reserve(sizeof(int64_t) * (tiles + 2)));
+    int64_t *ts = ctx->scan_tmp.as<int64_t>();
+    if (n == 0) {
+        GG_HIP(ctx, hipMemsetAsync(total_out, 0, sizeof(int64_t), ctx->stream));
+        return GG_OK;
+    }
+    hipLaunchKernelGGL(flag_tile_sums, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, ctx->stream, flag, n, ts);
+    hipLaunchKernelGGL(scan_tile_offsets, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, ts, tiles, total_out);
+    hipLaunchKernelGGL(flag_compact, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, ctx->stream, flag, n, ts, list);
+    GG_HIP(ctx, hipGetLastError());
+    return GG_OK;
+}
+
 // ------------------------------------------------------------------ K6 window pairs
 // pairs of path[:-1] with |i-j| <= window, i != j, in the reference's (i, then j) order.
 // `flag` = the walk launch's status word: 2 means the launch is being rerun (its outputs are not
@@ -164,6 +211,84 @@ __global__ __launch_bounds__(256) void pair_reward_kernel(const float *E, const 
             s = fminf(fmaxf(s, -10.0f), 10.0f);
             out[p] = logf(1.0f + expf(s));  // tf.log(1 + tf.exp(score)), fp32
         }
+    }
+}
+
+// The same rewards for the window pairs of whole walks (prepare_g, window <= 2): one 16-lane group per walk slides a
+// 5-row window over the path, so every discriminator row is read ONCE instead of once per pair (up to 8 times; the
+// re-reads hit L2, but each still costs a 512-byte gather).  Pair order and arithmetic (lane t owns float4 chunks t, t+16,
+// ...; fmaf chain, xor butterfly) are those of pair_fill_kernel + pair_reward_kernel: bit-identical rewards.
+template <int NCH>
+__global__ __launch_bounds__(256) void path_reward_kernel(const float *E, const float *bias, int ld, const int32_t *paths,
+                                                          const int32_t *path_len, int stride, int64_t n_walks, int window,
+                                                          const int64_t *ptr, float *out, const unsigned long long *flag) {
+    const int t = threadIdx.x & 15;
+    const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (w >= n_walks || *flag == 2ull) return;
+    const int L = path_len[w] - 1;
+    if (L <= 1) return;
+    const int32_t *p = paths + w * (int64_t)stride;
+    const int nchunk = ld >> 2;
+    int64_t pi = ptr[w];
+    float4 R[5][NCH];  // window slots 0..4 = path positions c-2 .. c+2 of the centre c
+    float bv[5];
+    bool have[5];
+    auto fetch = [&](int pos, float4 (&row)[NCH], float &b, bool &ok) {
+        ok = pos >= 0 && pos < L;
+        const int nd = ok ? p[pos] : 0;
+        b = ok ? bias[nd] : 0.f;
+        const float4 *r = (const float4 *)(E + (int64_t)nd * ld);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = t + 16 * i;
+            row[i] = (ok && c < nchunk) ? r[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    have[0] = have[1] = false;
+    bv[0] = bv[1] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) R[0][i] = R[1][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    fetch(0, R[2], bv[2], have[2]);
+    fetch(1, R[3], bv[3], have[3]);
+    fetch(2, R[4], bv[4], have[4]);
+    for (int c = 0; c < L; ++c) {
+        float4 Rn[NCH];
+        float nb;
+        bool nh;
+        fetch(c + 3, Rn, nb, nh);  // in flight while the centre's pairs are evaluated
+#pragma unroll
+        for (int sl = 0; sl < 5; ++sl) {
+            if (sl == 2 || !have[sl] || sl < 2 - window || sl > 2 + window) continue;
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                acc = __builtin_fmaf(R[2][i].x, R[sl][i].x, acc);
+                acc = __builtin_fmaf(R[2][i].y, R[sl][i].y, acc);
+                acc = __builtin_fmaf(R[2][i].z, R[sl][i].z, acc);
+                acc = __builtin_fmaf(R[2][i].w, R[sl][i].w, acc);
+            }
+            acc += __shfl_xor(acc, 8, 64);
+            acc += __shfl_xor(acc, 4, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            acc += __shfl_xor(acc, 1, 64);
+            if (t == 0) {
+                float sc = acc + bv[sl];
+                sc = fminf(fmaxf(sc, -10.0f), 10.0f);
+                out[pi] = logf(1.0f + expf(sc));
+            }
+            ++pi;
+        }
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            have[sl] = have[sl + 1];
+            bv[sl] = bv[sl + 1];
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) R[sl][i] = R[sl + 1][i];
+        }
+        have[4] = nh;
+        bv[4] = nb;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) R[4][i] = Rn[i];
     }
 }
 
@@ -237,12 +362,12 @@ extern "C" {
 // rows of gg_prepare_d behind the walk on the same stream; capacity = 2 * (walks launched) >= rows
 static int enqueue_d_rows(gg_ctx *ctx, int32_t n_slots) {
     hipLaunchKernelGGL(d_count_kernel, dim3(cdiv(n_slots, 256)), dim3(256), 0, ctx->stream, ctx->w_status.as<int32_t>(),
-                       ctx->w_ptr.as<int64_t>(), n_slots, ctx->d_cnt.as<int32_t>(), ctx->dev_ctr + 3);
+                       ctx->w_ptr_buf().as<int64_t>(), n_slots, ctx->d_cnt.as<int32_t>(), ctx->dev_ctr + 3);
     int rc = device_exclusive_scan(ctx, ctx->d_cnt.as<int32_t>(), ctx->d_ptr.as<int64_t>(), n_slots);
     if (rc != GG_OK) return rc;
     hipLaunchKernelGGL(d_fill_kernel, dim3(cdiv((int64_t)n_slots * 64, 256)), dim3(256), 0, ctx->stream,
-                       ctx->w_slots.as<int32_t>(), ctx->t_root, ctx->g_rowptr, ctx->g_col, ctx->w_samples.as<int32_t>(),
-                       ctx->w_ptr.as<int64_t>(), ctx->d_ptr.as<int64_t>(), n_slots, ctx->d_center.as<int32_t>(),
+                       ctx->w_slots_buf().as<int32_t>(), ctx->t_root, ctx->g_rowptr, ctx->g_col, ctx->w_samples.as<int32_t>(),
+                       ctx->w_ptr_buf().as<int64_t>(), ctx->d_ptr.as<int64_t>(), n_slots, ctx->d_center.as<int32_t>(),
                        ctx->d_neighbor.as<int32_t>(), ctx->d_label.as<float>(), ctx->dev_ctr + 3);
     GG_HIP(ctx, hipMemcpyAsync(ctx->h_pin + gg_ctx::H_TOTAL, ctx->d_ptr.as<int64_t>() + n_slots, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     GG_HIP(ctx, hipGetLastError());
@@ -317,8 +442,20 @@ static int enqueue_g_pairs(gg_ctx *ctx, int64_t nw, int64_t cap) {
     const Model &D = ctx->model[1];
     const int ts = ctx->walk_timed ? timing_slot(ctx) : -1;  // profiled call: HIP events around the reward kernel
     if (ts >= 0) GG_HIP(ctx, hipEventRecord(ctx->tm_ev[ts][0], ctx->stream));
-    hipLaunchKernelGGL(pair_reward_kernel, dim3(256 * 16), dim3(256), 0, ctx->stream, D.E, D.b, ctx->ld, ctx->g_node1.as<int32_t>(),
-                       ctx->g_node2.as<int32_t>(), (int64_t)-1, ctx->g_ptr.as<int64_t>() + nw, ctx->g_reward.as<float>());
+    const int nch = (ctx->ld / 4 + 15) / 16;
+    if (window <= 2 && nch <= 4 && ctx->ld % 4 == 0 && !getenv("GG_NO_PATH_REWARD")) {
+        const dim3 grid(cdiv(nw * 16, 256)), blk(256);
+#define GG_PATH_REWARD(N)                                                                                                              \
+    hipLaunchKernelGGL(path_reward_kernel<N>, grid, blk, 0, ctx->stream, D.E, D.b, ctx->ld, ctx->w_paths.as<int32_t>(),                 \
+                       ctx->w_len.as<int32_t>(), ctx->w_stride, nw, window, ctx->g_ptr.as<int64_t>(), ctx->g_reward.as<float>(), ctx->dev_ctr + 3)
+        if (nch <= 1) GG_PATH_REWARD(1);
+        else if (nch == 2) GG_PATH_REWARD(2);
+        else GG_PATH_REWARD(4);
+#undef GG_PATH_REWARD
+    } else {
+        hipLaunchKernelGGL(pair_reward_kernel, dim3(256 * 16), dim3(256), 0, ctx->stream, D.E, D.b, ctx->ld, ctx->g_node1.as<int32_t>(),
+                           ctx->g_node2.as<int32_t>(), (int64_t)-1, ctx->g_ptr.as<int64_t>() + nw, ctx->g_reward.as<float>());
+    }
     if (ts >= 0) {
         GG_HIP(ctx, hipEventRecord(ctx->tm_ev[ts][1], ctx->stream));
         GG_HIP(ctx, hipEventRecord(ctx->tm_ev[ts][2], ctx->stream));
@@ -354,6 +491,7 @@ int gg_prepare_g(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, int32_t n_s
         if (rc != GG_OK) return rc;
     }
     bool retried = false;
+    const int64_t hops_before = ctx->ctr.hops;
     rc = walk_finalize(ctx, &retried);  // the only host synchronisation of the call
     ctx->dc_request = 0;
     if (rc != GG_OK) return rc;
@@ -365,7 +503,10 @@ int gg_prepare_g(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, int32_t n_s
         }
         ctx->g_pairs = (int64_t)ctx->h_pin[gg_ctx::H_TOTAL];
         ctx->ctr.reward_pairs += ctx->g_pairs;
-        if (ctx->walk_timed) ctx->ctr.reward_pairs_timed += ctx->g_pairs;  // its kernel time is folded in by harvest_timings
+        if (ctx->walk_timed) {  // the reward kernel's time is folded in by harvest_timings
+            ctx->ctr.reward_pairs_timed += ctx->g_pairs;
+            ctx->ctr.g_walk_nodes_timed += ctx->ctr.hops - hops_before;
+        }
         ctx->g_paths_valid = true;
     }
     if (root_status && n_slots) GG_HIP(ctx, hipMemcpy(root_status, ctx->w_status.p, sizeof(int32_t) * n_slots, hipMemcpyDeviceToHost));

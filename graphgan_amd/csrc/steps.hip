@@ -420,7 +420,10 @@ __device__ __forceinline__ void opt_row(const OptArgs &a, int row, int t, int nc
 // ... over the compacted row list (flag array -> scan -> list: deterministic row order; the replica exchange packs the same list).
 // (Measured and not kept: updating straight from the flags without the scan / compaction launches -- 30 us SLOWER per call:
 // the list gives every group exactly one row; and summing one root's walk gradients in LDS before the global atomics --
-// 80 us slower per G pass: the 20 walks of a root share too few rows below its first level.)
+// 80 us slower per G pass: the 20 walks of a root share too few rows below its first level.  Bound on what a sort + segmented
+// reduce could buy: path_grad_kernel with plain stores in place of its fp32 atomics (wrong sums, timing only) runs 319 us
+// against 728 us -- a staged gradient (319 us) + key sort + a reducing optimizer over 470 MB of staged rows would land
+// within ~30 % of today's 728 + 233 us, for a deterministic sum; not built.)
 template <int SGD>
 __global__ __launch_bounds__(256) void sparse_opt_kernel(const OptArgs a) {
     const int t = threadIdx.x & 15;
@@ -472,11 +475,7 @@ __global__ __launch_bounds__(256) void add_rows_kernel(float *gE, float *gb, int
     }
 }
 
-// touched flags -> row list in row order (deterministic), via the exclusive scan of the flags
-__global__ void compact_touched_kernel(const OptArgs a) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < a.n_node && a.touched[i] > 0) a.touched_list[a.touched_ptr[i]] = i;
-}
+// (touched flags -> row list in row order, deterministic: device_compact_flags, prepare.hip)
 
 int apply_optimizer(gg_ctx *ctx, int which, int64_t n);
 int run_path_step(gg_ctx *ctx);
@@ -618,9 +617,8 @@ static int exchange_sparse(gg_ctx *ctx, OptArgs &o, int world, int64_t bound) {
         ctx->comm_steps_dense += 1;
         return GG_OK;
     }
-    int rc = device_exclusive_scan(ctx, ctx->touched, ctx->touched_ptr.as<int64_t>(), n);
+    int rc = device_compact_flags(ctx, ctx->touched, n, ctx->touched_list, ctx->touched_ptr.as<int64_t>() + n);
     if (rc != GG_OK) return rc;
-    hipLaunchKernelGGL(compact_touched_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, o);
     const size_t row_f = (size_t)ld + 1;
     GG_HIP(ctx, ctx->x_send_ids.reserve(sizeof(int32_t) * cap));
     GG_HIP(ctx, ctx->x_send_rows.reserve(sizeof(float) * cap * row_f));
@@ -695,9 +693,8 @@ int apply_optimizer(gg_ctx *ctx, int which, int64_t n) {
             rc = exchange_sparse(ctx, o, world < 1 ? 1 : world, ctx->step_bound > 0 ? ctx->step_bound : n);
             if (rc != GG_OK) return rc;
         }
-        rc = device_exclusive_scan(ctx, ctx->touched, ctx->touched_ptr.as<int64_t>(), ctx->n_node);
+        rc = device_compact_flags(ctx, ctx->touched, ctx->n_node, ctx->touched_list, ctx->touched_ptr.as<int64_t>() + ctx->n_node);
         if (rc != GG_OK) return rc;
-        hipLaunchKernelGGL(compact_touched_kernel, dim3(cdiv(ctx->n_node, 256)), dim3(256), 0, ctx->stream, o);
         int nb = cdiv((int64_t)std::min<int64_t>(2ll * n * ctx->world, ctx->n_node) * 16, 256);
         if (nb > 4096) nb = 4096;
         if (nb < 1) nb = 1;

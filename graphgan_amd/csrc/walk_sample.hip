@@ -216,6 +216,7 @@ static int score_blocks() {
 }
 constexpr int BIG_TASK = 256;   // owner tasks with more candidates get a whole workgroup for their prefix sums
 constexpr int CTR_NONFINITE = 6; // ctr[6]: a distribution had total weight 0 (non-finite generator scores) -> GG_EINVAL
+constexpr int CTR_FIN = 7;      // ctr[7]: walks still alive behind the last streamed level = entries of the finisher's walk list
 constexpr int CTR_ALIVE = 8;    // ctr[CTR_ALIVE + level]: walks alive when hop `level` was set up
 constexpr int CTR_BIG = 72;     // ctr[CTR_BIG + level]:   owner tasks of hop `level` that need the weights kernel: big ones (k > BIG_TASK) in
                                 //                         the low 32 bits, small multi-chunk ones in the high 32 bits (one atomic hands out both)
@@ -422,7 +423,18 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
             atomicAdd(&a.ctr[CTR_READS_V + (blockIdx.x & 63)], my_k);
         }
     }
-    if (!do_setup) return;
+    if (!do_setup) {
+        // behind the last streamed level: the walks that are still going, as a compact list for the finisher (it used to
+        // draw one ticket per WALK, finished or not: 160 k same-address atomics, ~2 ms, to find a few thousand live walks)
+        const unsigned long long abal = __ballot(alive);
+        if (abal) {
+            unsigned long long base = 0;
+            if (lane == __ffsll((long long)abal) - 1) base = atomicAdd(&a.ctr[CTR_FIN], (unsigned long long)__popcll(abal));
+            base = __shfl(base, __ffsll((long long)abal) - 1, 64);
+            if (alive) a.lv_big[base + __popcll(abal & ((1ull << lane) - 1ull))] = (int32_t)w;
+        }
+        return;
+    }
     // G launch: was this very distribution evaluated by the D launch of the step?  (Same slot, same node, same
     // father flag => same candidate list; same generator tables => same prefix sums, bit for bit.)
     bool cached = false;
@@ -793,8 +805,10 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void walk_sample_kernel(const
     // dynamic work distribution: waves pull the next walk from one ticket counter, so a wave that
     // drew a hub hop does not hold back a fixed share of the remaining walks (the first n_waves
     // walks keep the XCD-contiguous static assignment)
-    for (int64_t w = (int64_t)lblock * WAVES_PER_BLOCK + wib; w < a.total_walks;) {
-        if (!resume || a.st_alive[w]) {
+    const int64_t n_items = resume ? (int64_t)a.ctr[CTR_FIN] : a.total_walks;  // resume: the live walks listed by the last level_advance_kernel
+    for (int64_t it = (int64_t)lblock * WAVES_PER_BLOCK + wib; it < n_items;) {
+        const int64_t w = resume ? (int64_t)a.lv_big[it] : it;
+        {
             const int item = find_item(a.walk_ptr, a.n_slots, w);
             const uint32_t j = (uint32_t)(w - a.walk_ptr[item]);
             const int slot = a.slots[item];
@@ -892,7 +906,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void walk_sample_kernel(const
         }
         unsigned long long nw = 0;
         if (lane == 0) nw = atomicAdd(&a.ctr[4], 1ull);
-        w = n_waves + (int64_t)__shfl(nw, 0, 64);
+        it = n_waves + (int64_t)__shfl(nw, 0, 64);
     }
 
     if (lane == 0) {
@@ -966,6 +980,11 @@ static int reserve_prefix(gg_ctx *ctx, WalkArgs &a, int64_t chunks, bool keep) {
     return GG_OK;
 }
 
+__global__ __launch_bounds__(256) void fill_ones_kernel(uint4 *p, int64_t n16) {
+    const uint4 v = make_uint4(~0u, ~0u, ~0u, ~0u);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) p[i] = v;
+}
+
 // end of a D launch that registered its distributions: chunks now in the prefix buffer = where the G launch appends
 __global__ void dc_finish_kernel(const WalkArgs a, int64_t *words, int n_levels) {
     if (a.ctr[3] == 2ull) { words[1] = 0; return; }  // the launch is being rerun
@@ -979,7 +998,7 @@ __global__ void dc_finish_kernel(const WalkArgs a, int64_t *words, int n_levels)
 // sized == false: no host synchronisation at all, buffers hold ctx->lv_cap_chunks chunks and a
 // level that needs more raises flag 2 (the caller reruns the launch in sized mode).
 template <int NCH>
-static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_levels, bool sized, bool *any_alive) {
+static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_levels, bool sized, bool finisher_follows, bool *any_alive) {
     const dim3 blk(WAVES_PER_BLOCK * 64);
     int64_t cap = sized ? 0 : ctx->lv_cap_chunks;
     const bool keep = a.dc_mode != 0;  // cached prefix regions must survive a growing buffer
@@ -998,7 +1017,7 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
     }
     const unsigned wblocks = (unsigned)cdiv(total_walks, 256);
     const bool all_levels = n_levels >= ctx->tree_max_depth + 2;
-    if (!sized && all_levels && ctx->lv_levels_learned > 0) n_levels = std::min(n_levels, ctx->lv_levels_learned + 1);
+    if (!sized && all_levels && !finisher_follows && ctx->lv_levels_learned > 0) n_levels = std::min(n_levels, ctx->lv_levels_learned + 1);
     *any_alive = true;
     ctx->lv_ev_used = 0;
     int level = 0;
@@ -1012,6 +1031,7 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
             GG_HIP(ctx, hipStreamSynchronize(ctx->walk_stream));
             if (alive == 0) {  // every walk has finished
                 *any_alive = false;
+                ctx->w_levels_run = level + 1;
                 if (a.dc_mode == 1) hipLaunchKernelGGL(dc_finish_kernel, dim3(1), dim3(1), 0, ctx->walk_stream, a, ctx->dc_words.as<int64_t>(), level + 1);
                 return GG_OK;
             }
@@ -1045,7 +1065,8 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
     }
     // finish the last prepared hop
     a.level = level;
-    hipLaunchKernelGGL(level_advance_kernel, dim3(wblocks), dim3(256), 0, ctx->walk_stream, a, 1, 0, (!sized && all_levels) ? 2 : 0, 0);
+    hipLaunchKernelGGL(level_advance_kernel, dim3(wblocks), dim3(256), 0, ctx->walk_stream, a, 1, 0, (!sized && all_levels && !finisher_follows) ? 2 : 0, 0);
+    ctx->w_levels_run = level;
     if (a.dc_mode == 1) hipLaunchKernelGGL(dc_finish_kernel, dim3(1), dim3(1), 0, ctx->walk_stream, a, ctx->dc_words.as<int64_t>(), level);
     GG_HIP(ctx, hipGetLastError());
     return GG_OK;
@@ -1061,6 +1082,8 @@ static int run_levels_and_finish(gg_ctx *ctx, WalkArgs &a, int64_t total_walks) 
     if (n_levels > MAX_LEVELS) n_levels = MAX_LEVELS;
     bool any_alive = true;
     ctx->lv_ev_used = 0;
+    ctx->w_levels_run = 0;
+    ctx->w_fin_follows = true;
     if (n_levels > 0) {
         GG_HIP(ctx, ctx->st_cur.reserve(sizeof(int32_t) * total_walks));
         GG_HIP(ctx, ctx->st_prev.reserve(sizeof(int32_t) * total_walks));
@@ -1087,10 +1110,20 @@ static int run_levels_and_finish(gg_ctx *ctx, WalkArgs &a, int64_t total_walks) 
         a.lv_coff = ctx->lv_coff.as<int64_t>();
         a.lv_pfx = ctx->lv_pfx.as<int64_t>();
         const bool sized = ctx->lv_cap_chunks == 0 || ctx->walk_force_sized;
-        int rc = run_levels<NCH>(ctx, a, total_walks, n_levels, sized, &any_alive);
+        // The deep hops hold a few thousand walks but cost a full advance / score / weights round each (~60 us of pure
+        // latency): stop streaming where the previous launch of this mode had fewer than fin_threshold walks left and let
+        // the finisher (one wavefront per listed walk, to the end of the walk) take those.  Any split gives the same walks.
+        bool early = false;
+        if (all_levels && !sized && ctx->fin_threshold > 0) {
+            const int64_t *prof = ctx->alive_prof[a.for_d ? 1 : 0];
+            for (int l = 1; l < n_levels && l < MAX_LEVELS; ++l)
+                if (prof[l] >= 0 && prof[l] < ctx->fin_threshold) { n_levels = l; early = true; break; }
+        }
+        ctx->w_fin_follows = early || !all_levels;
+        int rc = run_levels<NCH>(ctx, a, total_walks, n_levels, sized, early, &any_alive);
         if (rc != GG_OK) return rc;
         ctx->walk_used_speculation = !sized;
-        if (all_levels) any_alive = false;
+        if (all_levels && !early) any_alive = false;
     }
     if (any_alive) {
         a.level = n_levels;
@@ -1122,8 +1155,8 @@ int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int fo
     a.t_base = ctx->t_base;
     a.t_q3 = ctx->t_q3;
     a.t_q3off = ctx->t_q3off;
-    a.slots = ctx->w_slots.as<int32_t>();
-    a.walk_ptr = ctx->w_ptr.as<int64_t>();
+    a.slots = ctx->w_slots_buf().as<int32_t>();
+    a.walk_ptr = ctx->w_ptr_buf().as<int64_t>();
     a.n_slots = n_slots;
     a.total_walks = total_walks;
     a.for_d = for_d;
@@ -1149,7 +1182,8 @@ int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int fo
             GG_HIP(ctx, ctx->dc_vals.reserve(sizeof(unsigned long long) * want));
             ctx->dc_size = want;
         }
-        GG_HIP(ctx, hipMemsetAsync(ctx->dc_keys.p, 0xFF, sizeof(unsigned long long) * ctx->dc_size, ctx->walk_stream));
+        // (hipMemsetAsync of these 16 MB took ~150 us on the walk stream; a plain store kernel takes a few)
+        hipLaunchKernelGGL(fill_ones_kernel, dim3(1024), dim3(256), 0, ctx->walk_stream, (uint4 *)ctx->dc_keys.p, (int64_t)(ctx->dc_size / 2));
     }
     a.dc_keys = ctx->dc_keys.as<unsigned long long>();
     a.dc_vals = ctx->dc_vals.as<unsigned long long>();

@@ -103,6 +103,7 @@ typedef struct gg_counters {
     double g_grad_ms, g_opt_ms;
     int64_t g_pairs_timed, g_rows_timed;
     int64_t d_passes_timed, g_passes_timed;
+    int64_t g_walk_nodes_timed;            /* path nodes (= hops) of the gg_prepare_g calls counted in reward_pairs_timed */
 } gg_counters;
 
 typedef struct gg_ctx gg_ctx;

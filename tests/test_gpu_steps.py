@@ -177,6 +177,15 @@ def test_prepare_d_and_g_match_oracle(ga):
         assert np.array_equal(st, want["root_status"])
         assert np.array_equal(g1, np.array(n1, np.int32)) and np.array_equal(g2, np.array(n2, np.int32))
         assert np.max(np.abs(rew - dis.reward(g1.astype(np.int64), g2.astype(np.int64)))) <= 1e-5
+        # the whole-walk reward kernel (every row read once per walk) == the per-pair kernel, bit for bit
+        os.environ["GG_NO_PATH_REWARD"] = "1"
+        try:
+            h1, h2, rew_pairs, _ = eng.prepare_g(slots, 20, 9, 2 * rnd + 1)
+        finally:
+            del os.environ["GG_NO_PATH_REWARD"]
+        assert np.array_equal(h1, g1) and np.array_equal(h2, g2)
+        assert np.array_equal(rew_pairs.view(np.uint32), rew.view(np.uint32))
+        assert np.array_equal(eng.pair_reward(g1, g2).view(np.uint32), rew.view(np.uint32))
     eng.close()
 
 
