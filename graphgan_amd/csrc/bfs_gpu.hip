@@ -73,7 +73,9 @@ __device__ __forceinline__ int lanes_below(unsigned long long m) {  // popcount 
 // chunks, most of the last two levels -- leave after one barrier.  (Measured and not kept: lane-consecutive positions
 // for fully coalesced loads, and a per-wave node-start bitmap instead of the map -- same speed or slower: more
 // instructions per edge, and the loads were never the limit.)
-template <bool LDS_BM>
+// INSTR: the phase clocks (GG_BFS_PROFILE) and the ablation switches (GG_BFS_EXPERIMENT) are compiled into a second
+// instance only -- tested at run time in the production kernel they cost 10 % (85.7 -> 95.7 us per tree).
+template <bool LDS_BM, bool INSTR>
 __global__ __launch_bounds__(BFS_T) void bfs_order_kernel(const BfsArgs a) {
     extern __shared__ uint32_t lds_bm[];           // [bm_words] when LDS_BM
     __shared__ int32_t eoff[BFS_NB + 1];           // exclusive scan of the batch's degrees
@@ -121,9 +123,9 @@ __global__ __launch_bounds__(BFS_T) void bfs_order_kernel(const BfsArgs a) {
         int head = 0, tail = 1, level_end = 1, depth = 0;
         // phase clocks of wave 0 (time to the barrier that ends the phase = what the whole workgroup waited for)
         unsigned long long pc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        long long tprev = a.prof ? (long long)clock64() : 0;
+        long long tprev = (INSTR && a.prof) ? (long long)clock64() : 0;
 #define BFS_TICK(k)                                             \
-    if (a.prof) {                                               \
+    if (INSTR && a.prof) {                                      \
         const long long tn = (long long)clock64();              \
         pc[k] += (unsigned long long)(tn - tprev);              \
         tprev = tn;                                             \
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(BFS_T) void bfs_order_kernel(const BfsArgs a) {
                                 e = e0s[idx];
                                 nextb = eoff[idx + 1];
                             }
-                            w[j] = (a.exp & 2) ? (int)((e * 2654435761u) % (uint32_t)a.n_node) : a.col[e];
+                            w[j] = (INSTR && (a.exp & 2)) ? (int)((e * 2654435761u) % (uint32_t)a.n_node) : a.col[e];
                             ++e;
                             vmask |= 1u << j;
                             if (p + 1 == nextb) lmask |= 1u << j;
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(BFS_T) void bfs_order_kernel(const BfsArgs a) {
                     while (lm) {
                         const int j = __ffs(lm) - 1;
                         lm &= lm - 1;
-                        if (!(a.exp & 1)) cstart[head + qfirst + __popc(lmask & ((1u << j) - 1u)) + 1] = tail;
+                        if (!(INSTR && (a.exp & 1))) cstart[head + qfirst + __popc(lmask & ((1u << j) - 1u)) + 1] = tail;
                     }
                     BFS_TICK(3)  // chunk without new nodes
                     pc[10] += 1;
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(BFS_T) void bfs_order_kernel(const BfsArgs a) {
                             ++rank;
                         }
                         if ((lmask >> j) & 1u) {  // children of this queue node end here
-                            if (!(a.exp & 1)) cstart[q] = rank;
+                            if (!(INSTR && (a.exp & 1))) cstart[q] = rank;
                             ++q;
                         }
                     }
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(BFS_T) void bfs_order_kernel(const BfsArgs a) {
             head += nb;
             __syncthreads();
         }
-        if (a.prof && tid == 0)
+        if (INSTR && a.prof && tid == 0)
             for (int k = 0; k < 12; ++k) atomicAdd(&a.prof[k], pc[k]);
 #undef BFS_TICK
 
@@ -394,7 +396,7 @@ extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t 
     const int bm_words = (n + 31) / 32;
     // static LDS of the kernel (eoff, e0s, duplicate list, mask, counters) ~ 21.5 KB; the CU has 160 KB
     hipFuncAttributes fa;
-    GG_HIP(ctx, hipFuncGetAttributes(&fa, (const void *)bfs_order_kernel<true>));
+    GG_HIP(ctx, hipFuncGetAttributes(&fa, (const void *)bfs_order_kernel<true, false>));
     const size_t lds_total = 160 * 1024;
     const bool lds_bm = !getenv("GG_BFS_GLOBAL_BITMAP") && fa.sharedSizeBytes + (size_t)bm_words * 4 <= lds_total;
 
@@ -429,11 +431,16 @@ extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t 
     (void)hipEventRecord(ctx->ev0, ctx->stream);
     if (lds_bm) {
         const size_t dyn = (size_t)bm_words * 4;
-        e = hipFuncSetAttribute((const void *)bfs_order_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        const bool instr = prof || a.exp != 0;
+        const void *fn = instr ? (const void *)bfs_order_kernel<true, true> : (const void *)bfs_order_kernel<true, false>;
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
         if (e != hipSuccess) { cleanup(); return fail(ctx, GG_EHIP, "gg_build_trees_device: %zu bytes of LDS: %s", dyn, hipGetErrorString(e)); }
-        hipLaunchKernelGGL(bfs_order_kernel<true>, dim3(grid), dim3(BFS_T), dyn, ctx->stream, a);
+        if (instr) hipLaunchKernelGGL((bfs_order_kernel<true, true>), dim3(grid), dim3(BFS_T), dyn, ctx->stream, a);
+        else hipLaunchKernelGGL((bfs_order_kernel<true, false>), dim3(grid), dim3(BFS_T), dyn, ctx->stream, a);
+    } else if (prof || a.exp != 0) {
+        hipLaunchKernelGGL((bfs_order_kernel<false, true>), dim3(grid), dim3(BFS_T), 0, ctx->stream, a);
     } else {
-        hipLaunchKernelGGL(bfs_order_kernel<false>, dim3(grid), dim3(BFS_T), 0, ctx->stream, a);
+        hipLaunchKernelGGL((bfs_order_kernel<false, false>), dim3(grid), dim3(BFS_T), 0, ctx->stream, a);
     }
     (void)hipEventRecord(ctx->ev1, ctx->stream);
     int32_t stats[3] = {0, 0, 0};

@@ -171,6 +171,11 @@ struct gg_ctx {
     gg::DevBuf bfs_key, bfs_bm, bfs_misc;  // scratch of gg_build_trees_device (bfs_gpu.hip)
     int n_cus = 256;                       // compute units of the device (gg_create; hipGetDeviceProperties costs milliseconds)
     gg::DevBuf scan_tmp, step_u, step_v, step_x;
+    // staged generator gradient (steps.hip, run_path_step): per-row counts / segment offsets, per path node slot, row list,
+    // the stage itself (gradient rows + bias gradients of the small rows, segment by segment), two total words
+    gg::DevBuf sg_cnt, sg_off, sg_slot, sg_list, sg_rows, sg_bias, sg_tot;
+    bool sg_active = false;            // a staged G pass is applying its hub rows (apply_optimizer resets their counts)
+    int sg_threshold = 64;             // GG_STAGE_T: rows with more staged gradients than this keep the atomic path; 0 = everything atomic
 
     // device-side counters of the walk launch in flight (zeroed at its start): [0]=hops [1]=nbr_reads [3]=error flag
     // [4]=ticket [5]=rows scored by the finisher; per-level and spread words from [8] on (walk_sample.hip)
@@ -216,6 +221,7 @@ int fail(gg_ctx *ctx, int code, const char *fmt, ...);
 // exclusive scan of n int32 counts into n+1 int64 offsets (prepare.hip)
 int device_exclusive_scan(gg_ctx *ctx, const int32_t *cnt, int64_t *ptr, int64_t n);
 int device_compact_flags(gg_ctx *ctx, const int32_t *flag, int64_t n, int32_t *list, int64_t *total_out);  // prepare.hip
+int device_segment_rows(gg_ctx *ctx, const int32_t *cnt, int64_t n, int T, int32_t *off, int4 *list, int64_t *totals);  // prepare.hip
 
 // trees (gg_api.hip / tree_builder.cpp)
 int alloc_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int64_t *node_counts, const int64_t *root_children);

@@ -143,6 +143,63 @@ int device_compact_flags(gg_ctx *ctx, const int32_t *flag, int64_t n, int32_t *l
     return GG_OK;
 }
 
+// Row segments of the staged generator gradient (steps.hip): cnt[r] = gradient rows staged for table row r.  Rows with
+// 0 < cnt <= T ("small") get a contiguous segment of the stage buffer: off[r] = exclusive sum of the small rows' counts,
+// list = {row, off, cnt} of the small rows in ascending row order; totals[0] = small rows, totals[1] = their staged rows.  One scan, three launches.
+__global__ __launch_bounds__(SCAN_THREADS) void seg_tile_sums(const int32_t *cnt, int64_t n, int T, int64_t *tile_rows, int64_t *tile_occ) {
+    __shared__ int64_t sh[SCAN_THREADS / 64];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int64_t rows = 0, occ = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i)
+        if (base + i < n) {
+            const int c = cnt[base + i];
+            if (c > 0 && c <= T) { rows += 1; occ += c; }
+        }
+    int64_t tot;
+    (void)block_excl_scan(rows, &tot, sh);
+    if (threadIdx.x == 0) tile_rows[blockIdx.x] = tot;
+    (void)block_excl_scan(occ, &tot, sh);
+    if (threadIdx.x == 0) tile_occ[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void seg_apply(const int32_t *cnt, int64_t n, int T, const int64_t *tile_rows, const int64_t *tile_occ,
+                                                          int32_t *off, int4 *list) {
+    __shared__ int64_t sh[SCAN_THREADS / 64];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int c[SCAN_ITEMS];
+    int64_t rows = 0, occ = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        const int v = base + i < n ? cnt[base + i] : 0;
+        c[i] = (v > 0 && v <= T) ? v : 0;
+        rows += c[i] ? 1 : 0;
+        occ += c[i];
+    }
+    int64_t tot;
+    int64_t rrun = tile_rows[blockIdx.x] + block_excl_scan(rows, &tot, sh);
+    int64_t orun = tile_occ[blockIdx.x] + block_excl_scan(occ, &tot, sh);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i)
+        if (c[i]) {
+            list[rrun++] = make_int4((int32_t)(base + i), (int32_t)orun, c[i], 0);  // {row, first stage row, stage rows}
+            off[base + i] = (int32_t)orun;
+            orun += c[i];
+        }
+}
+
+int device_segment_rows(gg_ctx *ctx, const int32_t *cnt, int64_t n, int T, int32_t *off, int4 *list, int64_t *totals) {
+    const int64_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    GG_HIP(ctx, ctx->scan_tmp.reserve(sizeof(int64_t) * (2 * tiles + 4)));
+    int64_t *tr = ctx->scan_tmp.as<int64_t>(), *to = tr + tiles + 1;
+    hipLaunchKernelGGL(seg_tile_sums, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, ctx->stream, cnt, n, T, tr, to);
+    hipLaunchKernelGGL(scan_tile_offsets, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, tr, tiles, totals);
+    hipLaunchKernelGGL(scan_tile_offsets, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, to, tiles, totals + 1);
+    hipLaunchKernelGGL(seg_apply, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, ctx->stream, cnt, n, T, tr, to, off, list);
+    GG_HIP(ctx, hipGetLastError());
+    return GG_OK;
+}
+
 // ------------------------------------------------------------------ K6 window pairs
 // pairs of path[:-1] with |i-j| <= window, i != j, in the reference's (i, then j) order.
 // `flag` = the walk launch's status word: 2 means the launch is being rerun (its outputs are not

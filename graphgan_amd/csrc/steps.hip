@@ -226,9 +226,41 @@ struct PathArgs {
     int64_t n_walks;
     float lambda, inv_n;
     const int64_t *n_glob;  // multi-GPU: pairs of all ranks (device word), see StepArgs
+    // STAGED: slot[w * stride + pos] = row of the stage buffer that receives the gradient of that path node (plain
+    // stores), or -1 = the node's table row collects too many gradients for one reducing group -> atomics as before
+    const int32_t *slot;
+    float *stage, *stage_b;
 };
 
-template <int NF>
+// Staged generator gradient (single replica, lazy Adam / SGD).  The gradient rows of a G pass used to be ADDED to the
+// accumulator table with fp32 atomics -- 116 M lane-atomics per pass at the L2's ~270 G/s, 56 % of the kernel.  Now the
+// path nodes are counted per table row first (path_count_kernel: one int atomic per node, returning its rank), rows with
+// <= T gradients get a contiguous segment of a stage buffer (device_segment_rows), the gradient kernel STORES each node's
+// row into its segment slot, and staged_opt_kernel sums a row's segment in slot order and applies the optimizer in the
+// same pass: no accumulator round trip, and a deterministic sum for those rows.  Hub rows (> T gradients) keep the
+// atomic path and the flag -> list -> sparse_opt_kernel update.
+__global__ __launch_bounds__(256) void path_count_kernel(const int32_t *paths, const int32_t *path_len, int stride, int64_t n_walks,
+                                                         int32_t *cnt, int32_t *slot) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t w = idx / stride;
+    if (w >= n_walks) return;
+    const int c = (int)(idx - w * stride), L = path_len[w] - 1;
+    if (L <= 1 || c >= L) return;  // walks without pairs flush nothing
+    slot[idx] = atomicAdd(&cnt[paths[idx]], 1);
+}
+
+__global__ __launch_bounds__(256) void path_slot_kernel(const int32_t *paths, const int32_t *path_len, int stride, int64_t n_walks,
+                                                        const int32_t *cnt, const int32_t *off, int T, int32_t *slot) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t w = idx / stride;
+    if (w >= n_walks) return;
+    const int c = (int)(idx - w * stride), L = path_len[w] - 1;
+    if (L <= 1 || c >= L) return;
+    const int nd = paths[idx];
+    slot[idx] = cnt[nd] <= T ? off[nd] + slot[idx] : -1;
+}
+
+template <int NF, bool STAGED>
 __global__ __launch_bounds__(256) void path_grad_kernel(const PathArgs a) {
     const int t = threadIdx.x & 15;
     const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -240,16 +272,18 @@ __global__ __launch_bounds__(256) void path_grad_kernel(const PathArgs a) {
     int64_t pi = a.pair_ptr[w];
     // window slots 0..4 hold path positions c-2 .. c+2 of the current centre c
     float R[5][NF], A[5][NF], bv[5], gb[5];
-    int node[5];
+    int node[5], sslot[5];
+    const int32_t *const wslot = STAGED ? a.slot + w * (int64_t)a.stride : nullptr;
 #pragma unroll
     for (int sl = 0; sl < 5; ++sl) {
-        node[sl] = -1; bv[sl] = 0.f; gb[sl] = 0.f;
+        node[sl] = -1; bv[sl] = 0.f; gb[sl] = 0.f; sslot[sl] = -1;
 #pragma unroll
         for (int i = 0; i < NF; ++i) { R[sl][i] = 0.f; A[sl][i] = 0.f; }
     }
     auto load = [&](int sl, int pos) {
         const int nd = (pos >= 0 && pos < L) ? p[pos] : -1;
         node[sl] = nd;
+        sslot[sl] = (STAGED && nd >= 0) ? wslot[pos] : -1;
         gb[sl] = 0.f;
         bv[sl] = nd >= 0 ? a.b[nd] : 0.f;
         const float *row = a.E + (int64_t)(nd >= 0 ? nd : 0) * a.ld;
@@ -263,6 +297,16 @@ __global__ __launch_bounds__(256) void path_grad_kernel(const PathArgs a) {
     auto flush = [&](int sl) {
         const int nd = node[sl];
         if (nd < 0) return;
+        if (STAGED && sslot[sl] >= 0) {
+            float *g = a.stage + (int64_t)sslot[sl] * a.ld;
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const int f = t + 16 * i;
+                if (f < a.ld) g[f] = A[sl][i];
+            }
+            if (t == 0) a.stage_b[sslot[sl]] = gb[sl];
+            return;
+        }
         float *g = a.gE + (int64_t)nd * a.ld;
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
@@ -277,7 +321,36 @@ __global__ __launch_bounds__(256) void path_grad_kernel(const PathArgs a) {
     load(2, 0);
     load(3, 1);
     load(4, 2);
+    // Rows are fetched TWO centres ahead (positions c+3 and c+4 are in flight while centre c is evaluated): with three
+    // waves per SIMD one iteration of arithmetic does not cover an HBM round trip.  The path's node ids (and stage slots)
+    // sit in the group's lanes, so a row's address never waits for an id load.
+    const int myid = (t < L) ? p[t] : -1;
+    const int myslot = (STAGED && t < L) ? wslot[t] : -1;
+    auto id_at = [&](int pos) { return pos < 16 ? __shfl(myid, pos, 16) : (pos < L ? p[pos] : -1); };
+    auto slot_at = [&](int pos) { return !STAGED ? -1 : (pos < 16 ? __shfl(myslot, pos, 16) : (pos < L ? wslot[pos] : -1)); };
+    // ... and the walk's rewards too (<= 4L - 6 of them): a reward fetched where it is used is one more L2 round trip on
+    // the chain of every pair
+    const int64_t pi0 = pi;
+    const int n_pairs = (int)(a.pair_ptr[w + 1] - pi0);
+    const float rw0 = (t < n_pairs) ? a.reward[pi0 + t] : 0.f;
+    const float rw1 = (16 + t < n_pairs) ? a.reward[pi0 + 16 + t] : 0.f;
+    float Rq[2][NF], qbv[2];
+    int qnode[2], qslot[2];
+    auto fetch = [&](int q, int pos) {
+        const int nd = id_at(pos);
+        qnode[q] = nd;
+        qslot[q] = nd >= 0 ? slot_at(pos) : -1;
+        qbv[q] = nd >= 0 ? a.b[nd] : 0.f;
+        const float *row = a.E + (int64_t)(nd >= 0 ? nd : 0) * a.ld;
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int f = t + 16 * i;
+            Rq[q][i] = (nd >= 0 && f < a.ld) ? row[f] : 0.f;
+        }
+    };
+    fetch(0, 3);
     for (int c = 0; c < L; ++c) {
+        fetch(1, c + 4);
 #pragma unroll
         for (int sl = 0; sl < 5; ++sl) {
             if (sl == 2 || node[sl] < 0) continue;
@@ -292,7 +365,9 @@ __global__ __launch_bounds__(256) void path_grad_kernel(const PathArgs a) {
             const float s = acc + bv[sl];
             const float sg = 1.0f / (1.0f + expf(-s));
             const bool inside = (sg >= 1e-5f) && (sg <= 1.0f);
-            const float ds = inside ? -(a.reward[pi] * inv_n) * (1.0f - sg) : 0.0f;
+            const int k = (int)(pi - pi0);
+            const float rw = k < 16 ? __shfl(rw0, k, 16) : (k < 32 ? __shfl(rw1, k - 16, 16) : a.reward[pi]);
+            const float ds = inside ? -(rw * inv_n) * (1.0f - sg) : 0.0f;
             ++pi;
 #pragma unroll
             for (int i = 0; i < NF; ++i) {
@@ -301,30 +376,17 @@ __global__ __launch_bounds__(256) void path_grad_kernel(const PathArgs a) {
             }
             gb[sl] += ds;
         }
-        // issue the next row's loads BEFORE the flush: vmcnt retires in order, so a load queued behind
-        // the 2*NF atomics of a flush would wait for all of them
-        const int npos = c + 3;
-        const int nnode = (npos < L) ? p[npos] : -1;
-        const float nbv = nnode >= 0 ? a.b[nnode] : 0.f;
-        float Rn[NF];
-        {
-            const float *row = a.E + (int64_t)(nnode >= 0 ? nnode : 0) * a.ld;
-#pragma unroll
-            for (int i = 0; i < NF; ++i) {
-                const int f = t + 16 * i;
-                Rn[i] = (nnode >= 0 && f < a.ld) ? row[f] : 0.f;
-            }
-        }
         flush(0);  // node c-2 has received its last contribution
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) {
-            node[sl] = node[sl + 1]; bv[sl] = bv[sl + 1]; gb[sl] = gb[sl + 1];
+            node[sl] = node[sl + 1]; bv[sl] = bv[sl + 1]; gb[sl] = gb[sl + 1]; sslot[sl] = sslot[sl + 1];
 #pragma unroll
             for (int i = 0; i < NF; ++i) { R[sl][i] = R[sl + 1][i]; A[sl][i] = A[sl + 1][i]; }
         }
-        node[4] = nnode; bv[4] = nbv; gb[4] = 0.f;
+        node[4] = qnode[0]; bv[4] = qbv[0]; gb[4] = 0.f; sslot[4] = qslot[0];
+        qnode[0] = qnode[1]; qbv[0] = qbv[1]; qslot[0] = qslot[1];
 #pragma unroll
-        for (int i = 0; i < NF; ++i) { R[4][i] = Rn[i]; A[4][i] = 0.f; }
+        for (int i = 0; i < NF; ++i) { R[4][i] = Rq[0][i]; A[4][i] = 0.f; Rq[0][i] = Rq[1][i]; }
     }
     flush(0);
     flush(1);
@@ -338,6 +400,12 @@ struct OptArgs {
     int n_node, ld;
     float lr_t, b1, b2, eps, lr;
     int32_t *touched, *touched_list, *touched_cnt;
+    // staged generator gradient: per-row counts (reset by whoever updates the row), segment offsets, the small-row list,
+    // {small rows, staged rows} totals, the stage
+    int32_t *sg_cnt;
+    const int4 *sg_list;  // {row, first stage row, stage rows} per small row
+    const int64_t *sg_tot;
+    const float *stage, *stage_b;
 };
 
 __device__ __forceinline__ void adam_elem(float &var, float &m, float &v, float g, const OptArgs &a) {
@@ -413,6 +481,7 @@ __device__ __forceinline__ void opt_row(const OptArgs &a, int row, int t, int nc
             a.b[row] = var;
             a.gb[row] = 0.f;
             a.touched[row] = 0;
+            if (a.sg_cnt) a.sg_cnt[row] = 0;
         }
     }
 }
@@ -433,6 +502,92 @@ __global__ __launch_bounds__(256) void sparse_opt_kernel(const OptArgs a) {
     const int nchunk = a.ld >> 2;
     for (int r = g0; r < cnt; r += ng) opt_row<SGD>(a, a.touched_list[r], t, nchunk);
 }
+
+// Small rows of the staged generator gradient: one 16-lane group per row sums the row's segment of the stage buffer in
+// slot order (contiguous 512-byte rows, four in flight) and applies lazy Adam / SGD with the sum in registers.
+template <int SGD>
+__global__ __launch_bounds__(256) void staged_opt_kernel(const OptArgs a) {
+    const int t = threadIdx.x & 15;
+    const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4, ng = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    const int64_t n_rows = a.sg_tot[0];
+    const int nchunk = a.ld >> 2;  // <= 64: up to 4 float4 chunks per lane
+    for (int64_t r = g0; r < n_rows; r += ng) {
+        const int4 e = a.sg_list[r];
+        const int row = e.x, n = e.z;
+        const float4 *src = (const float4 *)(a.stage + (int64_t)e.y * a.ld);
+        float4 g[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // four stage rows in flight, added in slot order
+        int o = 0;
+        for (; o + 4 <= n; o += 4, src += 4 * nchunk) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = t + 16 * i;
+                if (c < nchunk) {
+                    const float4 x0 = src[c], x1 = src[c + nchunk], x2 = src[c + 2 * nchunk], x3 = src[c + 3 * nchunk];
+                    g[i].x += x0.x; g[i].y += x0.y; g[i].z += x0.z; g[i].w += x0.w;
+                    g[i].x += x1.x; g[i].y += x1.y; g[i].z += x1.z; g[i].w += x1.w;
+                    g[i].x += x2.x; g[i].y += x2.y; g[i].z += x2.z; g[i].w += x2.w;
+                    g[i].x += x3.x; g[i].y += x3.y; g[i].z += x3.z; g[i].w += x3.w;
+                }
+            }
+        }
+        for (; o < n; ++o, src += nchunk) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = t + 16 * i;
+                if (c < nchunk) {
+                    const float4 x = src[c];
+                    g[i].x += x.x; g[i].y += x.y; g[i].z += x.z; g[i].w += x.w;
+                }
+            }
+        }
+        float gbias = 0.f;
+        {
+            const float *sb = a.stage_b + e.y;
+            for (int o = t; o < n; o += 16) gbias += sb[o];
+            gbias += __shfl_xor(gbias, 8, 64);
+            gbias += __shfl_xor(gbias, 4, 64);
+            gbias += __shfl_xor(gbias, 2, 64);
+            gbias += __shfl_xor(gbias, 1, 64);
+        }
+        const int64_t o4 = ((int64_t)row * a.ld) >> 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = t + 16 * i;
+            if (c >= nchunk) continue;
+            float4 var = ((float4 *)a.E)[o4 + c];
+            if (SGD) {
+                var.x -= a.lr * g[i].x; var.y -= a.lr * g[i].y; var.z -= a.lr * g[i].z; var.w -= a.lr * g[i].w;
+            } else {
+                float4 m = ((float4 *)a.mE)[o4 + c], v = ((float4 *)a.vE)[o4 + c];
+                adam_elem(var.x, m.x, v.x, g[i].x, a);
+                adam_elem(var.y, m.y, v.y, g[i].y, a);
+                adam_elem(var.z, m.z, v.z, g[i].z, a);
+                adam_elem(var.w, m.w, v.w, g[i].w, a);
+                ((float4 *)a.mE)[o4 + c] = m;
+                ((float4 *)a.vE)[o4 + c] = v;
+            }
+            ((float4 *)a.E)[o4 + c] = var;
+        }
+        if (t == 0) {
+            float var = a.b[row];
+            if (SGD) {
+                var -= a.lr * gbias;
+            } else {
+                float m = a.mb[row], v = a.vb[row];
+                adam_elem(var, m, v, gbias, a);
+                a.mb[row] = m;
+                a.vb[row] = v;
+            }
+            a.b[row] = var;
+            a.sg_cnt[row] = 0;
+        }
+    }
+}
+
+__global__ void add_word_kernel(int64_t *dst, const int64_t *src) { *dst += *src; }
 
 // ---- sparse gradient exchange between replicas (lazy / sgd modes).  A step touches a small part of
 // the tables, so instead of all-reducing N*(ld+1) floats each rank packs its touched rows
@@ -479,6 +634,20 @@ __global__ __launch_bounds__(256) void add_rows_kernel(float *gE, float *gb, int
 
 int apply_optimizer(gg_ctx *ctx, int which, int64_t n);
 int run_path_step(gg_ctx *ctx);
+
+static OptArgs make_opt_args(gg_ctx *ctx, int which) {
+    Model &M = ctx->model[which];
+    OptArgs o{};
+    o.E = M.E; o.b = M.b; o.mE = M.mE; o.vE = M.vE; o.mb = M.mb; o.vb = M.vb; o.gE = ctx->gradE; o.gb = ctx->gradb;
+    o.nE = (int64_t)ctx->n_node * ctx->ld;
+    o.n_node = ctx->n_node; o.ld = ctx->ld;
+    o.b1 = ctx->cfg.adam_beta1; o.b2 = ctx->cfg.adam_beta2; o.eps = ctx->cfg.adam_eps;
+    o.lr = M.lr;
+    // lr_t = lr * sqrt(1 - beta2_power) / (1 - beta1_power), all fp32 (TF keeps the powers as fp32 variables)
+    o.lr_t = (M.lr * sqrtf(1.0f - M.b2p)) / (1.0f - M.b1p);
+    o.touched = ctx->touched; o.touched_list = ctx->touched_list; o.touched_cnt = ctx->touched_cnt;
+    return o;
+}
 
 __global__ void set_count_kernel(int64_t *dst, int64_t v) { *dst = v; }
 
@@ -572,11 +741,55 @@ int run_path_step(gg_ctx *ctx) {
     }
     const int blocks = cdiv(p.n_walks * 16, 256);
     const int nf = (ctx->ld + 15) / 16;
-    if (nf <= 4) hipLaunchKernelGGL(path_grad_kernel<4>, dim3(blocks), dim3(256), 0, ctx->stream, p);
-    else if (nf <= 8) hipLaunchKernelGGL(path_grad_kernel<8>, dim3(blocks), dim3(256), 0, ctx->stream, p);
-    else hipLaunchKernelGGL(path_grad_kernel<16>, dim3(blocks), dim3(256), 0, ctx->stream, p);
-    if (ctx->tm_cur >= 0) GG_HIP(ctx, hipEventRecord(ctx->tm_ev[ctx->tm_cur][1], ctx->stream));  // gradient | exchange + optimizer
-    return apply_optimizer(ctx, 0, n);
+    const int opt = ctx->cfg.optimizer;
+    const int64_t n_pos = p.n_walks * (int64_t)p.stride;
+    const bool staged = ctx->sg_threshold > 0 && !ctx->comm && ctx->fake_world <= 1 && opt != GG_OPT_ADAM_DENSE && n_pos < (1ll << 31) &&
+                        !getenv("GG_NO_STAGED_GRAD");
+    if (!staged) {
+        if (nf <= 4) hipLaunchKernelGGL((path_grad_kernel<4, false>), dim3(blocks), dim3(256), 0, ctx->stream, p);
+        else if (nf <= 8) hipLaunchKernelGGL((path_grad_kernel<8, false>), dim3(blocks), dim3(256), 0, ctx->stream, p);
+        else hipLaunchKernelGGL((path_grad_kernel<16, false>), dim3(blocks), dim3(256), 0, ctx->stream, p);
+        if (ctx->tm_cur >= 0) GG_HIP(ctx, hipEventRecord(ctx->tm_ev[ctx->tm_cur][1], ctx->stream));  // gradient | exchange + optimizer
+        return apply_optimizer(ctx, 0, n);
+    }
+    // ---- staged gradient (see path_count_kernel)
+    const size_t cnt_before = ctx->sg_cnt.bytes;
+    GG_HIP(ctx, ctx->sg_cnt.reserve(sizeof(int32_t) * (size_t)ctx->n_node));
+    if (ctx->sg_cnt.bytes != cnt_before) GG_HIP(ctx, hipMemsetAsync(ctx->sg_cnt.p, 0, ctx->sg_cnt.bytes, ctx->stream));  // afterwards every update resets its rows
+    GG_HIP(ctx, ctx->sg_off.reserve(sizeof(int32_t) * (size_t)ctx->n_node));
+    GG_HIP(ctx, ctx->sg_list.reserve(sizeof(int4) * (size_t)ctx->n_node));
+    GG_HIP(ctx, ctx->sg_slot.reserve(sizeof(int32_t) * (size_t)n_pos));
+    GG_HIP(ctx, ctx->sg_rows.reserve(sizeof(float) * (size_t)n_pos * ctx->ld));
+    GG_HIP(ctx, ctx->sg_bias.reserve(sizeof(float) * (size_t)n_pos));
+    GG_HIP(ctx, ctx->sg_tot.reserve(sizeof(int64_t) * 4));
+    int32_t *cnt = ctx->sg_cnt.as<int32_t>(), *off = ctx->sg_off.as<int32_t>(), *slot = ctx->sg_slot.as<int32_t>();
+    const dim3 pgrid((unsigned)cdiv(n_pos, 256));
+    hipLaunchKernelGGL(path_count_kernel, pgrid, dim3(256), 0, ctx->stream, p.paths, p.path_len, p.stride, p.n_walks, cnt, slot);
+    int rc = device_segment_rows(ctx, cnt, ctx->n_node, ctx->sg_threshold, off, ctx->sg_list.as<int4>(), ctx->sg_tot.as<int64_t>());
+    if (rc != GG_OK) return rc;
+    hipLaunchKernelGGL(path_slot_kernel, pgrid, dim3(256), 0, ctx->stream, p.paths, p.path_len, p.stride, p.n_walks, cnt, off, ctx->sg_threshold, slot);
+    p.slot = slot;
+    p.stage = ctx->sg_rows.as<float>();
+    p.stage_b = ctx->sg_bias.as<float>();
+    if (nf <= 4) hipLaunchKernelGGL((path_grad_kernel<4, true>), dim3(blocks), dim3(256), 0, ctx->stream, p);
+    else if (nf <= 8) hipLaunchKernelGGL((path_grad_kernel<8, true>), dim3(blocks), dim3(256), 0, ctx->stream, p);
+    else hipLaunchKernelGGL((path_grad_kernel<16, true>), dim3(blocks), dim3(256), 0, ctx->stream, p);
+    if (ctx->tm_cur >= 0) GG_HIP(ctx, hipEventRecord(ctx->tm_ev[ctx->tm_cur][1], ctx->stream));  // gradient | optimizer
+    OptArgs o = make_opt_args(ctx, 0);  // before apply_optimizer advances the step count and the beta powers
+    o.sg_cnt = cnt; o.sg_list = ctx->sg_list.as<int4>(); o.sg_tot = ctx->sg_tot.as<int64_t>();
+    o.stage = p.stage; o.stage_b = p.stage_b;
+    int nb = cdiv((int64_t)std::min<int64_t>(n_pos, ctx->n_node) * 16, 256);
+    if (nb > 4096) nb = 4096;
+    if (opt == GG_OPT_SGD) hipLaunchKernelGGL(staged_opt_kernel<1>, dim3(nb), dim3(256), 0, ctx->stream, o);
+    else hipLaunchKernelGGL(staged_opt_kernel<0>, dim3(nb), dim3(256), 0, ctx->stream, o);
+    ctx->sg_active = true;  // the hub rows: flags -> list -> sparse_opt_kernel, which also resets their counts
+    rc = apply_optimizer(ctx, 0, n);
+    ctx->sg_active = false;
+    if (rc != GG_OK) return rc;
+    // rows this pass updated (read back by the timing harvest): hub rows + small rows
+    hipLaunchKernelGGL(add_word_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->touched_ptr.as<int64_t>() + ctx->n_node, ctx->sg_tot.as<int64_t>());
+    GG_HIP(ctx, hipGetLastError());
+    return GG_OK;
 }
 
 __global__ void normalize_flags_kernel(int32_t *f, int n) {  // after the cross-rank sum: counts -> 0/1
@@ -669,15 +882,8 @@ int apply_optimizer(gg_ctx *ctx, int which, int64_t n) {
     }
     if (rc != GG_OK) return rc;
 
-    OptArgs o{};
-    o.E = M.E; o.b = M.b; o.mE = M.mE; o.vE = M.vE; o.mb = M.mb; o.vb = M.vb; o.gE = ctx->gradE; o.gb = ctx->gradb;
-    o.nE = (int64_t)ctx->n_node * ctx->ld;
-    o.n_node = ctx->n_node; o.ld = ctx->ld;
-    o.b1 = ctx->cfg.adam_beta1; o.b2 = ctx->cfg.adam_beta2; o.eps = ctx->cfg.adam_eps;
-    o.lr = M.lr;
-    // lr_t = lr * sqrt(1 - beta2_power) / (1 - beta1_power), all fp32 (TF keeps the powers as fp32 variables)
-    o.lr_t = (M.lr * sqrtf(1.0f - M.b2p)) / (1.0f - M.b1p);
-    o.touched = ctx->touched; o.touched_list = ctx->touched_list; o.touched_cnt = ctx->touched_cnt;
+    OptArgs o = make_opt_args(ctx, which);
+    if (ctx->sg_active) o.sg_cnt = ctx->sg_cnt.as<int32_t>();  // hub rows of a staged G pass: the row's count is reset with its flag
     if (opt == GG_OPT_ADAM_DENSE) {
         int64_t nb = (o.nE / 4 + 255) / 256;
         if (nb > 2048) nb = 2048;
