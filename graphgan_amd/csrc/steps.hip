@@ -260,8 +260,12 @@ __global__ __launch_bounds__(256) void path_slot_kernel(const int32_t *paths, co
     slot[idx] = cnt[nd] <= T ? off[nd] + slot[idx] : -1;
 }
 
-template <int NF, bool STAGED>
-__global__ __launch_bounds__(256) void path_grad_kernel(const PathArgs a) {
+// SHORT: every path has at most 16 nodes (stride <= 17: trees of depth <= 14), so the walk's node ids, stage slots and
+// rewards live in the group's lanes and are handed out with shuffles -- no load, and above all no BRANCH, sits between a
+// row prefetch and its use (with branches in the loop body the compiler falls back to s_waitcnt vmcnt(0) at every join,
+// which drains the prefetches it was asked to keep in flight).
+template <int NF, bool STAGED, bool SHORT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NF <= 8 ? 3 : 1, 4))) void path_grad_kernel(const PathArgs a) {
     const int t = threadIdx.x & 15;
     const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     if (w >= a.n_walks) return;
@@ -270,33 +274,76 @@ __global__ __launch_bounds__(256) void path_grad_kernel(const PathArgs a) {
     const float inv_n = a.n_glob ? 1.0f / (float)(*a.n_glob) : a.inv_n;
     const int32_t *p = a.paths + w * (int64_t)a.stride;
     int64_t pi = a.pair_ptr[w];
-    // window slots 0..4 hold path positions c-2 .. c+2 of the current centre c
-    float R[5][NF], A[5][NF], bv[5], gb[5];
-    int node[5], sslot[5];
     const int32_t *const wslot = STAGED ? a.slot + w * (int64_t)a.stride : nullptr;
+    // the walk's ids / stage slots / rewards in the lanes of its group
+    const int myid = (t < L) ? p[t] : -1;
+    const int myslot = (STAGED && t < L) ? wslot[t] : -1;
+    const int64_t pi0 = pi;
+    const int n_pairs = (int)(a.pair_ptr[w + 1] - pi0);
+    float rwl[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rwl[q] = (16 * q + t < n_pairs) ? a.reward[pi0 + 16 * q + t] : 0.f;
+    auto id_at = [&](int pos) -> int {
+        if (SHORT) {
+            const int v = __shfl(myid, pos & 15, 16);
+            return (pos >= 0 && pos < L) ? v : -1;
+        }
+        return (pos >= 0 && pos < L) ? (pos < 16 ? __shfl(myid, pos, 16) : p[pos]) : -1;
+    };
+    auto slot_at = [&](int pos) -> int {
+        if (!STAGED) return -1;
+        if (SHORT) {
+            const int v = __shfl(myslot, pos & 15, 16);
+            return (pos >= 0 && pos < L) ? v : -1;
+        }
+        return (pos >= 0 && pos < L) ? (pos < 16 ? __shfl(myslot, pos, 16) : wslot[pos]) : -1;
+    };
+    auto reward_at = [&](int k, int64_t pidx) -> float {
+        const float src = k < 16 ? rwl[0] : (k < 32 ? rwl[1] : (k < 48 ? rwl[2] : rwl[3]));
+        const float v = __shfl(src, k & 15, 16);
+        if (SHORT) return v;  // <= 4 * 16 - 6 pairs
+        return k < 64 ? v : a.reward[pidx];
+    };
+    // window slots 0..4 hold path positions c-2 .. c+2 of the current centre c
+    float R[5][NF], A[5][NF], bv[5], gb[5], npair[5];
+    int node[5], sslot[5];
 #pragma unroll
     for (int sl = 0; sl < 5; ++sl) {
-        node[sl] = -1; bv[sl] = 0.f; gb[sl] = 0.f; sslot[sl] = -1;
+        node[sl] = -1; bv[sl] = 0.f; gb[sl] = 0.f; sslot[sl] = -1; npair[sl] = 0.f;
 #pragma unroll
         for (int i = 0; i < NF; ++i) { R[sl][i] = 0.f; A[sl][i] = 0.f; }
     }
-    auto load = [&](int sl, int pos) {
-        const int nd = (pos >= 0 && pos < L) ? p[pos] : -1;
-        node[sl] = nd;
-        sslot[sl] = (STAGED && nd >= 0) ? wslot[pos] : -1;
-        gb[sl] = 0.f;
-        bv[sl] = nd >= 0 ? a.b[nd] : 0.f;
-        const float *row = a.E + (int64_t)(nd >= 0 ? nd : 0) * a.ld;
+    // A row is fetched RAW -- unconditional loads from a clamped address (row 0 behind the path's end, the last float for
+    // the lanes behind the row's end) -- and masked only where it enters the window, an iteration later: a select next
+    // to the load would make the compiler wait for the load right there.
+    auto fetch_raw = [&](int pos, float (&row)[NF], int &nd_out, int &slot_out, float &b_out) {
+        const int nd = id_at(pos);
+        const int ndc = nd >= 0 ? nd : 0;
+        b_out = a.b[ndc];
+        const float *src = a.E + (int64_t)ndc * a.ld;
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
             const int f = t + 16 * i;
-            R[sl][i] = (nd >= 0 && f < a.ld) ? row[f] : 0.f;
+            row[i] = src[f < a.ld ? f : a.ld - 1];
+        }
+        nd_out = nd;
+        slot_out = slot_at(pos);
+    };
+    auto enter = [&](int sl, const float (&row)[NF], int nd, int slot, float b) {
+        node[sl] = nd; sslot[sl] = slot; gb[sl] = 0.f; npair[sl] = 0.f;
+        bv[sl] = nd >= 0 ? b : 0.f;
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            R[sl][i] = (nd >= 0 && t + 16 * i < a.ld) ? row[i] : 0.f;
             A[sl][i] = 0.f;
         }
     };
     auto flush = [&](int sl) {
         const int nd = node[sl];
         if (nd < 0) return;
+        const float lam_n = a.lambda * npair[sl];
+#pragma unroll
+        for (int i = 0; i < NF; ++i) A[sl][i] = __builtin_fmaf(lam_n, R[sl][i], A[sl][i]);
         if (STAGED && sslot[sl] >= 0) {
             float *g = a.stage + (int64_t)sslot[sl] * a.ld;
 #pragma unroll
@@ -318,43 +365,26 @@ __global__ __launch_bounds__(256) void path_grad_kernel(const PathArgs a) {
             if (a.track) a.touched[nd] = 1;
         }
     };
-    load(2, 0);
-    load(3, 1);
-    load(4, 2);
     // Rows are fetched TWO centres ahead (positions c+3 and c+4 are in flight while centre c is evaluated): with three
-    // waves per SIMD one iteration of arithmetic does not cover an HBM round trip.  The path's node ids (and stage slots)
-    // sit in the group's lanes, so a row's address never waits for an id load.
-    const int myid = (t < L) ? p[t] : -1;
-    const int myslot = (STAGED && t < L) ? wslot[t] : -1;
-    auto id_at = [&](int pos) { return pos < 16 ? __shfl(myid, pos, 16) : (pos < L ? p[pos] : -1); };
-    auto slot_at = [&](int pos) { return !STAGED ? -1 : (pos < 16 ? __shfl(myslot, pos, 16) : (pos < L ? wslot[pos] : -1)); };
-    // ... and the walk's rewards too (<= 4L - 6 of them): a reward fetched where it is used is one more L2 round trip on
-    // the chain of every pair
-    const int64_t pi0 = pi;
-    const int n_pairs = (int)(a.pair_ptr[w + 1] - pi0);
-    const float rw0 = (t < n_pairs) ? a.reward[pi0 + t] : 0.f;
-    const float rw1 = (16 + t < n_pairs) ? a.reward[pi0 + 16 + t] : 0.f;
+    // waves per SIMD one iteration of arithmetic does not cover an HBM round trip.
     float Rq[2][NF], qbv[2];
     int qnode[2], qslot[2];
-    auto fetch = [&](int q, int pos) {
-        const int nd = id_at(pos);
-        qnode[q] = nd;
-        qslot[q] = nd >= 0 ? slot_at(pos) : -1;
-        qbv[q] = nd >= 0 ? a.b[nd] : 0.f;
-        const float *row = a.E + (int64_t)(nd >= 0 ? nd : 0) * a.ld;
-#pragma unroll
-        for (int i = 0; i < NF; ++i) {
-            const int f = t + 16 * i;
-            Rq[q][i] = (nd >= 0 && f < a.ld) ? row[f] : 0.f;
-        }
-    };
-    fetch(0, 3);
+    {
+        float r0[NF], r1[NF], r2[NF], b0, b1, b2;
+        int n0, n1, n2, s0, s1, s2;
+        fetch_raw(0, r0, n0, s0, b0);
+        fetch_raw(1, r1, n1, s1, b1);
+        fetch_raw(2, r2, n2, s2, b2);
+        fetch_raw(3, Rq[0], qnode[0], qslot[0], qbv[0]);
+        enter(2, r0, n0, s0, b0);
+        enter(3, r1, n1, s1, b1);
+        enter(4, r2, n2, s2, b2);
+    }
     for (int c = 0; c < L; ++c) {
-        fetch(1, c + 4);
+        fetch_raw(c + 4, Rq[1], qnode[1], qslot[1], qbv[1]);
 #pragma unroll
         for (int sl = 0; sl < 5; ++sl) {
-            if (sl == 2 || node[sl] < 0) continue;
-            if (sl < 2 - a.window || sl > 2 + a.window) continue;
+            if (sl == 2 || node[sl] < 0 || sl < 2 - a.window || sl > 2 + a.window) continue;
             float acc = 0.f;
 #pragma unroll
             for (int i = 0; i < NF; ++i) acc = __builtin_fmaf(R[2][i], R[sl][i], acc);
@@ -365,28 +395,31 @@ __global__ __launch_bounds__(256) void path_grad_kernel(const PathArgs a) {
             const float s = acc + bv[sl];
             const float sg = 1.0f / (1.0f + expf(-s));
             const bool inside = (sg >= 1e-5f) && (sg <= 1.0f);
-            const int k = (int)(pi - pi0);
-            const float rw = k < 16 ? __shfl(rw0, k, 16) : (k < 32 ? __shfl(rw1, k - 16, 16) : a.reward[pi]);
+            const float rw = reward_at((int)(pi - pi0), pi);
             const float ds = inside ? -(rw * inv_n) * (1.0f - sg) : 0.0f;
             ++pi;
+            // data term now; the l2 term lambda * row once per pair the row takes part in is added at the flush
+            // (npair[] counts them): 2 instead of 6 operations per float and pair -- the kernel is VALU bound
 #pragma unroll
             for (int i = 0; i < NF; ++i) {
-                A[2][i] += ds * R[sl][i] + a.lambda * R[2][i];
-                A[sl][i] += ds * R[2][i] + a.lambda * R[sl][i];
+                A[2][i] = __builtin_fmaf(ds, R[sl][i], A[2][i]);
+                A[sl][i] = __builtin_fmaf(ds, R[2][i], A[sl][i]);
             }
+            npair[2] += 1.0f;
+            npair[sl] += 1.0f;
             gb[sl] += ds;
         }
         flush(0);  // node c-2 has received its last contribution
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) {
-            node[sl] = node[sl + 1]; bv[sl] = bv[sl + 1]; gb[sl] = gb[sl + 1]; sslot[sl] = sslot[sl + 1];
+            node[sl] = node[sl + 1]; bv[sl] = bv[sl + 1]; gb[sl] = gb[sl + 1]; sslot[sl] = sslot[sl + 1]; npair[sl] = npair[sl + 1];
 #pragma unroll
             for (int i = 0; i < NF; ++i) { R[sl][i] = R[sl + 1][i]; A[sl][i] = A[sl + 1][i]; }
         }
-        node[4] = qnode[0]; bv[4] = qbv[0]; gb[4] = 0.f; sslot[4] = qslot[0];
+        enter(4, Rq[0], qnode[0], qslot[0], qbv[0]);
         qnode[0] = qnode[1]; qbv[0] = qbv[1]; qslot[0] = qslot[1];
 #pragma unroll
-        for (int i = 0; i < NF; ++i) { R[4][i] = Rq[0][i]; A[4][i] = 0.f; Rq[0][i] = Rq[1][i]; }
+        for (int i = 0; i < NF; ++i) Rq[0][i] = Rq[1][i];
     }
     flush(0);
     flush(1);
@@ -717,6 +750,20 @@ int run_step(gg_ctx *ctx, int which, const int32_t *d_u, const int32_t *d_v, con
     return apply_optimizer(ctx, which, n);
 }
 
+template <bool STAGED>
+static void launch_path_grad(gg_ctx *ctx, const PathArgs &p, int blocks, int nf) {
+    const dim3 g(blocks), b(256);
+    if (p.stride <= 17) {  // every path has <= 16 nodes
+        if (nf <= 4) hipLaunchKernelGGL((path_grad_kernel<4, STAGED, true>), g, b, 0, ctx->stream, p);
+        else if (nf <= 8) hipLaunchKernelGGL((path_grad_kernel<8, STAGED, true>), g, b, 0, ctx->stream, p);
+        else hipLaunchKernelGGL((path_grad_kernel<16, STAGED, true>), g, b, 0, ctx->stream, p);
+    } else {
+        if (nf <= 4) hipLaunchKernelGGL((path_grad_kernel<4, STAGED, false>), g, b, 0, ctx->stream, p);
+        else if (nf <= 8) hipLaunchKernelGGL((path_grad_kernel<8, STAGED, false>), g, b, 0, ctx->stream, p);
+        else hipLaunchKernelGGL((path_grad_kernel<16, STAGED, false>), g, b, 0, ctx->stream, p);
+    }
+}
+
 // G step over whole walks of the resident prepare_g data (see path_grad_kernel).
 int run_path_step(gg_ctx *ctx) {
     Model &M = ctx->model[0];
@@ -746,9 +793,7 @@ int run_path_step(gg_ctx *ctx) {
     const bool staged = ctx->sg_threshold > 0 && !ctx->comm && ctx->fake_world <= 1 && opt != GG_OPT_ADAM_DENSE && n_pos < (1ll << 31) &&
                         !getenv("GG_NO_STAGED_GRAD");
     if (!staged) {
-        if (nf <= 4) hipLaunchKernelGGL((path_grad_kernel<4, false>), dim3(blocks), dim3(256), 0, ctx->stream, p);
-        else if (nf <= 8) hipLaunchKernelGGL((path_grad_kernel<8, false>), dim3(blocks), dim3(256), 0, ctx->stream, p);
-        else hipLaunchKernelGGL((path_grad_kernel<16, false>), dim3(blocks), dim3(256), 0, ctx->stream, p);
+        launch_path_grad<false>(ctx, p, blocks, nf);
         if (ctx->tm_cur >= 0) GG_HIP(ctx, hipEventRecord(ctx->tm_ev[ctx->tm_cur][1], ctx->stream));  // gradient | exchange + optimizer
         return apply_optimizer(ctx, 0, n);
     }
@@ -771,9 +816,7 @@ int run_path_step(gg_ctx *ctx) {
     p.slot = slot;
     p.stage = ctx->sg_rows.as<float>();
     p.stage_b = ctx->sg_bias.as<float>();
-    if (nf <= 4) hipLaunchKernelGGL((path_grad_kernel<4, true>), dim3(blocks), dim3(256), 0, ctx->stream, p);
-    else if (nf <= 8) hipLaunchKernelGGL((path_grad_kernel<8, true>), dim3(blocks), dim3(256), 0, ctx->stream, p);
-    else hipLaunchKernelGGL((path_grad_kernel<16, true>), dim3(blocks), dim3(256), 0, ctx->stream, p);
+    launch_path_grad<true>(ctx, p, blocks, nf);
     if (ctx->tm_cur >= 0) GG_HIP(ctx, hipEventRecord(ctx->tm_ev[ctx->tm_cur][1], ctx->stream));  // gradient | optimizer
     OptArgs o = make_opt_args(ctx, 0);  // before apply_optimizer advances the step count and the beta powers
     o.sg_cnt = cnt; o.sg_list = ctx->sg_list.as<int4>(); o.sg_tot = ctx->sg_tot.as<int64_t>();
