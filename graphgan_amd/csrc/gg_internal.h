@@ -174,6 +174,7 @@ struct gg_ctx {
     // staged generator gradient (steps.hip, run_path_step): per-row counts / segment offsets, per path node slot, row list,
     // the stage itself (gradient rows + bias gradients of the small rows, segment by segment), two total words
     gg::DevBuf sg_cnt, sg_off, sg_slot, sg_list, sg_rows, sg_bias, sg_tot;
+    bool g_pairs_filled = false;       // g_node1 / g_node2 hold the pairs of the resident G walks (prepare.hip, ensure_g_pairs)
     bool sg_active = false;            // a staged G pass is applying its hub rows (apply_optimizer resets their counts)
     int sg_threshold = 64;             // GG_STAGE_T: rows with more staged gradients than this keep the atomic path; 0 = everything atomic
 
@@ -220,6 +221,7 @@ int fail(gg_ctx *ctx, int code, const char *fmt, ...);
 
 // exclusive scan of n int32 counts into n+1 int64 offsets (prepare.hip)
 int device_exclusive_scan(gg_ctx *ctx, const int32_t *cnt, int64_t *ptr, int64_t n);
+int ensure_g_pairs(gg_ctx *ctx);  // prepare.hip: (node_1, node_2) of the resident G walks, written on first use
 int device_compact_flags(gg_ctx *ctx, const int32_t *flag, int64_t n, int32_t *list, int64_t *total_out);  // prepare.hip
 int device_segment_rows(gg_ctx *ctx, const int32_t *cnt, int64_t n, int T, int32_t *off, int4 *list, int64_t *totals);  // prepare.hip
 

@@ -410,6 +410,25 @@ __global__ __launch_bounds__(256) void d_fill_kernel(const int32_t *slots, const
     }
 }
 
+static int fill_g_pairs(gg_ctx *ctx) {
+    const int64_t nw = ctx->w_total;
+    hipLaunchKernelGGL(pair_fill_kernel, dim3(cdiv(nw, 256)), dim3(256), 0, ctx->stream, ctx->w_paths.as<int32_t>(),
+                       ctx->w_len.as<int32_t>(), ctx->w_stride, nw, ctx->cfg.window_size, ctx->g_ptr.as<int64_t>(),
+                       ctx->g_node1.as<int32_t>(), ctx->g_node2.as<int32_t>(), ctx->dev_ctr + 3);
+    GG_HIP(ctx, hipGetLastError());
+    ctx->g_pairs_filled = true;
+    return GG_OK;
+}
+
+// K6 on demand: expand the resident walks into the (node_1, node_2) arrays (graph_gan.py:272-291) on the main stream.
+int ensure_g_pairs(gg_ctx *ctx) {
+    if (ctx->g_pairs_filled || ctx->g_pairs == 0) return GG_OK;
+    GG_CHECK(ctx, ctx->g_paths_valid, GG_EINVAL,
+             "the walks of the last gg_prepare_g were overwritten by a later walk launch before its pairs were read: fetch the pairs "
+             "(gg_get_g_data) or run the minibatch passes before the next prepare call");
+    return fill_g_pairs(ctx);
+}
+
 }  // namespace gg
 
 using namespace gg;
@@ -492,15 +511,20 @@ static int enqueue_g_pairs(gg_ctx *ctx, int64_t nw, int64_t cap) {
                        ctx->g_cnt.as<int32_t>(), ctx->dev_ctr + 3);
     int rc = device_exclusive_scan(ctx, ctx->g_cnt.as<int32_t>(), ctx->g_ptr.as<int64_t>(), nw);
     if (rc != GG_OK) return rc;
-    hipLaunchKernelGGL(pair_fill_kernel, dim3(cdiv(nw, 256)), dim3(256), 0, ctx->stream, ctx->w_paths.as<int32_t>(),
-                       ctx->w_len.as<int32_t>(), ctx->w_stride, nw, window, ctx->g_ptr.as<int64_t>(),
-                       ctx->g_node1.as<int32_t>(), ctx->g_node2.as<int32_t>(), ctx->dev_ctr + 3);
+    // The (node_1, node_2) arrays are written only for whoever reads them -- gg_get_g_data, minibatch passes, the per-pair
+    // reward kernel (gg_ensure_g_pairs): the whole-walk kernels take the pairs from the paths themselves.
+    const int nch = (ctx->ld / 4 + 15) / 16;
+    const bool path_reward = window <= 2 && nch <= 4 && ctx->ld % 4 == 0 && !getenv("GG_NO_PATH_REWARD");
+    ctx->g_pairs_filled = false;
+    if (!path_reward) {
+        rc = fill_g_pairs(ctx);
+        if (rc != GG_OK) return rc;
+    }
     // rewards for the device-side pair count (the host does not know it yet)
     const Model &D = ctx->model[1];
     const int ts = ctx->walk_timed ? timing_slot(ctx) : -1;  // profiled call: HIP events around the reward kernel
     if (ts >= 0) GG_HIP(ctx, hipEventRecord(ctx->tm_ev[ts][0], ctx->stream));
-    const int nch = (ctx->ld / 4 + 15) / 16;
-    if (window <= 2 && nch <= 4 && ctx->ld % 4 == 0 && !getenv("GG_NO_PATH_REWARD")) {
+    if (path_reward) {
         const dim3 grid(cdiv(nw * 16, 256)), blk(256);
 #define GG_PATH_REWARD(N)                                                                                                              \
     hipLaunchKernelGGL(path_reward_kernel<N>, grid, blk, 0, ctx->stream, D.E, D.b, ctx->ld, ctx->w_paths.as<int32_t>(),                 \
@@ -578,6 +602,10 @@ int gg_get_g_data(gg_ctx *ctx, int32_t *node_1, int32_t *node_2, float *reward) 
     const int64_t n = ctx->g_pairs;
     if (n == 0) return GG_OK;
     GG_HIP(ctx, hipSetDevice(ctx->device));
+    if (node_1 || node_2) {
+        int rc = ensure_g_pairs(ctx);
+        if (rc != GG_OK) return rc;
+    }
     GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (node_1) GG_HIP(ctx, hipMemcpy(node_1, ctx->g_node1.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
     if (node_2) GG_HIP(ctx, hipMemcpy(node_2, ctx->g_node2.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost));

@@ -1041,6 +1041,10 @@ static int run_pass(gg_ctx *ctx, int which, const int64_t *starts, int64_t n_bat
         int rc = run_path_step(ctx);
         if (rc != GG_OK) { ctx->tm_cur = -1; return rc; }
     } else {
+        if (which == 0) {  // minibatches read the pair arrays
+            int rc = ensure_g_pairs(ctx);
+            if (rc != GG_OK) { ctx->tm_cur = -1; return rc; }
+        }
         for (int64_t k = 0; k < n_batches; ++k) {
             const int64_t s = starts[k];
             if (s < 0) {  // this rank's share of the step is empty (the replicas' batch lists have different lengths)

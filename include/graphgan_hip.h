@@ -188,6 +188,9 @@ int gg_prepare_d(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, uint64_t se
 int gg_get_d_data(gg_ctx *ctx, int32_t *center, int32_t *neighbor, float *label);
 int gg_prepare_g(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, int32_t n_sample, uint64_t seed,
                  uint32_t stream, int64_t *n_pairs_out, int32_t *root_status);
+/* The (node_1, node_2) arrays of gg_prepare_g are expanded from its walks on first use -- gg_get_g_data, or a gg_g_pass in
+ * minibatches -- which must therefore come before the next walk launch of the context (gg_prepare_d / gg_prepare_g /
+ * gg_walk_sample); later it is GG_EINVAL.  Rewards, and whole-batch passes over the walks, do not need them. */
 int gg_get_g_data(gg_ctx *ctx, int32_t *node_1, int32_t *node_2, float *reward);
 
 /* gg_d_pass / gg_g_pass: one inner epoch over the prepared rows = the minibatch loops
