@@ -44,6 +44,10 @@ struct StepArgs {
 // The u-side gradient is therefore accumulated in registers while u stays the same and flushed
 // with one row of atomics per run; the v side goes out per pair.  Lane t owns floats t, t+16, ...
 // so that one atomic instruction of the group covers one contiguous 64-byte line.
+// Measured and not kept (round 2, D pass beside the generator's walks): a grid capped at 6 workgroups per CU with a
+// grid-stride loop (the walks of the other stream start no earlier, this kernel +10 %); plain stores instead of atomics for
+// rows the batch names once (needs a counting pass; step time unchanged -- the pass shares the chip with the walks and
+// the sum of the work is what counts).
 constexpr int PAIRS_PER_GROUP = 16;  // large fused batches; small (B = 64) batches use 1 pair per group: latency, not contention, rules there
 
 template <int NF>  // NF = ceil(ld / 16) floats per lane

@@ -943,6 +943,12 @@ __global__ void walk_d_postpass_kernel(const WalkArgs a) {
     }
 }
 
+__global__ void walk_reset_kernel(unsigned long long *ctr, int n_words, int64_t *dc_words, int append) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_words) ctr[i] = 0ull;
+    if (i == 0) dc_words[0] = append ? dc_words[1] : 0;
+}
+
 __global__ void walk_init_status_kernel(const WalkArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_slots) return;
@@ -1188,14 +1194,13 @@ int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int fo
     a.dc_keys = ctx->dc_keys.as<unsigned long long>();
     a.dc_vals = ctx->dc_vals.as<unsigned long long>();
     a.dc_mask = (uint32_t)(ctx->dc_size ? ctx->dc_size - 1 : 0);
-    if (a.dc_mode == 2)  // append behind the D launch's regions
-        GG_HIP(ctx, hipMemcpyAsync(ctx->dc_words.as<int64_t>(), ctx->dc_words.as<int64_t>() + 1, sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->walk_stream));
-    else
-        GG_HIP(ctx, hipMemsetAsync(ctx->dc_words.p, 0, sizeof(int64_t), ctx->walk_stream));
-
-    // every counter word belongs to ONE launch (the host accumulates, walk_finalize): hops / reads / rows, error
-    // flag [3], ticket [4], per-level counters and the spread words
-    GG_HIP(ctx, hipMemsetAsync(ctx->dev_ctr, 0, sizeof(unsigned long long) * CTR_WORDS, ctx->walk_stream));
+    // One small kernel resets the launch's words: the base of its prefix regions (behind the D launch's regions when it
+    // looks distributions up, else 0) and every counter word -- they belong to ONE launch (the host accumulates,
+    // walk_finalize): hops / reads / rows, error flag [3], ticket [4], per-level counters and the spread words.  (As a
+    // hipMemcpyAsync + hipMemsetAsync pair these were blit kernels with system-scope fences: the copy took ~130 us on the side
+    // stream while the discriminator's gradient kernel was filling the L2 with atomics.)
+    hipLaunchKernelGGL(walk_reset_kernel, dim3(cdiv(CTR_WORDS, 256)), dim3(256), 0, ctx->walk_stream, ctx->dev_ctr, (int)CTR_WORDS,
+                       ctx->dc_words.as<int64_t>(), a.dc_mode == 2 ? 1 : 0);
     // HIP events around every profile_every-th call (a rerun keeps the decision of the launch it repeats)
     if (!ctx->walk_force_sized) ctx->walk_timed = ctx->profile_every > 0 && (ctx->walk_call_index++ % ctx->profile_every) == 0;
     if (ctx->walk_timed && ctx->walk_stream != ctx->stream && ctx->profile_solo) {
