@@ -12,7 +12,7 @@ if [ "$Q" != "quick" ]; then
   python -c "import __graft_entry__ as g; g.smoke()" > $R/gpurun_out/${T}_smoke.txt 2>&1
 fi
 cd /tmp && export TMPDIR=/tmp
-PB="--no-cpu-baseline --no-strict --fresh-batches 1 --overlap-steps 3"
+PB="--no-cpu-baseline --no-strict --fresh-batches 1 --overlap-steps 3"  # (the 3 extra steps measure the side-stream launches solo)
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${T}_kt -o b -- python $R/bench.py $PB > $R/gpurun_out/${T}_kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${T}_fetch -o f -- python $R/bench.py --steps 3 --warmup 1 $PB > $R/gpurun_out/${T}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${T}_write -o w -- python $R/bench.py --steps 3 --warmup 1 $PB > $R/gpurun_out/${T}_write.log 2>&1
