@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn rocprofv3 outputs (gpurun_out/, scratch) into the committed per-round summaries.
 
-    python profiles/summarize.py <round-tag> <kernel_trace_dir> <fetch_dir> <write_dir>
+    python profiles/summarize.py <round-tag> <kernel_trace_dir> <fetch_dir> <write_dir> [<l2_dir>]
 
 Commands that produced the inputs (on the MI355X box, `cd /tmp && export TMPDIR=/tmp` first):
     rocprofv3 --kernel-trace --stats --output-format csv -d <kernel_trace_dir> -o b -- python bench.py --no-cpu-baseline
@@ -46,6 +46,17 @@ def main():
         json.dump(out, fjs, indent=1, sort_keys=True)
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_sampled"])[:6]:
         print("%-60s %4d launches  %.1f MB/launch" % (k[:60], v["launches_sampled"], v["hbm_bytes_per_launch"] / 1e6))
+    if len(sys.argv) > 5:  # optional: directory of the `--pmc TCC_HIT_sum TCC_MISS_sum` pass
+        hit = pmc(os.path.join(sys.argv[5], "l_counter_collection.csv"), "TCC_HIT_sum")
+        miss = pmc(os.path.join(sys.argv[5], "l_counter_collection.csv"), "TCC_MISS_sum")
+        l2 = {}
+        for name in sorted(hit):
+            h, m = sum(hit[name]), sum(miss.get(name, []))
+            if h + m > 0:
+                l2[name] = {"l2_hit_rate": h / (h + m), "TCC_HIT_sum_mean": h / len(hit[name]), "TCC_MISS_sum_mean": m / len(hit[name]),
+                            "launches_sampled": len(hit[name])}
+        with open(os.path.join(here, "%s_pmc_l2_hit_rate.json" % tag), "w") as fjs:
+            json.dump(l2, fjs, indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
