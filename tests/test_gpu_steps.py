@@ -343,6 +343,70 @@ def test_whole_walk_g_pass_equals_generic_pair_kernel(ga, opt, monkeypatch):
     eng2.close()
 
 
+@pytest.mark.parametrize("opt", ["lazy", "sgd"])
+@pytest.mark.parametrize("threshold", ["64", "3"])
+def test_staged_generator_gradient_equals_the_atomic_path(ga, opt, threshold, monkeypatch):
+    """The fused G pass stages its gradient rows (plain stores into per-row segments, summed by the optimizer kernel)
+    instead of adding them with fp32 atomics; rows with more gradients than the threshold keep the atomic path.  Both
+    ways, and the mix (threshold 3: most rows of this graph are "hubs"), give the oracle's update; two passes in a row
+    check that every row's count is reset by whichever kernel updated it."""
+    optimizer = ga.GG_OPT_ADAM_LAZY if opt == "lazy" else ga.GG_OPT_SGD
+    monkeypatch.setenv("GG_STAGE_T", threshold)
+    g, n, graph, rowptr, col, Ed, eng = _setup_graph_engine(ga, optimizer=optimizer)
+    monkeypatch.setenv("GG_STAGE_T", "0")  # everything atomic
+    _, _, _, _, _, _, eng2 = _setup_graph_engine(ga, optimizer=optimizer)
+    slots = np.arange(n, dtype=np.int32)
+    gen = orc.Generator(g["E"], 1e-3, lazy=True) if opt == "lazy" else None
+    if gen is not None:
+        gen.b[:] = g["b"]
+    for rnd in range(2):
+        n1, n2, rew, _ = eng.prepare_g(slots, 20, 4, 2 * rnd + 1)
+        eng2.prepare_g(slots, 20, 4, 2 * rnd + 1, fetch=False)
+        eng.g_pass([0], len(n1))
+        eng2.g_pass([0], len(n1))
+        assert np.allclose(eng.get_embeddings(0), eng2.get_embeddings(0), rtol=2e-5, atol=2e-6)
+        assert np.allclose(eng.get_bias(0), eng2.get_bias(0), rtol=2e-5, atol=2e-6)
+        if gen is not None and rnd == 0:
+            gen.g_step(n1.astype(np.int64), n2.astype(np.int64), rew, 1e-5)
+            assert np.allclose(eng.get_embeddings(0), gen.E, rtol=2e-5, atol=2e-6)
+            assert np.allclose(eng.get_bias(0), gen.b, rtol=2e-5, atol=2e-6)
+    # the staged sum is deterministic: a third engine repeats the staged run bit for bit when no row is a hub
+    if threshold == "64":
+        monkeypatch.setenv("GG_STAGE_T", "100000")
+        _, _, _, _, _, _, e3 = _setup_graph_engine(ga, optimizer=optimizer)
+        _, _, _, _, _, _, e4 = _setup_graph_engine(ga, optimizer=optimizer)
+        for e in (e3, e4):
+            e.prepare_g(slots, 20, 4, 1, fetch=False)
+            e.g_pass([0], 1 << 30)
+        assert np.array_equal(e3.get_embeddings(0).view(np.uint32), e4.get_embeddings(0).view(np.uint32))
+        e3.close()
+        e4.close()
+    eng.close()
+    eng2.close()
+
+
+def test_pairs_are_expanded_on_first_use_and_guarded(ga):
+    """gg_prepare_g keeps the walks; the (node_1, node_2) arrays are written when something reads them.  A minibatch pass
+    straight after an un-fetched prepare sees the same pairs as a fetched one; reading them after the walks were
+    overwritten by another launch is refused instead of returning stale ids."""
+    g, n, graph, rowptr, col, Ed, eng = _setup_graph_engine(ga)
+    _, _, _, _, _, _, eng2 = _setup_graph_engine(ga)
+    slots = np.arange(n, dtype=np.int32)
+    n1, n2, rew, _ = eng.prepare_g(slots, 20, 4, 1)           # fetched: pairs expanded by the fetch
+    pairs = eng2.prepare_g(slots, 20, 4, 1, fetch=False)      # not fetched
+    assert pairs == len(n1)
+    starts = np.arange(0, len(n1), 4096, dtype=np.int64)
+    eng.g_pass(starts, 4096)
+    eng2.g_pass(starts, 4096)                                  # minibatches: expands the pairs itself
+    assert np.allclose(eng.get_embeddings(0), eng2.get_embeddings(0), rtol=2e-5, atol=2e-6)
+    eng2.prepare_g(slots, 20, 4, 3, fetch=False)
+    eng2.prepare_d(slots, 4, 4, fetch=False)                   # overwrites the walk buffers
+    with pytest.raises(ga.GraphGANHipError):
+        eng2.g_pass(starts, 4096)
+    eng.close()
+    eng2.close()
+
+
 @pytest.mark.parametrize("n,d", [(300, 50), (1000, 128), (77, 6), (4100, 256)])
 def test_all_score_rows_on_mfma(ga, n, d):
     """K7: rows of generator.all_score (generator.py:21) from the fp32 MFMA kernel: BIT-EXACT against

@@ -57,12 +57,16 @@ def run_both(ga, n, rowptr, col, roots, E, b, rounds, seed, n_sample=20, stride=
     return hops
 
 
-@pytest.fixture(params=["finisher", "hybrid2", "levels"])
+@pytest.fixture(params=["finisher", "hybrid2", "levels", "adaptive"])
 def walk_mode(request, monkeypatch):
-    """The three decompositions of the sampler: GG_WALK_LEVELS = 0 (one wavefront per walk, the
+    """The decompositions of the sampler: GG_WALK_LEVELS = 0 (one wavefront per walk, the
     finisher kernel alone), 2 (two hops through the level pipeline, the finisher takes over), 64 (level pipeline to
-    the end; the default).  gg_create reads the variable, so it is set before the engine exists."""
-    monkeypatch.setenv("GG_WALK_LEVELS", {"finisher": "0", "hybrid2": "2", "levels": "64"}[request.param])
+    the end; the default), and 64 with GG_FIN_THRESHOLD (the hand-over level follows the previous launch of the mode:
+    the later rounds of a test switch to the finisher's walk list wherever fewer than that many walks were left).
+    gg_create reads the variables, so they are set before the engine exists."""
+    monkeypatch.setenv("GG_WALK_LEVELS", {"finisher": "0", "hybrid2": "2", "levels": "64", "adaptive": "64"}[request.param])
+    if request.param == "adaptive":
+        monkeypatch.setenv("GG_FIN_THRESHOLD", "2000")
     return request.param
 
 
