@@ -203,7 +203,8 @@ int gg::walk_finalize(gg_ctx *ctx, bool *retried) {
     }
     const int64_t total = ctx->w_total;
     unsigned long long *c = ctx->h_pin;  // the launch's counter words, one asynchronous read-back into pinned memory
-    GG_HIP(ctx, hipMemcpyAsync(c, ctx->dev_ctr, sizeof(unsigned long long) * 456, hipMemcpyDeviceToHost, ctx->stream));
+    constexpr int CW = gg_ctx::CTR_WORDS;
+    GG_HIP(ctx, hipMemcpyAsync(c, ctx->dev_ctr, sizeof(unsigned long long) * 2 * CW, hipMemcpyDeviceToHost, ctx->stream));
     GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     harvest_timings(ctx);
     if (c[3] == 2ull) {
@@ -213,10 +214,14 @@ int gg::walk_finalize(gg_ctx *ctx, bool *retried) {
         int rc = launch_and_join(ctx, ctx->w_nslots, total, ctx->w_args.for_d, ctx->w_args.seed, ctx->w_args.stream, ctx->w_stride);
         ctx->walk_force_sized = false;
         if (rc != GG_OK) return rc;
-        GG_HIP(ctx, hipMemcpyAsync(c, ctx->dev_ctr, sizeof(unsigned long long) * 456, hipMemcpyDeviceToHost, ctx->stream));
+        GG_HIP(ctx, hipMemcpyAsync(c, ctx->dev_ctr, sizeof(unsigned long long) * 2 * CW, hipMemcpyDeviceToHost, ctx->stream));
         GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (retried) *retried = true;
     }
+    // a launch that ran as two halves counted per half (per-level and spread words, index 8 and up): fold the second block in
+    const int n_half = ctx->w_split ? 2 : 1;
+    if (n_half == 2)
+        for (int i = 8; i < CW; ++i) c[i] += c[CW + i];
     {   // walks alive per streamed level, and behind the last one: where the next launch of this mode hands over to the finisher
         int64_t *prof = ctx->alive_prof[ctx->w_args.for_d ? 1 : 0];
         const int run = ctx->w_levels_run;
@@ -238,9 +243,13 @@ int gg::walk_finalize(gg_ctx *ctx, bool *retried) {
         ctx->ctr.walk_launches += 1;
         for (int i = 0; i < ctx->lv_ev_used; ++i) {
             float lms = 0.f;
-            GG_HIP(ctx, hipEventElapsedTime(&lms, ctx->lv_ev[2 * i], ctx->lv_ev[2 * i + 1]));
+            for (int k = 0; k < n_half; ++k) {  // the halves' score kernels are chained: their durations add up
+                float e = 0.f;
+                GG_HIP(ctx, hipEventElapsedTime(&e, ctx->lv_ev[4 * i + 2 * k], ctx->lv_ev[4 * i + 2 * k + 1]));
+                lms += e;
+            }
             ctx->ctr.score_kernel_ms += lms;
-            ctx->ctr.score_launches += 1;
+            ctx->ctr.score_launches += n_half;
             ctx->ctr.score_chunks += (int64_t)c[136 + i];
             if (getenv("GG_WALK_DEBUG"))
                 fprintf(stderr, "[walk] for_d=%d level %d alive %llu chunks %llu big %llu score %.1f us\n", ctx->w_args.for_d, i,
@@ -303,6 +312,8 @@ int gg_create(int32_t n_node, int32_t n_emb, const float *emb_gen, const float *
     if (const char *nc = getenv("GG_NO_DIST_CACHE")) ctx->dc_enabled = atoi(nc) == 0;
     if (const char *ft = getenv("GG_FIN_THRESHOLD")) ctx->fin_threshold = std::max(0, atoi(ft));
     if (const char *st = getenv("GG_STAGE_T")) ctx->sg_threshold = std::max(0, atoi(st));
+    if (const char *ws = getenv("GG_WALK_SPLIT")) ctx->split_enabled = atoi(ws) != 0;
+    if (const char *wm = getenv("GG_WALK_SPLIT_MIN")) ctx->split_min_walks = std::max(512, atoi(wm));
     for (auto &m : ctx->alive_prof) for (auto &v : m) v = -1;
     if (const char *dr = getenv("GG_COMM_DENSE_RATIO")) ctx->dense_exchange_ratio = (float)atof(dr);
 #define GG_TRY(call)                        \
@@ -317,14 +328,19 @@ int gg_create(int32_t n_node, int32_t n_emb, const float *emb_gen, const float *
     auto body = [&]() -> int {
         GG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         GG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        GG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
+        GG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        GG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        GG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_score[0], hipEventDisableTiming));
+        GG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_score[1], hipEventDisableTiming));
         ctx->walk_stream = ctx->stream;
         GG_HIP(ctx, hipEventCreate(&ctx->ev0));
         GG_HIP(ctx, hipEventCreate(&ctx->ev1));
         GG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_walk_done, hipEventDisableTiming));
         GG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_gen_pass, hipEventDisableTiming));
         GG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_main_mark, hipEventDisableTiming));
-        GG_HIP(ctx, hipHostMalloc((void **)&ctx->h_pin, sizeof(unsigned long long) * 512, hipHostMallocDefault));
-        memset(ctx->h_pin, 0, sizeof(unsigned long long) * 512);
+        GG_HIP(ctx, hipHostMalloc((void **)&ctx->h_pin, sizeof(unsigned long long) * 1024, hipHostMallocDefault));
+        memset(ctx->h_pin, 0, sizeof(unsigned long long) * 1024);
         const size_t tb = sizeof(float) * (size_t)n_node * ctx->ld, vb = sizeof(float) * (size_t)n_node;
         for (int m = 0; m < 2; ++m) {
             Model &M = ctx->model[m];
@@ -358,8 +374,8 @@ int gg_create(int32_t n_node, int32_t n_emb, const float *emb_gen, const float *
         GG_HIP(ctx, hipMalloc((void **)&ctx->touched_cnt, sizeof(int32_t) * 4));
         GG_HIP(ctx, hipMemset(ctx->touched, 0, sizeof(int32_t) * n_node));
         GG_HIP(ctx, hipMemset(ctx->touched_cnt, 0, sizeof(int32_t) * 4));
-        GG_HIP(ctx, hipMalloc((void **)&ctx->dev_ctr, sizeof(unsigned long long) * 512));
-        GG_HIP(ctx, hipMemset(ctx->dev_ctr, 0, sizeof(unsigned long long) * 512));
+        GG_HIP(ctx, hipMalloc((void **)&ctx->dev_ctr, sizeof(unsigned long long) * 1024));
+        GG_HIP(ctx, hipMemset(ctx->dev_ctr, 0, sizeof(unsigned long long) * 1024));
         GG_HIP(ctx, hipDeviceSynchronize());
         return GG_OK;
     };
@@ -389,7 +405,7 @@ int gg_destroy(gg_ctx *ctx) {
                       &ctx->d_ptr, &ctx->g_node1, &ctx->g_node2, &ctx->g_reward, &ctx->g_cnt, &ctx->g_ptr, &ctx->scan_tmp,
                       &ctx->step_u, &ctx->step_v, &ctx->step_x, &ctx->sg_cnt, &ctx->sg_off, &ctx->sg_slot, &ctx->sg_list, &ctx->sg_rows, &ctx->sg_bias, &ctx->sg_tot, &ctx->touched_ptr, &ctx->x_cnt, &ctx->x_send_ids, &ctx->x_send_rows,
                       &ctx->x_recv_ids, &ctx->x_recv_rows, &ctx->x_nglob, &ctx->st_item, &ctx->st_cur, &ctx->st_prev, &ctx->st_len,
-                      &ctx->st_alive, &ctx->st_rank, &ctx->bfs_key, &ctx->bfs_bm, &ctx->bfs_misc, &ctx->lv_pfx, &ctx->dc_keys, &ctx->dc_vals, &ctx->dc_words, &ctx->lv_beg, &ctx->lv_k, &ctx->lv_chunks, &ctx->lv_coff, &ctx->lv_scores, &ctx->lv_chunk_owner, &ctx->lv_prefix, &ctx->lv_big};
+                      &ctx->st_alive, &ctx->st_rank, &ctx->bfs_key, &ctx->bfs_bm, &ctx->bfs_misc, &ctx->lv_pfx, &ctx->dc_keys, &ctx->dc_vals, &ctx->dc_words, &ctx->lv_beg, &ctx->lv_k, &ctx->lv_chunks, &ctx->lv_coff, &ctx->lv_scores, &ctx->lv_chunk_owner, &ctx->lv_prefix, &ctx->lv_big, &ctx->fin_list};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : ctx->lv_ev)
         if (e) (void)hipEventDestroy(e);
@@ -397,8 +413,12 @@ int gg_destroy(gg_ctx *ctx) {
         for (hipEvent_t e : tr)
             if (e) (void)hipEventDestroy(e);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
-    for (hipEvent_t e : {ctx->ev_walk_done, ctx->ev_gen_pass, ctx->ev_main_mark})
+    for (hipEvent_t e : {ctx->ev_walk_done, ctx->ev_gen_pass, ctx->ev_main_mark, ctx->ev_fork, ctx->ev_join, ctx->ev_score[0], ctx->ev_score[1]})
         if (e) (void)hipEventDestroy(e);
+    if (ctx->stream3) {
+        (void)hipStreamSynchronize(ctx->stream3);
+        (void)hipStreamDestroy(ctx->stream3);
+    }
     if (ctx->stream2) {
         (void)hipStreamSynchronize(ctx->stream2);
         (void)hipStreamDestroy(ctx->stream2);

@@ -64,7 +64,14 @@ struct gg_ctx {
     hipEvent_t ev_main_mark = nullptr;   // profiled side-stream launches wait for all of `stream` (measured alone)
     bool gen_pass_recorded = false;
     bool gen_dirty = false;  // a generator update was enqueued and ev_gen_pass does not cover it yet (error path, single steps)
-    hipEvent_t lv_ev[128] = {};  // per-level event pairs around level_score_kernel
+    hipEvent_t lv_ev[256] = {};  // per level and half: event pairs around level_score_kernel ([4 * level + 2 * half + {0, 1}])
+    // two-half walk launches (walk_sample.hip, run_levels): second stream, fork / join events, the chain of the score kernels
+    hipStream_t stream3 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_score[2] = {nullptr, nullptr};
+    bool split_enabled = false; // GG_WALK_SPLIT=1 switches the two-half launches on (measured slower on the bench workload, see run_levels)
+    int64_t split_min_walks = 32768;  // GG_WALK_SPLIT_MIN: smaller launches stay on one stream (their levels are latency bound end to end)
+    bool w_split = false;       // the current launch runs as two halves
+    gg::DevBuf fin_list;        // walks handed to the finisher
     int lv_ev_used = 0;
     gg::Model model[2];  // 0 = generator, 1 = discriminator (config.modes order)
 
@@ -142,12 +149,13 @@ struct gg_ctx {
     int32_t w_uniform = -1;  // walks per root of the resident launch when every root has the same number (prepare_g), else -1
     struct { int32_t for_d; uint64_t seed; uint32_t stream; } w_args{};
 
-    // pinned host mirror: [0, 456) the launch's device counters, [H_TOTAL] the row / pair count of a prepare call --
+    // pinned host mirror: [0, 912) the launch's device counters (two halves), [H_TOTAL] the row / pair count of a prepare call --
     // both arrive with asynchronous copies behind the kernels and ONE stream synchronisation (pageable destinations
     // would make every copy its own host round trip)
-    static constexpr int H_TOTAL = 500;
-    static constexpr int H_ROWS = 480;    // [H_ROWS + k]: touched-row count of pending pass timing k (copied behind its optimizer kernel)
-    unsigned long long *h_pin = nullptr;  // [512], hipHostMalloc
+    static constexpr int CTR_WORDS = 456;  // counter words per half of a walk launch (walk_sample.hip)
+    static constexpr int H_TOTAL = 960;
+    static constexpr int H_ROWS = 940;    // [H_ROWS + k]: touched-row count of pending pass timing k (copied behind its optimizer kernel)
+    unsigned long long *h_pin = nullptr;  // [1024], hipHostMalloc
     // profiling (gg_set_profiling): HIP events around every profile_every-th walk call; 1 = every call and every pass
     // (passes then wait for their events), 0 = never; an event pair costs ~6 us of stream bubble on each side
     int32_t profile_every = 1;

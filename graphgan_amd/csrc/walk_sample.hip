@@ -79,7 +79,13 @@ struct WalkArgs {
     unsigned long long *dc_keys, *dc_vals;
     uint32_t dc_mask;      // table size - 1 (power of two)
     const int64_t *dc_words;  // [0] global chunk offset this launch starts at, [1] chunks in the buffer after the D launch
-    int32_t *lv_big;       // [total_walks] owner walks with k > BIG_TASK, appended per level
+    int32_t *lv_big;       // [lv_big_cap] task lists of the weights kernel, per level: hub tasks from the front, small multi-chunk tasks from the back
+    // A launch may run as two halves of its walks on two streams (run_levels): each half has its own walk range, task
+    // list, chunk buffers, prefix region and level counters `lc`; flags, finisher list and finisher counters are shared.
+    unsigned long long *lc;  // this half's counter block: indices CTR_ALIVE and up
+    int64_t w0, w_end;       // walks [w0, w_end) of the launch
+    int64_t lv_big_cap;
+    int32_t *fin_list;       // [total_walks] walks still alive behind the last streamed level (CTR_FIN entries)
 };
 
 __device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, int lane) {
@@ -231,7 +237,7 @@ constexpr int MAX_LEVELS = 64;
 // Global chunk offset of the first chunk of hop a.level: the launch's base + the chunks of its earlier hops.
 __device__ __forceinline__ int64_t level_chunk_base(const WalkArgs &a) {
     int64_t b = a.dc_words[0];
-    for (int l = 0; l < a.level; ++l) b += (int64_t)a.ctr[CTR_CHUNKS + l];
+    for (int l = 0; l < a.level; ++l) b += (int64_t)a.lc[CTR_CHUNKS + l];
     return b;
 }
 
@@ -265,13 +271,13 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     __shared__ int blk_skip;
     if (threadIdx.x == 0)
         blk_skip = (__atomic_load_n(&a.ctr[3], __ATOMIC_RELAXED) == 2ull ||                                  // an earlier level overflowed: the host reruns in sized mode
-                    (a.level > 0 && __atomic_load_n(&a.ctr[CTR_ALIVE + a.level - 1], __ATOMIC_RELAXED) == 0ull))  // every walk has finished: empty level
+                    (a.level > 0 && __atomic_load_n(&a.lc[CTR_ALIVE + a.level - 1], __ATOMIC_RELAXED) == 0ull))  // every walk has finished: empty level
                        ? 1 : 0;
     __syncthreads();
     if (blk_skip) return;
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t w = a.w0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const bool in_range = w < a.total_walks;
+    const bool in_range = w < a.w_end;
     bool alive = false, sampled = false;
     int item = 0, cur = -1, k = 0, hf = 0, father = -1, slot_w = 0, rank_w = 0;
     unsigned long long my_k = 0;
@@ -419,8 +425,8 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) my_k += __shfl_xor(my_k, off, 64);
         if (lane == 0 && bal) {
-            atomicAdd(&a.ctr[CTR_HOPS_V + (blockIdx.x & 63)], (unsigned long long)__popcll(bal));
-            atomicAdd(&a.ctr[CTR_READS_V + (blockIdx.x & 63)], my_k);
+            atomicAdd(&a.lc[CTR_HOPS_V + (blockIdx.x & 63)], (unsigned long long)__popcll(bal));
+            atomicAdd(&a.lc[CTR_READS_V + (blockIdx.x & 63)], my_k);
         }
     }
     if (!do_setup) {
@@ -431,7 +437,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
             unsigned long long base = 0;
             if (lane == __ffsll((long long)abal) - 1) base = atomicAdd(&a.ctr[CTR_FIN], (unsigned long long)__popcll(abal));
             base = __shfl(base, __ffsll((long long)abal) - 1, 64);
-            if (alive) a.lv_big[base + __popcll(abal & ((1ull << lane) - 1ull))] = (int32_t)w;
+            if (alive) a.fin_list[base + __popcll(abal & ((1ull << lane) - 1ull))] = (int32_t)w;
         }
         return;
     }
@@ -498,11 +504,11 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     if (threadIdx.x == 0) {
         const int tc = wv_chunks[0] + wv_chunks[1] + wv_chunks[2] + wv_chunks[3];
         const int tb = wv_big[0] + wv_big[1] + wv_big[2] + wv_big[3];
-        blk_base[0] = tc ? atomicAdd(&a.ctr[CTR_CHUNKS + a.level], (unsigned long long)tc) : 0ull;
+        blk_base[0] = tc ? atomicAdd(&a.lc[CTR_CHUNKS + a.level], (unsigned long long)tc) : 0ull;
         const int ts = wv_small[0] + wv_small[1] + wv_small[2] + wv_small[3];
-        blk_base[1] = (tb | ts) ? atomicAdd(&a.ctr[CTR_BIG + a.level], (unsigned long long)tb | ((unsigned long long)ts << 32)) : 0ull;
+        blk_base[1] = (tb | ts) ? atomicAdd(&a.lc[CTR_BIG + a.level], (unsigned long long)tb | ((unsigned long long)ts << 32)) : 0ull;
         const int to = wv_own[0] + wv_own[1] + wv_own[2] + wv_own[3];
-        if (to) atomicAdd(&a.ctr[CTR_DISTS + (blockIdx.x & 63)], (unsigned long long)to);
+        if (to) atomicAdd(&a.lc[CTR_DISTS + (blockIdx.x & 63)], (unsigned long long)to);
     }
     __syncthreads();
     int chunks_before = 0, big_before = 0, small_before = 0, blk_chunks = 0;
@@ -536,7 +542,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         }
         // the two task lists of the weights kernel share one array: big tasks from the front, small ones from the back
         if (big) a.lv_big[(blk_base[1] & 0xffffffffull) + big_before + __popcll(big_bal & ((1ull << lane) - 1ull))] = (int32_t)w;
-        if (small) a.lv_big[a.total_walks - 1 - (int64_t)((blk_base[1] >> 32) + small_before + __popcll(small_bal & ((1ull << lane) - 1ull)))] = (int32_t)w;
+        if (small) a.lv_big[a.lv_big_cap - 1 - (int64_t)((blk_base[1] >> 32) + small_before + __popcll(small_bal & ((1ull << lane) - 1ull)))] = (int32_t)w;
         if (write_desc == 1 && fits)
             for (int i = 0; i < chunks; ++i) a.lv_chunk_desc[coff + i] = chunk_desc(cur, k, hf, father, beg_abs, i);
     }
@@ -547,7 +553,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     __syncthreads();
     if (threadIdx.x == 0) {
         const int ta = wv_alive[0] + wv_alive[1] + wv_alive[2] + wv_alive[3];
-        if (ta) atomicAdd(&a.ctr[CTR_ALIVE + a.level], (unsigned long long)ta);
+        if (ta) atomicAdd(&a.lc[CTR_ALIVE + a.level], (unsigned long long)ta);
     }
 }
 
@@ -586,7 +592,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const
     __shared__ unsigned long long blk_rows;
     if (threadIdx.x == 0) blk_rows = 0;
     __syncthreads();
-    const int64_t total_chunks = (int64_t)a.ctr[CTR_CHUNKS + a.level];
+    const int64_t total_chunks = (int64_t)a.lc[CTR_CHUNKS + a.level];
     const int64_t lbase = level_chunk_base(a);
     if (total_chunks > cap_chunks || lbase + total_chunks > a.cap_total) return;
     const int t = threadIdx.x & 15;
@@ -662,7 +668,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const
     // 2 x 2048 of them at the end of every launch were a 20 us tail on the short levels (the host folds the words)
     if (t == 0 && rows) atomicAdd(&blk_rows, rows);
     __syncthreads();
-    if (threadIdx.x == 0 && blk_rows) atomicAdd(&a.ctr[CTR_ROWS + (blockIdx.x & 63)], blk_rows);
+    if (threadIdx.x == 0 && blk_rows) atomicAdd(&a.lc[CTR_ROWS + (blockIdx.x & 63)], blk_rows);
 }
 
 // Small owner tasks (16 < k <= BIG_TASK): one 16-lane group per walk -- max, exact fixed-point weights
@@ -701,8 +707,8 @@ __device__ __forceinline__ void weights_small_task(const WalkArgs &a, const int6
 constexpr int SMALL_BLOCKS = 2048;  // workgroups of the weights launch that serve the small-task list (16 tasks each per round)
 __device__ __forceinline__ void weights_small_blocks(const WalkArgs &a, const int block) {
     const int t = threadIdx.x & 15;
-    const int64_t n_small = (int64_t)(a.ctr[CTR_BIG + a.level] >> 32);
-    for (int64_t i = (int64_t)block * 16 + (threadIdx.x >> 4); i < n_small; i += (int64_t)SMALL_BLOCKS * 16) weights_small_task(a, a.lv_big[a.total_walks - 1 - i], t);
+    const int64_t n_small = (int64_t)(a.lc[CTR_BIG + a.level] >> 32);
+    for (int64_t i = (int64_t)block * 16 + (threadIdx.x >> 4); i < n_small; i += (int64_t)SMALL_BLOCKS * 16) weights_small_task(a, a.lv_big[a.lv_big_cap - 1 - i], t);
 }
 
 // Big owner tasks (hubs): one 256-thread workgroup per task, from the level's big-task list.  Tasks of up to
@@ -714,7 +720,7 @@ __device__ __forceinline__ void weights_big_blocks(const WalkArgs &a) {
     __shared__ float red[4];
     __shared__ uint64_t wave_tot[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int n_big = (int)(a.ctr[CTR_BIG + a.level] & 0xffffffffull);
+    const int n_big = (int)(a.lc[CTR_BIG + a.level] & 0xffffffffull);
     for (int b = blockIdx.x; b < n_big; b += BIG_BLOCKS) {
         const int64_t w = a.lv_big[b];
         const int k = a.lv_k[w] & 0x7fffffff;
@@ -771,7 +777,7 @@ __device__ __forceinline__ void weights_big_blocks(const WalkArgs &a) {
 // longest, so they are dispatched first), the others take 16 walks each.  As two back-to-back launches the two
 // classes cost the sum of their latency-bound run times; together, the longer of the two.
 __global__ __launch_bounds__(256) void level_weights_kernel(const WalkArgs a, const int64_t cap_chunks) {
-    const unsigned long long total_chunks = a.ctr[CTR_CHUNKS + a.level];
+    const unsigned long long total_chunks = a.lc[CTR_CHUNKS + a.level];
     if ((int64_t)total_chunks > cap_chunks || total_chunks == 0ull || level_chunk_base(a) + (int64_t)total_chunks > a.cap_total) return;
     if (blockIdx.x < BIG_BLOCKS) weights_big_blocks(a);
     else weights_small_blocks(a, (int)blockIdx.x - BIG_BLOCKS);
@@ -807,7 +813,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void walk_sample_kernel(const
     // walks keep the XCD-contiguous static assignment)
     const int64_t n_items = resume ? (int64_t)a.ctr[CTR_FIN] : a.total_walks;  // resume: the live walks listed by the last level_advance_kernel
     for (int64_t it = (int64_t)lblock * WAVES_PER_BLOCK + wib; it < n_items;) {
-        const int64_t w = resume ? (int64_t)a.lv_big[it] : it;
+        const int64_t w = resume ? (int64_t)a.fin_list[it] : it;
         {
             const int item = find_item(a.walk_ptr, a.n_slots, w);
             const uint32_t j = (uint32_t)(w - a.walk_ptr[item]);
@@ -943,10 +949,22 @@ __global__ void walk_d_postpass_kernel(const WalkArgs a) {
     }
 }
 
-__global__ void walk_reset_kernel(unsigned long long *ctr, int n_words, int64_t *dc_words, int append) {
+// Counter words of both halves, and the base of each half's prefix region: dc_words = {base 0, end 0, base 1, end 1} in
+// global chunk offsets.  A launch that looks distributions up (append) starts behind what the D launch of the step left in
+// the region(s) it uses; a single-stream launch uses one region behind everything.
+__global__ void walk_reset_kernel(unsigned long long *ctr, int n_words, int64_t *dc_words, int append, int split, int64_t S) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_words) ctr[i] = 0ull;
-    if (i == 0) dc_words[0] = append ? dc_words[1] : 0;
+    if (i == 0) {
+        if (!append) dc_words[1] = dc_words[3] = 0;
+        const int64_t e0 = dc_words[1], e1 = dc_words[3];
+        if (split) {
+            dc_words[0] = append ? e0 : 0;
+            dc_words[2] = (append && e1 > S) ? e1 : S;
+        } else {
+            dc_words[0] = append ? (e0 > e1 ? e0 : e1) : 0;
+        }
+    }
 }
 
 __global__ void walk_init_status_kernel(const WalkArgs a) {
@@ -995,7 +1013,7 @@ __global__ __launch_bounds__(256) void fill_ones_kernel(uint4 *p, int64_t n16) {
 __global__ void dc_finish_kernel(const WalkArgs a, int64_t *words, int n_levels) {
     if (a.ctr[3] == 2ull) { words[1] = 0; return; }  // the launch is being rerun
     int64_t b = words[0];
-    for (int l = 0; l < n_levels; ++l) b += (int64_t)a.ctr[CTR_CHUNKS + l];
+    for (int l = 0; l < n_levels; ++l) b += (int64_t)a.lc[CTR_CHUNKS + l];
     words[1] = b;
 }
 
@@ -1003,15 +1021,31 @@ __global__ void dc_finish_kernel(const WalkArgs a, int64_t *words, int n_levels)
 // per level sizes the buffers exactly (and learns the capacity for later launches);
 // sized == false: no host synchronisation at all, buffers hold ctx->lv_cap_chunks chunks and a
 // level that needs more raises flag 2 (the caller reruns the launch in sized mode).
+//
+// A sync-free launch of enough walks runs as TWO HALVES of its walks on two streams (walk_stream and stream3): a level is
+// advance -> score -> weights, and only the score kernel moves data -- the other two are chains of dependent loads, 60-110 us
+// per level with the chip nearly idle.  With two halves the advance / weights kernels of one half run under the score kernel
+// of the other (which leaves two wave slots per SIMD free for exactly that); the score kernels themselves are chained by
+// events so that they never share the HBM with each other.  Each half has its own walk range, task lists, chunk buffers,
+// prefix region [h * S, (h + 1) * S) and level counters; dedup, registration and sampling are per workgroup of 256
+// consecutive walks either way, so the split (at a multiple of 256) cannot change a walk (tested bit-exact).
+// MEASURED AND OFF BY DEFAULT (GG_WALK_SPLIT=1 enables it): on the bench workload the walk call takes 1.93 ms split against
+// 1.81 ms unsplit, the step 4.62 against 4.42 ms -- the advance / weights rounds do hide (about -0.2 ms per call), but a
+// half-size score launch runs at 0.55-0.59 of the HBM peak instead of 0.68-0.70 (the persistent grid's ramp-up and tail are
+// paid twice per level, and the kernel shares the chip with the other half's latency-bound kernels), which costs more.
+
 template <int NCH>
 static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_levels, bool sized, bool finisher_follows, bool *any_alive) {
     const dim3 blk(WAVES_PER_BLOCK * 64);
     int64_t cap = sized ? 0 : ctx->lv_cap_chunks;
     const bool keep = a.dc_mode != 0;  // cached prefix regions must survive a growing buffer
     int64_t base_host = 0, cum = 0;    // sized mode: global chunk offset of the launch / chunks of its hops so far
+    const bool split = ctx->w_split;   // decided by launch_walk_sample (the reset kernel already set up both halves' words)
+    const int n_half = split ? 2 : 1;
+    const int64_t S = ctx->lv_cap_total;  // prefix region of a half
     if (!sized) {
-        int rc = reserve_level_buffers(ctx, a, cap);
-        if (rc == GG_OK) rc = reserve_prefix(ctx, a, std::max<int64_t>(ctx->lv_cap_total, cap), keep);
+        int rc = reserve_level_buffers(ctx, a, cap * n_half);
+        if (rc == GG_OK) rc = reserve_prefix(ctx, a, std::max<int64_t>(S, cap) * n_half, keep);
         if (rc != GG_OK) return rc;
     } else {
         if (a.dc_mode == 2) {  // where the D launch of the step stopped
@@ -1021,59 +1055,96 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
         int rc = reserve_prefix(ctx, a, std::max<int64_t>(base_host, 1), keep);
         if (rc != GG_OK) return rc;
     }
-    const unsigned wblocks = (unsigned)cdiv(total_walks, 256);
+    // the halves: walk ranges split at a multiple of the workgroup size
+    WalkArgs h[2] = {a, a};
+    hipStream_t hs[2] = {ctx->walk_stream, ctx->stream3};
+    if (split) {
+        const int64_t mid = ((total_walks / 2 + 255) / 256) * 256;
+        h[0].w0 = 0; h[0].w_end = mid;
+        h[1].w0 = mid; h[1].w_end = total_walks;
+        for (int k = 0; k < 2; ++k) {
+            h[k].lc = ctx->dev_ctr + (size_t)k * CTR_WORDS;
+            h[k].lv_big = a.lv_big + h[k].w0;
+            h[k].lv_big_cap = h[k].w_end - h[k].w0;
+            h[k].lv_scores = a.lv_scores + (size_t)k * cap * CHUNK;
+            h[k].lv_chunk_desc = a.lv_chunk_desc + (size_t)k * cap;
+            h[k].dc_words = a.dc_words + 2 * k;
+            h[k].cap_total = std::min<int64_t>((k + 1) * S, a.cap_total);
+        }
+        GG_HIP(ctx, hipEventRecord(ctx->ev_fork, hs[0]));
+        GG_HIP(ctx, hipStreamWaitEvent(hs[1], ctx->ev_fork, 0));
+    }
     const bool all_levels = n_levels >= ctx->tree_max_depth + 2;
     if (!sized && all_levels && !finisher_follows && ctx->lv_levels_learned > 0) n_levels = std::min(n_levels, ctx->lv_levels_learned + 1);
     *any_alive = true;
     ctx->lv_ev_used = 0;
     int level = 0;
     for (; level < n_levels; ++level) {
-        a.level = level;
-        hipLaunchKernelGGL(level_advance_kernel, dim3(wblocks), dim3(256), 0, ctx->walk_stream, a, level > 0 ? 1 : 0, 1, sized ? 0 : 1, cap);
-        if (sized) {
-            unsigned long long total_chunks = 0, alive = 0;
-            GG_HIP(ctx, hipMemcpyAsync(&total_chunks, ctx->dev_ctr + CTR_CHUNKS + level, sizeof(total_chunks), hipMemcpyDeviceToHost, ctx->walk_stream));
-            GG_HIP(ctx, hipMemcpyAsync(&alive, ctx->dev_ctr + CTR_ALIVE + level, sizeof(alive), hipMemcpyDeviceToHost, ctx->walk_stream));
-            GG_HIP(ctx, hipStreamSynchronize(ctx->walk_stream));
-            if (alive == 0) {  // every walk has finished
-                *any_alive = false;
-                ctx->w_levels_run = level + 1;
-                if (a.dc_mode == 1) hipLaunchKernelGGL(dc_finish_kernel, dim3(1), dim3(1), 0, ctx->walk_stream, a, ctx->dc_words.as<int64_t>(), level + 1);
-                return GG_OK;
+        for (int k = 0; k < n_half; ++k) {
+            WalkArgs &x = h[k];
+            x.level = level;
+            const unsigned wblocks = (unsigned)cdiv(x.w_end - x.w0, 256);
+            hipLaunchKernelGGL(level_advance_kernel, dim3(wblocks), dim3(256), 0, hs[k], x, level > 0 ? 1 : 0, 1, sized ? 0 : 1, cap);
+            if (sized) {
+                unsigned long long total_chunks = 0, alive = 0;
+                GG_HIP(ctx, hipMemcpyAsync(&total_chunks, ctx->dev_ctr + CTR_CHUNKS + level, sizeof(total_chunks), hipMemcpyDeviceToHost, ctx->walk_stream));
+                GG_HIP(ctx, hipMemcpyAsync(&alive, ctx->dev_ctr + CTR_ALIVE + level, sizeof(alive), hipMemcpyDeviceToHost, ctx->walk_stream));
+                GG_HIP(ctx, hipStreamSynchronize(ctx->walk_stream));
+                if (alive == 0) {  // every walk has finished
+                    *any_alive = false;
+                    ctx->w_levels_run = level + 1;
+                    if (a.dc_mode == 1) hipLaunchKernelGGL(dc_finish_kernel, dim3(1), dim3(1), 0, ctx->walk_stream, x, ctx->dc_words.as<int64_t>(), level + 1);
+                    return GG_OK;
+                }
+                if (level + 1 > ctx->lv_levels_learned) ctx->lv_levels_learned = level + 1;
+                cap = (int64_t)total_chunks;
+                if (cap + cap / 4 + 4096 > ctx->lv_cap_chunks) ctx->lv_cap_chunks = cap + cap / 4 + 4096;
+                int rc = reserve_level_buffers(ctx, x, cap);
+                if (rc == GG_OK) rc = reserve_prefix(ctx, x, base_host + cum + cap, true);
+                if (rc != GG_OK) return rc;
+                cum += cap;
+                if (base_host + cum + (base_host + cum) / 4 + 4096 > ctx->lv_cap_total) ctx->lv_cap_total = base_host + cum + (base_host + cum) / 4 + 4096;
+                hipLaunchKernelGGL(level_expand_kernel, dim3(wblocks), dim3(256), 0, ctx->walk_stream, x);
             }
-            if (level + 1 > ctx->lv_levels_learned) ctx->lv_levels_learned = level + 1;
-            cap = (int64_t)total_chunks;
-            if (cap + cap / 4 + 4096 > ctx->lv_cap_chunks) ctx->lv_cap_chunks = cap + cap / 4 + 4096;
-            int rc = reserve_level_buffers(ctx, a, cap);
-            if (rc == GG_OK) rc = reserve_prefix(ctx, a, base_host + cum + cap, true);
-            if (rc != GG_OK) return rc;
-            cum += cap;
-            if (base_host + cum + (base_host + cum) / 4 + 4096 > ctx->lv_cap_total) ctx->lv_cap_total = base_host + cum + (base_host + cum) / 4 + 4096;
-            hipLaunchKernelGGL(level_expand_kernel, dim3(wblocks), dim3(256), 0, ctx->walk_stream, a);
-        }
-        int64_t blocks = sized ? (cap + WAVES_PER_BLOCK * 4 - 1) / (WAVES_PER_BLOCK * 4) : score_blocks();
-        if (blocks > score_blocks()) blocks = score_blocks();
-        if (blocks >= 8) blocks -= blocks % 8;
-        if (blocks < 1) blocks = 1;
-        if (ctx->walk_timed) {
-            if (!ctx->lv_ev[2 * level]) {
-                GG_HIP(ctx, hipEventCreate(&ctx->lv_ev[2 * level]));
-                GG_HIP(ctx, hipEventCreate(&ctx->lv_ev[2 * level + 1]));
+            int64_t blocks = sized ? (cap + WAVES_PER_BLOCK * 4 - 1) / (WAVES_PER_BLOCK * 4) : score_blocks();
+            if (blocks > score_blocks()) blocks = score_blocks();
+            if (blocks >= 8) blocks -= blocks % 8;
+            if (blocks < 1) blocks = 1;
+            // the score kernels of the two halves are chained: this one starts behind the other half's previous one
+            if (split && (level > 0 || k == 1)) GG_HIP(ctx, hipStreamWaitEvent(hs[k], ctx->ev_score[1 - k], 0));
+            hipEvent_t *ev = ctx->lv_ev + 4 * level + 2 * k;
+            if (ctx->walk_timed) {
+                if (!ev[0]) {
+                    GG_HIP(ctx, hipEventCreate(&ev[0]));
+                    GG_HIP(ctx, hipEventCreate(&ev[1]));
+                }
+                GG_HIP(ctx, hipEventRecord(ev[0], hs[k]));
             }
-            GG_HIP(ctx, hipEventRecord(ctx->lv_ev[2 * level], ctx->walk_stream));
+            hipLaunchKernelGGL(level_score_kernel<NCH>, dim3((unsigned)blocks), blk, 0, hs[k], x, cap);
+            if (ctx->walk_timed) {
+                GG_HIP(ctx, hipEventRecord(ev[1], hs[k]));
+                ctx->lv_ev_used = level + 1;
+            }
+            if (split) GG_HIP(ctx, hipEventRecord(ctx->ev_score[k], hs[k]));
+            const int64_t half_walks = x.w_end - x.w0;
+            hipLaunchKernelGGL(level_weights_kernel, dim3((unsigned)(BIG_BLOCKS + std::min<int64_t>(SMALL_BLOCKS, cdiv(half_walks * 16, 256)))), dim3(256), 0, hs[k], x, cap);
         }
-        hipLaunchKernelGGL(level_score_kernel<NCH>, dim3((unsigned)blocks), blk, 0, ctx->walk_stream, a, cap);
-        if (ctx->walk_timed) {
-            GG_HIP(ctx, hipEventRecord(ctx->lv_ev[2 * level + 1], ctx->walk_stream));
-            ctx->lv_ev_used = level + 1;
-        }
-        hipLaunchKernelGGL(level_weights_kernel, dim3((unsigned)(BIG_BLOCKS + std::min<int64_t>(SMALL_BLOCKS, cdiv(total_walks * 16, 256)))), dim3(256), 0, ctx->walk_stream, a, cap);
     }
     // finish the last prepared hop
-    a.level = level;
-    hipLaunchKernelGGL(level_advance_kernel, dim3(wblocks), dim3(256), 0, ctx->walk_stream, a, 1, 0, (!sized && all_levels && !finisher_follows) ? 2 : 0, 0);
+    for (int k = 0; k < n_half; ++k) {
+        WalkArgs &x = h[k];
+        x.level = level;
+        const unsigned wblocks = (unsigned)cdiv(x.w_end - x.w0, 256);
+        hipLaunchKernelGGL(level_advance_kernel, dim3(wblocks), dim3(256), 0, hs[k], x, 1, 0, (!sized && all_levels && !finisher_follows) ? 2 : 0, 0);
+        if (a.dc_mode == 1) hipLaunchKernelGGL(dc_finish_kernel, dim3(1), dim3(1), 0, hs[k], x, ctx->dc_words.as<int64_t>() + 2 * k, level);
+    }
+    if (split) {
+        GG_HIP(ctx, hipEventRecord(ctx->ev_join, hs[1]));
+        GG_HIP(ctx, hipStreamWaitEvent(hs[0], ctx->ev_join, 0));
+    }
+    a = h[0];  // (level, pointers of half 0: what the finisher resumes with -- it works on the shared lists)
+    a.w0 = 0; a.w_end = total_walks;
     ctx->w_levels_run = level;
-    if (a.dc_mode == 1) hipLaunchKernelGGL(dc_finish_kernel, dim3(1), dim3(1), 0, ctx->walk_stream, a, ctx->dc_words.as<int64_t>(), level);
     GG_HIP(ctx, hipGetLastError());
     return GG_OK;
 }
@@ -1176,8 +1247,14 @@ int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int fo
     a.first_child = ctx->w_first.as<int32_t>();
     a.abort_walk = ctx->w_abort.as<int32_t>();
     a.ctr = ctx->dev_ctr;
+    a.lc = ctx->dev_ctr;
+    a.w0 = 0;
+    a.w_end = total_walks;
+    a.lv_big_cap = total_walks;
+    GG_HIP(ctx, ctx->fin_list.reserve(sizeof(int32_t) * (size_t)(total_walks + 1)));
+    a.fin_list = ctx->fin_list.as<int32_t>();
     // distribution cache: mode requested by gg_prepare_d (register) / gg_prepare_g (look up); anything else runs without it
-    GG_HIP(ctx, ctx->dc_words.reserve(sizeof(int64_t) * 4));
+    GG_HIP(ctx, ctx->dc_words.reserve(sizeof(int64_t) * 8));
     a.dc_words = ctx->dc_words.as<int64_t>();
     a.dc_mode = (ctx->walk_levels > 0 && total_walks > 0) ? ctx->dc_request : 0;
     if (a.dc_mode == 1) {
@@ -1199,8 +1276,10 @@ int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int fo
     // walk_finalize): hops / reads / rows, error flag [3], ticket [4], per-level counters and the spread words.  (As a
     // hipMemcpyAsync + hipMemsetAsync pair these were blit kernels with system-scope fences: the copy took ~130 us on the side
     // stream while the discriminator's gradient kernel was filling the L2 with atomics.)
-    hipLaunchKernelGGL(walk_reset_kernel, dim3(cdiv(CTR_WORDS, 256)), dim3(256), 0, ctx->walk_stream, ctx->dev_ctr, (int)CTR_WORDS,
-                       ctx->dc_words.as<int64_t>(), a.dc_mode == 2 ? 1 : 0);
+    const bool will_size = ctx->lv_cap_chunks == 0 || ctx->walk_force_sized;
+    ctx->w_split = ctx->split_enabled && ctx->walk_levels > 0 && !will_size && total_walks >= ctx->split_min_walks;
+    hipLaunchKernelGGL(walk_reset_kernel, dim3(cdiv(2 * CTR_WORDS, 256)), dim3(256), 0, ctx->walk_stream, ctx->dev_ctr, 2 * (int)CTR_WORDS,
+                       ctx->dc_words.as<int64_t>(), a.dc_mode == 2 ? 1 : 0, ctx->w_split ? 1 : 0, ctx->lv_cap_total);
     // HIP events around every profile_every-th call (a rerun keeps the decision of the launch it repeats)
     if (!ctx->walk_force_sized) ctx->walk_timed = ctx->profile_every > 0 && (ctx->walk_call_index++ % ctx->profile_every) == 0;
     if (ctx->walk_timed && ctx->walk_stream != ctx->stream && ctx->profile_solo) {

@@ -57,16 +57,20 @@ def run_both(ga, n, rowptr, col, roots, E, b, rounds, seed, n_sample=20, stride=
     return hops
 
 
-@pytest.fixture(params=["finisher", "hybrid2", "levels", "adaptive"])
+@pytest.fixture(params=["finisher", "hybrid2", "levels", "adaptive", "split"])
 def walk_mode(request, monkeypatch):
     """The decompositions of the sampler: GG_WALK_LEVELS = 0 (one wavefront per walk, the
     finisher kernel alone), 2 (two hops through the level pipeline, the finisher takes over), 64 (level pipeline to
     the end; the default), and 64 with GG_FIN_THRESHOLD (the hand-over level follows the previous launch of the mode:
-    the later rounds of a test switch to the finisher's walk list wherever fewer than that many walks were left).
+    the later rounds of a test switch to the finisher's walk list wherever fewer than that many walks were left); "split"
+    runs the sync-free launches as two halves of their walks on two streams (opt-in, GG_WALK_SPLIT=1; from 512 walks here).
     gg_create reads the variables, so they are set before the engine exists."""
-    monkeypatch.setenv("GG_WALK_LEVELS", {"finisher": "0", "hybrid2": "2", "levels": "64", "adaptive": "64"}[request.param])
+    monkeypatch.setenv("GG_WALK_LEVELS", {"finisher": "0", "hybrid2": "2", "levels": "64", "adaptive": "64", "split": "64"}[request.param])
     if request.param == "adaptive":
         monkeypatch.setenv("GG_FIN_THRESHOLD", "2000")
+    if request.param == "split":  # two-half launches (two streams, per-half buffers and counters) already for small launches
+        monkeypatch.setenv("GG_WALK_SPLIT", "1")
+        monkeypatch.setenv("GG_WALK_SPLIT_MIN", "512")
     return request.param
 
 
