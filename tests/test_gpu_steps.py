@@ -385,6 +385,41 @@ def test_staged_generator_gradient_equals_the_atomic_path(ga, opt, threshold, mo
     eng2.close()
 
 
+@pytest.mark.parametrize("d", [50, 200, 256])
+def test_fused_g_pass_embedding_widths(ga, d, monkeypatch):
+    """Whole-walk reward + staged path gradient + reducing optimizer for rows that are not a multiple of 16 floats (d = 50:
+    the reference's own width, 200) and for the widest template instance (d = 256), against the per-pair kernels."""
+    g, n, graph = load_small(3)
+    rs = np.random.RandomState(d)
+    Eg = (rs.randn(n, d) * (1.2 / np.sqrt(d))).astype(np.float32)
+    Ed = (rs.randn(n, d) * (1.2 / np.sqrt(d))).astype(np.float32)
+    rowptr, col = ga.graph_to_csr(n, graph)
+    engs = []
+    for _ in range(2):
+        e = ga.Engine(Eg, Ed, optimizer=ga.GG_OPT_ADAM_LAZY)
+        e.set_graph_csr(rowptr, col)
+        e.build_trees(np.arange(n))
+        engs.append(e)
+    slots = np.arange(n, dtype=np.int32)
+    n1, n2, rew, _ = engs[0].prepare_g(slots, 20, 7, 1)
+    monkeypatch.setenv("GG_NO_PATH_REWARD", "1")
+    m1, m2, rew2, _ = engs[1].prepare_g(slots, 20, 7, 1)
+    monkeypatch.delenv("GG_NO_PATH_REWARD")
+    assert np.array_equal(n1, m1) and np.array_equal(n2, m2)
+    assert np.array_equal(rew.view(np.uint32), rew2.view(np.uint32))
+    engs[0].g_pass([0], len(n1))
+    monkeypatch.setenv("GG_NO_PATH_GRAD", "1")
+    engs[1].g_pass([0], len(n1))
+    monkeypatch.delenv("GG_NO_PATH_GRAD")
+    assert np.allclose(engs[0].get_embeddings(0), engs[1].get_embeddings(0), rtol=2e-5, atol=2e-6)
+    assert np.allclose(engs[0].get_bias(0), engs[1].get_bias(0), rtol=2e-5, atol=2e-6)
+    gen = orc.Generator(Eg, 1e-3, lazy=True)
+    gen.g_step(n1.astype(np.int64), n2.astype(np.int64), rew, 1e-5)
+    assert np.allclose(engs[0].get_embeddings(0), gen.E, rtol=2e-5, atol=2e-6)
+    for e in engs:
+        e.close()
+
+
 def test_pairs_are_expanded_on_first_use_and_guarded(ga):
     """gg_prepare_g keeps the walks; the (node_1, node_2) arrays are written when something reads them.  A minibatch pass
     straight after an un-fetched prepare sees the same pairs as a fetched one; reading them after the walks were
