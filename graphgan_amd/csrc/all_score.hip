@@ -278,6 +278,99 @@ __global__ __launch_bounds__(256) void all_score_reduce_bf16_kernel(const uint4 
     tile_finish<16 * RB>(run, lse != 0, r0, n_rows, split, gridDim.x, part_max, part_arg, part_sum, sh_m, sh_s, sh_a);
 }
 
+// The same consumer for MANY rows: the 4 wavefronts of a workgroup take 4 DIFFERENT row blocks (RB x 32 rows each) and walk the
+// SAME 32-column tiles, so one sweep of the table serves 128 x RB rows instead of 32 x RB -- in the variant above every
+// 32 x RB rows re-stream the whole bf16 table from HBM (4 096 rows x 10^7 nodes: 128 sweeps of 5 GB = 8.3 TB/s at 266 TFLOP/s:
+// it ran at the HBM roofline, not the matrix cores').  The four wavefronts load the same B fragments within a few cycles
+// of each other: one of them misses, the others hit the CU's vector cache.  No cross-wave merge: a wave owns its rows.
+// With one wavefront per SIMD the kernel runs at (bytes in flight) / (memory latency) until the matrix cores saturate: one
+// 16 KB tile per wave at d = 256 -- two row blocks per wave (RB = 2) double the work per byte in flight.
+template <int KS, int RB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void all_score_reduce_bf16_rows_kernel(const uint4 *Eb, const float *bias, int n_node, const int32_t *rows,
+                                                                         int n_rows, int cols_per_split, int lse, float *part_max,
+                                                                         int32_t *part_arg, float *part_sum) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, half = lane >> 5;
+    const int split = blockIdx.x, r0 = blockIdx.y * (128 * RB) + wv * (32 * RB);
+    union Frag { uint4 u; bf16x8 v; };
+    Frag afrag[RB][KS];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int r = r0 + rb * 32 + (lane & 31);
+        const int node = r < n_rows ? (rows ? rows[r] : r) : -1;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) afrag[rb][s].u = node >= 0 ? Eb[(int64_t)node * (2 * KS) + 2 * s + half] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    // (three scalar arrays instead of one array of structs: 64 x 12 bytes is more than the compiler promotes to registers)
+    float rm[RB][16], rs[RB][16];
+    int ra[RB][16];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { rm[rb][i] = -INFINITY; rs[rb][i] = 0.f; ra[rb][i] = 0x7fffffff; }
+    const int cbeg = split * cols_per_split, cend = min(n_node, cbeg + cols_per_split);
+    auto load_tile = [&](Frag (&dst)[KS], int c0t) {
+        const int colt = c0t + (lane & 31);
+        const uint4 *brow = Eb + (int64_t)((c0t < cend && colt < cend) ? colt : cbeg) * (2 * KS) + half;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) dst[s].u = brow[2 * s];
+    };
+    // B fragments double buffered in registers (as above).  Measured and not kept: three buffers (two tiles in flight) with the
+    // loop unrolled over them -- the unrolled consumer bodies cost more than the extra tile in flight brings (390 -> 309 TFLOP/s).
+    Frag bcur[KS], bnxt[KS];
+    load_tile(bcur, cbeg);
+    for (int c0 = cbeg; c0 < cend; c0 += 32) {
+        const int col = c0 + (lane & 31);
+        const bool ok = col < cend;
+        load_tile(bnxt, c0 + 32);
+        f32x16 acc[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rb][i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[rb][s].v, bcur[s].v, acc[rb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) bcur[s] = bnxt[s];
+        if (ok) {
+            const float bj = bias[col];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    Running x{rm[rb][reg], rs[rb][reg], ra[rb][reg]};
+                    run_update(x, acc[rb][reg] + bj, col, lse != 0);
+                    rm[rb][reg] = x.m; rs[rb][reg] = x.s; ra[rb][reg] = x.arg;
+                }
+        }
+    }
+    // merge a row's 32 column lanes; lanes 0 and 32 then hold the wave's rows: row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            Running x{rm[rb][reg], rs[rb][reg], ra[rb][reg]};
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) {
+                const float m = __shfl_xor(x.m, off, 64), sx = __shfl_xor(x.s, off, 64);
+                const int ar = __shfl_xor(x.arg, off, 64);
+                run_merge(x, m, sx, ar, lse != 0);
+            }
+            if ((lane & 31) == 0) {
+                const int row = r0 + rb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                if (row < n_rows) {
+                    const int64_t o = (int64_t)row * gridDim.x + split;
+                    part_max[o] = x.m;
+                    part_arg[o] = x.arg;
+                    part_sum[o] = x.s;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace gg
 
 using namespace gg;
@@ -328,10 +421,13 @@ extern "C" int gg_all_score_reduce(gg_ctx *ctx, const int32_t *rows, int32_t n_r
     const int KS = ks_need <= 4 ? 4 : ks_need <= 8 ? 8 : ks_need <= 16 ? 16 : 32;
     const int ld16 = 16 * KS;
     const int RB = (precision == 1 && KS <= 8) ? 2 : 1;
-    const int tile_rows = 32 * RB;
+    // bf16, many rows: a workgroup's four wavefronts take four row blocks and share the table sweep (all_score_reduce_bf16_rows_kernel)
+    const bool wide = precision == 1 && n_rows >= 512 && !getenv("GG_ALLPAIRS_NARROW");
+    const int RBW = KS <= 8 ? 4 : (KS <= 16 ? 2 : 1);  // row blocks per wavefront of the wide kernel: as many as the registers of ONE wave per SIMD hold
+    const int tile_rows = wide ? 128 * RBW : 32 * RB;
     const int row_tiles = cdiv(n_rows, tile_rows);
     // enough workgroups for the chip: split the columns when there are few row tiles (multiples of 128 columns)
-    int splits = std::max(1, std::min(cdiv(n, 128), cdiv(2048, row_tiles)));
+    int splits = std::max(1, std::min(cdiv(n, 128), cdiv(wide ? 1024 : 2048, row_tiles)));
     int cps = cdiv(cdiv(n, splits), 128) * 128;
     splits = cdiv(n, cps);
     DevBuf d_rows, d_pm, d_pa, d_ps, d_bf;
@@ -362,11 +458,20 @@ extern "C" int gg_all_score_reduce(gg_ctx *ctx, const int32_t *rows, int32_t n_r
 #define GG_BF16_LAUNCH(KSV, RBV)                                                                                                    \
     hipLaunchKernelGGL((all_score_reduce_bf16_kernel<KSV, RBV>), grid, dim3(256), 0, ctx->stream, Eb, G.b, n, dr, n_rows, cps, want_lse, \
                        d_pm.as<float>(), d_pa.as<int32_t>(), d_ps.as<float>())
-        if (KS <= 4) { GG_BF16_LAUNCH(4, 2); }
+#define GG_BF16_ROWS(KSV, RBV)                                                                                                           \
+    hipLaunchKernelGGL((all_score_reduce_bf16_rows_kernel<KSV, RBV>), grid, dim3(256), 0, ctx->stream, Eb, G.b, n, dr, n_rows, cps, want_lse, \
+                       d_pm.as<float>(), d_pa.as<int32_t>(), d_ps.as<float>())
+        if (wide) {
+            if (KS <= 4) { GG_BF16_ROWS(4, 4); }
+            else if (KS <= 8) { GG_BF16_ROWS(8, 4); }
+            else if (KS <= 16) { GG_BF16_ROWS(16, 2); }
+            else { GG_BF16_ROWS(32, 1); }
+        } else if (KS <= 4) { GG_BF16_LAUNCH(4, 2); }
         else if (KS <= 8) { GG_BF16_LAUNCH(8, 2); }
         else if (KS <= 16) { GG_BF16_LAUNCH(16, 1); }
         else { GG_BF16_LAUNCH(32, 1); }
 #undef GG_BF16_LAUNCH
+#undef GG_BF16_ROWS
     }
     (void)hipEventRecord(ctx->ev1, ctx->stream);
     std::vector<float> pm(np), ps(np);

@@ -615,6 +615,17 @@ def test_all_score_streamed_consumer(ga, n, d, precision):
     all_rows = eng.all_score_reduce(None, precision=precision, logsumexp=False)
     assert np.array_equal(all_rows["argmax"][rows], res["argmax"]) and all_rows["logsumexp"] is None
     assert res["kernel_ms"] > 0
+    if precision == "bf16" and n >= 512:
+        # many rows: the workgroup's wavefronts take four row blocks and share the table sweep; same scores, same answers
+        wide = eng.all_score_reduce(None, precision=precision)
+        os.environ["GG_ALLPAIRS_NARROW"] = "1"
+        try:
+            narrow = eng.all_score_reduce(None, precision=precision)
+        finally:
+            del os.environ["GG_ALLPAIRS_NARROW"]
+        assert np.array_equal(wide["max"], narrow["max"]) and np.array_equal(wide["argmax"], narrow["argmax"])
+        assert np.allclose(wide["logsumexp"], narrow["logsumexp"], rtol=1e-5, atol=1e-5)
+        assert np.array_equal(wide["argmax"][rows], res["argmax"])
     eng.close()
 
 
