@@ -327,7 +327,7 @@ def main():
             return {"traffic": None}
         v = gbs(t * launches, ms)
         return {"traffic": t, "traffic_source": src, "traffic_GBs": v, "traffic_frac": frac(v)}
-    kd_g, kd_o = gbs((16.0 * d + 20.0) * c["d_pairs_timed"], c["d_grad_ms"]), gbs(row_b * c["d_rows_timed"], c["d_opt_ms"])
+    kd_g = gbs((16.0 * d + 20.0) * c["d_pairs_timed"], c["d_grad_ms"])
     kg_g = gbs((16.0 * d + 20.0) * c["g_pairs_timed"], c["g_grad_ms"])
     # G pass, staged gradient (single replica): the gradient kernel reads every path node's row once and stores one staged
     # row per node (8d + 16 per node); the reducing optimizer reads the staged rows (4d + 4 each) and reads + writes E, m, v
@@ -336,10 +336,14 @@ def main():
     g_nodes = nodes_per_pair * c["g_pairs_timed"]
     staged = world == 1 and args.optimizer != "adam_dense" and not os.environ.get("GG_NO_STAGED_GRAD") and os.environ.get("GG_STAGE_T") != "0"
     kg_nodes = gbs((8.0 * d + 16.0) * g_nodes, c["g_grad_ms"])
+    row_st = 24.0 * d + 24.0 if args.optimizer != "sgd" else 8.0 * d + 8.0
     if staged:
-        kg_o = gbs((24.0 * d + 24.0 if args.optimizer != "sgd" else 8.0 * d + 8.0) * c["g_rows_timed"] + (4.0 * d + 4.0) * g_nodes, c["g_opt_ms"])
+        kg_o = gbs(row_st * c["g_rows_timed"] + (4.0 * d + 4.0) * g_nodes, c["g_opt_ms"])
+        # D pass: one staged row per pair (v side) + one per run of equal centres inside 16 pairs (u side)
+        kd_o = gbs(row_st * c["d_rows_timed"] + (4.0 * d + 4.0) * c["d_pairs_timed"] * (1.0 + 1.0 / 16.0), c["d_opt_ms"])
     else:
         kg_o = gbs(row_b * c["g_rows_timed"], c["g_opt_ms"])
+        kd_o = gbs(row_b * c["d_rows_timed"], c["d_opt_ms"])
     kd_s = gbs((48.0 * d + 36.0) * c["d_pairs_timed"], c["d_grad_ms"] + c["d_opt_ms"])
     kg_s = gbs((48.0 * d + 36.0) * c["g_pairs_timed"], c["g_grad_ms"] + c["g_opt_ms"])
     out = {
@@ -392,7 +396,7 @@ def main():
         "roofline_k34": {"bound": "hbm (fp32 atomics in L2)", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "bytes_model": "gradient kernel 16d + 20 per pair; whole step (gradient + optimizer) 48d + 36 per pair (SURVEY 8d, lazy Adam); "
                                         "traffic_* = HBM bytes of the PMC passes / the same event time: what the atomics really move",
-                         "d": dict({"kernel": "pair_grad_kernel", "achieved": kd_g, "frac": frac(kd_g), "step_achieved": kd_s, "step_frac": frac(kd_s),
+                         "d": dict({"kernel": "pair_grad_kernel (+ count / segment / slot kernels when staged)", "staged": bool(staged), "achieved": kd_g, "frac": frac(kd_g), "step_achieved": kd_s, "step_frac": frac(kd_s),
                                     "pairs": int(c["d_pairs_timed"]), "grad_ms": c["d_grad_ms"], "passes": int(c["d_passes_timed"])},
                                    **by_traffic("pair_grad_kernel", c["d_grad_ms"], c["d_passes_timed"])),
                          "g": dict({"kernel": "path_grad_kernel (+ count / segment / slot kernels when staged): reads every path node once and emits one gradient row per node",
@@ -404,7 +408,8 @@ def main():
                                    **by_traffic("path_grad_kernel", c["g_grad_ms"], c["g_passes_timed"]))},
         "roofline_opt": {"kernel": "sparse_opt_kernel (+ flag scan / compaction%s)" % (", replica exchange" if world > 1 else ""), "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "bytes_model": "%s per touched row" % ("32d + 32 (E, m, v read + written, gradient read + cleared)" if args.optimizer != "sgd" else "16d + 16"),
-                         "d": {"achieved": kd_o, "frac": frac(kd_o), "rows": int(c["d_rows_timed"]), "ms": c["d_opt_ms"]},
+                         "d": {"achieved": kd_o, "frac": frac(kd_o), "rows": int(c["d_rows_timed"]), "ms": c["d_opt_ms"],
+                               "bytes_model": ("staged_opt_kernel: 24d + 24 per touched row + 4d + 4 per staged gradient row (pairs x 17/16)" if staged else "32d + 32 per touched row")},
                          "g": {"achieved": kg_o, "frac": frac(kg_o), "rows": int(c["g_rows_timed"]), "ms": c["g_opt_ms"],
                                "bytes_model": ("staged_opt_kernel: 24d + 24 per touched row (E, m, v read + written) + 4d + 4 per staged gradient row" if staged else "as d")}},
         "walk_phase": {"ms_per_walk_sample_call": walk_ms / max(launches, 1), "calls": calls, "calls_timed": int(launches),

@@ -36,7 +36,31 @@ struct StepArgs {
     const int64_t *n_glob; // multi-GPU G step: pairs of ALL ranks in this step (device word) -> inv_n = 1 / *n_glob
     int is_d;
     int ppg;               // consecutive pairs handled by one 16-lane group
+    // STAGED (large fused batches on one replica, see path_count_kernel): stage row of the v-side gradient of pair p, and of
+    // the u-side gradient of the run that ends at pair p (-2: no run ends there); -1 = hub row, atomics as before
+    const int32_t *slot_v, *slot_u;
+    float *stage, *stage_b;
 };
+
+// occurrences of every table row in a fused batch, as the gradient kernel will emit them: one per pair for v, one per
+// run of equal u inside a group's ppg pairs for u; the returned rank becomes the row's slot inside its stage segment
+__global__ __launch_bounds__(256) void pair_occ_count_kernel(const int32_t *u, const int32_t *v, int n, int ppg, int32_t *cnt,
+                                                             int32_t *slot_v, int32_t *slot_u) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    slot_v[p] = atomicAdd(&cnt[v[p]], 1);
+    const bool run_end = p == n - 1 || (p + 1) % ppg == 0 || u[p + 1] != u[p];
+    slot_u[p] = run_end ? atomicAdd(&cnt[u[p]], 1) : -2;
+}
+
+__global__ __launch_bounds__(256) void pair_occ_slot_kernel(const int32_t *u, const int32_t *v, int n, const int32_t *cnt, const int32_t *off,
+                                                            int T, int32_t *slot_v, int32_t *slot_u) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int iv = v[p], iu = u[p];
+    slot_v[p] = cnt[iv] <= T ? off[iv] + slot_v[p] : -1;
+    if (slot_u[p] != -2) slot_u[p] = cnt[iu] <= T ? off[iu] + slot_u[p] : -1;
+}
 
 // One 16-lane group per run of PAIRS_PER_GROUP consecutive pairs.  The reference's batches are
 // contiguous slices of the prepare-order lists (a13): a D slice is one root's rows (same u for
@@ -44,13 +68,13 @@ struct StepArgs {
 // The u-side gradient is therefore accumulated in registers while u stays the same and flushed
 // with one row of atomics per run; the v side goes out per pair.  Lane t owns floats t, t+16, ...
 // so that one atomic instruction of the group covers one contiguous 64-byte line.
+// Large fused batches on one replica stage their gradient rows instead (STAGED, see path_count_kernel).
 // Measured and not kept (round 2, D pass beside the generator's walks): a grid capped at 6 workgroups per CU with a
-// grid-stride loop (the walks of the other stream start no earlier, this kernel +10 %); plain stores instead of atomics for
-// rows the batch names once (needs a counting pass; step time unchanged -- the pass shares the chip with the walks and
-// the sum of the work is what counts).
+// grid-stride loop (the walks of the other stream start no earlier, this kernel +10 %); plain stores instead of atomics only
+// for rows the batch names once (no gain over atomics: the accumulator round trip stays).
 constexpr int PAIRS_PER_GROUP = 16;  // large fused batches; small (B = 64) batches use 1 pair per group: latency, not contention, rules there
 
-template <int NF>  // NF = ceil(ld / 16) floats per lane
+template <int NF, bool STAGED>  // NF = ceil(ld / 16) floats per lane
 __global__ __launch_bounds__(256) void pair_grad_kernel(const StepArgs a) {
     const int t = threadIdx.x & 15;
     const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -63,16 +87,32 @@ __global__ __launch_bounds__(256) void pair_grad_kernel(const StepArgs a) {
 #pragma unroll
     for (int i = 0; i < NF; ++i) accu[i] = 0.f;
     int run_u = a.u[p0];
-    for (int p = p0; p < p1; ++p) {
-        const int iu = a.u[p], iv = a.v[p];
-        if (iu != run_u) {  // flush the finished run of u
-            float *gu = a.gE + (int64_t)run_u * a.ld;
+    auto flush_u = [&](int q) {
+        const int sl = STAGED ? a.slot_u[q] : -1;
+        if (STAGED && sl >= 0) {
+            float *g = a.stage + (int64_t)sl * a.ld;
 #pragma unroll
             for (int i = 0; i < NF; ++i) {
                 const int f = t + 16 * i;
-                if (f < a.ld) atomicAdd(gu + f, accu[i]);
-                accu[i] = 0.f;
+                if (f < a.ld) g[f] = accu[i];
             }
+            if (t == 0) a.stage_b[sl] = 0.f;
+            return;
+        }
+        float *gu = a.gE + (int64_t)run_u * a.ld;
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int f = t + 16 * i;
+            if (f < a.ld) atomicAdd(gu + f, accu[i]);
+        }
+        if (t == 0 && a.track) a.touched[run_u] = 1;
+    };
+    for (int p = p0; p < p1; ++p) {
+        const int iu = a.u[p], iv = a.v[p];
+        if (iu != run_u) {  // flush the finished run of u (it ended at pair p - 1)
+            flush_u(p - 1);
+#pragma unroll
+            for (int i = 0; i < NF; ++i) accu[i] = 0.f;
             run_u = iu;
         }
         const float4 *ru = (const float4 *)(a.E + (int64_t)iu * a.ld);
@@ -99,31 +139,32 @@ __global__ __launch_bounds__(256) void pair_grad_kernel(const StepArgs a) {
             const bool inside = (sg >= 1e-5f) && (sg <= 1.0f);
             ds = inside ? -(a.x[p] * inv_n) * (1.0f - sg) : 0.0f;
         }
-        float *gv = a.gE + (int64_t)iv * a.ld;
         const float *fu = (const float *)ru, *fv = (const float *)rv;  // rows were just read: L1/L2 hits
+        const int slv = STAGED ? a.slot_v[p] : -1;
+        const bool st = STAGED && slv >= 0;
+        float *gv = st ? a.stage + (int64_t)slv * a.ld : a.gE + (int64_t)iv * a.ld;
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
             const int f = t + 16 * i;
             if (f < a.ld) {
                 const float x = fu[f], y = fv[f];
                 accu[i] += ds * y + a.lambda * x;
-                atomicAdd(gv + f, ds * x + a.lambda * y);
+                const float gval = ds * x + a.lambda * y;
+                if (st) gv[f] = gval;
+                else atomicAdd(gv + f, gval);
             }
         }
         if (t == 0) {
-            atomicAdd(a.gb + iv, a.is_d ? ds + a.lambda * bv : ds);
-            if (a.track) {  // plain flag stores; the row list is built by a scan (no contended atomics)
-                a.touched[iu] = 1;
-                a.touched[iv] = 1;
+            const float gbv = a.is_d ? ds + a.lambda * bv : ds;
+            if (st) {
+                a.stage_b[slv] = gbv;
+            } else {
+                atomicAdd(a.gb + iv, gbv);
+                if (a.track) a.touched[iv] = 1;  // plain flag stores; the row list is built by a scan (no contended atomics)
             }
         }
     }
-    float *gu = a.gE + (int64_t)run_u * a.ld;
-#pragma unroll
-    for (int i = 0; i < NF; ++i) {
-        const int f = t + 16 * i;
-        if (f < a.ld) atomicAdd(gu + f, accu[i]);
-    }
+    flush_u(p1 - 1);
 }
 
 // Deterministic variant for the reference's small batches (n <= DET_MAX_PAIRS; GG_DETERMINISTIC=1):
@@ -708,6 +749,46 @@ static int global_pair_count(gg_ctx *ctx, int64_t n_local, const int64_t **out) 
     return GG_OK;
 }
 
+// ---- staged gradient, host side (see path_count_kernel): buffers for up to n_occ staged rows ...
+static int staged_reserve(gg_ctx *ctx, int64_t n_occ) {
+    const size_t cnt_before = ctx->sg_cnt.bytes;
+    GG_HIP(ctx, ctx->sg_cnt.reserve(sizeof(int32_t) * (size_t)ctx->n_node));
+    if (ctx->sg_cnt.bytes != cnt_before) GG_HIP(ctx, hipMemsetAsync(ctx->sg_cnt.p, 0, ctx->sg_cnt.bytes, ctx->stream));  // afterwards every update resets its rows
+    GG_HIP(ctx, ctx->sg_off.reserve(sizeof(int32_t) * (size_t)ctx->n_node));
+    GG_HIP(ctx, ctx->sg_list.reserve(sizeof(int4) * (size_t)ctx->n_node));
+    GG_HIP(ctx, ctx->sg_slot.reserve(sizeof(int32_t) * (size_t)n_occ));
+    GG_HIP(ctx, ctx->sg_rows.reserve(sizeof(float) * (size_t)n_occ * ctx->ld));
+    GG_HIP(ctx, ctx->sg_bias.reserve(sizeof(float) * (size_t)n_occ));
+    GG_HIP(ctx, ctx->sg_tot.reserve(sizeof(int64_t) * 4));
+    return GG_OK;
+}
+
+// ... and the update behind the gradient kernel: the small rows by the reducing optimizer, the hub rows through the flag
+// list and sparse_opt_kernel (apply_optimizer, which also advances the step count), the updated-row total for the timing
+static int staged_finish(gg_ctx *ctx, int which, int64_t n, int64_t n_occ) {
+    const int opt = ctx->cfg.optimizer;
+    OptArgs o = make_opt_args(ctx, which);  // before apply_optimizer advances the step count and the beta powers
+    o.sg_cnt = ctx->sg_cnt.as<int32_t>(); o.sg_list = ctx->sg_list.as<int4>(); o.sg_tot = ctx->sg_tot.as<int64_t>();
+    o.stage = ctx->sg_rows.as<float>(); o.stage_b = ctx->sg_bias.as<float>();
+    int nb = cdiv((int64_t)std::min<int64_t>(n_occ, ctx->n_node) * 16, 256);
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    if (opt == GG_OPT_SGD) hipLaunchKernelGGL(staged_opt_kernel<1>, dim3(nb), dim3(256), 0, ctx->stream, o);
+    else hipLaunchKernelGGL(staged_opt_kernel<0>, dim3(nb), dim3(256), 0, ctx->stream, o);
+    ctx->sg_active = true;  // the hub rows: flags -> list -> sparse_opt_kernel, which also resets their counts
+    const int rc = apply_optimizer(ctx, which, n);
+    ctx->sg_active = false;
+    if (rc != GG_OK) return rc;
+    // rows this pass updated (read back by the timing harvest): hub rows + small rows
+    hipLaunchKernelGGL(add_word_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->touched_ptr.as<int64_t>() + ctx->n_node, ctx->sg_tot.as<int64_t>());
+    GG_HIP(ctx, hipGetLastError());
+    return GG_OK;
+}
+
+static bool staged_allowed(const gg_ctx *ctx) {
+    return ctx->sg_threshold > 0 && !ctx->comm && ctx->fake_world <= 1 && ctx->cfg.optimizer != GG_OPT_ADAM_DENSE && !getenv("GG_NO_STAGED_GRAD");
+}
+
 // One optimizer step of model `which` on n device-resident rows.
 // Strict mode (batch 64, dense TF1-Adam, the reference's default schedule) is two launches per step: the gradient kernel
 // and the dense sweep, ~8.8 us together on CA-GrQc -- the cost of two dependent kernel boundaries.  Measured on the
@@ -745,10 +826,29 @@ int run_step(gg_ctx *ctx, int which, const int32_t *d_u, const int32_t *d_v, con
     const int groups = cdiv(n, s.ppg);
     const int blocks = cdiv((int64_t)groups * 16, 256);
     const int nf = (ctx->ld + 15) / 16;
-    if (nf <= 4) hipLaunchKernelGGL(pair_grad_kernel<4>, dim3(blocks), dim3(256), 0, ctx->stream, s);
-    else if (nf <= 8) hipLaunchKernelGGL(pair_grad_kernel<8>, dim3(blocks), dim3(256), 0, ctx->stream, s);
-    else if (nf <= 16) hipLaunchKernelGGL(pair_grad_kernel<16>, dim3(blocks), dim3(256), 0, ctx->stream, s);
-    else hipLaunchKernelGGL(pair_grad_kernel<32>, dim3(blocks), dim3(256), 0, ctx->stream, s);
+    // large fused batches on one replica: staged gradient rows + reducing optimizer instead of fp32 atomics (see path_count_kernel)
+    const bool staged = n >= 16384 && staged_allowed(ctx);
+    if (staged) {
+        int rc = staged_reserve(ctx, 2 * (int64_t)n);
+        if (rc != GG_OK) return rc;
+        int32_t *cnt = ctx->sg_cnt.as<int32_t>(), *off = ctx->sg_off.as<int32_t>(), *slot_v = ctx->sg_slot.as<int32_t>(), *slot_u = slot_v + n;
+        hipLaunchKernelGGL(pair_occ_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, d_u, d_v, n, s.ppg, cnt, slot_v, slot_u);
+        rc = device_segment_rows(ctx, cnt, ctx->n_node, ctx->sg_threshold, off, ctx->sg_list.as<int4>(), ctx->sg_tot.as<int64_t>());
+        if (rc != GG_OK) return rc;
+        hipLaunchKernelGGL(pair_occ_slot_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, d_u, d_v, n, cnt, off, ctx->sg_threshold, slot_v, slot_u);
+        s.slot_v = slot_v; s.slot_u = slot_u;
+        s.stage = ctx->sg_rows.as<float>(); s.stage_b = ctx->sg_bias.as<float>();
+        if (nf <= 4) hipLaunchKernelGGL((pair_grad_kernel<4, true>), dim3(blocks), dim3(256), 0, ctx->stream, s);
+        else if (nf <= 8) hipLaunchKernelGGL((pair_grad_kernel<8, true>), dim3(blocks), dim3(256), 0, ctx->stream, s);
+        else if (nf <= 16) hipLaunchKernelGGL((pair_grad_kernel<16, true>), dim3(blocks), dim3(256), 0, ctx->stream, s);
+        else hipLaunchKernelGGL((pair_grad_kernel<32, true>), dim3(blocks), dim3(256), 0, ctx->stream, s);
+        if (ctx->tm_cur >= 0) GG_HIP(ctx, hipEventRecord(ctx->tm_ev[ctx->tm_cur][1], ctx->stream));  // gradient | optimizer
+        return staged_finish(ctx, which, n, 2 * (int64_t)n);
+    }
+    if (nf <= 4) hipLaunchKernelGGL((pair_grad_kernel<4, false>), dim3(blocks), dim3(256), 0, ctx->stream, s);
+    else if (nf <= 8) hipLaunchKernelGGL((pair_grad_kernel<8, false>), dim3(blocks), dim3(256), 0, ctx->stream, s);
+    else if (nf <= 16) hipLaunchKernelGGL((pair_grad_kernel<16, false>), dim3(blocks), dim3(256), 0, ctx->stream, s);
+    else hipLaunchKernelGGL((pair_grad_kernel<32, false>), dim3(blocks), dim3(256), 0, ctx->stream, s);
     if (ctx->tm_cur >= 0) GG_HIP(ctx, hipEventRecord(ctx->tm_ev[ctx->tm_cur][1], ctx->stream));  // gradient | exchange + optimizer
 
     return apply_optimizer(ctx, which, n);
@@ -792,29 +892,20 @@ int run_path_step(gg_ctx *ctx) {
     }
     const int blocks = cdiv(p.n_walks * 16, 256);
     const int nf = (ctx->ld + 15) / 16;
-    const int opt = ctx->cfg.optimizer;
     const int64_t n_pos = p.n_walks * (int64_t)p.stride;
-    const bool staged = ctx->sg_threshold > 0 && !ctx->comm && ctx->fake_world <= 1 && opt != GG_OPT_ADAM_DENSE && n_pos < (1ll << 31) &&
-                        !getenv("GG_NO_STAGED_GRAD");
+    const bool staged = staged_allowed(ctx) && n_pos < (1ll << 31);
     if (!staged) {
         launch_path_grad<false>(ctx, p, blocks, nf);
         if (ctx->tm_cur >= 0) GG_HIP(ctx, hipEventRecord(ctx->tm_ev[ctx->tm_cur][1], ctx->stream));  // gradient | exchange + optimizer
         return apply_optimizer(ctx, 0, n);
     }
     // ---- staged gradient (see path_count_kernel)
-    const size_t cnt_before = ctx->sg_cnt.bytes;
-    GG_HIP(ctx, ctx->sg_cnt.reserve(sizeof(int32_t) * (size_t)ctx->n_node));
-    if (ctx->sg_cnt.bytes != cnt_before) GG_HIP(ctx, hipMemsetAsync(ctx->sg_cnt.p, 0, ctx->sg_cnt.bytes, ctx->stream));  // afterwards every update resets its rows
-    GG_HIP(ctx, ctx->sg_off.reserve(sizeof(int32_t) * (size_t)ctx->n_node));
-    GG_HIP(ctx, ctx->sg_list.reserve(sizeof(int4) * (size_t)ctx->n_node));
-    GG_HIP(ctx, ctx->sg_slot.reserve(sizeof(int32_t) * (size_t)n_pos));
-    GG_HIP(ctx, ctx->sg_rows.reserve(sizeof(float) * (size_t)n_pos * ctx->ld));
-    GG_HIP(ctx, ctx->sg_bias.reserve(sizeof(float) * (size_t)n_pos));
-    GG_HIP(ctx, ctx->sg_tot.reserve(sizeof(int64_t) * 4));
+    int rc = staged_reserve(ctx, n_pos);
+    if (rc != GG_OK) return rc;
     int32_t *cnt = ctx->sg_cnt.as<int32_t>(), *off = ctx->sg_off.as<int32_t>(), *slot = ctx->sg_slot.as<int32_t>();
     const dim3 pgrid((unsigned)cdiv(n_pos, 256));
     hipLaunchKernelGGL(path_count_kernel, pgrid, dim3(256), 0, ctx->stream, p.paths, p.path_len, p.stride, p.n_walks, cnt, slot);
-    int rc = device_segment_rows(ctx, cnt, ctx->n_node, ctx->sg_threshold, off, ctx->sg_list.as<int4>(), ctx->sg_tot.as<int64_t>());
+    rc = device_segment_rows(ctx, cnt, ctx->n_node, ctx->sg_threshold, off, ctx->sg_list.as<int4>(), ctx->sg_tot.as<int64_t>());
     if (rc != GG_OK) return rc;
     hipLaunchKernelGGL(path_slot_kernel, pgrid, dim3(256), 0, ctx->stream, p.paths, p.path_len, p.stride, p.n_walks, cnt, off, ctx->sg_threshold, slot);
     p.slot = slot;
@@ -822,21 +913,7 @@ int run_path_step(gg_ctx *ctx) {
     p.stage_b = ctx->sg_bias.as<float>();
     launch_path_grad<true>(ctx, p, blocks, nf);
     if (ctx->tm_cur >= 0) GG_HIP(ctx, hipEventRecord(ctx->tm_ev[ctx->tm_cur][1], ctx->stream));  // gradient | optimizer
-    OptArgs o = make_opt_args(ctx, 0);  // before apply_optimizer advances the step count and the beta powers
-    o.sg_cnt = cnt; o.sg_list = ctx->sg_list.as<int4>(); o.sg_tot = ctx->sg_tot.as<int64_t>();
-    o.stage = p.stage; o.stage_b = p.stage_b;
-    int nb = cdiv((int64_t)std::min<int64_t>(n_pos, ctx->n_node) * 16, 256);
-    if (nb > 4096) nb = 4096;
-    if (opt == GG_OPT_SGD) hipLaunchKernelGGL(staged_opt_kernel<1>, dim3(nb), dim3(256), 0, ctx->stream, o);
-    else hipLaunchKernelGGL(staged_opt_kernel<0>, dim3(nb), dim3(256), 0, ctx->stream, o);
-    ctx->sg_active = true;  // the hub rows: flags -> list -> sparse_opt_kernel, which also resets their counts
-    rc = apply_optimizer(ctx, 0, n);
-    ctx->sg_active = false;
-    if (rc != GG_OK) return rc;
-    // rows this pass updated (read back by the timing harvest): hub rows + small rows
-    hipLaunchKernelGGL(add_word_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->touched_ptr.as<int64_t>() + ctx->n_node, ctx->sg_tot.as<int64_t>());
-    GG_HIP(ctx, hipGetLastError());
-    return GG_OK;
+    return staged_finish(ctx, 0, n, n_pos);
 }
 
 __global__ void normalize_flags_kernel(int32_t *f, int n) {  // after the cross-rank sum: counts -> 0/1
