@@ -581,10 +581,13 @@ __global__ __launch_bounds__(256) void sparse_opt_kernel(const OptArgs a) {
     for (int r = g0; r < cnt; r += ng) opt_row<SGD>(a, a.touched_list[r], t, nchunk);
 }
 
-// Small rows of the staged generator gradient: one 16-lane group per row sums the row's segment of the stage buffer in
-// slot order (contiguous 512-byte rows, four in flight) and applies lazy Adam / SGD with the sum in registers.
-template <int SGD>
+// Small rows of the staged gradient: one 16-lane group per row sums the row's segment of the stage buffer in slot order
+// (contiguous 512-byte rows, four in flight) and applies lazy Adam (MODE 0) / SGD (MODE 1) with the sum in registers.
+// MODE 2 (replicas): the sum goes to the gradient accumulators instead -- plain stores, the row's flag set -- and the
+// exchange + sparse_opt_kernel path takes it from there like an atomically accumulated gradient.
+template <int MODE>
 __global__ __launch_bounds__(256) void staged_opt_kernel(const OptArgs a) {
+    constexpr bool SGD = MODE == 1;
     const int t = threadIdx.x & 15;
     const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4, ng = ((int64_t)gridDim.x * blockDim.x) >> 4;
     const int64_t n_rows = a.sg_tot[0];
@@ -631,6 +634,19 @@ __global__ __launch_bounds__(256) void staged_opt_kernel(const OptArgs a) {
             gbias += __shfl_xor(gbias, 1, 64);
         }
         const int64_t o4 = ((int64_t)row * a.ld) >> 2;
+        if (MODE == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = t + 16 * i;
+                if (c < nchunk) ((float4 *)a.gE)[o4 + c] = g[i];
+            }
+            if (t == 0) {
+                a.gb[row] = gbias;
+                a.touched[row] = 1;
+                a.sg_cnt[row] = 0;
+            }
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = t + 16 * i;
@@ -773,20 +789,23 @@ static int staged_finish(gg_ctx *ctx, int which, int64_t n, int64_t n_occ) {
     int nb = cdiv((int64_t)std::min<int64_t>(n_occ, ctx->n_node) * 16, 256);
     if (nb > 4096) nb = 4096;
     if (nb < 1) nb = 1;
-    if (opt == GG_OPT_SGD) hipLaunchKernelGGL(staged_opt_kernel<1>, dim3(nb), dim3(256), 0, ctx->stream, o);
+    const bool replicas = ctx->comm || ctx->fake_world > 1;  // the summed rows go through the accumulators and the exchange
+    if (replicas) hipLaunchKernelGGL(staged_opt_kernel<2>, dim3(nb), dim3(256), 0, ctx->stream, o);
+    else if (opt == GG_OPT_SGD) hipLaunchKernelGGL(staged_opt_kernel<1>, dim3(nb), dim3(256), 0, ctx->stream, o);
     else hipLaunchKernelGGL(staged_opt_kernel<0>, dim3(nb), dim3(256), 0, ctx->stream, o);
     ctx->sg_active = true;  // the hub rows: flags -> list -> sparse_opt_kernel, which also resets their counts
     const int rc = apply_optimizer(ctx, which, n);
     ctx->sg_active = false;
     if (rc != GG_OK) return rc;
     // rows this pass updated (read back by the timing harvest): hub rows + small rows
-    hipLaunchKernelGGL(add_word_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->touched_ptr.as<int64_t>() + ctx->n_node, ctx->sg_tot.as<int64_t>());
+    if (!replicas)
+        hipLaunchKernelGGL(add_word_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->touched_ptr.as<int64_t>() + ctx->n_node, ctx->sg_tot.as<int64_t>());
     GG_HIP(ctx, hipGetLastError());
     return GG_OK;
 }
 
 static bool staged_allowed(const gg_ctx *ctx) {
-    return ctx->sg_threshold > 0 && !ctx->comm && ctx->fake_world <= 1 && ctx->cfg.optimizer != GG_OPT_ADAM_DENSE && !getenv("GG_NO_STAGED_GRAD");
+    return ctx->sg_threshold > 0 && ctx->cfg.optimizer != GG_OPT_ADAM_DENSE && !getenv("GG_NO_STAGED_GRAD");
 }
 
 // One optimizer step of model `which` on n device-resident rows.

@@ -465,13 +465,20 @@ def test_all_score_rows_on_mfma(ga, n, d):
     eng.close()
 
 
-@pytest.mark.parametrize("mode", ["sgd", "lazy", "sgd-dense-fallback"])
+@pytest.mark.parametrize("mode", ["sgd", "lazy", "sgd-dense-fallback", "lazy-staged", "sgd-staged-dense-fallback"])
 def test_sparse_exchange_with_simulated_ranks(ga, mode, monkeypatch):
     """The replica gradient exchange of the lazy / sgd modes packs touched rows, all-gathers the
     packs and adds them in rank order.  gpurun has one GPU, so GG_COMM_FAKE_WORLD=3 feeds the
     3-rank code path with three copies of the local pack: the applied gradient must be exactly
     3x the local one (offsets, counts, per-rank launches, flag union all exercised)."""
     monkeypatch.setenv("GG_COMM_FAKE_WORLD", "3")
+    # "-staged": batches large enough for the staged gradient (>= 16 384 pairs; every row counts as small): with replicas the
+    # reducing kernel writes the row sums into the accumulators and the exchange takes them from there
+    B = 2000
+    if "staged" in mode:
+        B = 20000
+        monkeypatch.setenv("GG_STAGE_T", "1000000")
+        mode = mode.replace("-staged", "")
     if mode.endswith("dense-fallback"):  # force the "replicas may touch most of the table" branch
         monkeypatch.setenv("GG_COMM_DENSE_RATIO", "0")
         mode = "sgd"
@@ -483,11 +490,11 @@ def test_sparse_exchange_with_simulated_ranks(ga, mode, monkeypatch):
     eng = engine_with(ga, Eg, Ed, bg, bd, optimizer=opt)
     monkeypatch.delenv("GG_COMM_FAKE_WORLD")
     monkeypatch.delenv("GG_COMM_DENSE_RATIO", raising=False)
+    monkeypatch.delenv("GG_STAGE_T", raising=False)
     dis = orc.Discriminator(Ed, 1e-3, lazy=True)
     dis.b[:] = bd
     rs = np.random.RandomState(8)
     for t in range(3):
-        B = 2000
         u, v = rs.randint(0, n // 2, B), rs.randint(0, n // 2, B)
         lab = (rs.rand(B) < 0.5).astype(np.float32)
         _, gu, gv, gb = dis.loss_and_grads(u, v, lab, 1e-5)
