@@ -183,6 +183,7 @@ struct gg_ctx {
     // the stage itself (gradient rows + bias gradients of the small rows, segment by segment), two total words
     gg::DevBuf sg_cnt, sg_off, sg_slot, sg_list, sg_rows, sg_bias, sg_tot;
     bool g_pairs_filled = false;       // g_node1 / g_node2 hold the pairs of the resident G walks (prepare.hip, ensure_g_pairs)
+    bool sg_cnt_dirty = false;         // a staged pass counted rows and has not (yet) applied them
     bool sg_active = false;            // a staged G pass is applying its hub rows (apply_optimizer resets their counts)
     int sg_threshold = 64;             // GG_STAGE_T: rows with more staged gradients than this keep the atomic path; 0 = everything atomic
 

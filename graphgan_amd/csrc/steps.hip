@@ -769,7 +769,10 @@ static int global_pair_count(gg_ctx *ctx, int64_t n_local, const int64_t **out) 
 static int staged_reserve(gg_ctx *ctx, int64_t n_occ) {
     const size_t cnt_before = ctx->sg_cnt.bytes;
     GG_HIP(ctx, ctx->sg_cnt.reserve(sizeof(int32_t) * (size_t)ctx->n_node));
-    if (ctx->sg_cnt.bytes != cnt_before) GG_HIP(ctx, hipMemsetAsync(ctx->sg_cnt.p, 0, ctx->sg_cnt.bytes, ctx->stream));  // afterwards every update resets its rows
+    // the counts are zero between passes -- every update resets the rows it applies -- unless the buffer is new or an earlier
+    // staged pass failed half way (sg_cnt_dirty stays set): then they are cleared here, stale counts would mis-place stage rows
+    if (ctx->sg_cnt.bytes != cnt_before || ctx->sg_cnt_dirty) GG_HIP(ctx, hipMemsetAsync(ctx->sg_cnt.p, 0, ctx->sg_cnt.bytes, ctx->stream));
+    ctx->sg_cnt_dirty = true;
     GG_HIP(ctx, ctx->sg_off.reserve(sizeof(int32_t) * (size_t)ctx->n_node));
     GG_HIP(ctx, ctx->sg_list.reserve(sizeof(int4) * (size_t)ctx->n_node));
     GG_HIP(ctx, ctx->sg_slot.reserve(sizeof(int32_t) * (size_t)n_occ));
@@ -801,6 +804,7 @@ static int staged_finish(gg_ctx *ctx, int which, int64_t n, int64_t n_occ) {
     if (!replicas)
         hipLaunchKernelGGL(add_word_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->touched_ptr.as<int64_t>() + ctx->n_node, ctx->sg_tot.as<int64_t>());
     GG_HIP(ctx, hipGetLastError());
+    ctx->sg_cnt_dirty = false;
     return GG_OK;
 }
 
