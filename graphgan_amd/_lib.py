@@ -122,7 +122,7 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.gg_abi_version() != 1:
+    if lib.gg_abi_version() != 2:
         raise ImportError("graphgan_amd: ABI version mismatch")
     return lib
 

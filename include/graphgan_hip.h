@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GG_ABI_VERSION 1
+#define GG_ABI_VERSION 2  /* round 2: gg_counters extended, tree cache / streamed consumer / evaluator entry points */
 
 enum {
     GG_OK = 0,
