@@ -385,6 +385,38 @@ def test_staged_generator_gradient_equals_the_atomic_path(ga, opt, threshold, mo
     eng2.close()
 
 
+@pytest.mark.parametrize("dense_ratio", ["100", "0"])
+def test_staged_fused_passes_with_simulated_replicas(ga, dense_ratio, monkeypatch):
+    """With replicas (GG_COMM_FAKE_WORLD=2: the exchange code runs, every simulated rank brings this rank's gradient) the
+    staged rows are summed into the gradient accumulators and travel through the row packs (ratio 100) or the dense
+    exchange (ratio 0) like an atomically accumulated gradient: same tables as the atomic path, for the whole-walk G pass
+    and a fused D pass."""
+    monkeypatch.setenv("GG_COMM_FAKE_WORLD", "2")
+    monkeypatch.setenv("GG_COMM_DENSE_RATIO", dense_ratio)
+    monkeypatch.setenv("GG_STAGE_T", "64")
+    g, n, graph, rowptr, col, Ed, a = _setup_graph_engine(ga, optimizer=ga.GG_OPT_ADAM_LAZY)
+    monkeypatch.setenv("GG_STAGE_T", "0")
+    _, _, _, _, _, _, b = _setup_graph_engine(ga, optimizer=ga.GG_OPT_ADAM_LAZY)
+    for k in ("GG_COMM_FAKE_WORLD", "GG_COMM_DENSE_RATIO", "GG_STAGE_T"):
+        monkeypatch.delenv(k)
+    slots = np.arange(n, dtype=np.int32)
+    for e in (a, b):
+        pairs = e.prepare_g(slots, 20, 4, 1, fetch=False)
+        e.g_pass([0], pairs)
+    assert np.abs(a.get_embeddings(0) - g["E"]).max() > 1e-4
+    assert np.allclose(a.get_embeddings(0), b.get_embeddings(0), rtol=2e-5, atol=2e-6)
+    assert np.allclose(a.get_bias(0), b.get_bias(0), rtol=2e-5, atol=2e-6)
+    rs = np.random.RandomState(5)
+    u, v = rs.randint(0, n, 20000), rs.randint(0, n, 20000)
+    lab = (rs.rand(20000) < 0.5).astype(np.float32)
+    for e in (a, b):
+        e.d_step(u, v, lab)
+    assert np.allclose(a.get_embeddings(1), b.get_embeddings(1), rtol=2e-5, atol=2e-6)
+    assert np.allclose(a.get_bias(1), b.get_bias(1), rtol=2e-5, atol=2e-6)
+    a.close()
+    b.close()
+
+
 @pytest.mark.parametrize("d", [50, 200, 256])
 def test_fused_g_pass_embedding_widths(ga, d, monkeypatch):
     """Whole-walk reward + staged path gradient + reducing optimizer for rows that are not a multiple of 16 floats (d = 50:
