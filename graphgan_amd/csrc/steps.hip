@@ -820,6 +820,9 @@ static bool staged_allowed(const gg_ctx *ctx) {
 // cross-XCD arrive-and-poll is an order of magnitude dearer than a kernel boundary; (b) one fused launch per step (every
 // workgroup recomputes the 64 pair coefficients, variables double-buffered): correct, no faster (the chain ids -> rows ->
 // update is as long as the boundary it saves); (c) hipGraph replay of the two launches (round 1): no gain.
+// Considered and not built: (d) replaying TF1's decay-only updates lazily, when a row is next touched (bit-exact: the
+// per-element operation sequence is unchanged) in ONE single-workgroup kernel per pass -- it removes every dense sweep, but the
+// sweeps' N x steps element updates then run on one CU instead of 256: ~18 us per step on CA-GrQc.
 int run_step(gg_ctx *ctx, int which, const int32_t *d_u, const int32_t *d_v, const float *d_x, int32_t n) {
     if (n <= 0) return GG_OK;
     Model &M = ctx->model[which];
