@@ -94,6 +94,36 @@ def test_reduced_schedule_matches_oracle(tmp_path):
     assert row0[1] == str(float(eg[0, 0]))
 
 
+def test_fast_mode_schedule_matches_oracle(tmp_path):
+    """The scale mode through the user-facing trainer: one fused batch per inner epoch (batch sizes above the prepared rows),
+    lazy Adam, asynchronous passes -- i.e. whole-walk rewards, staged path gradient + reducing optimizer for G, the generic
+    pair kernel for D, distribution cache between the prepares -- against the oracle trainer in the same mode."""
+    base = str(tmp_path)
+    d, n, graph = write_reference_layout(base)
+    big = 1 << 30
+    cfg = make_cfg(base, n_epochs=1, n_epochs_dis=3, n_epochs_gen=3, dis_interval=3, gen_interval=3, engine_seed=23,
+                   batch_size_gen=big, batch_size_dis=big, engine_optimizer="adam_lazy", engine_profile_every=3)
+    from graphgan_amd.graph_gan import GraphGAN
+    g = GraphGAN(cfg)
+    g.train()
+    ocfg = orc.Config()
+    ocfg.n_epochs_dis = ocfg.n_epochs_gen = ocfg.dis_interval = ocfg.gen_interval = 3
+    ocfg.batch_size_gen = ocfg.batch_size_dis = big
+    o = orc.GraphGANOracle(n, graph, g.node_embed_init_g, g.node_embed_init_d, cfg=ocfg, rng="counter", arith="spec", seed=23, lazy_adam=True)
+    o.train_epoch(0)
+    eg, ed = g.generator.embedding_matrix, g.discriminator.embedding_matrix
+    for got, want in ((eg, o.generator.E), (ed, o.discriminator.E)):
+        diff = np.abs(got - want)
+        print("abs diff: mean %.3g p99 %.3g max %.3g" % (diff.mean(), np.quantile(diff, 0.99), diff.max()))
+        assert diff.mean() < 2e-5 and np.quantile(diff, 0.99) < 2e-4
+    assert np.abs(eg - g.node_embed_init_g.astype(np.float32)).max() > 1e-3  # training moved the tables
+    lines = open(cfg.result_filename).read().split()
+    acc_g, acc_d = float(lines[2][4:]), float(lines[3][4:])
+    oacc_g = orc.eval_link_prediction(o.generator.E.astype(np.float64), d["test"].tolist(), d["test_neg"].tolist())
+    oacc_d = orc.eval_link_prediction(o.discriminator.E.astype(np.float64), d["test"].tolist(), d["test_neg"].tolist())
+    assert abs(acc_g - oacc_g) <= 0.005 and abs(acc_d - oacc_d) <= 0.005
+
+
 def test_user_facing_api_shapes(tmp_path):
     """prepare_data_for_d / prepare_data_for_g / sample / get_node_pairs_from_path keep the reference's
     return shapes (graph_gan.py:182-291)."""
