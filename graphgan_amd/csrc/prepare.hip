@@ -286,10 +286,14 @@ __global__ __launch_bounds__(256) void path_reward_kernel(const float *E, const 
     if (L <= 1) return;
     const int32_t *p = paths + w * (int64_t)stride;
     const int nchunk = ld >> 2;
-    int64_t pi = ptr[w];
-    float4 R[5][NCH];  // window slots 0..4 = path positions c-2 .. c+2 of the centre c
-    float bv[5];
-    bool have[5];
+    const int64_t pi0 = ptr[w];
+    // FORWARD pairs only: the centre c takes its neighbours c+1, c+2; one dot product serves the pair (c, c+d) [bias of c+d]
+    // and its mirror (c+d, c) [bias of c], whose place in the pair list follows from the path length alone:
+    // pairs of centre i = its min(i, W) backward then its min(L-1-i, W) forward neighbours.  The (up to four) scores of a
+    // centre are spread over lanes 0..3, so the softplus runs once per centre, not once per pair.
+    float4 R[3][NCH];  // slots 0..2 = path positions c, c+1, c+2
+    float bv[3];
+    bool have[3];
     auto fetch = [&](int pos, float4 (&row)[NCH], float &b, bool &ok) {
         ok = pos >= 0 && pos < L;
         const int nd = ok ? p[pos] : 0;
@@ -301,51 +305,49 @@ __global__ __launch_bounds__(256) void path_reward_kernel(const float *E, const 
             row[i] = (ok && c < nchunk) ? r[c] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    have[0] = have[1] = false;
-    bv[0] = bv[1] = 0.f;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) R[0][i] = R[1][i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    fetch(0, R[2], bv[2], have[2]);
-    fetch(1, R[3], bv[3], have[3]);
-    fetch(2, R[4], bv[4], have[4]);
+    fetch(0, R[0], bv[0], have[0]);
+    fetch(1, R[1], bv[1], have[1]);
+    fetch(2, R[2], bv[2], have[2]);
+    auto n_pairs_of = [&](int i) { return min(i, window) + min(L - 1 - i, window); };
+    int base = 0;  // pairs of the centres before c
     for (int c = 0; c < L; ++c) {
         float4 Rn[NCH];
         float nb;
         bool nh;
         fetch(c + 3, Rn, nb, nh);  // in flight while the centre's pairs are evaluated
+        const int back_c = min(c, window);
+        int base_d = base + n_pairs_of(c);  // first pair of centre c + 1 (then c + 2)
+        float myval = 0.f;
+        int myidx = -1;
 #pragma unroll
-        for (int sl = 0; sl < 5; ++sl) {
-            if (sl == 2 || !have[sl] || sl < 2 - window || sl > 2 + window) continue;
-            float acc = 0.f;
+        for (int d = 1; d <= 2; ++d) {
+            if (d <= window && have[d]) {
+                float acc = 0.f;
 #pragma unroll
-            for (int i = 0; i < NCH; ++i) {
-                acc = __builtin_fmaf(R[2][i].x, R[sl][i].x, acc);
-                acc = __builtin_fmaf(R[2][i].y, R[sl][i].y, acc);
-                acc = __builtin_fmaf(R[2][i].z, R[sl][i].z, acc);
-                acc = __builtin_fmaf(R[2][i].w, R[sl][i].w, acc);
+                for (int i = 0; i < NCH; ++i) {
+                    acc = __builtin_fmaf(R[0][i].x, R[d][i].x, acc);
+                    acc = __builtin_fmaf(R[0][i].y, R[d][i].y, acc);
+                    acc = __builtin_fmaf(R[0][i].z, R[d][i].z, acc);
+                    acc = __builtin_fmaf(R[0][i].w, R[d][i].w, acc);
+                }
+                acc += __shfl_xor(acc, 8, 64);
+                acc += __shfl_xor(acc, 4, 64);
+                acc += __shfl_xor(acc, 2, 64);
+                acc += __shfl_xor(acc, 1, 64);
+                if (t == 2 * d - 2) { myval = acc + bv[d]; myidx = base + back_c + (d - 1); }           // (c, c + d)
+                if (t == 2 * d - 1) { myval = acc + bv[0]; myidx = base_d + (c - max(c + d - window, 0)); }  // (c + d, c)
             }
-            acc += __shfl_xor(acc, 8, 64);
-            acc += __shfl_xor(acc, 4, 64);
-            acc += __shfl_xor(acc, 2, 64);
-            acc += __shfl_xor(acc, 1, 64);
-            if (t == 0) {
-                float sc = acc + bv[sl];
-                sc = fminf(fmaxf(sc, -10.0f), 10.0f);
-                out[pi] = logf(1.0f + expf(sc));
-            }
-            ++pi;
+            base_d += n_pairs_of(c + d);
         }
-#pragma unroll
-        for (int sl = 0; sl < 4; ++sl) {
-            have[sl] = have[sl + 1];
-            bv[sl] = bv[sl + 1];
-#pragma unroll
-            for (int i = 0; i < NCH; ++i) R[sl][i] = R[sl + 1][i];
+        if (myidx >= 0) {
+            const float sc = fminf(fmaxf(myval, -10.0f), 10.0f);
+            out[pi0 + myidx] = logf(1.0f + expf(sc));
         }
-        have[4] = nh;
-        bv[4] = nb;
+        base += n_pairs_of(c);
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) R[4][i] = Rn[i];
+        for (int i = 0; i < NCH; ++i) { R[0][i] = R[1][i]; R[1][i] = R[2][i]; R[2][i] = Rn[i]; }
+        have[0] = have[1]; have[1] = have[2]; have[2] = nh;
+        bv[0] = bv[1]; bv[1] = bv[2]; bv[2] = nb;
     }
 }
 

@@ -343,17 +343,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NF <= 8 ? 3
         }
         return (pos >= 0 && pos < L) ? (pos < 16 ? __shfl(myslot, pos, 16) : wslot[pos]) : -1;
     };
-    auto reward_at = [&](int k, int64_t pidx) -> float {
-        const float src = k < 16 ? rwl[0] : (k < 32 ? rwl[1] : (k < 48 ? rwl[2] : rwl[3]));
-        const float v = __shfl(src, k & 15, 16);
+    auto reward_at = [&](int k, int64_t pidx) -> float {  // k may differ from lane to lane: fetch, THEN select
+        const float v0 = __shfl(rwl[0], k & 15, 16), v1 = __shfl(rwl[1], k & 15, 16);
+        const float v2 = __shfl(rwl[2], k & 15, 16), v3 = __shfl(rwl[3], k & 15, 16);
+        const float v = k < 16 ? v0 : (k < 32 ? v1 : (k < 48 ? v2 : v3));
         if (SHORT) return v;  // <= 4 * 16 - 6 pairs
         return k < 64 ? v : a.reward[pidx];
     };
-    // window slots 0..4 hold path positions c-2 .. c+2 of the current centre c
-    float R[5][NF], A[5][NF], bv[5], gb[5], npair[5];
-    int node[5], sslot[5];
+    // window slots 0..2 hold path positions c, c+1, c+2 of the current centre c: a centre handles its FORWARD neighbours,
+    // one dot product per unordered pair {c, c+d} serving both ordered pairs (c, c+d) [bias of c+d] and (c+d, c) [bias of c]
+    float R[3][NF], A[3][NF], bv[3], gb[3], npair[3];
+    int node[3], sslot[3];
 #pragma unroll
-    for (int sl = 0; sl < 5; ++sl) {
+    for (int sl = 0; sl < 3; ++sl) {
         node[sl] = -1; bv[sl] = 0.f; gb[sl] = 0.f; sslot[sl] = -1; npair[sl] = 0.f;
 #pragma unroll
         for (int i = 0; i < NF; ++i) { R[sl][i] = 0.f; A[sl][i] = 0.f; }
@@ -421,53 +423,73 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NF <= 8 ? 3
         fetch_raw(1, r1, n1, s1, b1);
         fetch_raw(2, r2, n2, s2, b2);
         fetch_raw(3, Rq[0], qnode[0], qslot[0], qbv[0]);
-        enter(2, r0, n0, s0, b0);
-        enter(3, r1, n1, s1, b1);
-        enter(4, r2, n2, s2, b2);
+        enter(0, r0, n0, s0, b0);
+        enter(1, r1, n1, s1, b1);
+        enter(2, r2, n2, s2, b2);
     }
+    auto n_pairs_of = [&](int i) { return min(i, a.window) + min(L - 1 - i, a.window); };
+    int base = 0;  // pairs of the centres before c (the walk's pairs are listed centre by centre: backward, then forward neighbours)
     for (int c = 0; c < L; ++c) {
         fetch_raw(c + 4, Rq[1], qnode[1], qslot[1], qbv[1]);
+        // the scores of the centre's (up to four) ordered pairs go to lanes 0..3: one sigmoid sequence per centre
+        const int back_c = min(c, a.window);
+        int base_d = base + n_pairs_of(c);  // first pair of centre c + 1 (then c + 2)
+        float mys = 0.f;
+        int myk = -1;  // index of the lane's pair inside the walk
 #pragma unroll
-        for (int sl = 0; sl < 5; ++sl) {
-            if (sl == 2 || node[sl] < 0 || sl < 2 - a.window || sl > 2 + a.window) continue;
-            float acc = 0.f;
+        for (int d = 1; d <= 2; ++d) {
+            if (d <= a.window && node[d] >= 0) {
+                float acc = 0.f;
 #pragma unroll
-            for (int i = 0; i < NF; ++i) acc = __builtin_fmaf(R[2][i], R[sl][i], acc);
-            acc += __shfl_xor(acc, 8, 64);
-            acc += __shfl_xor(acc, 4, 64);
-            acc += __shfl_xor(acc, 2, 64);
-            acc += __shfl_xor(acc, 1, 64);
-            const float s = acc + bv[sl];
-            const float sg = 1.0f / (1.0f + expf(-s));
-            const bool inside = (sg >= 1e-5f) && (sg <= 1.0f);
-            const float rw = reward_at((int)(pi - pi0), pi);
-            const float ds = inside ? -(rw * inv_n) * (1.0f - sg) : 0.0f;
-            ++pi;
-            // data term now; the l2 term lambda * row once per pair the row takes part in is added at the flush
-            // (npair[] counts them): 2 instead of 6 operations per float and pair -- the kernel is VALU bound
-#pragma unroll
-            for (int i = 0; i < NF; ++i) {
-                A[2][i] = __builtin_fmaf(ds, R[sl][i], A[2][i]);
-                A[sl][i] = __builtin_fmaf(ds, R[2][i], A[sl][i]);
+                for (int i = 0; i < NF; ++i) acc = __builtin_fmaf(R[0][i], R[d][i], acc);
+                acc += __shfl_xor(acc, 8, 64);
+                acc += __shfl_xor(acc, 4, 64);
+                acc += __shfl_xor(acc, 2, 64);
+                acc += __shfl_xor(acc, 1, 64);
+                if (t == 2 * d - 2) { mys = acc + bv[d]; myk = base + back_c + (d - 1); }               // (c, c + d)
+                if (t == 2 * d - 1) { mys = acc + bv[0]; myk = base_d + (c - max(c + d - a.window, 0)); }  // (c + d, c)
             }
-            npair[2] += 1.0f;
-            npair[sl] += 1.0f;
-            gb[sl] += ds;
+            base_d += n_pairs_of(c + d);
         }
-        flush(0);  // node c-2 has received its last contribution
+        const int kk = myk >= 0 ? myk : 0;
+        const float rw = reward_at(kk, pi0 + kk);  // (shuffles: every lane takes part)
+        float myds = 0.f;
+        if (myk >= 0) {
+            const float sg = 1.0f / (1.0f + expf(-mys));
+            const bool inside = (sg >= 1e-5f) && (sg <= 1.0f);
+            myds = inside ? -(rw * inv_n) * (1.0f - sg) : 0.0f;
+        }
 #pragma unroll
-        for (int sl = 0; sl < 4; ++sl) {
+        for (int d = 1; d <= 2; ++d) {
+            const float ds_f = __shfl(myds, 2 * d - 2, 16), ds_r = __shfl(myds, 2 * d - 1, 16);
+            if (d <= a.window && node[d] >= 0) {
+                // data term now; the l2 term lambda * row once per pair the row takes part in is added at the flush
+                // (npair[] counts them) -- the kernel is VALU bound
+                const float dsum = ds_f + ds_r;
+#pragma unroll
+                for (int i = 0; i < NF; ++i) {
+                    A[0][i] = __builtin_fmaf(dsum, R[d][i], A[0][i]);
+                    A[d][i] = __builtin_fmaf(dsum, R[0][i], A[d][i]);
+                }
+                npair[0] += 2.0f;
+                npair[d] += 2.0f;
+                gb[d] += ds_f;
+                gb[0] += ds_r;
+            }
+        }
+        base += n_pairs_of(c);
+        flush(0);  // node c has met all its neighbours
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
             node[sl] = node[sl + 1]; bv[sl] = bv[sl + 1]; gb[sl] = gb[sl + 1]; sslot[sl] = sslot[sl + 1]; npair[sl] = npair[sl + 1];
 #pragma unroll
             for (int i = 0; i < NF; ++i) { R[sl][i] = R[sl + 1][i]; A[sl][i] = A[sl + 1][i]; }
         }
-        enter(4, Rq[0], qnode[0], qslot[0], qbv[0]);
+        enter(2, Rq[0], qnode[0], qslot[0], qbv[0]);
         qnode[0] = qnode[1]; qbv[0] = qbv[1]; qslot[0] = qslot[1];
 #pragma unroll
         for (int i = 0; i < NF; ++i) Rq[0][i] = Rq[1][i];
     }
-    flush(0);
-    flush(1);
 }
 
 struct OptArgs {
