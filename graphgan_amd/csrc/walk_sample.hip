@@ -1076,7 +1076,9 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
         GG_HIP(ctx, hipStreamWaitEvent(hs[1], ctx->ev_fork, 0));
     }
     const bool all_levels = n_levels >= ctx->tree_max_depth + 2;
-    if (!sized && all_levels && !finisher_follows && ctx->lv_levels_learned > 0) n_levels = std::min(n_levels, ctx->lv_levels_learned + 1);
+    // as many levels as earlier (sized) launches found walks alive in; the final advance raises flag 2 if a walk of THIS launch
+    // is still going after them (the rerun learns the new depth).  (One more level "for slack" was three empty launches per call.)
+    if (!sized && all_levels && !finisher_follows && ctx->lv_levels_learned > 0) n_levels = std::min(n_levels, ctx->lv_levels_learned);
     *any_alive = true;
     ctx->lv_ev_used = 0;
     int level = 0;
