@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn rocprofv3 outputs (gpurun_out/, scratch) into the committed per-round summaries.
 
-    python profiles/summarize.py <round-tag> <kernel_trace_dir> <fetch_dir> <write_dir> [<l2_dir>]
+    python profiles/summarize.py <round-tag> <kernel_trace_dir> <fetch_dir> <write_dir> [<l2_dir> [<sq_dir> [<timeline_dir>]]]
 
 Commands that produced the inputs (on the MI355X box, `cd /tmp && export TMPDIR=/tmp` first):
     rocprofv3 --kernel-trace --stats --output-format csv -d <kernel_trace_dir> -o b -- python bench.py --no-cpu-baseline
@@ -57,6 +57,45 @@ def main():
                             "launches_sampled": len(hit[name])}
         with open(os.path.join(here, "%s_pmc_l2_hit_rate.json" % tag), "w") as fjs:
             json.dump(l2, fjs, indent=1, sort_keys=True)
+    if len(sys.argv) > 6:  # optional: directory of the SQ activity pass
+        rows = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(os.path.join(sys.argv[6], "s_counter_collection.csv"))):
+            rows[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        sq = {}
+        for name, v in rows.items():
+            if not v.get("SQ_WAVE_CYCLES"):
+                continue
+            m = {c: sum(x) / len(x) for c, x in v.items()}
+            wc = m["SQ_WAVE_CYCLES"]
+            if wc > 0:
+                sq[name] = {"launches_sampled": len(v["SQ_WAVE_CYCLES"]), "SQ_WAVE_CYCLES": wc, "active_any": m.get("SQ_ACTIVE_INST_ANY", 0) / wc,
+                            "active_valu": m.get("SQ_ACTIVE_INST_VALU", 0) / wc, "wait_inst_any": m.get("SQ_WAIT_INST_ANY", 0) / wc,
+                            "wait_any": m.get("SQ_WAIT_ANY", 0) / wc, "SQ_INSTS_VALU": m.get("SQ_INSTS_VALU", 0)}
+        with open(os.path.join(here, "%s_pmc_sq_activity.json" % tag), "w") as fjs:
+            json.dump(sq, fjs, indent=1, sort_keys=True)
+    if len(sys.argv) > 7:  # optional: directory of the timeline trace -> one step, kernels of both streams in start order
+        ev = []
+        for r in csv.DictReader(open(os.path.join(sys.argv[7], "b_kernel_trace.csv"))):
+            name = r["Kernel_Name"].split("(")[0].replace("void gg::", "").replace("gg::", "")
+            ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, r["Queue_Id"]))
+        ev.sort()
+        idx = [i for i, e in enumerate(ev) if "walk_init_status" in e[2]]  # two walk launches per step
+        best = None
+        for k in range(len(idx) - 2, 4, -2):
+            a, b = idx[k - 2], idx[k]
+            if best is None or ev[b][0] - ev[a][0] < best[0]:
+                best = (ev[b][0] - ev[a][0], a, b)
+        if best:
+            _, a, b = best
+            while a > 0 and "walk_reset" in ev[a - 1][2]:
+                a -= 1
+            t0 = ev[a][0]
+            out = ["One step of the default bench (rocprofv3 --kernel-trace; kernels of both streams in start order; q = HIP queue: the main",
+                   "stream and the side stream that carries the G-mode walks).  Wall time of this step: %.0f us." % ((ev[b][0] - t0) / 1e3), "",
+                   "%10s %9s  %-3s %s" % ("start us", "dur us", "q", "kernel")]
+            out += ["%10.1f %9.1f  %-3s %s" % ((s0 - t0) / 1e3, (e0 - s0) / 1e3, q, n[:70]) for s0, e0, n, q in ev[a:b]]
+            with open(os.path.join(here, "%s_step_timeline.txt" % tag), "w") as ft:
+                ft.write("\n".join(out) + "\n")
 
 
 if __name__ == "__main__":

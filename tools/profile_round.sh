@@ -1,7 +1,7 @@
 #!/bin/bash
 # One box session that produces the files of profiles/ for a round (run through gpurun from the repo root:
 #   gpurun --timeout 1500 -- 'bash tools/profile_round.sh r2 [quick]'), then on the host:
-#   python profiles/summarize.py r2 gpurun_out/r2_kt gpurun_out/r2_fetch gpurun_out/r2_write
+#   python profiles/summarize.py r2 gpurun_out/r2_kt gpurun_out/r2_fetch gpurun_out/r2_write [gpurun_out/r2_l2 [gpurun_out/r2_sq [gpurun_out/r2_tl]]]
 # GPU tests + smoke, rocprofv3 kernel trace of the default bench, separate PMC passes (FETCH_SIZE, WRITE_SIZE,
 # TCC hit / miss; never combined with trace domains), un-profiled bench with the CPU baseline.  "quick": no tests, no L2 pass.
 T=${1:-r2}
@@ -18,6 +18,9 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${T}_fetch -o f 
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${T}_write -o w -- python $R/bench.py --steps 3 --warmup 1 $PB > $R/gpurun_out/${T}_write.log 2>&1
 if [ "$Q" != "quick" ]; then
   rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $R/gpurun_out/${T}_l2 -o l -- python $R/bench.py --steps 3 --warmup 1 $PB > $R/gpurun_out/${T}_l2.log 2>&1
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $R/gpurun_out/${T}_sq -o s -- python $R/bench.py --steps 3 --warmup 1 $PB > $R/gpurun_out/${T}_sq.log 2>&1
+  # kernel timeline of a few steps (start / end of every kernel on both streams): summarize.py condenses one step
+  rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${T}_tl -o b -- python $R/bench.py --no-cpu-baseline --no-strict --fresh-batches 0 --overlap-steps 0 --steps 6 --warmup 3 > $R/gpurun_out/${T}_tl.log 2>&1
 fi
 cd $R
 python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
