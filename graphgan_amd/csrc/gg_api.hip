@@ -403,7 +403,7 @@ int gg_destroy(gg_ctx *ctx) {
     DevBuf *bufs[] = {&ctx->w_slots_m[0], &ctx->w_slots_m[1], &ctx->w_ptr_m[0], &ctx->w_ptr_m[1], &ctx->w_samples, &ctx->w_paths, &ctx->w_len, &ctx->w_status,
                       &ctx->w_first, &ctx->w_abort, &ctx->w_scratch, &ctx->d_center, &ctx->d_neighbor, &ctx->d_label, &ctx->d_cnt,
                       &ctx->d_ptr, &ctx->g_node1, &ctx->g_node2, &ctx->g_reward, &ctx->g_cnt, &ctx->g_ptr, &ctx->scan_tmp,
-                      &ctx->step_u, &ctx->step_v, &ctx->step_x, &ctx->sg_cnt, &ctx->sg_off, &ctx->sg_slot, &ctx->sg_list, &ctx->sg_rows, &ctx->sg_bias, &ctx->sg_tot, &ctx->touched_ptr, &ctx->x_cnt, &ctx->x_send_ids, &ctx->x_send_rows,
+                      &ctx->step_u, &ctx->step_v, &ctx->step_x, &ctx->sg_cnt, &ctx->sg_off, &ctx->sg_slot, &ctx->sg_list, &ctx->sg_rows, &ctx->sg_bias, &ctx->sg_tot, &ctx->sg_key, &ctx->touched_ptr, &ctx->x_cnt, &ctx->x_send_ids, &ctx->x_send_rows,
                       &ctx->x_recv_ids, &ctx->x_recv_rows, &ctx->x_nglob, &ctx->st_item, &ctx->st_cur, &ctx->st_prev, &ctx->st_len,
                       &ctx->st_alive, &ctx->st_rank, &ctx->bfs_key, &ctx->bfs_bm, &ctx->bfs_misc, &ctx->lv_pfx, &ctx->dc_keys, &ctx->dc_vals, &ctx->dc_words, &ctx->lv_beg, &ctx->lv_k, &ctx->lv_chunks, &ctx->lv_coff, &ctx->lv_scores, &ctx->lv_chunk_owner, &ctx->lv_prefix, &ctx->lv_big, &ctx->fin_list};
     for (DevBuf *b : bufs) b->release();
@@ -617,6 +617,27 @@ struct TreeHeader {
     int64_t nodes;
 };
 
+// Structure check of trees that came from a file: the walk kernels index t_order / t_cstart without bounds tests, so a
+// corrupt cache of the right size must not reach them.  One thread per (slot, rank): node ids in range, rank 0 = the
+// root, child ranges ascending, behind their parent and inside [1, C], cstart[C] = C.
+__global__ __launch_bounds__(256) void validate_trees_kernel(const int32_t *order, const int32_t *cstart, const int64_t *base, const int32_t *root,
+                                                             int32_t n_roots, int32_t n_node, int32_t *bad) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= base[n_roots]) return;
+    int lo = 0, hi = n_roots;  // slot r with base[r] <= j < base[r + 1]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (base[mid] <= j) lo = mid; else hi = mid;
+    }
+    const int r = lo;
+    const int64_t i = j - base[r], C = base[r + 1] - base[r];
+    const int32_t nd = order[j];
+    const int32_t *cs = cstart + base[r] + r;
+    const int64_t c0 = cs[i], c1 = cs[i + 1];
+    bool ok = nd >= 0 && nd < n_node && (i != 0 || (nd == root[r] && c0 == 1)) && c0 > i && c0 <= c1 && c1 <= C && (i + 1 != C || c1 == C);
+    if (!ok) atomicOr(bad, 1);
+}
+
 int stream_dev(gg_ctx *ctx, FILE *f, int32_t *dev, size_t count, bool save) {
     const size_t step = 64u << 20;  // entries per staging round (256 MB)
     std::vector<int32_t> tmp(std::min(count, step));
@@ -699,7 +720,26 @@ int gg_load_trees(gg_ctx *ctx, const char *path) {
     if (rc == GG_OK) rc = stream_dev(ctx, f, ctx->t_order, (size_t)h.nodes, false);
     if (rc == GG_OK) rc = stream_dev(ctx, f, ctx->t_cstart, (size_t)h.nodes + h.n_roots, false);
     fclose(f);
-    if (rc != GG_OK) return rc;
+    if (rc == GG_OK) {
+        int32_t *bad = (int32_t *)(ctx->dev_ctr + 1000);  // a spare word behind the walk launches' counters ([0, 912))
+        int32_t h_bad = 0;
+        hipError_t e = hipMemset(bad, 0, sizeof(int32_t));
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(validate_trees_kernel, dim3((unsigned)cdiv(h.nodes, 256)), dim3(256), 0, ctx->stream, ctx->t_order, ctx->t_cstart,
+                               ctx->t_base, ctx->t_root, h.n_roots, ctx->n_node, bad);
+            e = hipStreamSynchronize(ctx->stream);
+        }
+        if (e == hipSuccess) e = hipMemcpy(&h_bad, bad, sizeof(int32_t), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemset(bad, 0, sizeof(int32_t));
+        if (e != hipSuccess) rc = fail(ctx, GG_EHIP, "gg_load_trees: %s", hipGetErrorString(e));
+        else if (h_bad || h.max_depth < 0 || h.max_depth > ctx->n_node || h.max_list < 0 || h.max_list > ctx->n_node)
+            rc = fail(ctx, GG_EIO, "gg_load_trees: %s: the tree arrays are corrupt (node id out of range or child ranges not a BFS order)", path);
+    }
+    if (rc != GG_OK) {  // nothing half-loaded stays resident
+        ctx->n_tree_roots = 0;
+        ctx->tree_nodes = 0;
+        return rc;
+    }
     ctx->tree_max_depth = h.max_depth;
     ctx->tree_max_list = h.max_list;
     return GG_OK;

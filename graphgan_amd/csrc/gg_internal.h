@@ -181,7 +181,7 @@ struct gg_ctx {
     gg::DevBuf scan_tmp, step_u, step_v, step_x;
     // staged generator gradient (steps.hip, run_path_step): per-row counts / segment offsets, per path node slot, row list,
     // the stage itself (gradient rows + bias gradients of the small rows, segment by segment), two total words
-    gg::DevBuf sg_cnt, sg_off, sg_slot, sg_list, sg_rows, sg_bias, sg_tot;
+    gg::DevBuf sg_cnt, sg_off, sg_slot, sg_list, sg_rows, sg_bias, sg_tot, sg_key;  // sg_key: source of each stage row (sum order)
     bool g_pairs_filled = false;       // g_node1 / g_node2 hold the pairs of the resident G walks (prepare.hip, ensure_g_pairs)
     bool sg_cnt_dirty = false;         // a staged pass counted rows and has not (yet) applied them
     bool sg_active = false;            // a staged G pass is applying its hub rows (apply_optimizer resets their counts)

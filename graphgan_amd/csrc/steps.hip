@@ -43,7 +43,9 @@ struct StepArgs {
 };
 
 // occurrences of every table row in a fused batch, as the gradient kernel will emit them: one per pair for v, one per
-// run of equal u inside a group's ppg pairs for u; the returned rank becomes the row's slot inside its stage segment
+// run of equal u inside a group's ppg pairs for u; the returned rank becomes the row's slot inside its stage segment.
+// The rank is the atomic's ARRIVAL order -- run dependent -- so every stage row also carries a key that names its source
+// (2 p + 1: v side of pair p, 2 q: the u run ending at pair q); the reducing kernel adds a segment in ascending key order.
 __global__ __launch_bounds__(256) void pair_occ_count_kernel(const int32_t *u, const int32_t *v, int n, int ppg, int32_t *cnt,
                                                              int32_t *slot_v, int32_t *slot_u) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -54,12 +56,18 @@ __global__ __launch_bounds__(256) void pair_occ_count_kernel(const int32_t *u, c
 }
 
 __global__ __launch_bounds__(256) void pair_occ_slot_kernel(const int32_t *u, const int32_t *v, int n, const int32_t *cnt, const int32_t *off,
-                                                            int T, int32_t *slot_v, int32_t *slot_u) {
+                                                            int T, int32_t *slot_v, int32_t *slot_u, int32_t *key) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const int iv = v[p], iu = u[p];
-    slot_v[p] = cnt[iv] <= T ? off[iv] + slot_v[p] : -1;
-    if (slot_u[p] != -2) slot_u[p] = cnt[iu] <= T ? off[iu] + slot_u[p] : -1;
+    const int sv = cnt[iv] <= T ? off[iv] + slot_v[p] : -1;
+    slot_v[p] = sv;
+    if (sv >= 0) key[sv] = 2 * p + 1;
+    if (slot_u[p] != -2) {
+        const int su = cnt[iu] <= T ? off[iu] + slot_u[p] : -1;
+        slot_u[p] = su;
+        if (su >= 0) key[su] = 2 * p;
+    }
 }
 
 // One 16-lane group per run of PAIRS_PER_GROUP consecutive pairs.  The reference's batches are
@@ -281,9 +289,11 @@ struct PathArgs {
 // accumulator table with fp32 atomics -- 116 M lane-atomics per pass at the L2's ~270 G/s, 56 % of the kernel.  Now the
 // path nodes are counted per table row first (path_count_kernel: one int atomic per node, returning its rank), rows with
 // <= T gradients get a contiguous segment of a stage buffer (device_segment_rows), the gradient kernel STORES each node's
-// row into its segment slot, and staged_opt_kernel sums a row's segment in slot order and applies the optimizer in the
-// same pass: no accumulator round trip, and a deterministic sum for those rows.  Hub rows (> T gradients) keep the
-// atomic path and the flag -> list -> sparse_opt_kernel update.
+// row into its segment slot, and staged_opt_kernel sums a row's segment and applies the optimizer in the same pass: no
+// accumulator round trip.  The slot inside a segment is the rank the counting atomic returned, i.e. arrival order, which
+// differs from run to run; the sum does not: every stage row carries the path position it came from (sg_key) and the
+// reducing group adds its segment in ascending key order -- a deterministic sum for those rows.  Hub rows (> T gradients)
+// keep the atomic path (run-dependent fp32 order) and the flag -> list -> sparse_opt_kernel update.
 __global__ __launch_bounds__(256) void path_count_kernel(const int32_t *paths, const int32_t *path_len, int stride, int64_t n_walks,
                                                          int32_t *cnt, int32_t *slot) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -295,14 +305,16 @@ __global__ __launch_bounds__(256) void path_count_kernel(const int32_t *paths, c
 }
 
 __global__ __launch_bounds__(256) void path_slot_kernel(const int32_t *paths, const int32_t *path_len, int stride, int64_t n_walks,
-                                                        const int32_t *cnt, const int32_t *off, int T, int32_t *slot) {
+                                                        const int32_t *cnt, const int32_t *off, int T, int32_t *slot, int32_t *key) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t w = idx / stride;
     if (w >= n_walks) return;
     const int c = (int)(idx - w * stride), L = path_len[w] - 1;
     if (L <= 1 || c >= L) return;
     const int nd = paths[idx];
-    slot[idx] = cnt[nd] <= T ? off[nd] + slot[idx] : -1;
+    const int sl = cnt[nd] <= T ? off[nd] + slot[idx] : -1;
+    slot[idx] = sl;
+    if (sl >= 0) key[sl] = (int32_t)idx;  // n_pos < 2^31 (run_path_step)
 }
 
 // SHORT: every path has at most 16 nodes (stride <= 17: trees of depth <= 14), so the walk's node ids, stage slots and
@@ -506,6 +518,7 @@ struct OptArgs {
     const int4 *sg_list;  // {row, first stage row, stage rows} per small row
     const int64_t *sg_tot;
     const float *stage, *stage_b;
+    const int32_t *stage_key;  // source of every stage row (unique inside a pass): a segment is summed in ascending key order
 };
 
 __device__ __forceinline__ void adam_elem(float &var, float &m, float &v, float g, const OptArgs &a) {
@@ -603,40 +616,38 @@ __global__ __launch_bounds__(256) void sparse_opt_kernel(const OptArgs a) {
     for (int r = g0; r < cnt; r += ng) opt_row<SGD>(a, a.touched_list[r], t, nchunk);
 }
 
-// Small rows of the staged gradient: one 16-lane group per row sums the row's segment of the stage buffer in slot order
-// (contiguous 512-byte rows, four in flight) and applies lazy Adam (MODE 0) / SGD (MODE 1) with the sum in registers.
+// Small rows of the staged gradient: one 16-lane group per row sums the row's segment of the stage buffer (contiguous
+// 512-byte rows, four in flight) and applies lazy Adam (MODE 0) / SGD (MODE 1) with the sum in registers.
+// ORDER OF THE SUM: the position of a gradient row inside its segment is the arrival order of the counting atomics
+// (path_count_kernel / pair_occ_count_kernel) and changes from run to run, so the group first ranks the segment's source
+// keys (stage_key: path position resp. pair side, unique inside a pass) -- segments of <= STAGE_SORT rows by counting
+// smaller keys with shuffles (16 shuffles per 16 keys), the permutation goes through 256 B of LDS per group; longer
+// segments (only with GG_STAGE_T > 64) by repeated minimum selection -- and adds the rows in ASCENDING KEY ORDER: the same
+// fp32 operation sequence in every run, whatever the scheduling was.
 // MODE 2 (replicas): the sum goes to the gradient accumulators instead -- plain stores, the row's flag set -- and the
 // exchange + sparse_opt_kernel path takes it from there like an atomically accumulated gradient.
+constexpr int STAGE_SORT = 64;
+
 template <int MODE>
 __global__ __launch_bounds__(256) void staged_opt_kernel(const OptArgs a) {
     constexpr bool SGD = MODE == 1;
+    __shared__ int32_t perm_s[16][STAGE_SORT];
     const int t = threadIdx.x & 15;
+    int32_t *const perm = perm_s[threadIdx.x >> 4];
     const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4, ng = ((int64_t)gridDim.x * blockDim.x) >> 4;
     const int64_t n_rows = a.sg_tot[0];
     const int nchunk = a.ld >> 2;  // <= 64: up to 4 float4 chunks per lane
     for (int64_t r = g0; r < n_rows; r += ng) {
         const int4 e = a.sg_list[r];
         const int row = e.x, n = e.z;
-        const float4 *src = (const float4 *)(a.stage + (int64_t)e.y * a.ld);
+        const float4 *const seg = (const float4 *)(a.stage + (int64_t)e.y * a.ld);
+        const float *const sb = a.stage_b + e.y;
+        const int32_t *const key = a.stage_key + e.y;
         float4 g[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        // four stage rows in flight, added in slot order
-        int o = 0;
-        for (; o + 4 <= n; o += 4, src += 4 * nchunk) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c = t + 16 * i;
-                if (c < nchunk) {
-                    const float4 x0 = src[c], x1 = src[c + nchunk], x2 = src[c + 2 * nchunk], x3 = src[c + 3 * nchunk];
-                    g[i].x += x0.x; g[i].y += x0.y; g[i].z += x0.z; g[i].w += x0.w;
-                    g[i].x += x1.x; g[i].y += x1.y; g[i].z += x1.z; g[i].w += x1.w;
-                    g[i].x += x2.x; g[i].y += x2.y; g[i].z += x2.z; g[i].w += x2.w;
-                    g[i].x += x3.x; g[i].y += x3.y; g[i].z += x3.z; g[i].w += x3.w;
-                }
-            }
-        }
-        for (; o < n; ++o, src += nchunk) {
+        float gbias = 0.f;
+        auto add_row = [&](const float4 *src) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int c = t + 16 * i;
@@ -645,16 +656,78 @@ __global__ __launch_bounds__(256) void staged_opt_kernel(const OptArgs a) {
                     g[i].x += x.x; g[i].y += x.y; g[i].z += x.z; g[i].w += x.w;
                 }
             }
+        };
+        if (n <= STAGE_SORT) {
+            if (n > 1) {  // rank of every key = number of smaller keys of the segment
+                int k[4], rk[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    k[i] = (t + 16 * i < n) ? key[t + 16 * i] : 0x7fffffff;
+                    rk[i] = 0;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (16 * j < n) {
+                        const int nl = min(n - 16 * j, 16);
+                        for (int l = 0; l < nl; ++l) {
+                            const int kk = __shfl(k[j], l, 16);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) rk[i] += kk < k[i];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (t + 16 * i < n) perm[rk[i]] = t + 16 * i;
+            } else if (t == 0) {
+                perm[0] = 0;
+            }
+            // the group's lanes sit in one wavefront: its LDS operations execute in program order
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // four stage rows in flight, added in key order
+            int o = 0;
+            for (; o + 4 <= n; o += 4) {
+                const float4 *s0 = seg + (int64_t)perm[o] * nchunk, *s1 = seg + (int64_t)perm[o + 1] * nchunk;
+                const float4 *s2 = seg + (int64_t)perm[o + 2] * nchunk, *s3 = seg + (int64_t)perm[o + 3] * nchunk;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = t + 16 * i;
+                    if (c < nchunk) {
+                        const float4 x0 = s0[c], x1 = s1[c], x2 = s2[c], x3 = s3[c];
+                        g[i].x += x0.x; g[i].y += x0.y; g[i].z += x0.z; g[i].w += x0.w;
+                        g[i].x += x1.x; g[i].y += x1.y; g[i].z += x1.z; g[i].w += x1.w;
+                        g[i].x += x2.x; g[i].y += x2.y; g[i].z += x2.z; g[i].w += x2.w;
+                        g[i].x += x3.x; g[i].y += x3.y; g[i].z += x3.z; g[i].w += x3.w;
+                    }
+                }
+            }
+            for (; o < n; ++o) add_row(seg + (int64_t)perm[o] * nchunk);
+            for (int q = t; q < n; q += 16) gbias += sb[perm[q]];  // lane t: ranks t, t + 16, ... in order, then the butterfly
+            __builtin_amdgcn_wave_barrier();  // the next row's permutation is written behind these reads
+        } else {
+            int last = -1;  // keys are >= 0
+            for (int q = 0; q < n; ++q) {
+                int best = 0x7fffffff, besto = 0;
+                for (int o = t; o < n; o += 16) {
+                    const int kk = key[o];
+                    if (kk > last && kk < best) { best = kk; besto = o; }
+                }
+#pragma unroll
+                for (int m = 8; m >= 1; m >>= 1) {
+                    const int ob = __shfl_xor(best, m, 16), oo = __shfl_xor(besto, m, 16);
+                    if (ob < best) { best = ob; besto = oo; }
+                }
+                add_row(seg + (int64_t)besto * nchunk);
+                if ((q & 15) == t) gbias += sb[besto];
+                last = best;
+            }
         }
-        float gbias = 0.f;
-        {
-            const float *sb = a.stage_b + e.y;
-            for (int o = t; o < n; o += 16) gbias += sb[o];
-            gbias += __shfl_xor(gbias, 8, 64);
-            gbias += __shfl_xor(gbias, 4, 64);
-            gbias += __shfl_xor(gbias, 2, 64);
-            gbias += __shfl_xor(gbias, 1, 64);
-        }
+        gbias += __shfl_xor(gbias, 8, 64);
+        gbias += __shfl_xor(gbias, 4, 64);
+        gbias += __shfl_xor(gbias, 2, 64);
+        gbias += __shfl_xor(gbias, 1, 64);
         const int64_t o4 = ((int64_t)row * a.ld) >> 2;
         if (MODE == 2) {
 #pragma unroll
@@ -788,7 +861,18 @@ static int global_pair_count(gg_ctx *ctx, int64_t n_local, const int64_t **out) 
 }
 
 // ---- staged gradient, host side (see path_count_kernel): buffers for up to n_occ staged rows ...
-static int staged_reserve(gg_ctx *ctx, int64_t n_occ) {
+// n_occ: entries of the slot array (one per gradient the kernel may emit); n_stage: upper bound of the rows that are
+// actually staged (<= n_occ).  Returns 1 (no error set) when the stage would not fit: the caller takes the atomic path.
+static int64_t stage_bytes_cap() {
+    static const int64_t cap = [] {
+        const char *e = getenv("GG_STAGE_MAX_BYTES");
+        return e ? (int64_t)atoll(e) : (int64_t)24 << 30;
+    }();
+    return cap;
+}
+
+static int staged_reserve(gg_ctx *ctx, int64_t n_occ, int64_t n_stage) {
+    if (n_stage * (int64_t)(ctx->ld + 2) * 4 > stage_bytes_cap()) return 1;
     const size_t cnt_before = ctx->sg_cnt.bytes;
     GG_HIP(ctx, ctx->sg_cnt.reserve(sizeof(int32_t) * (size_t)ctx->n_node));
     // the counts are zero between passes -- every update resets the rows it applies -- unless the buffer is new or an earlier
@@ -798,9 +882,13 @@ static int staged_reserve(gg_ctx *ctx, int64_t n_occ) {
     GG_HIP(ctx, ctx->sg_off.reserve(sizeof(int32_t) * (size_t)ctx->n_node));
     GG_HIP(ctx, ctx->sg_list.reserve(sizeof(int4) * (size_t)ctx->n_node));
     GG_HIP(ctx, ctx->sg_slot.reserve(sizeof(int32_t) * (size_t)n_occ));
-    GG_HIP(ctx, ctx->sg_rows.reserve(sizeof(float) * (size_t)n_occ * ctx->ld));
-    GG_HIP(ctx, ctx->sg_bias.reserve(sizeof(float) * (size_t)n_occ));
+    GG_HIP(ctx, ctx->sg_bias.reserve(sizeof(float) * (size_t)n_stage));
+    GG_HIP(ctx, ctx->sg_key.reserve(sizeof(int32_t) * (size_t)n_stage));
     GG_HIP(ctx, ctx->sg_tot.reserve(sizeof(int64_t) * 4));
+    if (ctx->sg_rows.reserve(sizeof(float) * (size_t)n_stage * ctx->ld) != hipSuccess) {
+        (void)hipGetLastError();  // out of memory for the stage: not an error, the atomic kernels need no stage
+        return 1;
+    }
     return GG_OK;
 }
 
@@ -810,7 +898,7 @@ static int staged_finish(gg_ctx *ctx, int which, int64_t n, int64_t n_occ) {
     const int opt = ctx->cfg.optimizer;
     OptArgs o = make_opt_args(ctx, which);  // before apply_optimizer advances the step count and the beta powers
     o.sg_cnt = ctx->sg_cnt.as<int32_t>(); o.sg_list = ctx->sg_list.as<int4>(); o.sg_tot = ctx->sg_tot.as<int64_t>();
-    o.stage = ctx->sg_rows.as<float>(); o.stage_b = ctx->sg_bias.as<float>();
+    o.stage = ctx->sg_rows.as<float>(); o.stage_b = ctx->sg_bias.as<float>(); o.stage_key = ctx->sg_key.as<int32_t>();
     int nb = cdiv((int64_t)std::min<int64_t>(n_occ, ctx->n_node) * 16, 256);
     if (nb > 4096) nb = 4096;
     if (nb < 1) nb = 1;
@@ -830,8 +918,9 @@ static int staged_finish(gg_ctx *ctx, int which, int64_t n, int64_t n_occ) {
     return GG_OK;
 }
 
+// (the reducing kernel holds a row's sum in 4 float4 per lane: ld <= 256; wider tables keep the atomic kernels)
 static bool staged_allowed(const gg_ctx *ctx) {
-    return ctx->sg_threshold > 0 && ctx->cfg.optimizer != GG_OPT_ADAM_DENSE && !getenv("GG_NO_STAGED_GRAD");
+    return ctx->sg_threshold > 0 && ctx->ld <= 256 && ctx->cfg.optimizer != GG_OPT_ADAM_DENSE && !getenv("GG_NO_STAGED_GRAD");
 }
 
 // One optimizer step of model `which` on n device-resident rows.
@@ -875,15 +964,20 @@ int run_step(gg_ctx *ctx, int which, const int32_t *d_u, const int32_t *d_v, con
     const int blocks = cdiv((int64_t)groups * 16, 256);
     const int nf = (ctx->ld + 15) / 16;
     // large fused batches on one replica: staged gradient rows + reducing optimizer instead of fp32 atomics (see path_count_kernel)
-    const bool staged = n >= 16384 && staged_allowed(ctx);
+    bool staged = n >= 16384 && n < (1 << 30) && staged_allowed(ctx);
     if (staged) {
-        int rc = staged_reserve(ctx, 2 * (int64_t)n);
-        if (rc != GG_OK) return rc;
+        int rc = staged_reserve(ctx, 2 * (int64_t)n, 2 * (int64_t)n);
+        if (rc < 0) return rc;
+        if (rc == 1) staged = false;  // the stage does not fit: atomics
+    }
+    if (staged) {
+        int rc;
         int32_t *cnt = ctx->sg_cnt.as<int32_t>(), *off = ctx->sg_off.as<int32_t>(), *slot_v = ctx->sg_slot.as<int32_t>(), *slot_u = slot_v + n;
         hipLaunchKernelGGL(pair_occ_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, d_u, d_v, n, s.ppg, cnt, slot_v, slot_u);
         rc = device_segment_rows(ctx, cnt, ctx->n_node, ctx->sg_threshold, off, ctx->sg_list.as<int4>(), ctx->sg_tot.as<int64_t>());
         if (rc != GG_OK) return rc;
-        hipLaunchKernelGGL(pair_occ_slot_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, d_u, d_v, n, cnt, off, ctx->sg_threshold, slot_v, slot_u);
+        hipLaunchKernelGGL(pair_occ_slot_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, d_u, d_v, n, cnt, off, ctx->sg_threshold, slot_v, slot_u,
+                           ctx->sg_key.as<int32_t>());
         s.slot_v = slot_v; s.slot_u = slot_u;
         s.stage = ctx->sg_rows.as<float>(); s.stage_b = ctx->sg_bias.as<float>();
         if (nf <= 4) hipLaunchKernelGGL((pair_grad_kernel<4, true>), dim3(blocks), dim3(256), 0, ctx->stream, s);
@@ -941,21 +1035,30 @@ int run_path_step(gg_ctx *ctx) {
     const int blocks = cdiv(p.n_walks * 16, 256);
     const int nf = (ctx->ld + 15) / 16;
     const int64_t n_pos = p.n_walks * (int64_t)p.stride;
-    const bool staged = staged_allowed(ctx) && n_pos < (1ll << 31);
+    bool staged = staged_allowed(ctx) && n_pos < (1ll << 31);
+    // staged rows = path nodes of the walks that have pairs: a walk of L >= 2 nodes has 4L - 6 (window 2; L = 2: 2) resp.
+    // 2L - 2 (window 1) pairs, so sum L <= (pairs + 6 walks) / 4 resp. (pairs + 2 walks) / 2 -- from host-side numbers, and
+    // several times smaller than the walks x stride slot array
+    const int64_t n_stage = std::min<int64_t>(n_pos, p.window >= 2 ? (n + 6 * p.n_walks) / 4 + 1 : (n + 2 * p.n_walks) / 2 + 1);
+    if (staged) {
+        const int rc = staged_reserve(ctx, n_pos, n_stage);
+        if (rc < 0) return rc;
+        if (rc == 1) staged = false;
+    }
     if (!staged) {
         launch_path_grad<false>(ctx, p, blocks, nf);
         if (ctx->tm_cur >= 0) GG_HIP(ctx, hipEventRecord(ctx->tm_ev[ctx->tm_cur][1], ctx->stream));  // gradient | exchange + optimizer
         return apply_optimizer(ctx, 0, n);
     }
     // ---- staged gradient (see path_count_kernel)
-    int rc = staged_reserve(ctx, n_pos);
-    if (rc != GG_OK) return rc;
+    int rc;
     int32_t *cnt = ctx->sg_cnt.as<int32_t>(), *off = ctx->sg_off.as<int32_t>(), *slot = ctx->sg_slot.as<int32_t>();
     const dim3 pgrid((unsigned)cdiv(n_pos, 256));
     hipLaunchKernelGGL(path_count_kernel, pgrid, dim3(256), 0, ctx->stream, p.paths, p.path_len, p.stride, p.n_walks, cnt, slot);
     rc = device_segment_rows(ctx, cnt, ctx->n_node, ctx->sg_threshold, off, ctx->sg_list.as<int4>(), ctx->sg_tot.as<int64_t>());
     if (rc != GG_OK) return rc;
-    hipLaunchKernelGGL(path_slot_kernel, pgrid, dim3(256), 0, ctx->stream, p.paths, p.path_len, p.stride, p.n_walks, cnt, off, ctx->sg_threshold, slot);
+    hipLaunchKernelGGL(path_slot_kernel, pgrid, dim3(256), 0, ctx->stream, p.paths, p.path_len, p.stride, p.n_walks, cnt, off, ctx->sg_threshold, slot,
+                       ctx->sg_key.as<int32_t>());
     p.slot = slot;
     p.stage = ctx->sg_rows.as<float>();
     p.stage_b = ctx->sg_bias.as<float>();

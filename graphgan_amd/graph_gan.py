@@ -102,14 +102,13 @@ class GraphGAN(object):
         budget = float(_cfg(cfg, "engine_tree_budget_gb", 160.0)) * 2.0 ** 30
         if cfg.update_ratio >= 1 or self.engine.tree_bytes_estimate(len(self.root_nodes)) <= budget:
             # construct or read BFS-trees (reference :31-46; the cache is a flat GGTR file instead of a pickle)
-            cache = _cfg(cfg, "cache_filename", None)
-            if cache and self.world > 1:
-                cache = "%s.rank%dof%d" % (cache, self.rank, self.world)  # every rank caches the trees of its own roots
+            cache = self._tree_cache_path(_cfg(cfg, "cache_filename", None))
             if cache and os.path.isfile(cache) and self._load_tree_cache(cache):
                 print("reading BFS-trees from cache...")
             else:
                 self.trees = self.construct_trees(self.root_nodes)
-                if cache and os.path.isdir(os.path.dirname(cache) or "."):  # the reference needs `mkdir cache` too (README.md:43)
+                # the reference needs `mkdir cache` too (README.md:43); a file of another format is never overwritten
+                if cache and os.path.isdir(os.path.dirname(cache) or ".") and self._is_ours_or_absent(cache):
                     self.engine.save_trees(cache)
             self._all_resident = True
 
@@ -148,6 +147,27 @@ class GraphGAN(object):
                                 device=bool(_cfg(self.config, "engine_tree_device", True)))
         self._slot_of_root = {int(r): i for i, r in enumerate(nodes)}
         return self._slot_of_root
+
+    def _tree_cache_path(self, name):
+        """File of the native tree cache for ``config.cache_filename``.  The reference pickles to that very name
+        (``cache/<dataset>.pkl``, :36-46); a pickle found there is neither readable by gg_load_trees nor ours to replace, so
+        the flat GGTR cache lives NEXT to it: ``<name>.ggtr`` (per rank with replicas: every rank caches its own roots)."""
+        if not name:
+            return None
+        path = name if name.endswith(".ggtr") else name + ".ggtr"
+        if self.world > 1:
+            path = "%s.rank%dof%d" % (path, self.rank, self.world)
+        return path
+
+    @staticmethod
+    def _is_ours_or_absent(path):
+        if not os.path.exists(path):
+            return True
+        try:
+            with open(path, "rb") as f:
+                return f.read(4) == b"GGTR"
+        except OSError:
+            return False
 
     def _load_tree_cache(self, path):
         """Resident trees from the cache file if it holds exactly the trees of ``root_nodes`` for this graph."""
@@ -246,13 +266,16 @@ class GraphGAN(object):
         self.trees = self.construct_trees([self.root_nodes[i] for i in take])
         return np.arange(len(take), dtype=np.int32)
 
+    # An empty draw (update_ratio < 1) still goes through the engine: gg_prepare_* ends with a collective over the replicas
+    # (the max of the ranks' row counts) that every rank must join, and it resets the resident row count that the passes and
+    # their row-pack capacity read -- skipping the call left stale rows behind and, with world > 1, the other ranks waiting.
     def _prepare_d_resident(self):
         slots = self._select_slots()
-        return self.engine.prepare_d(slots, self.seed, self._stream, fetch=False) if len(slots) else 0
+        return self.engine.prepare_d(slots, self.seed, self._stream, fetch=False)
 
     def _prepare_g_resident(self):
         slots = self._select_slots()
-        return self.engine.prepare_g(slots, self.config.n_sample_gen, self.seed, self._stream, fetch=False) if len(slots) else 0
+        return self.engine.prepare_g(slots, self.config.n_sample_gen, self.seed, self._stream, fetch=False)
 
     def prepare_data_for_d(self):
         """generate positive and negative samples for the discriminator (reference :182-202);

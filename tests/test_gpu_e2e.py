@@ -244,8 +244,11 @@ def test_tree_cache_file_replaces_the_pickle(tmp_path):
     os.makedirs(os.path.join(base, "cache"))
     cfg = make_cfg(base, engine_seed=5)
     from graphgan_amd.graph_gan import GraphGAN
+    open(cfg.cache_filename, "wb").write(b"\x80\x04a reference pickle")  # the reference's own cache: never touched
+    cache = cfg.cache_filename + ".ggtr"                                  # the native cache lives next to it
     g1 = GraphGAN(cfg)
-    assert os.path.getsize(cfg.cache_filename) > 8 * 16e6 and not os.path.exists(cfg.cache_filename + ".tmp")  # 16.3 M (root, node) pairs
+    assert open(cfg.cache_filename, "rb").read() == b"\x80\x04a reference pickle"
+    assert os.path.getsize(cache) > 8 * 16e6 and not os.path.exists(cache + ".tmp")  # 16.3 M (root, node) pairs
     assert g1.engine.counters()["bfs_trees"] == n
     t1 = g1.engine.get_trees()
     w1 = g1.engine.walk_sample(np.arange(n), np.full(n, 5), False, 3, 1)
@@ -266,16 +269,31 @@ def test_tree_cache_file_replaces_the_pickle(tmp_path):
     other = ga.Engine(np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32))
     other.set_graph_csr(rowptr, col)
     with pytest.raises(ga.GraphGANHipError) as ei:
-        other.load_trees(cfg.cache_filename)
+        other.load_trees(cache)
     assert ei.value.code == ga.GG_EINVAL
     other.close()
     # truncated: refused with GG_EIO; the trainer rebuilds and rewrites it
-    blob = open(cfg.cache_filename, "rb").read()
-    open(cfg.cache_filename, "wb").write(blob[: len(blob) // 3])
+    blob = open(cache, "rb").read()
+    open(cache, "wb").write(blob[: len(blob) // 3])
     with pytest.raises(ga.GraphGANHipError) as ei:
-        g2.engine.load_trees(cfg.cache_filename)
+        g2.engine.load_trees(cache)
     assert ei.value.code == ga.GG_EIO
     g2.engine.close()
     g3 = GraphGAN(cfg)
-    assert g3.engine.counters()["bfs_trees"] == n and os.path.getsize(cfg.cache_filename) == len(blob)
+    assert g3.engine.counters()["bfs_trees"] == n and os.path.getsize(cache) == len(blob)
+    # right size, corrupt contents (a node id out of range; a child range that points backwards): refused with GG_EIO --
+    # the walk kernels index the tree arrays without bounds tests -- and nothing stays resident
+    hdr = 48 + 4 * n + 8 * (n + 1)
+    nodes = (len(blob) - hdr - 4 * n) // 8
+    for pos, val in ((hdr + 4 * 12345, 0x7FFFFFF0), (hdr + 4 * nodes + 4 * 777, 0)):
+        bad = bytearray(blob)
+        bad[pos:pos + 4] = int(val).to_bytes(4, "little")
+        open(cache, "wb").write(bytes(bad))
+        with pytest.raises(ga.GraphGANHipError) as ei:
+            g3.engine.load_trees(cache)
+        assert ei.value.code == ga.GG_EIO and "corrupt" in str(ei.value)
+        with pytest.raises(ga.GraphGANHipError):
+            g3.engine.walk_sample([0], [1], False, 1, 1)   # no trees loaded
+    open(cache, "wb").write(blob)
+    g3.engine.load_trees(cache)
     g3.engine.close()

@@ -370,19 +370,79 @@ def test_staged_generator_gradient_equals_the_atomic_path(ga, opt, threshold, mo
             gen.g_step(n1.astype(np.int64), n2.astype(np.int64), rew, 1e-5)
             assert np.allclose(eng.get_embeddings(0), gen.E, rtol=2e-5, atol=2e-6)
             assert np.allclose(eng.get_bias(0), gen.b, rtol=2e-5, atol=2e-6)
-    # the staged sum is deterministic: a third engine repeats the staged run bit for bit when no row is a hub
+    # The staged sum is deterministic when no row is a hub: the slot of a gradient row inside its segment is the arrival
+    # order of an atomic counter (run dependent), but the reducing kernel adds a segment in the order of the rows' SOURCES
+    # (path position).  Four engines repeat the staged G pass bit for bit (threshold 100000 on this 90-node graph: segments
+    # of hundreds of rows, the minimum-selection path; test_staged_sums_are_bit_reproducible covers the in-register ranking)
     if threshold == "64":
         monkeypatch.setenv("GG_STAGE_T", "100000")
-        _, _, _, _, _, _, e3 = _setup_graph_engine(ga, optimizer=optimizer)
-        _, _, _, _, _, _, e4 = _setup_graph_engine(ga, optimizer=optimizer)
-        for e in (e3, e4):
+        tabs = []
+        for _ in range(4):
+            _, _, _, _, _, _, e = _setup_graph_engine(ga, optimizer=optimizer)
             e.prepare_g(slots, 20, 4, 1, fetch=False)
             e.g_pass([0], 1 << 30)
-        assert np.array_equal(e3.get_embeddings(0).view(np.uint32), e4.get_embeddings(0).view(np.uint32))
-        e3.close()
-        e4.close()
+            tabs.append((e.get_embeddings(0).view(np.uint32), e.get_bias(0).view(np.uint32)))
+            e.close()
+        for k in range(1, 4):
+            assert np.array_equal(tabs[0][0], tabs[k][0]) and np.array_equal(tabs[0][1], tabs[k][1])
     eng.close()
     eng2.close()
+
+
+@pytest.mark.parametrize("opt", ["lazy", "sgd"])
+def test_staged_sums_are_bit_reproducible(ga, opt):
+    """Fused D pass (>= 16 384 pairs) on a table large enough that no row collects more than the default 64 gradients:
+    every row is staged and summed in source order -- segments of 1 .. 64 rows, i.e. one to four keys per lane in the
+    ranking -- so repeated runs give bit-identical tables, and the result is the oracle's."""
+    n, d = 12000, 40
+    rs = np.random.RandomState(4)
+    Eg = (rs.randn(n, d) * 0.3).astype(np.float32)
+    Ed = (rs.randn(n, d) * 0.3).astype(np.float32)
+    hot = rs.choice(n, 200, replace=False)                        # 200 rows with 30-50 gradients each, the rest 1-6
+    v = np.concatenate([rs.randint(0, n, 14000), np.repeat(hot, 30)]).astype(np.int32)
+    rs.shuffle(v)
+    u = np.repeat(rs.randint(0, n, len(v) // 8 + 1), 8)[: len(v)].astype(np.int32)
+    lab = (rs.rand(len(v)) < 0.5).astype(np.float32)
+    c1, c2 = np.bincount(np.concatenate([u[::8], v]), minlength=n), np.bincount(np.concatenate([v, u]), minlength=n)
+    assert 32 < c1.max() <= 64 and 32 < c2.max() <= 64 and len(v) >= 16384
+    tabs = []
+    for _ in range(4):
+        e = ga.Engine(Eg, Ed, optimizer=ga.GG_OPT_ADAM_LAZY if opt == "lazy" else ga.GG_OPT_SGD)
+        e.d_step(u, v, lab)
+        e.d_step(v, u, lab)   # second pass: counts were reset, no runs on the u side
+        tabs.append((e.get_embeddings(1), e.get_bias(1)))
+        e.close()
+    for k in range(1, 4):
+        assert np.array_equal(tabs[0][0].view(np.uint32), tabs[k][0].view(np.uint32))
+        assert np.array_equal(tabs[0][1].view(np.uint32), tabs[k][1].view(np.uint32))
+    if opt == "lazy":
+        dis = orc.Discriminator(Ed, 1e-3, lazy=True)
+        dis.d_step(u.astype(np.int64), v.astype(np.int64), lab, 1e-5)
+        dis.d_step(v.astype(np.int64), u.astype(np.int64), lab, 1e-5)
+        assert np.allclose(tabs[0][0], dis.E, rtol=2e-5, atol=2e-6)
+        assert np.allclose(tabs[0][1], dis.b, rtol=2e-5, atol=2e-6)
+
+
+def test_fused_d_pass_wide_rows_keep_every_column(ga):
+    """ld = 512 (the widest gradient kernel): a fused batch >= 16 384 pairs must update ALL columns -- the reducing kernel of
+    the staged path holds 256 floats per row, so wider tables take the atomic kernels (columns >= 256 were
+    silently dropped)."""
+    n, d = 400, 512
+    rs = np.random.RandomState(2)
+    Eg = (rs.randn(n, d) * 0.05).astype(np.float32)
+    Ed = (rs.randn(n, d) * 0.05).astype(np.float32)
+    eng = ga.Engine(Eg, Ed, optimizer=ga.GG_OPT_ADAM_LAZY)
+    u = np.repeat(rs.randint(0, n, 2500), 8).astype(np.int32)
+    v = rs.randint(0, n, len(u)).astype(np.int32)
+    lab = (rs.rand(len(u)) < 0.5).astype(np.float32)
+    dis = orc.Discriminator(Ed, 1e-3, lazy=True)
+    dis.d_step(u.astype(np.int64), v.astype(np.int64), lab, 1e-5)
+    eng.d_step(u, v, lab)
+    got = eng.get_embeddings(1)
+    assert np.abs(got[:, 256:] - Ed[:, 256:]).max() > 1e-4
+    assert np.allclose(got, dis.E, rtol=2e-5, atol=2e-6)
+    assert np.allclose(eng.get_bias(1), dis.b, rtol=2e-5, atol=2e-6)
+    eng.close()
 
 
 @pytest.mark.parametrize("dense_ratio", ["100", "0"])
@@ -450,6 +510,24 @@ def test_fused_g_pass_embedding_widths(ga, d, monkeypatch):
     assert np.allclose(engs[0].get_embeddings(0), gen.E, rtol=2e-5, atol=2e-6)
     for e in engs:
         e.close()
+
+
+def test_empty_draw_resets_the_resident_rows(ga):
+    """update_ratio < 1 can select no root at all: gg_prepare_* with an empty slot list yields 0 rows / pairs and replaces
+    what the previous call left resident (the trainer always makes the call -- with replicas it ends with a collective)."""
+    g, n, graph, rowptr, col, Ed, eng = _setup_graph_engine(ga)
+    slots = np.arange(n, dtype=np.int32)
+    none = np.zeros(0, dtype=np.int32)
+    assert eng.prepare_d(slots, 4, 4, fetch=False) > 0 and eng.prepare_g(slots, 20, 4, 5, fetch=False) > 0
+    assert eng.prepare_d(none, 4, 6, fetch=False) == 0 and eng.prepare_g(none, 20, 4, 7, fetch=False) == 0
+    before = [eng.get_embeddings(w).copy() for w in (0, 1)]
+    eng.d_pass([], 64)
+    eng.g_pass([], 64)
+    eng.d_pass([0], 64)   # nothing resident: no stale row is trained on
+    eng.g_pass([0], 1 << 30)
+    for w in (0, 1):
+        assert np.array_equal(before[w], eng.get_embeddings(w))
+    eng.close()
 
 
 def test_pairs_are_expanded_on_first_use_and_guarded(ga):

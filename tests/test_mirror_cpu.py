@@ -104,12 +104,12 @@ class _FakeEngine(object):
     def prepare_d(self, slots, seed, stream, fetch=True):
         self.calls.append(("prepare_d", len(slots), seed, stream, fetch))
         self.last_slots = np.array(slots)
-        return 200
+        return 200 if len(slots) else 0   # gg_prepare_d with no slots: zero rows (and still its collective)
 
     def prepare_g(self, slots, n_sample, seed, stream, fetch=True):
         self.calls.append(("prepare_g", len(slots), n_sample, seed, stream, fetch))
         self.last_slots = np.array(slots)
-        return 333
+        return 333 if len(slots) else 0
     def d_pass(self, starts, batch): self.calls.append(("d_pass", list(starts), batch))
     def g_pass(self, starts, batch): self.calls.append(("g_pass", list(starts), batch))
     def get_embeddings(self, which): return self.E[which]
@@ -217,10 +217,13 @@ def test_update_ratio_with_trees_over_budget_builds_per_draw(pkg, tmp_path, monk
         assert calls.index(b) + 1 == calls.index(p)             # trees of the subset right before its prepare
     roots = g.engine.tree_roots
     assert roots == sorted(roots) and len(set(roots)) == len(roots) and g._slot_of_root[roots[5]] == 5
-    # empty draw: nothing built, nothing prepared, zero rows
+    # empty draw: nothing built, zero rows -- but the engine IS called with the empty slot list: gg_prepare_* ends with a
+    # collective every replica must join, and it resets the resident row count the passes read
     g.config.update_ratio = 0.0
     nb = len([c for c in g.engine.calls if c[0] == "build_trees"])
+    np_ = len([c for c in g.engine.calls if c[0] in ("prepare_d", "prepare_g")])
     assert g._prepare_d_resident() == 0 and g._prepare_g_resident() == 0
+    assert [c[:2] for c in g.engine.calls if c[0] in ("prepare_d", "prepare_g")][np_:] == [("prepare_d", 0), ("prepare_g", 0)]
     assert g.prepare_data_for_d() == ([], [], [])
     assert len([c for c in g.engine.calls if c[0] == "build_trees"]) == nb
     # sample() of a root that is not in the last draw: its tree is built on demand
@@ -245,7 +248,7 @@ def test_tree_cache_is_read_or_written_like_the_pickle(pkg, tmp_path, monkeypatc
     os.makedirs(os.path.dirname(cfg.cache_filename))
     g = graph_gan.GraphGAN(cfg)
     names = [c[0] for c in g.engine.calls]
-    assert names.index("build_trees") < names.index("save_trees") and os.path.isfile(cfg.cache_filename)
+    assert names.index("build_trees") < names.index("save_trees") and os.path.isfile(cfg.cache_filename + ".ggtr")
     g = graph_gan.GraphGAN(cfg)
     names = [c[0] for c in g.engine.calls]
     assert "load_trees" in names and "build_trees" not in names and g.trees[5] == 5 and g._all_resident
