@@ -13,8 +13,8 @@ steps, inputs resident in HBM.  Workload at N=1: synthetic power-law graph, 1M n
 edges, n_emb = 128 (the configuration the north-star target is quoted on), R roots per step.
 Weak scaling: every rank walks its own R roots; replicas exchange gradients through RCCL.
 
-    python bench.py [--gpus N --steps K --warmup W]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N --steps K --warmup W]              (N > 1: spawns its own N ranks, one per GPU)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (the driver's launcher: same ranks)
 """
 import argparse
 import json
@@ -184,17 +184,42 @@ def strict_mode_line(ga, _lib, seconds=1.5):
     return out
 
 
+def self_launch(n, script=None):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves -- one process per GPU with the
+    environment torch.distributed.run would export (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT; rendezvous
+    on 127.0.0.1) -- pass rank 0's stdout (the JSON line) through, and fail if any rank fails."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GG_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL between processes of one node)
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit("bench.py --gpus %d: rank exit codes %s" % (n, rcs))
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     share_gpu = os.environ.get("GG_BENCH_SHARE_GPU") == "1"  # plumbing test on a 1-GPU box: all ranks on device 0, no RCCL
     if share_gpu:
         local_rank = 0
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    if world != args.gpus:  # started by a launcher with another --nproc-per-node: the launcher's world is what runs
         args.gpus = world
 
     import graphgan_amd as ga  # loads libgraphgan_hip.so (and with it the HIP runtime) before anything else
@@ -222,6 +247,8 @@ def main():
     slots = np.arange(len(roots), dtype=np.int32)
     if not share_gpu:
         ctl.connect_engine(eng)
+        if world > 1:  # the replicas really are one RCCL communicator of N ranks
+            assert eng.comm_stats()["world"] == world, "RCCL communicator has %d ranks, expected %d" % (eng.comm_stats()["world"], world)
     setup_s = time.time() - t_setup
     eng.set_profiling(args.profile_every)
 
@@ -249,6 +276,7 @@ def main():
     dt = time.perf_counter() - t0
     c1 = eng.counters()
     c = delta(c1, c0)
+    comm = eng.comm_stats() if world > 1 and not share_gpu else None
 
     # ---- behind the timed region (every rank takes part: the steps contain collectives) -------------------------
     nxt = args.warmup + args.steps
@@ -417,6 +445,9 @@ def main():
                        "reference_equivalent_GBs": (ref_bytes / calls) / (walk_ms / launches * 1e-3) / 1e9 if walk_ms > 0 and launches else None,
                        "distributions_shared": reads / max(rows_scored, 1)},
     }
+    if comm:
+        out["comm"] = dict(comm, what="rank 0's gradient exchanges up to the end of the timed region (RCCL over xGMI): optimizer steps that exchanged "
+                                      "fixed-capacity row packs (sparse) / reduce-scatter + all-gather of the accumulators (dense), bytes sent")
     if e2e:
         out["end_to_end_with_tree_build"] = {
             "value": sums[3] / e2e_dt, "unit": "edges/s",

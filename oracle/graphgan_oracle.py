@@ -417,6 +417,15 @@ class PairModel:
     def score(self, u, v):
         return np.sum(self.E[u] * self.E[v], axis=1, dtype=np.float32) + self.b[v]
 
+    def _bias_slices(self, u, v, gb):
+        """Gradient slices of the bias vector.  Dense TF1-Adam (the reference): indices v only (the gather of the
+        graph), every element decays anyway.  Lazy mode -- the engine's scale mode, not a reference mode -- is
+        NODE-granular: a node a step touches advances its embedding row AND its bias (gradient 0 where the node
+        was only a centre), which is what the engine's per-row optimizer kernels do."""
+        if self.opt.lazy:
+            return np.concatenate([np.asarray(u), np.asarray(v)]), np.concatenate([np.zeros(len(u), np.float32), gb])
+        return np.asarray(v), gb
+
 
 class Discriminator(PairModel):
     def reward(self, u, v):
@@ -441,7 +450,7 @@ class Discriminator(PairModel):
     def d_step(self, u, v, label, lam):
         _, gu, gv, gb = self.loss_and_grads(u, v, label, lam)
         idx = np.concatenate([u, v])
-        self.opt.step([self.E, self.b], [(idx, np.concatenate([gu, gv])), (np.asarray(v), gb)])
+        self.opt.step([self.E, self.b], [(idx, np.concatenate([gu, gv])), self._bias_slices(u, v, gb)])
 
 
 class Generator(PairModel):
@@ -468,7 +477,7 @@ class Generator(PairModel):
     def g_step(self, u, v, reward, lam):
         _, gu, gv, gb = self.loss_and_grads(u, v, reward, lam)
         idx = np.concatenate([u, v])
-        self.opt.step([self.E, self.b], [(idx, np.concatenate([gu, gv])), (np.asarray(v), gb)])
+        self.opt.step([self.E, self.b], [(idx, np.concatenate([gu, gv])), self._bias_slices(u, v, gb)])
 
 
 # ----------------------------------------------------------------------------- the trainer

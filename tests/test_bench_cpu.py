@@ -25,3 +25,32 @@ def test_pmc_summary_lookup_takes_the_latest_round():
     data = json.load(open(os.path.join(ROOT, src)))
     assert any("level_score_kernel" in k for k in data)
     assert bench.pmc_traffic("no_such_kernel") == (None, None)
+
+
+def test_gpus_n_launches_its_own_ranks(tmp_path, monkeypatch):
+    """`python bench.py --gpus N` with no launcher around it starts N ranks itself (it used to exit): every rank
+    gets the environment torch.distributed.run would export, rank 0's stdout is the bench's stdout, a failing rank fails
+    the whole run.  The ranks here are a stand-in script (no GPU in this container)."""
+    import subprocess
+    import bench
+    child = tmp_path / "child.py"
+    child.write_text(
+        "import json, os, sys\n"
+        "r = int(os.environ['RANK'])\n"
+        "open(os.path.join(os.path.dirname(__file__), 'rank%d' % r), 'w').write(' '.join(sys.argv[1:]))\n"
+        "print(json.dumps({k: os.environ[k] for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}))\n"
+        "sys.exit(int(os.environ.get('CHILD_FAIL_RANK', '-1')) == r)\n")
+    driver = ("import sys; sys.argv = ['bench.py', '--gpus', '3', '--steps', '2']; sys.path.insert(0, %r); import bench; "
+              "bench.self_launch(3, %r)" % (ROOT, str(child)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-c", driver], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr
+    line = json.loads(r.stdout)   # exactly one line: rank 0's
+    assert line["RANK"] == "0" and line["WORLD_SIZE"] == "3" and line["MASTER_ADDR"] == "127.0.0.1" and int(line["MASTER_PORT"]) > 0
+    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("rank")) == ["rank0", "rank1", "rank2"]
+    assert (tmp_path / "rank2").read_text() == "--gpus 3 --steps 2"
+    r = subprocess.run([sys.executable, "-c", driver], capture_output=True, text=True, env=dict(env, CHILD_FAIL_RANK="1"), timeout=120)
+    assert r.returncode != 0 and "rank exit codes [0, 1, 0]" in r.stderr
+    # main() takes that path exactly when no launcher exported WORLD_SIZE
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'if "WORLD_SIZE" not in os.environ and args.gpus > 1:' in src and "must be launched with" not in src

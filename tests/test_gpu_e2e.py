@@ -297,3 +297,29 @@ def test_tree_cache_file_replaces_the_pickle(tmp_path):
     open(cache, "wb").write(blob)
     g3.engine.load_trees(cache)
     g3.engine.close()
+
+
+def test_bench_gpus_2_self_launches_two_ranks():
+    """`python bench.py --gpus 2` with no launcher: bench.py spawns the two ranks itself (gloo control plane, rank 0 prints
+    the one JSON line).  This box has one GPU, so the ranks share device 0 and skip RCCL (GG_BENCH_SHARE_GPU=1: plumbing
+    only); each rank walks its own roots of the same graph, so the whole-job hop count is about twice the one-rank run's."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    flags = ["--nodes", "20000", "--roots", "256", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-strict",
+             "--fresh-batches", "0", "--overlap-steps", "0"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    lines = {}
+    for n in (1, 2):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n)] + flags, capture_output=True, text=True,
+                           env=dict(env, GG_BENCH_SHARE_GPU="1"), timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(out) == 1
+        lines[n] = json.loads(out[0])
+    assert lines[1]["n_gpus"] == 1 and lines[2]["n_gpus"] == 2 and lines[2]["scaling"] == "weak"
+    h1 = lines[1]["value"] * lines[1]["ms_per_step"]   # ~ hops per step (all ranks)
+    h2 = lines[2]["value"] * lines[2]["ms_per_step"]
+    assert 1.6 < h2 / h1 < 2.4
+    assert 1.6 < lines[2]["g_pairs_per_step_all_ranks"] / lines[1]["g_pairs_per_step_all_ranks"] < 2.4

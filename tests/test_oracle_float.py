@@ -117,3 +117,37 @@ def test_lazy_adam_only_moves_touched_rows():
     after1 = var.copy()
     opt.step([var], [(np.array([2]), np.ones((1, 2), np.float32))])
     assert np.array_equal(var[1], after1[1]) and var[2, 0] < 1.0 and var[0, 0] == 1.0
+
+
+def test_tf1_adam_dense_equals_torch_adam_with_rescaled_eps():
+    """Independent pin of the dense TF1-Adam restatement (a12).  TF 1.8 moves a variable by
+    lr * sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + eps); torch.optim.Adam by lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps').
+    The two are the same map for eps' = eps / sqrt(1 - b2^t), so a whole training trajectory of the oracle's optimizer
+    (sparse slices with duplicates, all rows decaying every step) must equal torch's Adam fed with the densified
+    gradients and that per-step eps -- 40 steps of the discriminator's real loss through torch autograd in fp64."""
+    rs = np.random.RandomState(3)
+    n, d, B, lam = 40, 9, 64, 1e-5
+    E0 = (rs.randn(n, d) * 0.5).astype(np.float32)
+    dis = orc.Discriminator(E0, 1e-3)
+    E = torch.tensor(E0.astype(np.float64), requires_grad=True)
+    b = torch.zeros(n, dtype=torch.float64, requires_grad=True)
+    opt = torch.optim.Adam([E, b], lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    for t in range(1, 41):
+        u, v = rs.randint(0, n, B), rs.randint(0, n // 2, B)   # rows >= n/2 are touched rarely: decay-only steps matter
+        u[:16] = u[0]
+        y = (rs.rand(B) < 0.5).astype(np.float32)
+        dis.d_step(u, v, y, lam)
+        ut, vt, yt = torch.tensor(u), torch.tensor(v), torch.tensor(y.astype(np.float64))
+        s = (E[ut] * E[vt]).sum(1) + b[vt]
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(s, yt, reduction="sum")
+        loss = loss + lam * 0.5 * ((E[vt] ** 2).sum() + (E[ut] ** 2).sum() + (b[vt] ** 2).sum())
+        opt.zero_grad()
+        loss.backward()
+        for g in opt.param_groups:
+            g["eps"] = 1e-8 / np.sqrt(1.0 - 0.999 ** t)
+        opt.step()
+        # fp32 oracle vs fp64 torch: the trajectories stay together to fp32 rounding (a first Adam step is lr * sign(g),
+        # so elements whose gradient is ~0 may differ by up to 2 lr in principle; none do with this seed)
+        assert np.abs(dis.E - E.detach().numpy()).max() < 2e-5, t
+        assert np.abs(dis.b - b.detach().numpy()).max() < 2e-5, t
+    assert np.abs(dis.E - E0).max() > 5e-3   # the tables moved
