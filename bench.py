@@ -403,7 +403,7 @@ def main():
         "setup_s": setup_s,
         "tree_build": {"where": "host threads" if args.host_bfs else "gpu bfs (one workgroup per root, visited bitmap in LDS)", "trees": int(R), "call_s": trees_s,
                        "kernel_ms": c_trees["bfs_kernel_ms"], "us_per_tree": 1e3 * c_trees["bfs_kernel_ms"] / max(c_trees["bfs_trees"], 1) if c_trees["bfs_trees"] else None,
-                       "resident_bytes_per_tree": 8.0 * n},
+                       "resident_bytes_per_tree": 12.0 * n},
         "roofline": {"kernel": "level_score_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": frac(achieved), "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": sc_bytes / max(sc_launches, 1), "avg_launch_ms": c["score_kernel_ms"] / max(sc_launches, 1),

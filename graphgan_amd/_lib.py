@@ -40,7 +40,8 @@ class GGCounters(ctypes.Structure):
                 ("d_grad_ms", ctypes.c_double), ("d_opt_ms", ctypes.c_double), ("d_pairs_timed", ctypes.c_int64), ("d_rows_timed", ctypes.c_int64),
                 ("g_grad_ms", ctypes.c_double), ("g_opt_ms", ctypes.c_double), ("g_pairs_timed", ctypes.c_int64), ("g_rows_timed", ctypes.c_int64),
                 ("d_passes_timed", ctypes.c_int64), ("g_passes_timed", ctypes.c_int64),
-                ("g_walk_nodes_timed", ctypes.c_int64)]
+                ("g_walk_nodes_timed", ctypes.c_int64),
+                ("es_gathers", ctypes.c_int64), ("es_nodes", ctypes.c_int64), ("score_gathers", ctypes.c_int64), ("score_nodes", ctypes.c_int64)]
 
 
 class GGGraph(ctypes.Structure):
@@ -73,6 +74,7 @@ SIGNATURES = {
     "gg_save_trees": (ctypes.c_int, [_P, ctypes.c_char_p]),
     "gg_load_trees": (ctypes.c_int, [_P, ctypes.c_char_p]),
     "gg_get_trees": (ctypes.c_int, [_P, _P, _P, _P]),
+    "gg_get_tree_order": (ctypes.c_int, [_P, _P, _P, _P, _P, _P]),
     "gg_walk_sample": (ctypes.c_int, [_P, _P, _P, _i32, _i32, _u64, _u32, _P, _P, _P, _i32, _P]),
     "gg_walk_info": (ctypes.c_int, [_P, _P, _P, _P]),
     "gg_get_walks": (ctypes.c_int, [_P, _P, _P, _P, _P]),
@@ -122,7 +124,7 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.gg_abi_version() != 2:
+    if lib.gg_abi_version() != 3:
         raise ImportError("graphgan_amd: ABI version mismatch")
     return lib
 

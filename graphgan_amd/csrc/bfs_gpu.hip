@@ -51,6 +51,7 @@ struct BfsArgs {
     const int64_t *base;     // [n_roots + 1] device (t_base)
     int32_t *order;          // t_order
     int32_t *cstart;         // t_cstart
+    int32_t *edge;           // t_edge: CSR index of the edge a node was appended at (father -> node)
     unsigned int *ticket;    // next root to take
     int32_t *stats;          // [0] max depth, [1] longest list (1 + most children), [2] error flag
     uint32_t *gbitmap;       // [grid][bm_words]  (graphs too large for the LDS bitmap)
@@ -109,12 +110,14 @@ __global__ __launch_bounds__(BFS_T) void bfs_order_kernel(const BfsArgs a) {
         const int root = a.roots[r];
         int32_t *const order = a.order + a.base[r];
         int32_t *const cstart = a.cstart + a.base[r] + r;
+        int32_t *const tedge = a.edge + a.base[r];
         const int expect = (int)(a.base[r + 1] - a.base[r]);
         for (int i = tid; i < a.bm_words; i += BFS_T) bm[i] = 0u;
         __syncthreads();
         if (tid == 0) {
             bm[root >> 5] = 1u << (root & 31);
             order[0] = root;
+            tedge[0] = -1;
             cstart[0] = 1;
             if (a.rowptr[root + 1] == a.rowptr[root]) cstart[1] = 1;  // isolated root: no edge ever closes its (empty) child range
         }
@@ -331,12 +334,23 @@ __global__ __launch_bounds__(BFS_T) void bfs_order_kernel(const BfsArgs a) {
                 int rank = tail + wpre + before;
                 int q = head + qfirst + 1;
                 if (mine | lmask) {
+                    // the CSR index of this thread's stream positions again (as in the load loop): an appended node records
+                    // the edge it was appended at -- the edge-score cache of the walk sampler is indexed by it
+                    int idx2 = qfirst;
+                    uint32_t e2 = e0s[idx2] + (uint32_t)(p0 - eoff[idx2]);
+                    int nextb2 = eoff[idx2 + 1];
 #pragma unroll
                     for (int j = 0; j < BFS_U; ++j) {
+                        if (p0 + j < TE && p0 + j == nextb2) {
+                            ++idx2;
+                            e2 = e0s[idx2];
+                            nextb2 = eoff[idx2 + 1];
+                        }
                         if ((mine >> j) & 1u) {
-                            if (rank < expect) order[rank] = w[j];
+                            if (rank < expect) { order[rank] = w[j]; tedge[rank] = (int32_t)e2; }
                             ++rank;
                         }
+                        ++e2;
                         if ((lmask >> j) & 1u) {  // children of this queue node end here
                             if (!(INSTR && (a.exp & 1))) cstart[q] = rank;
                             ++q;
@@ -417,6 +431,7 @@ extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t 
     a.base = ctx->t_base;
     a.order = ctx->t_order;
     a.cstart = ctx->t_cstart;
+    a.edge = ctx->t_edge;
     a.ticket = misc.as<unsigned int>();
     a.stats = misc.as<int32_t>() + 1;
     a.gbitmap = gbm.as<uint32_t>();
@@ -466,6 +481,7 @@ extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t 
     GG_CHECK(ctx, stats[2] == 0 || a.exp, GG_EINVAL, "gg_build_trees_device: a BFS reached a different number of nodes than the component sweep of the graph");
     ctx->tree_max_depth = stats[0];
     ctx->tree_max_list = stats[1];
+    ctx->t_edge_valid = a.exp == 0;
     ctx->ctr.bfs_kernel_ms += ms;
     ctx->ctr.bfs_trees += n_roots;
     return GG_OK;

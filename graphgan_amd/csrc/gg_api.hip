@@ -29,10 +29,11 @@ int fail(gg_ctx *ctx, int code, const char *fmt, ...) {
 }
 
 static void free_trees(gg_ctx *ctx) {
-    void *ps[] = {ctx->t_root, ctx->t_order, ctx->t_cstart, ctx->t_base, ctx->t_q3, ctx->t_q3off};
+    void *ps[] = {ctx->t_root, ctx->t_order, ctx->t_cstart, ctx->t_base, ctx->t_q3, ctx->t_q3off, ctx->t_edge};
     for (void *p : ps)
         if (p) (void)hipFree(p);
-    ctx->t_root = ctx->t_order = ctx->t_cstart = nullptr;
+    ctx->t_root = ctx->t_order = ctx->t_cstart = ctx->t_edge = nullptr;
+    ctx->t_edge_valid = false;
     ctx->t_base = ctx->t_q3off = nullptr;
     ctx->t_q3 = nullptr;
     ctx->t_cap_nodes = ctx->t_cap_roots = ctx->t_cap_q3 = 0;
@@ -49,6 +50,7 @@ static void free_trees(gg_ctx *ctx) {
 int alloc_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int64_t *node_counts, const int64_t *root_children) {
     (void)hipDeviceSynchronize();  // walks of calls that returned early may still read the old trees
     ctx->dc_valid = false;
+    ctx->t_edge_valid = false;  // set by whoever fills the arrays (GPU BFS: in the same pass; otherwise derive_tree_edges)
     const int n = ctx->n_node;
     if (!node_counts && ctx->h_comp_size.empty()) component_sizes(n, ctx->h_rowptr.data(), ctx->h_col.data(), ctx->h_comp_size);
     ctx->h_tbase.assign(n_roots + 1, 0);
@@ -71,6 +73,7 @@ int alloc_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int64_
         // cstart holds nodes + roots entries: both capacities are tied to the same allocation
         const int64_t cn = std::max<int64_t>(nodes, 1), cr = std::max<int64_t>(nr, ctx->t_cap_roots);
         GG_HIP(ctx, regrow((void **)&ctx->t_order, sizeof(int32_t) * (size_t)cn));
+        GG_HIP(ctx, regrow((void **)&ctx->t_edge, sizeof(int32_t) * (size_t)cn));
         GG_HIP(ctx, regrow((void **)&ctx->t_cstart, sizeof(int32_t) * (size_t)(cn + cr)));
         GG_HIP(ctx, regrow((void **)&ctx->t_root, sizeof(int32_t) * (size_t)cr));
         GG_HIP(ctx, regrow((void **)&ctx->t_base, sizeof(int64_t) * (size_t)(cr + 1)));
@@ -94,6 +97,20 @@ int alloc_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int64_
     ctx->tree_entries = 2 * nodes - n_roots;
     ctx->h_troot.assign(roots, roots + n_roots);
     return GG_OK;
+}
+
+// The generator's tables changed (optimizer step, upload, restore): distributions cached by the D launch and every edge
+// score are stale.  Edge scores are invalidated by moving on to the next epoch (stamps of older epochs never match).
+void generator_changed(gg_ctx *ctx) {
+    ctx->dc_valid = false;
+    if (ctx->es_epoch >= 0x7ffffff0) {  // wrap-around: forget every stamp
+        if (ctx->es_stamp) {
+            (void)hipDeviceSynchronize();
+            (void)hipMemset(ctx->es_stamp, 0, sizeof(int32_t) * (size_t)ctx->n_node);
+        }
+        ctx->es_epoch = 0;
+    }
+    ctx->es_epoch += 1;
 }
 
 static int upload_table(gg_ctx *ctx, float *dst, const float *src) {
@@ -211,6 +228,7 @@ int gg::walk_finalize(gg_ctx *ctx, bool *retried) {
         // nothing the overflowed launch wrote or counted is final (the D-mode post-pass is gated by the same flag,
         // the counter words are zeroed again by the new launch)
         ctx->walk_force_sized = true;
+        generator_changed(ctx);  // nodes the aborted launch claimed were never scored: no stamp of it may stay valid
         int rc = launch_and_join(ctx, ctx->w_nslots, total, ctx->w_args.for_d, ctx->w_args.seed, ctx->w_args.stream, ctx->w_stride);
         ctx->walk_force_sized = false;
         if (rc != GG_OK) return rc;
@@ -230,7 +248,10 @@ int gg::walk_finalize(gg_ctx *ctx, bool *retried) {
     }
     // c[0], c[1], c[5]: counts of the per-walk finisher; the level pipeline's counts sit in 64 spread words each
     unsigned long long hops = c[0], reads = c[1], rows = c[5];
-    for (int i = 0; i < 64; ++i) { hops += c[264 + i]; reads += c[328 + i]; rows += c[200 + i]; }
+    unsigned long long gathers = 0, nodes = 0;
+    for (int i = 0; i < 64; ++i) { hops += c[264 + i]; reads += c[328 + i]; rows += c[200 + i]; gathers += c[520 + i]; nodes += c[584 + i]; }
+    ctx->ctr.es_gathers += (int64_t)gathers;
+    ctx->ctr.es_nodes += (int64_t)nodes;
     ctx->ctr.hops += (int64_t)hops;
     ctx->ctr.nbr_reads += (int64_t)reads;
     ctx->ctr.rows_scored += (int64_t)rows;
@@ -250,18 +271,21 @@ int gg::walk_finalize(gg_ctx *ctx, bool *retried) {
             }
             ctx->ctr.score_kernel_ms += lms;
             ctx->ctr.score_launches += n_half;
-            ctx->ctr.score_chunks += (int64_t)c[136 + i];
+            ctx->ctr.score_chunks += (int64_t)(c[136 + i] >> 32);
             if (getenv("GG_WALK_DEBUG"))
-                fprintf(stderr, "[walk] for_d=%d level %d alive %llu chunks %llu big %llu score %.1f us\n", ctx->w_args.for_d, i,
-                        c[8 + i], c[136 + i], c[72 + i] & 0xffffffffull, lms * 1e3);
+                fprintf(stderr, "[walk] for_d=%d level %d alive %llu score chunks %llu prefix chunks %llu big %llu small %llu tiny %llu score %.1f us\n", ctx->w_args.for_d, i,
+                        c[8 + i], c[136 + i] >> 32, c[136 + i] & 0xffffffffull, c[72 + i] & 0xffffffffull, c[72 + i] >> 32, c[456 + i], lms * 1e3);
         }
         if (ctx->lv_ev_used) {
             ctx->ctr.score_rows += (int64_t)(rows - c[5]);  // rows of the timed score launches
             unsigned long long dists = 0;
             for (int i = 0; i < 64; ++i) dists += c[392 + i];
             ctx->ctr.score_dists += (int64_t)dists;
+            ctx->ctr.score_gathers += (int64_t)gathers;
+            ctx->ctr.score_nodes += (int64_t)nodes;
         }
     }
+    if (c[3] || c[6]) generator_changed(ctx);  // a failed launch leaves nothing behind that a later one may reuse
     if (c[3]) return fail(ctx, GG_ECAPACITY, "walk: a path needed more than stride=%d entries", ctx->w_stride);
     if (c[6]) return fail(ctx, GG_EINVAL, "walk: non-finite generator scores (a softmax had total weight 0)");
     return GG_OK;
@@ -313,6 +337,9 @@ int gg_create(int32_t n_node, int32_t n_emb, const float *emb_gen, const float *
     if (const char *ft = getenv("GG_FIN_THRESHOLD")) ctx->fin_threshold = std::max(0, atoi(ft));
     if (const char *st = getenv("GG_STAGE_T")) ctx->sg_threshold = std::max(0, atoi(st));
     if (const char *ws = getenv("GG_WALK_SPLIT")) ctx->split_enabled = atoi(ws) != 0;
+    if (const char *em = getenv("GG_ES_MODE")) ctx->es_mode = std::min(2, std::max(0, atoi(em)));
+    if (const char *er = getenv("GG_ES_RATIO")) ctx->es_ratio_num = std::max(1, atoi(er));
+    if (const char *eh = getenv("GG_ES_HUB")) ctx->es_hub = std::max(0, atoi(eh));
     if (const char *wm = getenv("GG_WALK_SPLIT_MIN")) ctx->split_min_walks = std::max(512, atoi(wm));
     for (auto &m : ctx->alive_prof) for (auto &v : m) v = -1;
     if (const char *dr = getenv("GG_COMM_DENSE_RATIO")) ctx->dense_exchange_ratio = (float)atof(dr);
@@ -339,8 +366,8 @@ int gg_create(int32_t n_node, int32_t n_emb, const float *emb_gen, const float *
         GG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_walk_done, hipEventDisableTiming));
         GG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_gen_pass, hipEventDisableTiming));
         GG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_main_mark, hipEventDisableTiming));
-        GG_HIP(ctx, hipHostMalloc((void **)&ctx->h_pin, sizeof(unsigned long long) * 1024, hipHostMallocDefault));
-        memset(ctx->h_pin, 0, sizeof(unsigned long long) * 1024);
+        GG_HIP(ctx, hipHostMalloc((void **)&ctx->h_pin, sizeof(unsigned long long) * gg_ctx::PIN_WORDS, hipHostMallocDefault));
+        memset(ctx->h_pin, 0, sizeof(unsigned long long) * gg_ctx::PIN_WORDS);
         const size_t tb = sizeof(float) * (size_t)n_node * ctx->ld, vb = sizeof(float) * (size_t)n_node;
         for (int m = 0; m < 2; ++m) {
             Model &M = ctx->model[m];
@@ -374,8 +401,8 @@ int gg_create(int32_t n_node, int32_t n_emb, const float *emb_gen, const float *
         GG_HIP(ctx, hipMalloc((void **)&ctx->touched_cnt, sizeof(int32_t) * 4));
         GG_HIP(ctx, hipMemset(ctx->touched, 0, sizeof(int32_t) * n_node));
         GG_HIP(ctx, hipMemset(ctx->touched_cnt, 0, sizeof(int32_t) * 4));
-        GG_HIP(ctx, hipMalloc((void **)&ctx->dev_ctr, sizeof(unsigned long long) * 1024));
-        GG_HIP(ctx, hipMemset(ctx->dev_ctr, 0, sizeof(unsigned long long) * 1024));
+        GG_HIP(ctx, hipMalloc((void **)&ctx->dev_ctr, sizeof(unsigned long long) * gg_ctx::PIN_WORDS));
+        GG_HIP(ctx, hipMemset(ctx->dev_ctr, 0, sizeof(unsigned long long) * gg_ctx::PIN_WORDS));
         GG_HIP(ctx, hipDeviceSynchronize());
         return GG_OK;
     };
@@ -396,7 +423,8 @@ int gg_destroy(gg_ctx *ctx) {
         for (float *p : ps)
             if (p) (void)hipFree(p);
     }
-    void *ps[] = {ctx->gradE, ctx->gradb, ctx->touched, ctx->touched_list, ctx->touched_cnt, ctx->g_rowptr, ctx->g_col, ctx->dev_ctr};
+    void *ps[] = {ctx->gradE, ctx->gradb, ctx->touched, ctx->touched_list, ctx->touched_cnt, ctx->g_rowptr, ctx->g_col, ctx->dev_ctr,
+                  ctx->es, ctx->es_stamp, ctx->g_rev};
     for (void *p : ps)
         if (p) (void)hipFree(p);
     free_trees(ctx);
@@ -405,7 +433,7 @@ int gg_destroy(gg_ctx *ctx) {
                       &ctx->d_ptr, &ctx->g_node1, &ctx->g_node2, &ctx->g_reward, &ctx->g_cnt, &ctx->g_ptr, &ctx->scan_tmp,
                       &ctx->step_u, &ctx->step_v, &ctx->step_x, &ctx->sg_cnt, &ctx->sg_off, &ctx->sg_slot, &ctx->sg_list, &ctx->sg_rows, &ctx->sg_bias, &ctx->sg_tot, &ctx->sg_key, &ctx->touched_ptr, &ctx->x_cnt, &ctx->x_send_ids, &ctx->x_send_rows,
                       &ctx->x_recv_ids, &ctx->x_recv_rows, &ctx->x_nglob, &ctx->st_item, &ctx->st_cur, &ctx->st_prev, &ctx->st_len,
-                      &ctx->st_alive, &ctx->st_rank, &ctx->bfs_key, &ctx->bfs_bm, &ctx->bfs_misc, &ctx->lv_pfx, &ctx->dc_keys, &ctx->dc_vals, &ctx->dc_words, &ctx->lv_beg, &ctx->lv_k, &ctx->lv_chunks, &ctx->lv_coff, &ctx->lv_scores, &ctx->lv_chunk_owner, &ctx->lv_prefix, &ctx->lv_big, &ctx->fin_list};
+                      &ctx->st_alive, &ctx->st_rank, &ctx->bfs_key, &ctx->bfs_bm, &ctx->bfs_misc, &ctx->lv_pfx, &ctx->dc_keys, &ctx->dc_vals, &ctx->dc_words, &ctx->lv_beg, &ctx->lv_k, &ctx->lv_chunks, &ctx->lv_coff, &ctx->lv_scores, &ctx->lv_chunk_owner, &ctx->lv_prefix, &ctx->lv_big, &ctx->lv_fe, &ctx->fin_list};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : ctx->lv_ev)
         if (e) (void)hipEventDestroy(e);
@@ -439,10 +467,15 @@ int gg_set_graph_csr(gg_ctx *ctx, const int64_t *rowptr, const int32_t *col) {
     for (int v = 0; v < n; ++v) GG_CHECK(ctx, rowptr[v + 1] >= rowptr[v], GG_EINVAL, "gg_set_graph_csr: rowptr not monotone at %d", v);
     for (int64_t e = 0; e < nnz; ++e) GG_CHECK(ctx, col[e] >= 0 && col[e] < n, GG_EINVAL, "gg_set_graph_csr: col[%lld]=%d out of range", (long long)e, col[e]);
     GG_HIP(ctx, hipSetDevice(ctx->device));
-    if (ctx->g_rowptr) (void)hipFree(ctx->g_rowptr);
-    if (ctx->g_col) (void)hipFree(ctx->g_col);
+    (void)hipDeviceSynchronize();
+    for (void *p : {(void *)ctx->g_rowptr, (void *)ctx->g_col, (void *)ctx->es, (void *)ctx->es_stamp, (void *)ctx->g_rev})
+        if (p) (void)hipFree(p);
     ctx->g_rowptr = nullptr;
     ctx->g_col = nullptr;
+    ctx->es = nullptr;
+    ctx->es_stamp = nullptr;
+    ctx->g_rev = nullptr;
+    ctx->t_edge_valid = false;  // edge indices of resident trees named the old graph
     GG_HIP(ctx, hipMalloc((void **)&ctx->g_rowptr, sizeof(int64_t) * (n + 1)));
     GG_HIP(ctx, hipMalloc((void **)&ctx->g_col, sizeof(int32_t) * std::max<int64_t>(nnz, 1)));
     GG_HIP(ctx, hipMemcpy(ctx->g_rowptr, rowptr, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
@@ -457,6 +490,16 @@ int gg_set_graph_csr(gg_ctx *ctx, const int64_t *rowptr, const int32_t *col) {
     for (int64_t e = 0; e + 1 < nnz; e += 2) h = (h ^ ((uint64_t)(uint32_t)col[e] | ((uint64_t)(uint32_t)col[e + 1] << 32))) * 1099511628211ull;
     if (nnz & 1) h = (h ^ (uint64_t)(uint32_t)col[nnz - 1]) * 1099511628211ull;
     ctx->g_hash = h;
+    // edge-score cache of the walk sampler (gg_internal.h): scores, per-node stamps, reverse-edge index
+    if (nnz > 0 && nnz < (1ll << 31)) {
+        GG_HIP(ctx, hipMalloc((void **)&ctx->es, sizeof(float) * (size_t)nnz));
+        GG_HIP(ctx, hipMalloc((void **)&ctx->es_stamp, sizeof(int32_t) * (size_t)n));
+        GG_HIP(ctx, hipMalloc((void **)&ctx->g_rev, sizeof(int32_t) * (size_t)nnz));
+        GG_HIP(ctx, hipMemset(ctx->es_stamp, 0, sizeof(int32_t) * (size_t)n));
+        generator_changed(ctx);
+        int rc = compute_reverse_edges(ctx);
+        if (rc != GG_OK) return rc;
+    }
     return GG_OK;
 }
 
@@ -507,7 +550,7 @@ int gg_build_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, int32_t n
     }
     ctx->tree_max_depth = md;
     ctx->tree_max_list = ml;
-    return GG_OK;
+    return derive_tree_edges(ctx);
 }
 
 // Upload trees given in the reference's shape (per node the list [father, child...]): converted to BFS-order form.
@@ -551,7 +594,7 @@ int gg_set_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int32
     if (ctx->h_q3off[n_roots]) GG_HIP(ctx, hipMemcpy(ctx->t_q3, q3_h.data(), sizeof(uint32_t) * (size_t)ctx->h_q3off[n_roots], hipMemcpyHostToDevice));
     ctx->tree_max_depth = max_depth > 0 ? std::max(max_depth, md) : md;
     ctx->tree_max_list = ml;
-    return GG_OK;
+    return derive_tree_edges(ctx);  // (lists that are no subgraph of the resident graph: walks score privately, no error)
 }
 
 int gg_tree_info(const gg_ctx *ctx, int32_t *n_roots, int64_t *n_entries, int32_t *max_depth) {
@@ -599,6 +642,21 @@ int gg_get_trees(gg_ctx *ctx, int32_t *off, int32_t *nbr, int64_t *nbr_base) {
     for (int t = 1; t < nt; ++t) th.emplace_back(work);
     work();
     for (auto &t : th) t.join();
+    return GG_OK;
+}
+
+int gg_get_tree_order(gg_ctx *ctx, int64_t *base, int32_t *order, int32_t *cstart, int32_t *edge, int32_t *edges_valid) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    GG_CHECK(ctx, ctx->n_tree_roots > 0, GG_EINVAL, "gg_get_tree_order: no trees loaded");
+    GG_HIP(ctx, hipSetDevice(ctx->device));
+    GG_HIP(ctx, hipDeviceSynchronize());
+    const int R = ctx->n_tree_roots;
+    const size_t nodes = (size_t)ctx->tree_nodes;
+    if (base) memcpy(base, ctx->h_tbase.data(), sizeof(int64_t) * ((size_t)R + 1));
+    if (order) GG_HIP(ctx, hipMemcpy(order, ctx->t_order, sizeof(int32_t) * nodes, hipMemcpyDeviceToHost));
+    if (cstart) GG_HIP(ctx, hipMemcpy(cstart, ctx->t_cstart, sizeof(int32_t) * (nodes + R), hipMemcpyDeviceToHost));
+    if (edge) GG_HIP(ctx, hipMemcpy(edge, ctx->t_edge, sizeof(int32_t) * nodes, hipMemcpyDeviceToHost));
+    if (edges_valid) *edges_valid = ctx->t_edge_valid ? 1 : 0;
     return GG_OK;
 }
 
@@ -721,7 +779,7 @@ int gg_load_trees(gg_ctx *ctx, const char *path) {
     if (rc == GG_OK) rc = stream_dev(ctx, f, ctx->t_cstart, (size_t)h.nodes + h.n_roots, false);
     fclose(f);
     if (rc == GG_OK) {
-        int32_t *bad = (int32_t *)(ctx->dev_ctr + 1000);  // a spare word behind the walk launches' counters ([0, 912))
+        int32_t *bad = (int32_t *)(ctx->dev_ctr + 2000);  // a spare word behind the walk launches' counters ([0, 2 * CTR_WORDS))
         int32_t h_bad = 0;
         hipError_t e = hipMemset(bad, 0, sizeof(int32_t));
         if (e == hipSuccess) {
@@ -742,7 +800,7 @@ int gg_load_trees(gg_ctx *ctx, const char *path) {
     }
     ctx->tree_max_depth = h.max_depth;
     ctx->tree_max_list = h.max_list;
-    return GG_OK;
+    return derive_tree_edges(ctx);
 }
 
 int gg_walk_sample(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, int32_t n_slots, int32_t for_d,
@@ -790,7 +848,7 @@ static int table_io(gg_ctx *ctx, int32_t which, float *out, const float *in, boo
     GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     Model &M = ctx->model[which];
     const int n = ctx->n_node, d = ctx->n_emb, ld = ctx->ld;
-    if (in && which == 0) ctx->dc_valid = false;
+    if (in && which == 0) generator_changed(ctx);
     if (bias) {
         if (out) GG_HIP(ctx, hipMemcpy(out, M.b, sizeof(float) * n, hipMemcpyDeviceToHost));
         else GG_HIP(ctx, hipMemcpy(M.b, in, sizeof(float) * n, hipMemcpyHostToDevice));
@@ -976,7 +1034,7 @@ int state_io(gg_ctx *ctx, const char *path, bool save) {
         return rc;
     }
     fclose(f);
-    ctx->dc_valid = false;
+    generator_changed(ctx);
     if (rc == GG_OK)  // step counts / beta powers only once every table arrived
         for (int m = 0; m < 2; ++m) { ctx->model[m].t = loaded[m].t; ctx->model[m].b1p = loaded[m].b1p; ctx->model[m].b2p = loaded[m].b2p; }
     return rc;

@@ -89,6 +89,16 @@ struct gg_ctx {
     uint64_t g_hash = 0;  // fingerprint of the adjacency (tree cache validation)
     std::vector<int64_t> h_rowptr;  // host copies (tree builder, degrees)
     std::vector<int32_t> h_col;
+    // Edge-score cache (walk_sample.hip): s(u, col[e]) = g_u . g_col[e] + b[col[e]] of graph edge e (generator.py:21) does not
+    // depend on the ROOT whose tree a walk moves in, so the walks of all roots, levels and both launches of a step share
+    // one copy: es[e], valid when es_stamp[u] == es_epoch (adj(u) was scored since the generator last changed).
+    float *es = nullptr;          // [g_nnz]
+    int32_t *es_stamp = nullptr;  // [n_node]
+    int32_t *g_rev = nullptr;     // [g_nnz] index of the reverse edge (col[e] -> u): a walk's father candidate
+    int32_t es_epoch = 1;         // bumped by every generator update / table upload / aborted launch
+    int32_t es_mode = 1;          // GG_ES_MODE: 0 = off (every distribution scores its own candidates), 1 = policy, 2 = always share
+    int32_t es_ratio_num = 2;     // GG_ES_RATIO: a stale node is scored whole when k * ratio >= deg (k = candidates the asking root needs)
+    int32_t es_hub = 0;           // GG_ES_HUB: ... or when deg >= hub (0 = off)
 
     // BFS trees of n_tree_roots root slots in BFS-ORDER form.  For slot r with C_r reached nodes:
     //   t_order [t_base[r] + i]       node id of BFS pop rank i (rank 0 = the root): the reference's queue
@@ -107,6 +117,12 @@ struct gg_ctx {
     int32_t *t_root = nullptr;   // [R] root node id of each slot
     int32_t *t_order = nullptr;  // [tree_nodes]
     int32_t *t_cstart = nullptr; // [tree_nodes + R]
+    // t_edge[t_base[r] + i]: CSR index of the graph edge (father -> node) the BFS appended rank i at (-1 for rank 0); the
+    // child's score against its father is then ONE gather from the edge-score cache below.  Written by the GPU BFS in
+    // the same pass as t_order; derived by tree_edges_kernel for host-built / uploaded / cached trees.  Not valid
+    // (t_edge_valid = false) for uploaded lists that are no subgraph of the resident graph: those walks score privately.
+    int32_t *t_edge = nullptr;   // [tree_nodes]
+    bool t_edge_valid = false;
     int64_t *t_base = nullptr;   // [R+1]
     uint32_t *t_q3 = nullptr;    // [t_q3off[R]] words
     int64_t *t_q3off = nullptr;  // [R+1] word offsets (ceil(deg(root) / 32) words per slot: children of the root <= its degree)
@@ -132,7 +148,7 @@ struct gg_ctx {
     const gg::DevBuf &w_ptr_buf() const { return w_ptr_m[w_mode]; }
     gg::DevBuf w_samples, w_paths, w_len, w_status, w_first, w_abort, w_scratch;
     // level-synchronous front end of the walk sampler (walk_sample.hip): per-walk state + per-level tasks
-    gg::DevBuf st_cur, st_prev, st_len, st_alive, st_rank, st_item, lv_beg, lv_k, lv_chunks, lv_coff, lv_scores, lv_chunk_owner, lv_prefix, lv_big;
+    gg::DevBuf st_cur, st_prev, st_len, st_alive, st_rank, st_item, lv_beg, lv_k, lv_chunks, lv_coff, lv_scores, lv_chunk_owner, lv_prefix, lv_big, lv_fe;
     gg::DevBuf lv_pfx, dc_keys, dc_vals, dc_words;  // distribution cache (walk_sample.hip): prefix offsets per walk, hash table, base words
     size_t dc_size = 0;                // hash table entries (power of two)
     int32_t dc_request = 0;            // mode of the NEXT walk launch: 0 off, 1 register (gg_prepare_d), 2 look up (gg_prepare_g)
@@ -149,13 +165,14 @@ struct gg_ctx {
     int32_t w_uniform = -1;  // walks per root of the resident launch when every root has the same number (prepare_g), else -1
     struct { int32_t for_d; uint64_t seed; uint32_t stream; } w_args{};
 
-    // pinned host mirror: [0, 912) the launch's device counters (two halves), [H_TOTAL] the row / pair count of a prepare call --
+    // pinned host mirror: [0, 2 * CTR_WORDS) the launch's device counters (two halves), [H_TOTAL] the row / pair count of a prepare call --
     // both arrive with asynchronous copies behind the kernels and ONE stream synchronisation (pageable destinations
     // would make every copy its own host round trip)
-    static constexpr int CTR_WORDS = 456;  // counter words per half of a walk launch (walk_sample.hip)
-    static constexpr int H_TOTAL = 960;
-    static constexpr int H_ROWS = 940;    // [H_ROWS + k]: touched-row count of pending pass timing k (copied behind its optimizer kernel)
-    unsigned long long *h_pin = nullptr;  // [1024], hipHostMalloc
+    static constexpr int CTR_WORDS = 648;  // counter words per half of a walk launch (walk_sample.hip)
+    static constexpr int PIN_WORDS = 2048;
+    static constexpr int H_TOTAL = 1960;
+    static constexpr int H_ROWS = 1940;   // [H_ROWS + k]: touched-row count of pending pass timing k (copied behind its optimizer kernel)
+    unsigned long long *h_pin = nullptr;  // [PIN_WORDS], hipHostMalloc
     // profiling (gg_set_profiling): HIP events around every profile_every-th walk call; 1 = every call and every pass
     // (passes then wait for their events), 0 = never; an event pair costs ~6 us of stream bubble on each side
     int32_t profile_every = 1;
@@ -252,7 +269,10 @@ int walk_launch_async(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks,
 int walk_finalize(gg_ctx *ctx, bool *retried);
 int timing_slot(gg_ctx *ctx);
 int check_exchange_flag(gg_ctx *ctx);
-void harvest_timings(gg_ctx *ctx);  // after a synchronisation of ctx->stream: fold finished event triples into the counters
+void harvest_timings(gg_ctx *ctx);
+int derive_tree_edges(gg_ctx *ctx);   // walk_sample.hip: t_edge from t_order / t_cstart and the resident graph (sets t_edge_valid)
+int compute_reverse_edges(gg_ctx *ctx);  // walk_sample.hip: g_rev of the resident graph
+void generator_changed(gg_ctx *ctx);  // gg_api.hip: cached distributions and edge scores are stale  // after a synchronisation of ctx->stream: fold finished event triples into the counters
 int walk_resident(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, int32_t uniform_walks, int32_t n_slots,
                   int32_t for_d, uint64_t seed, uint32_t stream, int32_t stride);
 int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int for_d, uint64_t seed, uint32_t stream,

@@ -1183,7 +1183,7 @@ int apply_optimizer(gg_ctx *ctx, int which, int64_t n) {
         else hipLaunchKernelGGL(sparse_opt_kernel<0>, dim3(nb), dim3(256), 0, ctx->stream, o);
     }
     GG_HIP(ctx, hipGetLastError());
-    if (which == 0) { ctx->gen_dirty = true; ctx->dc_valid = false; }  // the generator moved: cached distributions are stale
+    if (which == 0) { ctx->gen_dirty = true; generator_changed(ctx); }  // the generator moved: cached distributions and edge scores are stale
     M.t += 1;
     M.b1p = M.b1p * ctx->cfg.adam_beta1;
     M.b2p = M.b2p * ctx->cfg.adam_beta2;

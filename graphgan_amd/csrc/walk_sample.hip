@@ -86,6 +86,19 @@ struct WalkArgs {
     int64_t w0, w_end;       // walks [w0, w_end) of the launch
     int64_t lv_big_cap;
     int32_t *fin_list;       // [total_walks] walks still alive behind the last streamed level (CTR_FIN entries)
+    // Edge-score cache (gg_internal.h): the score of graph edge e = (u -> col[e]) is the same for every root, so a node's
+    // adjacency is scored ONCE per generator state (es_stamp[u] == es_epoch) and every (root, u) distribution gathers its
+    // candidates' scores through the tree's edge indices: child rank i -> es[t_edge[i]], father -> es[g_rev[t_edge[rank(u)]]].
+    const int64_t *rowptr;
+    const int32_t *col;
+    const int32_t *t_edge;
+    const int32_t *rev;
+    float *es;
+    int32_t *es_stamp;
+    int32_t es_epoch;
+    int32_t es_mode;         // 0 = off, 1 = a stale node is scored whole when the asking distribution needs most of it, 2 = always
+    int32_t es_ratio, es_hub;
+    int32_t *lv_fe;          // [total_walks] es index of the father candidate's score (gather tasks with a father entry)
 };
 
 __device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, int lane) {
@@ -226,18 +239,27 @@ constexpr int CTR_FIN = 7;      // ctr[7]: walks still alive behind the last str
 constexpr int CTR_ALIVE = 8;    // ctr[CTR_ALIVE + level]: walks alive when hop `level` was set up
 constexpr int CTR_BIG = 72;     // ctr[CTR_BIG + level]:   owner tasks of hop `level` that need the weights kernel: big ones (k > BIG_TASK) in
                                 //                         the low 32 bits, small multi-chunk ones in the high 32 bits (one atomic hands out both)
-constexpr int CTR_CHUNKS = 136; // ctr[CTR_CHUNKS + level]: chunks of hop `level` (chunk offsets are handed out per wave)
+constexpr int CTR_CHUNKS = 136; // ctr[CTR_CHUNKS + level]: chunks of hop `level`, two index spaces handed out by one atomic: low 32 bits = PREFIX
+                                //                         chunks (every owner: ceil(k / 16), addresses lv_prefix), high 32 bits = SCORE chunks (descriptors /
+                                //                         lv_scores: private owners ceil(k / 16), node scorings ceil(deg / 16), gather-only owners none)
 constexpr int CTR_ROWS = 200;   // ctr[CTR_ROWS + (block & 63)]: candidate rows scored by this launch (spread words, folded by the host)
 constexpr int CTR_HOPS_V = 264;  // ctr[CTR_HOPS_V + (block & 63)]: hop counts of the level pipeline, spread over 64 words
 constexpr int CTR_READS_V = 328; // (same-address atomics serialise at ~12 ns each); summed by the host
 constexpr int CTR_DISTS = 392;   // ctr[CTR_DISTS + (block & 63)]: (root, node) distributions set up by the level pipeline (owners), spread words
-constexpr int CTR_WORDS = 456;
+constexpr int CTR_TINY = 456;    // ctr[CTR_TINY + level]: gather tasks with <= 16 candidates (third task list of the weights kernel)
+constexpr int CTR_GATHER = 520;  // ctr[CTR_GATHER + (block & 63)]: owner distributions that gather their scores from the edge-score cache, spread words
+constexpr int CTR_NODES = 584;   // ctr[CTR_NODES + (block & 63)]: nodes whose adjacency this launch scored into the cache, spread words
+constexpr int CTR_WORDS = 648;
+static_assert(CTR_WORDS == gg_ctx::CTR_WORDS, "counter layout");
 constexpr int MAX_LEVELS = 64;
+constexpr int LVK_GATHER = 1 << 30;  // lv_k flag: the distribution's scores come from the edge-score cache
+constexpr int LVK_NODE = 1 << 29;    // lv_k flag: ... and this owner scores the node's adjacency (its score chunks are node chunks)
+constexpr int LVK_MASK = (1 << 29) - 1;
 
 // Global chunk offset of the first chunk of hop a.level: the launch's base + the chunks of its earlier hops.
 __device__ __forceinline__ int64_t level_chunk_base(const WalkArgs &a) {
     int64_t b = a.dc_words[0];
-    for (int l = 0; l < a.level; ++l) b += (int64_t)a.lc[CTR_CHUNKS + l];
+    for (int l = 0; l < a.level; ++l) b += (int64_t)(a.lc[CTR_CHUNKS + l] & 0xffffffffull);
     return b;
 }
 
@@ -245,15 +267,24 @@ __device__ __forceinline__ unsigned long long dc_key(int slot, int rank, int hf)
     return ((unsigned long long)(unsigned)slot << 32) | ((unsigned long long)(unsigned)rank << 1) | (unsigned long long)hf;
 }
 
-// Descriptor of chunk i of a k-candidate distribution: {cur, rows | flags | offset bits 32..47, offset bits 0..31, father id}.
-// Candidate c of the distribution is the father (c == 0, only if hf) or the child order[beg_abs + c - hf]; `offset` is the
-// t_order index of the chunk's candidate 0 (for the first chunk of a list with a father entry that is ONE BEFORE the first
-// child -- never dereferenced: lane 0 takes the father id from the descriptor instead).
+// Descriptor of score chunk c: two int4 {cur, rows | flags, offset bits 0..31, offset bits 32..63} {father id, prefix chunk
+// bits 0..31, bits 32..63, 0}.  Private chunk i of a k-candidate distribution: candidate j of the distribution is the father
+// (j == 0, only if hf) or the child order[beg_abs + j - hf]; `offset` is the t_order index of the chunk's candidate 0 (for
+// the first chunk of a list with a father entry that is ONE BEFORE the first child -- never dereferenced: lane 0 takes the
+// father id from the descriptor).  Node chunk i of node cur: its graph neighbours col[offset .. offset + rows), scores to
+// es[offset ..].  `prefix chunk` (single-chunk private distributions): where the score kernel writes the prefix sums.
 constexpr int DESC_HAS_FATHER = 0x200;
-__device__ __forceinline__ int4 chunk_desc(int cur, int k, int hf, int father, int64_t beg_abs, int i) {
+constexpr int DESC_NODE = 0x400;
+__device__ __forceinline__ void write_chunk_desc(int4 *desc, int64_t c, int cur, int k, int hf, int father, int64_t beg_abs, int i, int64_t pfx) {
     const int64_t o = beg_abs + (int64_t)i * CHUNK - hf;
     const int flags = (k <= CHUNK ? SINGLE_CHUNK : 0) | ((hf && i == 0) ? DESC_HAS_FATHER : 0);
-    return make_int4(cur, min(CHUNK, k - i * CHUNK) | flags | (int)((o >> 32) << 16), (int)(o & 0xffffffffll), father);
+    desc[2 * c] = make_int4(cur, min(CHUNK, k - i * CHUNK) | flags, (int)(o & 0xffffffffll), (int)(o >> 32));
+    desc[2 * c + 1] = make_int4(father, (int)(pfx & 0xffffffffll), (int)(pfx >> 32), 0);
+}
+__device__ __forceinline__ void write_node_desc(int4 *desc, int64_t c, int cur, int deg, int64_t e0, int i) {
+    const int64_t o = e0 + (int64_t)i * CHUNK;
+    desc[2 * c] = make_int4(cur, min(CHUNK, deg - i * CHUNK) | DESC_NODE, (int)(o & 0xffffffffll), (int)(o >> 32));
+    desc[2 * c + 1] = make_int4(-1, 0, 0, 0);
 }
 
 // One thread per walk (a wave = 64 consecutive walks), fused per hop boundary:
@@ -279,7 +310,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     const int lane = threadIdx.x & 63;
     const bool in_range = w < a.w_end;
     bool alive = false, sampled = false;
-    int item = 0, cur = -1, k = 0, hf = 0, father = -1, slot_w = 0, rank_w = 0;
+    int item = 0, cur = -1, k = 0, hf = 0, father = -1, slot_w = 0, rank_w = 0, up_edge = -1;
     unsigned long long my_k = 0;
     int64_t beg_abs = 0;
     // finished walks (the majority at the deeper hops) leave after ONE load
@@ -310,7 +341,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
             {
                 sampled = true;
                 const int kraw = a.lv_k[w];
-                const int kk = kraw & 0x7fffffff, hf0 = (int)((unsigned)kraw >> 31);
+                const int kk = kraw & LVK_MASK, hf0 = (int)((unsigned)kraw >> 31);
                 my_k = (unsigned long long)kk;
                 const uint64_t *const pf = a.lv_prefix + a.lv_pfx[w] * CHUNK;
                 const int64_t beg0 = a.lv_beg[w];
@@ -379,6 +410,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         if (alive && do_setup) {
             const int32_t *const cs = a.t_cstart + tbase + slot;
             const int cbeg = cs[rank], cend = cs[rank + 1];  // children of cur = ranks [cbeg, cend)
+            if (a.es_mode && a.level > 0) up_edge = a.t_edge[tbase + rank];  // the edge (father -> cur): independent of the loads around it
             const int nchild = cend - cbeg;
             // list of cur (graph_gan.py:250): the root's is children only (tree[root][1:]); any other node's is
             // [father] ++ children unless D-mode removed the father entry of this depth-1 child earlier (Q3)
@@ -478,73 +510,121 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         }
     }
     const bool owns = alive && !cached && owner == (int)threadIdx.x;
-    const int chunks = owns ? (k + CHUNK - 1) / CHUNK : 0;
+    // ---- where do this distribution's scores come from?  (edge-score cache, see WalkArgs)
+    //   gather : adj(cur) has been scored since the generator last changed (this level by another root, an earlier level,
+    //            or the D launch of the step) -> no rows at all, the weights kernel gathers k four-byte scores;
+    //   node   : stale, and this distribution needs most of adj(cur) anyway (k * ratio >= deg; or a hub): the first owner to
+    //            swing the stamp scores the WHOLE adjacency into the cache (node chunks), everybody else gathers;
+    //   private: stale and k << deg (deep levels: most neighbours already belong to other subtrees): score the k
+    //            candidates only, as before.
+    // Which of two racing owners wins a node only decides WHO scores it: the scores (spec S1) and therefore the walks are
+    // the same in every outcome.
+    int mode = 0, deg = 0, fe = -1;
+    int64_t e0 = 0;
+    if (owns && a.es_mode) {
+        e0 = a.rowptr[cur];
+        deg = (int)(a.rowptr[cur + 1] - e0);
+        const int st = __hip_atomic_load(&a.es_stamp[cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (st == a.es_epoch) {
+            mode = 1;
+        } else if (a.es_mode == 2 || (int64_t)k * a.es_ratio >= (int64_t)deg || (a.es_hub > 0 && deg >= a.es_hub)) {
+            const int old = atomicCAS(&a.es_stamp[cur], st, a.es_epoch);
+            mode = old == st ? 2 : (old == a.es_epoch ? 1 : 0);
+        }
+        if (mode && hf) fe = a.rev[up_edge];  // s(cur, father) sits at the reverse of the edge (father -> cur), inside adj(cur)
+    }
+    const int p_chunks = owns ? (k + CHUNK - 1) / CHUNK : 0;                                       // prefix region
+    const int s_chunks = !owns ? 0 : (mode == 0 ? p_chunks : (mode == 2 ? (deg + CHUNK - 1) / CHUNK : 0));  // score chunks
     const bool big = owns && k > BIG_TASK;
-    const bool small = owns && chunks > 1 && !big;  // 16 < k <= BIG_TASK: a 16-lane group of the weights kernel
-    // chunk offsets and big-task slots: in-wave exclusive scans, per-block totals through LDS, and ONE
-    // returning atomic per block and counter (a single word serves only ~88 returning atomics per us);
-    // the order of the blocks' regions in the score buffer is irrelevant
-    __shared__ int wv_chunks[4], wv_big[4], wv_own[4], wv_small[4];
-    __shared__ unsigned long long blk_base[2];
-    int inc = chunks;
+    const bool small = owns && p_chunks > 1 && !big;  // 16 < k <= BIG_TASK: a 16-lane group of the weights kernel
+    const bool tiny = owns && mode != 0 && p_chunks == 1;  // gather, k <= 16 (private ones are finished by the score kernel)
+    // chunk offsets and task slots: in-wave exclusive scans, per-block totals through LDS, and ONE returning atomic per
+    // block and counter word (a single word serves only ~88 returning atomics per us); the order of the blocks' regions
+    // in the buffers is irrelevant
+    __shared__ int wv_pch[4], wv_sch[4], wv_big[4], wv_own[4], wv_small[4], wv_tiny[4], wv_gat[4], wv_node[4];
+    __shared__ unsigned long long blk_base[3];
+    int inc_p = p_chunks, inc_s = s_chunks;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += o;
+        const int op = __shfl_up(inc_p, off, 64), os = __shfl_up(inc_s, off, 64);
+        if (lane >= off) { inc_p += op; inc_s += os; }
     }
     const unsigned long long big_bal = __ballot(big);
     const int wv = threadIdx.x >> 6;
-    if (lane == 63) wv_chunks[wv] = inc;
+    if (lane == 63) { wv_pch[wv] = inc_p; wv_sch[wv] = inc_s; }
     if (lane == 0) wv_big[wv] = __popcll(big_bal);
     const unsigned long long small_bal = __ballot(small);
     if (lane == 0) wv_small[wv] = __popcll(small_bal);
-    const unsigned long long own_bal = __ballot(owns);
+    const unsigned long long tiny_bal = __ballot(tiny);
+    if (lane == 0) wv_tiny[wv] = __popcll(tiny_bal);
+    const unsigned long long own_bal = __ballot(owns && mode != 1);  // tasks that read a current row: private owners + node scorings
     if (lane == 0) wv_own[wv] = __popcll(own_bal);
+    const unsigned long long gat_bal = __ballot(owns && mode != 0);
+    if (lane == 0) wv_gat[wv] = __popcll(gat_bal);
+    const unsigned long long node_bal = __ballot(owns && mode == 2);
+    if (lane == 0) wv_node[wv] = __popcll(node_bal);
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int tc = wv_chunks[0] + wv_chunks[1] + wv_chunks[2] + wv_chunks[3];
+        const int tp = wv_pch[0] + wv_pch[1] + wv_pch[2] + wv_pch[3];
+        const int tsc = wv_sch[0] + wv_sch[1] + wv_sch[2] + wv_sch[3];
         const int tb = wv_big[0] + wv_big[1] + wv_big[2] + wv_big[3];
-        blk_base[0] = tc ? atomicAdd(&a.lc[CTR_CHUNKS + a.level], (unsigned long long)tc) : 0ull;
+        blk_base[0] = (tp | tsc) ? atomicAdd(&a.lc[CTR_CHUNKS + a.level], (unsigned long long)tp | ((unsigned long long)tsc << 32)) : 0ull;
         const int ts = wv_small[0] + wv_small[1] + wv_small[2] + wv_small[3];
         blk_base[1] = (tb | ts) ? atomicAdd(&a.lc[CTR_BIG + a.level], (unsigned long long)tb | ((unsigned long long)ts << 32)) : 0ull;
+        const int tt = wv_tiny[0] + wv_tiny[1] + wv_tiny[2] + wv_tiny[3];
+        blk_base[2] = tt ? atomicAdd(&a.lc[CTR_TINY + a.level], (unsigned long long)tt) : 0ull;
         const int to = wv_own[0] + wv_own[1] + wv_own[2] + wv_own[3];
         if (to) atomicAdd(&a.lc[CTR_DISTS + (blockIdx.x & 63)], (unsigned long long)to);
+        const int tg = wv_gat[0] + wv_gat[1] + wv_gat[2] + wv_gat[3];
+        if (tg) atomicAdd(&a.lc[CTR_GATHER + (blockIdx.x & 63)], (unsigned long long)tg);
+        const int tn = wv_node[0] + wv_node[1] + wv_node[2] + wv_node[3];
+        if (tn) atomicAdd(&a.lc[CTR_NODES + (blockIdx.x & 63)], (unsigned long long)tn);
     }
     __syncthreads();
-    int chunks_before = 0, big_before = 0, small_before = 0, blk_chunks = 0;
+    int pch_before = 0, sch_before = 0, big_before = 0, small_before = 0, tiny_before = 0, blk_pch = 0, blk_sch = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        if (i < wv) { chunks_before += wv_chunks[i]; big_before += wv_big[i]; small_before += wv_small[i]; }
-        blk_chunks += wv_chunks[i];
+        if (i < wv) { pch_before += wv_pch[i]; sch_before += wv_sch[i]; big_before += wv_big[i]; small_before += wv_small[i]; tiny_before += wv_tiny[i]; }
+        blk_pch += wv_pch[i];
+        blk_sch += wv_sch[i];
     }
-    const int64_t coff_own = (int64_t)blk_base[0] + chunks_before + inc - chunks;
-    blk_coff[threadIdx.x] = coff_own;
+    const int64_t base_p = (int64_t)(blk_base[0] & 0xffffffffull), base_s = (int64_t)(blk_base[0] >> 32);
+    const int64_t coff_p_own = base_p + pch_before + inc_p - p_chunks;
+    const int64_t coff_s = base_s + sch_before + inc_s - s_chunks;
+    blk_coff[threadIdx.x] = coff_p_own;
     __syncthreads();
-    const int64_t coff = blk_coff[owner];  // non-owners sample from their owner's region
+    const int64_t coff_p = blk_coff[owner];  // non-owners sample from their owner's region
     const int64_t lbase = blk_lbase;
-    const bool fits = (int64_t)blk_base[0] + blk_chunks <= cap_chunks && lbase + (int64_t)blk_base[0] + blk_chunks <= a.cap_total;
+    const bool fits = base_s + blk_sch <= cap_chunks && lbase + base_p + blk_pch <= a.cap_total;
     if (write_desc == 1 && !fits && threadIdx.x == 0) a.ctr[3] = 2ull;  // speculative capacity exceeded: the host reruns in sized mode
     if (in_range) {
         a.lv_beg[w] = beg_abs;
-        a.lv_k[w] = k | (hf << 31);
-        a.lv_chunks[w] = chunks;
-        a.lv_coff[w] = coff;
-        a.lv_pfx[w] = cached ? cached_off : lbase + coff;
+        a.lv_k[w] = k | (hf << 31) | (mode != 0 ? LVK_GATHER : 0) | (mode == 2 ? LVK_NODE : 0);
+        a.lv_chunks[w] = s_chunks;
+        a.lv_coff[w] = coff_s;
+        a.lv_pfx[w] = cached ? cached_off : lbase + coff_p;
+        if (mode != 0) a.lv_fe[w] = fe;
         if (owns && a.dc_mode == 1 && (fits || write_desc == 0)) {  // D launch: register the distribution for the G launch of the step (sized mode: the buffers are sized after this kernel)
             const unsigned long long key2 = dc_key(slot_w, rank_w, hf);
             uint32_t h = (uint32_t)((key2 * 0x9E3779B97F4A7C15ull) >> 40) & a.dc_mask;
             for (int tries = 0; tries < 64; ++tries) {
                 const unsigned long long old = atomicCAS(&a.dc_keys[h], ~0ull, key2);
-                if (old == ~0ull) { a.dc_vals[h] = ((unsigned long long)(lbase + coff) << 32) | (unsigned long long)(unsigned)k; break; }
+                if (old == ~0ull) { a.dc_vals[h] = ((unsigned long long)(lbase + coff_p) << 32) | (unsigned long long)(unsigned)k; break; }
                 if (old == key2) break;  // another workgroup registered the same distribution: one copy is enough
                 h = (h + 1) & a.dc_mask;
             }
         }
-        // the two task lists of the weights kernel share one array: big tasks from the front, small ones from the back
+        // the task lists of the weights kernel: big tasks from the front of the first half of lv_big, small ones from its back,
+        // tiny gather tasks in the second half
         if (big) a.lv_big[(blk_base[1] & 0xffffffffull) + big_before + __popcll(big_bal & ((1ull << lane) - 1ull))] = (int32_t)w;
         if (small) a.lv_big[a.lv_big_cap - 1 - (int64_t)((blk_base[1] >> 32) + small_before + __popcll(small_bal & ((1ull << lane) - 1ull)))] = (int32_t)w;
-        if (write_desc == 1 && fits)
-            for (int i = 0; i < chunks; ++i) a.lv_chunk_desc[coff + i] = chunk_desc(cur, k, hf, father, beg_abs, i);
+        if (tiny) a.lv_big[a.lv_big_cap + (int64_t)blk_base[2] + tiny_before + __popcll(tiny_bal & ((1ull << lane) - 1ull))] = (int32_t)w;
+        if (write_desc == 1 && fits) {
+            if (mode == 2)
+                for (int i = 0; i < s_chunks; ++i) write_node_desc(a.lv_chunk_desc, coff_s + i, cur, deg, e0, i);
+            else
+                for (int i = 0; i < s_chunks; ++i) write_chunk_desc(a.lv_chunk_desc, coff_s + i, cur, k, hf, father, beg_abs, i, lbase + coff_p);
+        }
     }
     // walks still alive at this hop: one atomic per block
     __shared__ int wv_alive[4];
@@ -567,10 +647,16 @@ __global__ void level_expand_kernel(const WalkArgs a) {
     if (n == 0) return;
     const int64_t c0 = a.lv_coff[w];
     const int kraw = a.lv_k[w], cur = a.st_cur[w];
-    const int k = kraw & 0x7fffffff, hf = (int)((unsigned)kraw >> 31);
+    const int k = kraw & LVK_MASK, hf = (int)((unsigned)kraw >> 31);
+    if (kraw & LVK_NODE) {
+        const int64_t e0 = a.rowptr[cur];
+        const int deg = (int)(a.rowptr[cur + 1] - e0);
+        for (int i = 0; i < n; ++i) write_node_desc(a.lv_chunk_desc, c0 + i, cur, deg, e0, i);
+        return;
+    }
     const int father = hf ? a.st_prev[w] : -1;
-    const int64_t beg = a.lv_beg[w];
-    for (int i = 0; i < n; ++i) a.lv_chunk_desc[c0 + i] = chunk_desc(cur, k, hf, father, beg, i);
+    const int64_t beg = a.lv_beg[w], pfx = a.lv_pfx[w];
+    for (int i = 0; i < n; ++i) write_chunk_desc(a.lv_chunk_desc, c0 + i, cur, k, hf, father, beg, i, pfx);
 }
 
 __device__ __forceinline__ uint64_t group16_incl_scan_u64(uint64_t v, int t) {
@@ -592,9 +678,9 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const
     __shared__ unsigned long long blk_rows;
     if (threadIdx.x == 0) blk_rows = 0;
     __syncthreads();
-    const int64_t total_chunks = (int64_t)a.lc[CTR_CHUNKS + a.level];
-    const int64_t lbase = level_chunk_base(a);
-    if (total_chunks > cap_chunks || lbase + total_chunks > a.cap_total) return;
+    const unsigned long long cw = a.lc[CTR_CHUNKS + a.level];
+    const int64_t total_chunks = (int64_t)(cw >> 32);  // score chunks
+    if (total_chunks > cap_chunks || level_chunk_base(a) + (int64_t)(cw & 0xffffffffull) > a.cap_total) return;
     const int t = threadIdx.x & 15;
     const int nblk = gridDim.x;
     // consecutive chunks (same task / same root) -> consecutive logical blocks -> one XCD's L2.  (Giving every XCD
@@ -603,11 +689,13 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const
     const int64_t n_groups = (int64_t)nblk * (WAVES_PER_BLOCK * 4);
     unsigned long long rows = 0;
     for (int64_t c = (int64_t)lblock * (WAVES_PER_BLOCK * 4) + (threadIdx.x >> 4); c < total_chunks; c += n_groups) {
-        const int4 d = a.lv_chunk_desc[c];
+        const int4 d = a.lv_chunk_desc[2 * c], d2 = a.lv_chunk_desc[2 * c + 1];
         const int cur = d.x, nblock = d.y & 0xff;
-        const bool single = (d.y & SINGLE_CHUNK) != 0;
-        const int32_t *const ids = a.t_order + (((int64_t)((unsigned)d.y >> 16) << 32) | (unsigned)d.z);
-        float *const out = a.lv_scores + c * CHUNK;
+        const bool single = (d.y & SINGLE_CHUNK) != 0, node = (d.y & DESC_NODE) != 0;
+        const int64_t off = ((int64_t)d.w << 32) | (unsigned)d.z;
+        // candidate ids: the children of (root, cur) in BFS order, or -- node chunk -- cur's graph neighbours
+        const int32_t *const ids = (node ? a.col : a.t_order) + off;
+        float *const out = node ? a.es + off : a.lv_scores + c * CHUNK;
         float4 gc[NCH];
         const float4 *const crow = (const float4 *)(a.E + (int64_t)cur * a.ld);
 #pragma unroll
@@ -616,7 +704,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const
             gc[cc] = (ch < a.nchunk) ? crow[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         // the chunk's ids with one coalesced load (candidate 0 of a list with a father entry comes with the descriptor)
-        const int myid = (t < nblock) ? (((d.y & DESC_HAS_FATHER) && t == 0) ? d.w : ids[t]) : -1;
+        const int myid = (t < nblock) ? (((d.y & DESC_HAS_FATHER) && t == 0) ? d2.x : ids[t]) : -1;
         const float mybias = (t < nblock) ? a.bias[myid] : 0.f;  // ... and its biases with one 16-lane gather
         float mysc = 0.f;
         for (int j0 = 0; j0 < nblock; j0 += UNROLL) {
@@ -655,12 +743,13 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const
             // inclusive prefix sums (spec S2, S3) right here -- no score round trip, no second kernel
             float mx = (t < nblock) ? mysc : -INFINITY;
 #pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 16));
+            for (int off2 = 8; off2 >= 1; off2 >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off2, 16));
             const uint64_t wgt = (t < nblock) ? weight_fix40(exp_spec(mysc - mx)) : 0ull;
             const uint64_t C = group16_incl_scan_u64(wgt, t);
-            if (t < nblock) a.lv_prefix[(lbase + c) * CHUNK + t] = C;
+            const int64_t pfx = ((int64_t)d2.z << 32) | (unsigned)d2.y;
+            if (t < nblock) a.lv_prefix[pfx * CHUNK + t] = C;
         } else if (t < nblock) {
-            out[t] = mysc;  // one coalesced 64-byte store per chunk
+            out[t] = mysc;  // one coalesced 64-byte store per chunk (score region of the task, or the edge-score cache)
         }
         rows += (unsigned long long)nblock;
     }
@@ -671,20 +760,51 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const
     if (threadIdx.x == 0 && blk_rows) atomicAdd(&a.lc[CTR_ROWS + (blockIdx.x & 63)], blk_rows);
 }
 
-// Small owner tasks (16 < k <= BIG_TASK): one 16-lane group per walk -- max, exact fixed-point weights
+// Where the scores of owner walk w's distribution are: its private score region, or (gather) the edge-score cache through
+// the tree's edge indices -- candidate j is the father (j == 0, only if hf: es[fe]) or child rank beg + j - hf: es[t_edge[..]].
+struct TaskScores {
+    const float *sc;        // private region (gather: unused)
+    const int32_t *edges;   // t_edge + beg - hf (gather)
+    int k, hf, fe;
+    bool gather;
+};
+__device__ __forceinline__ TaskScores task_scores(const WalkArgs &a, const int64_t w) {
+    TaskScores s;
+    const int kraw = a.lv_k[w];
+    s.k = kraw & LVK_MASK;
+    s.hf = (int)((unsigned)kraw >> 31);
+    s.gather = (kraw & LVK_GATHER) != 0;
+    s.sc = a.lv_scores + a.lv_coff[w] * CHUNK;
+    s.edges = a.t_edge + a.lv_beg[w] - s.hf;
+    s.fe = (s.gather && s.hf) ? a.lv_fe[w] : -1;
+    return s;
+}
+
+// Small owner tasks (k <= 16 * PER_LANE): one 16-lane group per walk -- max, exact fixed-point weights
 // (spec S2, S3) and their inclusive prefix sums, computed once per (root, node).  All of the task's
-// scores are fetched with independent loads up front (<= 16 per lane): the kernel used to be two
-// dependent passes of k/16 load -> use steps each.
+// scores are fetched with independent loads up front (<= PER_LANE per lane; gather tasks: the edge indices first,
+// then the scores): the kernel used to be two dependent passes of k/16 load -> use steps each.
+template <int PER_LANE>
 __device__ __forceinline__ void weights_small_task(const WalkArgs &a, const int64_t w, const int t) {
-    const int k = a.lv_k[w] & 0x7fffffff;
-    const float *const sc = a.lv_scores + a.lv_coff[w] * CHUNK;
-    uint64_t *const pf = a.lv_prefix + a.lv_pfx[w] * CHUNK;  // (an owner's prefix region = level base + its score region)
-    constexpr int PER_LANE = BIG_TASK / 16;
+    const TaskScores ts = task_scores(a, w);
+    const int k = ts.k;
+    uint64_t *const pf = a.lv_prefix + a.lv_pfx[w] * CHUNK;  // (an owner's prefix region)
     float v[PER_LANE];
+    if (ts.gather) {
+        int e[PER_LANE];
 #pragma unroll
-    for (int i = 0; i < PER_LANE; ++i) {
-        const int jj = i * 16 + t;
-        v[i] = (jj < k) ? sc[jj] : -INFINITY;
+        for (int i = 0; i < PER_LANE; ++i) {
+            const int jj = i * 16 + t;
+            e[i] = (jj < k) ? ((jj == 0 && ts.hf) ? ts.fe : ts.edges[jj]) : -1;
+        }
+#pragma unroll
+        for (int i = 0; i < PER_LANE; ++i) v[i] = (e[i] >= 0) ? a.es[e[i]] : -INFINITY;
+    } else {
+#pragma unroll
+        for (int i = 0; i < PER_LANE; ++i) {
+            const int jj = i * 16 + t;
+            v[i] = (jj < k) ? ts.sc[jj] : -INFINITY;
+        }
     }
     float mx = v[0];
 #pragma unroll
@@ -705,10 +825,18 @@ __device__ __forceinline__ void weights_small_task(const WalkArgs &a, const int6
 }
 
 constexpr int SMALL_BLOCKS = 2048;  // workgroups of the weights launch that serve the small-task list (16 tasks each per round)
+constexpr int TINY_BLOCKS = 2048;   // ... and the tiny-task list (gather tasks with <= 16 candidates)
 __device__ __forceinline__ void weights_small_blocks(const WalkArgs &a, const int block) {
     const int t = threadIdx.x & 15;
     const int64_t n_small = (int64_t)(a.lc[CTR_BIG + a.level] >> 32);
-    for (int64_t i = (int64_t)block * 16 + (threadIdx.x >> 4); i < n_small; i += (int64_t)SMALL_BLOCKS * 16) weights_small_task(a, a.lv_big[a.lv_big_cap - 1 - i], t);
+    for (int64_t i = (int64_t)block * 16 + (threadIdx.x >> 4); i < n_small; i += (int64_t)SMALL_BLOCKS * 16)
+        weights_small_task<BIG_TASK / 16>(a, a.lv_big[a.lv_big_cap - 1 - i], t);
+}
+__device__ __forceinline__ void weights_tiny_blocks(const WalkArgs &a, const int block) {
+    const int t = threadIdx.x & 15;
+    const int64_t n_tiny = (int64_t)a.lc[CTR_TINY + a.level];
+    for (int64_t i = (int64_t)block * 16 + (threadIdx.x >> 4); i < n_tiny; i += (int64_t)TINY_BLOCKS * 16)
+        weights_small_task<1>(a, a.lv_big[a.lv_big_cap + i], t);
 }
 
 // Big owner tasks (hubs): one 256-thread workgroup per task, from the level's big-task list.  Tasks of up to
@@ -724,8 +852,12 @@ __device__ __forceinline__ void weights_big_blocks(const WalkArgs &a) {
     const int n_big = (int)(a.lc[CTR_BIG + a.level] & 0xffffffffull);
     for (int b = blockIdx.x; b < n_big; b += BIG_BLOCKS) {
         const int64_t w = a.lv_big[b];
-        const int k = a.lv_k[w] & 0x7fffffff;
-        const float *const sc = a.lv_scores + a.lv_coff[w] * CHUNK;
+        const TaskScores ts = task_scores(a, w);
+        const int k = ts.k;
+        auto score_at = [&](int jj) -> float {  // jj < k
+            if (!ts.gather) return ts.sc[jj];
+            return a.es[(jj == 0 && ts.hf) ? ts.fe : ts.edges[jj]];
+        };
         uint64_t *const pf = a.lv_prefix + a.lv_pfx[w] * CHUNK;
         constexpr int PER_THREAD = BIG_REG / 256;
         const bool in_regs = k <= BIG_REG;  // uniform in the workgroup
@@ -735,12 +867,12 @@ __device__ __forceinline__ void weights_big_blocks(const WalkArgs &a) {
 #pragma unroll
             for (int i = 0; i < PER_THREAD; ++i) {
                 const int jj = i * 256 + threadIdx.x;
-                v[i] = (jj < k) ? sc[jj] : -INFINITY;
+                v[i] = (jj < k) ? score_at(jj) : -INFINITY;
             }
 #pragma unroll
             for (int i = 0; i < PER_THREAD; ++i) mx = fmaxf(mx, v[i]);
         } else {
-            for (int jj = threadIdx.x; jj < k; jj += 256) mx = fmaxf(mx, sc[jj]);
+            for (int jj = threadIdx.x; jj < k; jj += 256) mx = fmaxf(mx, score_at(jj));
         }
         mx = wave_max_f32(mx);
         __syncthreads();
@@ -769,19 +901,21 @@ __device__ __forceinline__ void weights_big_blocks(const WalkArgs &a) {
             for (int i = 0; i < PER_THREAD; ++i)
                 if (i * 256 < k) scan_block(i * 256, v[i]);
         } else {
-            for (int j0 = 0; j0 < k; j0 += 256) scan_block(j0, (j0 + threadIdx.x < k) ? sc[j0 + threadIdx.x] : 0.f);
+            for (int j0 = 0; j0 < k; j0 += 256) scan_block(j0, (j0 + threadIdx.x < k) ? score_at(j0 + threadIdx.x) : 0.f);
         }
     }
 }
 
-// One launch per level for both task classes: the first BIG_BLOCKS workgroups walk the big-task list (they run
-// longest, so they are dispatched first), the others take 16 walks each.  As two back-to-back launches the two
-// classes cost the sum of their latency-bound run times; together, the longer of the two.
+// One launch per level for all task classes: the first BIG_BLOCKS workgroups walk the big-task list (they run
+// longest, so they are dispatched first), the next SMALL_BLOCKS take 16 small tasks each per round, the rest the tiny gather
+// tasks.  As back-to-back launches the classes cost the sum of their latency-bound run times; together, the longest.
 __global__ __launch_bounds__(256) void level_weights_kernel(const WalkArgs a, const int64_t cap_chunks) {
-    const unsigned long long total_chunks = a.lc[CTR_CHUNKS + a.level];
-    if ((int64_t)total_chunks > cap_chunks || total_chunks == 0ull || level_chunk_base(a) + (int64_t)total_chunks > a.cap_total) return;
+    const unsigned long long cw = a.lc[CTR_CHUNKS + a.level];
+    const int64_t pch = (int64_t)(cw & 0xffffffffull), sch = (int64_t)(cw >> 32);
+    if (sch > cap_chunks || pch == 0 || level_chunk_base(a) + pch > a.cap_total) return;
     if (blockIdx.x < BIG_BLOCKS) weights_big_blocks(a);
-    else weights_small_blocks(a, (int)blockIdx.x - BIG_BLOCKS);
+    else if (blockIdx.x < BIG_BLOCKS + SMALL_BLOCKS) weights_small_blocks(a, (int)blockIdx.x - BIG_BLOCKS);
+    else weights_tiny_blocks(a, (int)blockIdx.x - BIG_BLOCKS - SMALL_BLOCKS);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -977,7 +1111,7 @@ __global__ void walk_init_status_kernel(const WalkArgs a) {
 
 static int reserve_level_buffers(gg_ctx *ctx, WalkArgs &a, int64_t chunks) {
     GG_HIP(ctx, ctx->lv_scores.reserve(sizeof(float) * CHUNK * (size_t)chunks + 256));
-    GG_HIP(ctx, ctx->lv_chunk_owner.reserve(sizeof(int4) * (size_t)chunks + 256));
+    GG_HIP(ctx, ctx->lv_chunk_owner.reserve(sizeof(int4) * 2 * (size_t)chunks + 256));
     a.lv_scores = ctx->lv_scores.as<float>();
     a.lv_chunk_desc = ctx->lv_chunk_owner.as<int4>();
     return GG_OK;
@@ -1014,7 +1148,7 @@ __global__ __launch_bounds__(256) void fill_ones_kernel(uint4 *p, int64_t n16) {
 __global__ void dc_finish_kernel(const WalkArgs a, int64_t *words, int n_levels) {
     if (a.ctr[3] == 2ull) { words[1] = 0; return; }  // the launch is being rerun
     int64_t b = words[0];
-    for (int l = 0; l < n_levels; ++l) b += (int64_t)a.lc[CTR_CHUNKS + l];
+    for (int l = 0; l < n_levels; ++l) b += (int64_t)(a.lc[CTR_CHUNKS + l] & 0xffffffffull);
     words[1] = b;
 }
 
@@ -1100,12 +1234,16 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
                     return GG_OK;
                 }
                 if (level + 1 > ctx->lv_levels_learned) ctx->lv_levels_learned = level + 1;
-                cap = (int64_t)total_chunks;
-                if (cap + cap / 4 + 4096 > ctx->lv_cap_chunks) ctx->lv_cap_chunks = cap + cap / 4 + 4096;
+                const int64_t pch = (int64_t)(total_chunks & 0xffffffffull);  // prefix chunks of the level
+                cap = (int64_t)(total_chunks >> 32);                           // score chunks
+                // (one learned capacity for both index spaces; which nodes are scored whole varies a little from launch to
+                // launch -- the stamp races -- so the margin is generous)
+                const int64_t need = std::max(cap, pch);
+                if (need + need / 2 + 4096 > ctx->lv_cap_chunks) ctx->lv_cap_chunks = need + need / 2 + 4096;
                 int rc = reserve_level_buffers(ctx, x, cap);
-                if (rc == GG_OK) rc = reserve_prefix(ctx, x, base_host + cum + cap, true);
+                if (rc == GG_OK) rc = reserve_prefix(ctx, x, base_host + cum + pch, true);
                 if (rc != GG_OK) return rc;
-                cum += cap;
+                cum += pch;
                 if (base_host + cum + (base_host + cum) / 4 + 4096 > ctx->lv_cap_total) ctx->lv_cap_total = base_host + cum + (base_host + cum) / 4 + 4096;
                 hipLaunchKernelGGL(level_expand_kernel, dim3(wblocks), dim3(256), 0, ctx->walk_stream, x);
             }
@@ -1130,7 +1268,9 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
             }
             if (split) GG_HIP(ctx, hipEventRecord(ctx->ev_score[k], hs[k]));
             const int64_t half_walks = x.w_end - x.w0;
-            hipLaunchKernelGGL(level_weights_kernel, dim3((unsigned)(BIG_BLOCKS + std::min<int64_t>(SMALL_BLOCKS, cdiv(half_walks * 16, 256)))), dim3(256), 0, hs[k], x, cap);
+            const unsigned wgrid = x.es_mode ? (unsigned)(BIG_BLOCKS + SMALL_BLOCKS + std::min<int64_t>(TINY_BLOCKS, cdiv(half_walks * 16, 256)))
+                                             : (unsigned)(BIG_BLOCKS + std::min<int64_t>(SMALL_BLOCKS, cdiv(half_walks * 16, 256)));
+            hipLaunchKernelGGL(level_weights_kernel, dim3(wgrid), dim3(256), 0, hs[k], x, cap);
         }
     }
     // finish the last prepared hop
@@ -1173,7 +1313,8 @@ static int run_levels_and_finish(gg_ctx *ctx, WalkArgs &a, int64_t total_walks) 
         GG_HIP(ctx, ctx->lv_beg.reserve(sizeof(int64_t) * total_walks));
         GG_HIP(ctx, ctx->lv_k.reserve(sizeof(int32_t) * total_walks));
         GG_HIP(ctx, ctx->lv_chunks.reserve(sizeof(int32_t) * total_walks));
-        GG_HIP(ctx, ctx->lv_big.reserve(sizeof(int32_t) * total_walks));
+        GG_HIP(ctx, ctx->lv_big.reserve(sizeof(int32_t) * 2 * total_walks));  // [0, W): big / small task lists, [W, 2W): tiny gather tasks
+        GG_HIP(ctx, ctx->lv_fe.reserve(sizeof(int32_t) * total_walks));
         GG_HIP(ctx, ctx->lv_coff.reserve(sizeof(int64_t) * (total_walks + 1)));
         GG_HIP(ctx, ctx->lv_pfx.reserve(sizeof(int64_t) * (total_walks + 1)));
         GG_HIP(ctx, ctx->st_item.reserve(sizeof(int4) * total_walks));
@@ -1187,6 +1328,7 @@ static int run_levels_and_finish(gg_ctx *ctx, WalkArgs &a, int64_t total_walks) 
         a.lv_k = ctx->lv_k.as<int32_t>();
         a.lv_chunks = ctx->lv_chunks.as<int32_t>();
         a.lv_big = ctx->lv_big.as<int32_t>();
+        a.lv_fe = ctx->lv_fe.as<int32_t>();
         a.lv_coff = ctx->lv_coff.as<int64_t>();
         a.lv_pfx = ctx->lv_pfx.as<int64_t>();
         const bool sized = ctx->lv_cap_chunks == 0 || ctx->walk_force_sized;
@@ -1251,6 +1393,16 @@ int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int fo
     a.abort_walk = ctx->w_abort.as<int32_t>();
     a.ctr = ctx->dev_ctr;
     a.lc = ctx->dev_ctr;
+    a.rowptr = ctx->g_rowptr;
+    a.col = ctx->g_col;
+    a.t_edge = ctx->t_edge;
+    a.rev = ctx->g_rev;
+    a.es = ctx->es;
+    a.es_stamp = ctx->es_stamp;
+    a.es_epoch = ctx->es_epoch;
+    a.es_ratio = ctx->es_ratio_num;
+    a.es_hub = ctx->es_hub;
+    a.es_mode = 0;  // set below once the launch is known to run unsplit
     a.w0 = 0;
     a.w_end = total_walks;
     a.lv_big_cap = total_walks;
@@ -1281,6 +1433,9 @@ int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int fo
     // stream while the discriminator's gradient kernel was filling the L2 with atomics.)
     const bool will_size = ctx->lv_cap_chunks == 0 || ctx->walk_force_sized;
     ctx->w_split = ctx->split_enabled && ctx->walk_levels > 0 && !will_size && total_walks >= ctx->split_min_walks;
+    // the edge-score cache needs the trees' edge indices and one stream per launch (the two halves of a split launch would
+    // gather scores the other half's score kernel has not written yet)
+    if (ctx->es && ctx->es_stamp && ctx->g_rev && ctx->t_edge_valid && !ctx->w_split && ctx->walk_levels > 0) a.es_mode = ctx->es_mode;
     hipLaunchKernelGGL(walk_reset_kernel, dim3(cdiv(2 * CTR_WORDS, 256)), dim3(256), 0, ctx->walk_stream, ctx->dev_ctr, 2 * (int)CTR_WORDS,
                        ctx->dc_words.as<int64_t>(), a.dc_mode == 2 ? 1 : 0, ctx->w_split ? 1 : 0, ctx->lv_cap_total);
     // HIP events around every profile_every-th call (a rerun keeps the decision of the launch it repeats)

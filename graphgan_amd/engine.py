@@ -169,7 +169,7 @@ class Engine:
 
     def tree_bytes_estimate(self, n_roots):
         """Upper bound of the HBM bytes ``n_roots`` resident trees need (every root reaching every node)."""
-        return float(n_roots) * 8.0 * (self.n_node + 1)
+        return float(n_roots) * 12.0 * (self.n_node + 1)  # pop order + first-child ranks + edge indices
 
     def set_trees(self, roots, off, nbr, nbr_base, max_depth=0):
         roots, off, nbr = _i32(roots), _i32(off), _i32(nbr)
@@ -204,6 +204,17 @@ class Engine:
         base = np.zeros(R + 1, dtype=np.int64)
         self._ck(lib.gg_get_trees(self._ctx, _ptr(off), _ptr(nbr), _ptr(base)))
         return off, nbr[: self.tree_entries], base
+
+    def get_tree_order(self):
+        """The resident trees in BFS-order form: (base [R+1], order, cstart, edge, edges_valid) -- see gg_get_tree_order."""
+        R = len(self.tree_roots)
+        base = np.zeros(R + 1, dtype=np.int64)
+        self._ck(lib.gg_get_tree_order(self._ctx, _ptr(base), None, None, None, None))
+        nodes = int(base[R])
+        order, cstart, edge = np.zeros(nodes, np.int32), np.zeros(nodes + R, np.int32), np.zeros(nodes, np.int32)
+        valid = ctypes.c_int32()
+        self._ck(lib.gg_get_tree_order(self._ctx, _ptr(base), _ptr(order), _ptr(cstart), _ptr(edge), ctypes.byref(valid)))
+        return base, order, cstart, edge, bool(valid.value)
 
     # ------------------------------------------------------------------ K1
     def walk_sample(self, slots, n_walks, for_d, seed, stream, stride=None, fetch=True):

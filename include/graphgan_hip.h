@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GG_ABI_VERSION 2  /* round 2: gg_counters extended, tree cache / streamed consumer / evaluator entry points */
+#define GG_ABI_VERSION 3  /* round 3: gg_counters extended (edge-score cache) */
 
 enum {
     GG_OK = 0,
@@ -104,6 +104,12 @@ typedef struct gg_counters {
     int64_t g_pairs_timed, g_rows_timed;
     int64_t d_passes_timed, g_passes_timed;
     int64_t g_walk_nodes_timed;            /* path nodes (= hops) of the gg_prepare_g calls counted in reward_pairs_timed */
+    /* edge-score cache of the walk sampler: the score of a graph edge does not depend on the root, so a node's adjacency is
+     * scored once per generator state and the (root, node) distributions of all roots gather from it */
+    int64_t es_gathers;     /* (root, node) distributions that took their scores from the cache (no rows streamed) */
+    int64_t es_nodes;       /* nodes whose whole adjacency was scored into the cache */
+    int64_t score_gathers;  /* ... of the timed launches (the cadence of score_rows / score_dists) */
+    int64_t score_nodes;
 } gg_counters;
 
 typedef struct gg_ctx gg_ctx;
@@ -154,6 +160,13 @@ int gg_tree_roots(const gg_ctx *ctx, int32_t *roots /*[n_roots]*/);  /* root nod
 int gg_save_trees(gg_ctx *ctx, const char *path);
 int gg_load_trees(gg_ctx *ctx, const char *path);
 int gg_get_trees(gg_ctx *ctx, int32_t *off, int32_t *nbr, int64_t *nbr_base);
+/* gg_get_tree_order: the resident trees in their internal BFS-ORDER form, slot by slot: base[r] =
+ * first entry of slot r (n_roots + 1 values); order[base[r] + i] = node of BFS pop rank i (the reference's queue,
+ * graph_gan.py:96-107); cstart[base[r] + r + i] = rank of the first child of rank i (C_r + 1 values per slot); edge[base[r] + i]
+ * = CSR index of the graph edge (father -> node) the BFS appended rank i at (-1 for the root) -- what the walk sampler's
+ * edge-score cache is indexed by.  *edges_valid = 0 when the resident trees carry no edge indices (uploaded lists that are
+ * no subgraph of the resident graph).  Any pointer may be NULL. */
+int gg_get_tree_order(gg_ctx *ctx, int64_t *base, int32_t *order, int32_t *cstart, int32_t *edge, int32_t *edges_valid);
 
 /* ---- K1 walk_sample.  Replaces GraphGAN.sample (graph_gan.py:225-270) including the
  * all_score fetch (:238, generator.py:21), utils.softmax (utils.py:131-133) and

@@ -677,6 +677,9 @@ def test_sampled_profiling_and_early_returning_passes(ga, every, monkeypatch):
     finished (stream-ordered).  Results and work counters are those of the default (every launch timed,
     synchronous passes) mode; the timing counters cover exactly the profiled launches."""
     monkeypatch.setenv("GG_DETERMINISTIC", "1")  # atomic-free B = 64 steps: the two runs are comparable bit for bit
+    # every stale node is scored whole exactly once: rows_scored is then a pure function of the walks (under the default
+    # policy it also depends on which of two racing roots asks for a node first)
+    monkeypatch.setenv("GG_ES_MODE", "2")
     g, n, graph, rowptr, col, Ed, eng = _setup_graph_engine(ga)
     _, _, _, _, _, _, ref = _setup_graph_engine(ga)
     eng.set_profiling(every)

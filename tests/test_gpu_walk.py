@@ -57,15 +57,20 @@ def run_both(ga, n, rowptr, col, roots, E, b, rounds, seed, n_sample=20, stride=
     return hops
 
 
-@pytest.fixture(params=["finisher", "hybrid2", "levels", "adaptive", "split"])
+@pytest.fixture(params=["finisher", "hybrid2", "levels", "adaptive", "split", "share_all", "share_off"])
 def walk_mode(request, monkeypatch):
     """The decompositions of the sampler: GG_WALK_LEVELS = 0 (one wavefront per walk, the
     finisher kernel alone), 2 (two hops through the level pipeline, the finisher takes over), 64 (level pipeline to
     the end; the default), and 64 with GG_FIN_THRESHOLD (the hand-over level follows the previous launch of the mode:
     the later rounds of a test switch to the finisher's walk list wherever fewer than that many walks were left); "split"
     runs the sync-free launches as two halves of their walks on two streams (opt-in, GG_WALK_SPLIT=1; from 512 walks here).
+    "share_all" / "share_off": the level pipeline with the edge-score cache forced on for every node (GG_ES_MODE=2: a stale
+    node's whole adjacency is scored once, every (root, node) distribution gathers) / switched off (0: every distribution
+    scores its own candidates); the other level modes run the default policy (1), "split" without the cache.
     gg_create reads the variables, so they are set before the engine exists."""
-    monkeypatch.setenv("GG_WALK_LEVELS", {"finisher": "0", "hybrid2": "2", "levels": "64", "adaptive": "64", "split": "64"}[request.param])
+    monkeypatch.setenv("GG_WALK_LEVELS", {"finisher": "0", "hybrid2": "2"}.get(request.param, "64"))
+    if request.param in ("share_all", "share_off"):
+        monkeypatch.setenv("GG_ES_MODE", "2" if request.param == "share_all" else "0")
     if request.param == "adaptive":
         monkeypatch.setenv("GG_FIN_THRESHOLD", "2000")
     if request.param == "split":  # two-half launches (two streams, per-half buffers and counters) already for small launches
@@ -240,6 +245,31 @@ def test_gpu_bfs_builds_the_reference_trees(ga, case):
     woff, wnbr, wbase, wdepth = ga.host_build_trees(n, rowptr, col, roots)
     assert np.array_equal(base, wbase) and np.array_equal(off, woff) and np.array_equal(nbr, wnbr)
     assert eng.max_depth == wdepth
+    # BFS-order form + the edge each node was appended at (what the edge-score cache is indexed by): written by the BFS
+    # kernel itself here, derived by tree_edges_kernel for the host-built trees -- both must name, for every non-root
+    # rank, the FIRST occurrence of the node in its father's adjacency (graph_gan.py:101-107)
+    tb, order, cstart, edge, valid = eng.get_tree_order()
+    assert valid
+    eng.build_trees(roots)  # host builder + derived edges
+    tb2, order2, cstart2, edge2, valid2 = eng.get_tree_order()
+    assert valid2 and np.array_equal(tb, tb2) and np.array_equal(order, order2) and np.array_equal(cstart, cstart2)
+    assert np.array_equal(edge, edge2)
+    row_of_edge = np.repeat(np.arange(n, dtype=np.int64), np.diff(rowptr))
+    for r in range(min(len(roots), 40)):
+        o, e = order[tb[r]:tb[r + 1]], edge[tb[r]:tb[r + 1]]
+        cs = cstart[tb[r] + r: tb[r + 1] + r + 1]
+        C = len(o)
+        assert o[0] == roots[r] and e[0] == -1 and cs[0] == 1 and cs[C] == C
+        if C == 1:
+            continue
+        father_rank = np.repeat(np.arange(C), np.diff(cs))          # father of ranks 1 .. C-1
+        assert len(father_rank) == C - 1
+        assert np.array_equal(col[e[1:]], o[1:])                      # the edge leads to the node ...
+        assert np.array_equal(row_of_edge[e[1:]], o[father_rank])     # ... from its father
+        for i in range(1, min(C, 200)):                               # first occurrence in the father's adjacency
+            f = o[father_rank[i - 1]]
+            adj = col[rowptr[f]:rowptr[f + 1]]
+            assert rowptr[f] + int(np.flatnonzero(adj == o[i])[0]) == e[i]
     eng.close()
 
 
