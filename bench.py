@@ -399,6 +399,9 @@ def main():
         "hops_per_step_rank0": hops / args.steps,
         "mean_k": reads / max(hops, 1),
         "rows_scored_per_step_rank0": rows_scored / args.steps,
+        "edge_score_cache": {"distributions_gathered_per_step": c["es_gathers"] / args.steps, "nodes_scored_whole_per_step": c["es_nodes"] / args.steps,
+                             "what": "s(u, v) of a graph edge does not depend on the root: a node's adjacency is scored once per generator state "
+                                     "and shared by the (root, node) distributions of all roots, levels and both walk launches of a step"},
         "nbr_reads_per_step_rank0": reads / args.steps,
         "setup_s": setup_s,
         "tree_build": {"where": "host threads" if args.host_bfs else "gpu bfs (one workgroup per root, visited bitmap in LDS)", "trees": int(R), "call_s": trees_s,
