@@ -103,14 +103,8 @@ int alloc_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int64_
 // score are stale.  Edge scores are invalidated by moving on to the next epoch (stamps of older epochs never match).
 void generator_changed(gg_ctx *ctx) {
     ctx->dc_valid = false;
-    if (ctx->es_epoch >= 0x7ffffff0) {  // wrap-around: forget every stamp
-        if (ctx->es_stamp) {
-            (void)hipDeviceSynchronize();
-            (void)hipMemset(ctx->es_stamp, 0, sizeof(int32_t) * (size_t)ctx->n_node);
-        }
-        ctx->es_epoch = 0;
-    }
-    ctx->es_epoch += 1;
+    ctx->es_tick += 256;  // (launches enqueued earlier keep their own ticks: nothing they stamp stays valid)
+    ctx->es_valid_from = ctx->es_tick;
 }
 
 static int upload_table(gg_ctx *ctx, float *dst, const float *src) {
@@ -493,9 +487,9 @@ int gg_set_graph_csr(gg_ctx *ctx, const int64_t *rowptr, const int32_t *col) {
     // edge-score cache of the walk sampler (gg_internal.h): scores, per-node stamps, reverse-edge index
     if (nnz > 0 && nnz < (1ll << 31)) {
         GG_HIP(ctx, hipMalloc((void **)&ctx->es, sizeof(float) * (size_t)nnz));
-        GG_HIP(ctx, hipMalloc((void **)&ctx->es_stamp, sizeof(int32_t) * (size_t)n));
+        GG_HIP(ctx, hipMalloc((void **)&ctx->es_stamp, sizeof(long long) * (size_t)n));
         GG_HIP(ctx, hipMalloc((void **)&ctx->g_rev, sizeof(int32_t) * (size_t)nnz));
-        GG_HIP(ctx, hipMemset(ctx->es_stamp, 0, sizeof(int32_t) * (size_t)n));
+        GG_HIP(ctx, hipMemset(ctx->es_stamp, 0, sizeof(long long) * (size_t)n));
         generator_changed(ctx);
         int rc = compute_reverse_edges(ctx);
         if (rc != GG_OK) return rc;

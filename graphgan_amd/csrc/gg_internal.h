@@ -91,11 +91,17 @@ struct gg_ctx {
     std::vector<int32_t> h_col;
     // Edge-score cache (walk_sample.hip): s(u, col[e]) = g_u . g_col[e] + b[col[e]] of graph edge e (generator.py:21) does not
     // depend on the ROOT whose tree a walk moves in, so the walks of all roots, levels and both launches of a step share
-    // one copy: es[e], valid when es_stamp[u] == es_epoch (adj(u) was scored since the generator last changed).
+    // one copy: es[e], valid when es_stamp[u] says adj(u) was scored since the generator last changed.
+    // Stamps are TICKS of a 64-bit clock the host advances: every score kernel of every walk launch has its own tick (a launch
+    // reserves 256: tick = launch base + 2 * level + half), and es_stamp[u] = tick of the score kernel that fills adj(u)'s
+    // scores.  A reader whose own score kernel has tick T may gather from u iff es_valid_from <= es_stamp[u] <= T: scored
+    // since the generator last changed, by a kernel that is stream-ordered before the reader's weights kernel (the two
+    // halves of a split launch chain their score kernels by events, so ticks order them).
     float *es = nullptr;          // [g_nnz]
-    int32_t *es_stamp = nullptr;  // [n_node]
+    long long *es_stamp = nullptr;  // [n_node]
     int32_t *g_rev = nullptr;     // [g_nnz] index of the reverse edge (col[e] -> u): a walk's father candidate
-    int32_t es_epoch = 1;         // bumped by every generator update / table upload / aborted launch
+    long long es_tick = 256;      // next free tick
+    long long es_valid_from = 256;  // moved to es_tick by every generator update / table upload / aborted launch
     int32_t es_mode = 1;          // GG_ES_MODE: 0 = off (every distribution scores its own candidates), 1 = policy, 2 = always share
     int32_t es_ratio_num = 2;     // GG_ES_RATIO: a stale node is scored whole when k * ratio >= deg (k = candidates the asking root needs)
     int32_t es_hub = 0;           // GG_ES_HUB: ... or when deg >= hub (0 = off)

@@ -87,18 +87,20 @@ struct WalkArgs {
     int64_t lv_big_cap;
     int32_t *fin_list;       // [total_walks] walks still alive behind the last streamed level (CTR_FIN entries)
     // Edge-score cache (gg_internal.h): the score of graph edge e = (u -> col[e]) is the same for every root, so a node's
-    // adjacency is scored ONCE per generator state (es_stamp[u] == es_epoch) and every (root, u) distribution gathers its
+    // adjacency is scored ONCE per generator state (stamped in es_stamp[u]) and every (root, u) distribution gathers its
     // candidates' scores through the tree's edge indices: child rank i -> es[t_edge[i]], father -> es[g_rev[t_edge[rank(u)]]].
     const int64_t *rowptr;
     const int32_t *col;
     const int32_t *t_edge;
     const int32_t *rev;
     float *es;
-    int32_t *es_stamp;
-    int32_t es_epoch;
+    long long *es_stamp;     // tick of the score kernel that fills the node's adjacency scores (gg_internal.h)
+    long long es_now;        // tick of THIS level's score kernel of this half
+    long long es_valid_from; // older stamps predate the generator's current tables
     int32_t es_mode;         // 0 = off, 1 = a stale node is scored whole when the asking distribution needs most of it, 2 = always
     int32_t es_ratio, es_hub;
     int32_t *lv_fe;          // [total_walks] es index of the father candidate's score (gather tasks with a father entry)
+    int32_t *lv_tiny;        // [walks of this half] third task list of the weights kernel: gather tasks with <= 16 candidates
 };
 
 __device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, int lane) {
@@ -524,12 +526,14 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     if (owns && a.es_mode) {
         e0 = a.rowptr[cur];
         deg = (int)(a.rowptr[cur + 1] - e0);
-        const int st = __hip_atomic_load(&a.es_stamp[cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (st == a.es_epoch) {
-            mode = 1;
+        const long long st = __hip_atomic_load(&a.es_stamp[cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (st >= a.es_valid_from) {
+            // scored (or about to be, by a score kernel that is ordered before this level's weights kernel): gather.  A stamp
+            // from the FUTURE belongs to the other half of a split launch (its later score kernel): score privately.
+            mode = st <= a.es_now ? 1 : 0;
         } else if (a.es_mode == 2 || (int64_t)k * a.es_ratio >= (int64_t)deg || (a.es_hub > 0 && deg >= a.es_hub)) {
-            const int old = atomicCAS(&a.es_stamp[cur], st, a.es_epoch);
-            mode = old == st ? 2 : (old == a.es_epoch ? 1 : 0);
+            const long long old = (long long)atomicCAS((unsigned long long *)&a.es_stamp[cur], (unsigned long long)st, (unsigned long long)a.es_now);
+            mode = old == st ? 2 : ((old >= a.es_valid_from && old <= a.es_now) ? 1 : 0);
         }
         if (mode && hf) fe = a.rev[up_edge];  // s(cur, father) sits at the reverse of the edge (father -> cur), inside adj(cur)
     }
@@ -618,7 +622,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         // tiny gather tasks in the second half
         if (big) a.lv_big[(blk_base[1] & 0xffffffffull) + big_before + __popcll(big_bal & ((1ull << lane) - 1ull))] = (int32_t)w;
         if (small) a.lv_big[a.lv_big_cap - 1 - (int64_t)((blk_base[1] >> 32) + small_before + __popcll(small_bal & ((1ull << lane) - 1ull)))] = (int32_t)w;
-        if (tiny) a.lv_big[a.lv_big_cap + (int64_t)blk_base[2] + tiny_before + __popcll(tiny_bal & ((1ull << lane) - 1ull))] = (int32_t)w;
+        if (tiny) a.lv_tiny[(int64_t)blk_base[2] + tiny_before + __popcll(tiny_bal & ((1ull << lane) - 1ull))] = (int32_t)w;
         if (write_desc == 1 && fits) {
             if (mode == 2)
                 for (int i = 0; i < s_chunks; ++i) write_node_desc(a.lv_chunk_desc, coff_s + i, cur, deg, e0, i);
@@ -836,7 +840,7 @@ __device__ __forceinline__ void weights_tiny_blocks(const WalkArgs &a, const int
     const int t = threadIdx.x & 15;
     const int64_t n_tiny = (int64_t)a.lc[CTR_TINY + a.level];
     for (int64_t i = (int64_t)block * 16 + (threadIdx.x >> 4); i < n_tiny; i += (int64_t)TINY_BLOCKS * 16)
-        weights_small_task<1>(a, a.lv_big[a.lv_big_cap + i], t);
+        weights_small_task<1>(a, a.lv_tiny[i], t);
 }
 
 // Big owner tasks (hubs): one 256-thread workgroup per task, from the level's big-task list.  Tasks of up to
@@ -1200,6 +1204,7 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
         for (int k = 0; k < 2; ++k) {
             h[k].lc = ctx->dev_ctr + (size_t)k * CTR_WORDS;
             h[k].lv_big = a.lv_big + h[k].w0;
+            h[k].lv_tiny = a.lv_tiny + h[k].w0;
             h[k].lv_big_cap = h[k].w_end - h[k].w0;
             h[k].lv_scores = a.lv_scores + (size_t)k * cap * CHUNK;
             h[k].lv_chunk_desc = a.lv_chunk_desc + (size_t)k * cap;
@@ -1220,6 +1225,7 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
         for (int k = 0; k < n_half; ++k) {
             WalkArgs &x = h[k];
             x.level = level;
+            x.es_now = a.es_now + 2 * level + k;  // the tick of this half's score kernel of this level (MAX_LEVELS = 64: < 256 per launch)
             const unsigned wblocks = (unsigned)cdiv(x.w_end - x.w0, 256);
             hipLaunchKernelGGL(level_advance_kernel, dim3(wblocks), dim3(256), 0, hs[k], x, level > 0 ? 1 : 0, 1, sized ? 0 : 1, cap);
             if (sized) {
@@ -1328,6 +1334,7 @@ static int run_levels_and_finish(gg_ctx *ctx, WalkArgs &a, int64_t total_walks) 
         a.lv_k = ctx->lv_k.as<int32_t>();
         a.lv_chunks = ctx->lv_chunks.as<int32_t>();
         a.lv_big = ctx->lv_big.as<int32_t>();
+        a.lv_tiny = a.lv_big + total_walks;
         a.lv_fe = ctx->lv_fe.as<int32_t>();
         a.lv_coff = ctx->lv_coff.as<int64_t>();
         a.lv_pfx = ctx->lv_pfx.as<int64_t>();
@@ -1399,10 +1406,12 @@ int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int fo
     a.rev = ctx->g_rev;
     a.es = ctx->es;
     a.es_stamp = ctx->es_stamp;
-    a.es_epoch = ctx->es_epoch;
+    a.es_valid_from = ctx->es_valid_from;
+    a.es_now = ctx->es_tick;  // base of the launch's ticks; run_levels adds 2 * level + half
+    ctx->es_tick += 256;
     a.es_ratio = ctx->es_ratio_num;
     a.es_hub = ctx->es_hub;
-    a.es_mode = 0;  // set below once the launch is known to run unsplit
+    a.es_mode = 0;  // set below
     a.w0 = 0;
     a.w_end = total_walks;
     a.lv_big_cap = total_walks;
@@ -1433,9 +1442,8 @@ int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int fo
     // stream while the discriminator's gradient kernel was filling the L2 with atomics.)
     const bool will_size = ctx->lv_cap_chunks == 0 || ctx->walk_force_sized;
     ctx->w_split = ctx->split_enabled && ctx->walk_levels > 0 && !will_size && total_walks >= ctx->split_min_walks;
-    // the edge-score cache needs the trees' edge indices and one stream per launch (the two halves of a split launch would
-    // gather scores the other half's score kernel has not written yet)
-    if (ctx->es && ctx->es_stamp && ctx->g_rev && ctx->t_edge_valid && !ctx->w_split && ctx->walk_levels > 0) a.es_mode = ctx->es_mode;
+    // the edge-score cache needs the trees' edge indices (and a symmetric adjacency: g_rev)
+    if (ctx->es && ctx->es_stamp && ctx->g_rev && ctx->t_edge_valid && ctx->walk_levels > 0) a.es_mode = ctx->es_mode;
     hipLaunchKernelGGL(walk_reset_kernel, dim3(cdiv(2 * CTR_WORDS, 256)), dim3(256), 0, ctx->walk_stream, ctx->dev_ctr, 2 * (int)CTR_WORDS,
                        ctx->dc_words.as<int64_t>(), a.dc_mode == 2 ? 1 : 0, ctx->w_split ? 1 : 0, ctx->lv_cap_total);
     // HIP events around every profile_every-th call (a rerun keeps the decision of the launch it repeats)
