@@ -426,7 +426,7 @@ int gg_destroy(gg_ctx *ctx) {
                       &ctx->w_first, &ctx->w_abort, &ctx->w_scratch, &ctx->d_center, &ctx->d_neighbor, &ctx->d_label, &ctx->d_cnt,
                       &ctx->d_ptr, &ctx->g_node1, &ctx->g_node2, &ctx->g_reward, &ctx->g_cnt, &ctx->g_ptr, &ctx->scan_tmp,
                       &ctx->step_u, &ctx->step_v, &ctx->step_x, &ctx->sg_cnt, &ctx->sg_off, &ctx->sg_slot, &ctx->sg_list, &ctx->sg_rows, &ctx->sg_bias, &ctx->sg_tot, &ctx->sg_key, &ctx->touched_ptr, &ctx->x_cnt, &ctx->x_send_ids, &ctx->x_send_rows,
-                      &ctx->x_recv_ids, &ctx->x_recv_rows, &ctx->x_nglob, &ctx->st_item, &ctx->st_cur, &ctx->st_prev, &ctx->st_len,
+                      &ctx->x_recv_ids, &ctx->x_recv_rows, &ctx->x_nglob, &ctx->st_item, &ctx->st_item2, &ctx->st_cur, &ctx->st_prev, &ctx->st_len,
                       &ctx->st_alive, &ctx->st_rank, &ctx->bfs_key, &ctx->bfs_bm, &ctx->bfs_misc, &ctx->lv_pfx, &ctx->dc_keys, &ctx->dc_vals, &ctx->dc_words, &ctx->lv_beg, &ctx->lv_k, &ctx->lv_chunks, &ctx->lv_coff, &ctx->lv_scores, &ctx->lv_chunk_owner, &ctx->lv_prefix, &ctx->lv_big, &ctx->lv_fe, &ctx->fin_list};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : ctx->lv_ev)

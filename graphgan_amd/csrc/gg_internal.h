@@ -154,7 +154,7 @@ struct gg_ctx {
     const gg::DevBuf &w_ptr_buf() const { return w_ptr_m[w_mode]; }
     gg::DevBuf w_samples, w_paths, w_len, w_status, w_first, w_abort, w_scratch;
     // level-synchronous front end of the walk sampler (walk_sample.hip): per-walk state + per-level tasks
-    gg::DevBuf st_cur, st_prev, st_len, st_alive, st_rank, st_item, lv_beg, lv_k, lv_chunks, lv_coff, lv_scores, lv_chunk_owner, lv_prefix, lv_big, lv_fe;
+    gg::DevBuf st_cur, st_prev, st_len, st_alive, st_rank, st_item, st_item2, lv_beg, lv_k, lv_chunks, lv_coff, lv_scores, lv_chunk_owner, lv_prefix, lv_big, lv_fe;
     gg::DevBuf lv_pfx, dc_keys, dc_vals, dc_words;  // distribution cache (walk_sample.hip): prefix offsets per walk, hash table, base words
     size_t dc_size = 0;                // hash table entries (power of two)
     int32_t dc_request = 0;            // mode of the NEXT walk launch: 0 off, 1 register (gg_prepare_d), 2 look up (gg_prepare_g)
@@ -174,7 +174,7 @@ struct gg_ctx {
     // pinned host mirror: [0, 2 * CTR_WORDS) the launch's device counters (two halves), [H_TOTAL] the row / pair count of a prepare call --
     // both arrive with asynchronous copies behind the kernels and ONE stream synchronisation (pageable destinations
     // would make every copy its own host round trip)
-    static constexpr int CTR_WORDS = 648;  // counter words per half of a walk launch (walk_sample.hip)
+    static constexpr int CTR_WORDS = 720;  // counter words per half of a walk launch (walk_sample.hip)
     static constexpr int PIN_WORDS = 2048;
     static constexpr int H_TOTAL = 1960;
     static constexpr int H_ROWS = 1940;   // [H_ROWS + k]: touched-row count of pending pass timing k (copied behind its optimizer kernel)

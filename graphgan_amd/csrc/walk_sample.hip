@@ -60,6 +60,7 @@ struct WalkArgs {
     int32_t *st_cur, *st_prev, *st_len, *st_alive;
     int32_t *st_rank;      // BFS rank of st_cur in its root's tree
     int4 *st_const;        // {item, slot, root, walk index inside the root}: fixed per walk, ONE load per hop
+    int4 *st_const2;       // {tree base of the slot (t_base), Q3 row of the slot (t_q3off)} as lo / hi words: no slot -> base hop on the chain
     int32_t level;         // hop index handled by this launch (level kernels) / first hop (finisher)
     // per-level tasks
     int64_t *lv_beg;       // absolute index in t_order of the first CHILD candidate
@@ -76,7 +77,7 @@ struct WalkArgs {
     // of a step, so a (root slot, node rank, father flag) distribution the D launch evaluated is NOT evaluated again by
     // the G launch: D owners register {key -> global prefix offset, k} in a hash table, G walks look their node up.
     int32_t dc_mode;       // 0 = off, 1 = register (D launch), 2 = look up (G launch)
-    unsigned long long *dc_keys, *dc_vals;
+    ulonglong2 *dc_tab;    // {key, value} entries: one 16-byte read per probe
     uint32_t dc_mask;      // table size - 1 (power of two)
     const int64_t *dc_words;  // [0] global chunk offset this launch starts at, [1] chunks in the buffer after the D launch
     int32_t *lv_big;       // [lv_big_cap] task lists of the weights kernel, per level: hub tasks from the front, small multi-chunk tasks from the back
@@ -251,19 +252,18 @@ constexpr int CTR_DISTS = 392;   // ctr[CTR_DISTS + (block & 63)]: (root, node) 
 constexpr int CTR_TINY = 456;    // ctr[CTR_TINY + level]: gather tasks with <= 16 candidates (third task list of the weights kernel)
 constexpr int CTR_GATHER = 520;  // ctr[CTR_GATHER + (block & 63)]: owner distributions that gather their scores from the edge-score cache, spread words
 constexpr int CTR_NODES = 584;   // ctr[CTR_NODES + (block & 63)]: nodes whose adjacency this launch scored into the cache, spread words
-constexpr int CTR_WORDS = 648;
+constexpr int CTR_BASE = 648;    // ctr[CTR_BASE + level]: global chunk offset of the first PREFIX chunk of hop `level` (launch base + the prefix chunks
+                                 //                        of the earlier hops): [0] by the reset kernel, [level + 1] by the score kernel of `level`
+constexpr int CTR_WORDS = 720;
 static_assert(CTR_WORDS == gg_ctx::CTR_WORDS, "counter layout");
 constexpr int MAX_LEVELS = 64;
 constexpr int LVK_GATHER = 1 << 30;  // lv_k flag: the distribution's scores come from the edge-score cache
 constexpr int LVK_NODE = 1 << 29;    // lv_k flag: ... and this owner scores the node's adjacency (its score chunks are node chunks)
 constexpr int LVK_MASK = (1 << 29) - 1;
 
-// Global chunk offset of the first chunk of hop a.level: the launch's base + the chunks of its earlier hops.
-__device__ __forceinline__ int64_t level_chunk_base(const WalkArgs &a) {
-    int64_t b = a.dc_words[0];
-    for (int l = 0; l < a.level; ++l) b += (int64_t)(a.lc[CTR_CHUNKS + l] & 0xffffffffull);
-    return b;
-}
+// Global chunk offset of the first prefix chunk of hop a.level (one word; it used to be a loop over the earlier levels'
+// counters -- up to `level` dependent reads at the head of every level kernel).
+__device__ __forceinline__ int64_t level_chunk_base(const WalkArgs &a) { return (int64_t)a.lc[CTR_BASE + a.level]; }
 
 __device__ __forceinline__ unsigned long long dc_key(int slot, int rank, int hf) {
     return ((unsigned long long)(unsigned)slot << 32) | ((unsigned long long)(unsigned)rank << 1) | (unsigned long long)hf;
@@ -296,41 +296,84 @@ __device__ __forceinline__ void write_node_desc(int4 *desc, int64_t c, int cur, 
 //   do_setup : prepare hop (level) -- tree list of (root, cur) with the reference's hop rules
 //              (root-only-children, Q2 abort, Q3 father removal) and the in-workgroup dedup: walks of
 //              one root standing on the same node need the SAME distribution -> one owner.
+// The kernel is ONE CHAIN OF DEPENDENT RANDOM READS per walk at two to three wavefronts per SIMD: its run time is the length
+// of that chain (a level with 1 800 live walks took as long as one with 160 000: ~35 us = 16 round trips).  So every load
+// is issued as early as its address is known, independent of the branches around it -- per-walk state before the liveness
+// test, the tree row / graph row / stamp of the picked node before the dedup decides who needs them -- the per-walk
+// constants include the tree base and the Q3 row (no slot -> base hop), the level's prefix base is one word (written by the
+// previous score kernel) instead of a loop over the earlier levels' counters, the dedup is an LDS hash instead of a
+// backward scan (up to 255 dependent LDS reads for a hub root's walks), and the block's returning atomics go out from
+// three lanes at once instead of one after the other: 6-7 round trips.
+__device__ __forceinline__ uint32_t dc_hash(unsigned long long key, uint32_t mask) { return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & mask; }
+
 __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, const int do_sample, const int do_setup, const int write_desc,
                                                             const int64_t cap_chunks) {
+    __shared__ int blk_skip;
+    __shared__ long long blk_lbase;
+    __shared__ long long hk[512];   // dedup hash: key (item, cur) -> ...
+    __shared__ int ho[512];         // ... smallest thread index that holds it
+    __shared__ long long blk_coff[256];
+    const int tid = (int)threadIdx.x;
+    const int64_t w = a.w0 + (int64_t)blockIdx.x * blockDim.x + tid;
+    const int lane = tid & 63;
+    const bool in_range = w < a.w_end;
+    // ---- loads that need nothing but the walk index (issued before the block learns whether it runs at all)
+    int alive_w = 1, kraw = 0, len = 0, cur0 = -1, prev0 = -1;
+    int4 sc = make_int4(0, 0, 0, 0), sc2 = make_int4(0, 0, 0, 0);
+    int64_t pfx0 = 0, beg0 = 0;
+    if (in_range && do_sample) {
+        alive_w = a.st_alive[w];
+        sc = a.st_const[w];
+        sc2 = a.st_const2[w];
+        kraw = a.lv_k[w];
+        pfx0 = a.lv_pfx[w];
+        beg0 = a.lv_beg[w];
+        len = a.st_len[w];
+        cur0 = a.st_cur[w];
+        prev0 = a.st_prev[w];
+    }
     // Block-uniform early exit: other blocks of this very launch may raise flag 2 (speculative overflow below, a walk
     // still alive after the last level), so every thread testing the global word itself could split a workgroup in
     // front of the barriers further down.  One thread reads, all threads test the shared copy.
-    __shared__ int blk_skip;
-    if (threadIdx.x == 0)
-        blk_skip = (__atomic_load_n(&a.ctr[3], __ATOMIC_RELAXED) == 2ull ||                                  // an earlier level overflowed: the host reruns in sized mode
-                    (a.level > 0 && __atomic_load_n(&a.lc[CTR_ALIVE + a.level - 1], __ATOMIC_RELAXED) == 0ull))  // every walk has finished: empty level
+    if (tid == 0) {
+        const unsigned long long flag = __atomic_load_n(&a.ctr[3], __ATOMIC_RELAXED);
+        const unsigned long long prev_alive = a.level > 0 ? __atomic_load_n(&a.lc[CTR_ALIVE + a.level - 1], __ATOMIC_RELAXED) : 1ull;
+        const unsigned long long lb = __atomic_load_n(&a.lc[CTR_BASE + a.level], __ATOMIC_RELAXED);
+        blk_skip = (flag == 2ull ||        // an earlier level overflowed: the host reruns in sized mode
+                    prev_alive == 0ull)   // every walk has finished: empty level
                        ? 1 : 0;
+        blk_lbase = (long long)lb;         // global chunk offset of this hop's first prefix chunk (launch base + earlier hops)
+    }
+    hk[tid] = -1ll; hk[tid + 256] = -1ll;
+    ho[tid] = 0x7fffffff; ho[tid + 256] = 0x7fffffff;
     __syncthreads();
     if (blk_skip) return;
-    const int64_t w = a.w0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const bool in_range = w < a.w_end;
     bool alive = false, sampled = false;
     int item = 0, cur = -1, k = 0, hf = 0, father = -1, slot_w = 0, rank_w = 0, up_edge = -1;
     unsigned long long my_k = 0;
     int64_t beg_abs = 0;
-    // finished walks (the majority at the deeper hops) leave after ONE load
-    if (in_range && (!do_sample || a.st_alive[w] != 0)) {
+    // graph row / stamp of the node the walk stands on: loaded for every live walk as soon as the node is known (only the
+    // distribution's owner uses them, but waiting for the dedup first would put them behind it on the chain)
+    int64_t e0 = 0, e1 = 0;
+    long long st = 0;
+    int fe = -1;
+    if (in_range && alive_w != 0) {
         int slot, root, j, rank = 0;
+        int64_t tbase, q3off;
         if (!do_sample) {
             item = find_item(a.walk_ptr, a.n_slots, w);
             slot = a.slots[item];
             root = a.t_root[slot];
             j = (int)(w - a.walk_ptr[item]);
+            tbase = a.t_base[slot];
+            q3off = a.t_q3off[slot];
             a.st_const[w] = make_int4(item, slot, root, j);
+            a.st_const2[w] = make_int4((int)(tbase & 0xffffffffll), (int)(tbase >> 32), (int)(q3off & 0xffffffffll), (int)(q3off >> 32));
         } else {
-            // every per-walk input of the hop is an independent load (this kernel is one chain of dependent
-            // random reads per walk, a few waves per SIMD: its run time IS the length of that chain)
-            const int4 sc = a.st_const[w];
             item = sc.x; slot = sc.y; root = sc.z; j = sc.w;
+            tbase = ((int64_t)sc2.y << 32) | (unsigned)sc2.x;
+            q3off = ((int64_t)sc2.w << 32) | (unsigned)sc2.z;
         }
-        const int64_t tbase = a.t_base[slot];
         if (!do_sample) {  // level 0: start the walk
             alive = true;
             cur = root;
@@ -340,85 +383,87 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
             if (a.for_d) a.first_child[w] = -1;
         } else {
             alive = true;
-            {
-                sampled = true;
-                const int kraw = a.lv_k[w];
-                const int kk = kraw & LVK_MASK, hf0 = (int)((unsigned)kraw >> 31);
-                my_k = (unsigned long long)kk;
-                const uint64_t *const pf = a.lv_prefix + a.lv_pfx[w] * CHUNK;
-                const int64_t beg0 = a.lv_beg[w];
-                const int len = a.st_len[w];
-                const int cur0 = a.st_cur[w], prev0 = a.st_prev[w];
-                // first j with C_j > thr by a 16-ary search: 15 independent pivot loads per round, ceil(log16 k)
-                // dependent rounds instead of log2 k (a hub hop was a chain of 12+ dependent random reads); the
-                // first round's pivots do not depend on the threshold and fly together with W = C_{k-1}
-                int lo = 0, n = kk;  // invariant: the answer lies in [lo, lo + n) and C_{lo+n-1} > thr
-                int step = (n + 15) >> 4;
-                uint64_t piv[15];
+            sampled = true;
+            const int kk = kraw & LVK_MASK, hf0 = (int)((unsigned)kraw >> 31);
+            my_k = (unsigned long long)kk;
+            const uint64_t *const pf = a.lv_prefix + pfx0 * CHUNK;
+            // first j with C_j > thr by a 16-ary search: 15 independent pivot loads per round, ceil(log16 k)
+            // dependent rounds instead of log2 k (a hub hop was a chain of 12+ dependent random reads); the
+            // first round's pivots do not depend on the threshold and fly together with W = C_{k-1}
+            int lo = 0, n = kk;  // invariant: the answer lies in [lo, lo + n) and C_{lo+n-1} > thr
+            int step = (n + 15) >> 4;
+            uint64_t piv[15];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) {
+                const int idx = i * step - 1;
+                piv[i - 1] = (idx < n - 1) ? pf[idx] : ~0ull;
+            }
+            const uint64_t Wtot = pf[kk - 1];
+            if (Wtot == 0ull) a.ctr[CTR_NONFINITE] = 1ull;  // non-finite scores: the search below stays inside [0, kk), the host reports the error
+            const uint64_t thr = threshold(uniform53(a.seed, a.stream, (uint32_t)root, (uint32_t)j, (uint32_t)(a.level - 1)), Wtot);
+            int seg = 0;
+#pragma unroll
+            for (int i = 0; i < 15; ++i) seg += (piv[i] <= thr) ? 1 : 0;  // C is non-decreasing: a prefix of the pivots
+            lo = seg * step;
+            n = min(step, n - seg * step);
+            while (n > 1) {
+                step = (n + 15) >> 4;
 #pragma unroll
                 for (int i = 1; i < 16; ++i) {
                     const int idx = i * step - 1;
-                    piv[i - 1] = (idx < n - 1) ? pf[idx] : ~0ull;
+                    piv[i - 1] = (idx < n - 1) ? pf[lo + idx] : ~0ull;
                 }
-                const uint64_t Wtot = pf[kk - 1];
-                if (Wtot == 0ull) a.ctr[CTR_NONFINITE] = 1ull;  // non-finite scores: the search below stays inside [0, kk), the host reports the error
-                const uint64_t thr = threshold(uniform53(a.seed, a.stream, (uint32_t)root, (uint32_t)j, (uint32_t)(a.level - 1)), Wtot);
-                int seg = 0;
+                seg = 0;
 #pragma unroll
-                for (int i = 0; i < 15; ++i) seg += (piv[i] <= thr) ? 1 : 0;  // C is non-decreasing: a prefix of the pivots
-                lo = seg * step;
+                for (int i = 0; i < 15; ++i) seg += (piv[i] <= thr) ? 1 : 0;
+                lo += seg * step;
                 n = min(step, n - seg * step);
-                while (n > 1) {
-                    step = (n + 15) >> 4;
-#pragma unroll
-                    for (int i = 1; i < 16; ++i) {
-                        const int idx = i * step - 1;
-                        piv[i - 1] = (idx < n - 1) ? pf[lo + idx] : ~0ull;
-                    }
-                    seg = 0;
-#pragma unroll
-                    for (int i = 0; i < 15; ++i) seg += (piv[i] <= thr) ? 1 : 0;
-                    lo += seg * step;
-                    n = min(step, n - seg * step);
-                }
-                // Candidate 0 of a list with a father entry IS the previous node (walks only move down the tree until
-                // their back-step), so the terminating condition (:264-266) needs no load: the walk ends iff it picked
-                // that entry.  Otherwise the pick is a child: its rank follows from the index alone, and the setup of
-                // the next hop (the cstart pair of that rank) does not wait for the node id.
-                const bool back = hf0 && lo == 0;
-                const int64_t pick = beg0 + lo - hf0;  // index in t_order (children only)
-                const int nxt = back ? prev0 : a.t_order[pick];
-                if (len >= a.stride) {
-                    a.ctr[3] = 1ull;
-                    a.path_len[w] = 0;
-                    a.samples[w] = -1;
+            }
+            // Candidate 0 of a list with a father entry IS the previous node (walks only move down the tree until
+            // their back-step), so the terminating condition (:264-266) needs no load: the walk ends iff it picked
+            // that entry.  Otherwise the pick is a child: its rank follows from the index alone, and the setup of
+            // the next hop (the cstart pair of that rank) does not wait for the node id.
+            const bool back = hf0 && lo == 0;
+            const int64_t pick = beg0 + lo - hf0;  // index in t_order (children only)
+            const int nxt = back ? prev0 : a.t_order[pick];
+            if (len >= a.stride) {
+                a.ctr[3] = 1ull;
+                a.path_len[w] = 0;
+                a.samples[w] = -1;
+                alive = false;
+            } else {
+                a.paths[w * (int64_t)a.stride + len] = nxt;
+                if (back) {                   // next == previous: sample = cur
+                    a.path_len[w] = len + 1;
+                    a.samples[w] = cur0;
                     alive = false;
                 } else {
-                    a.paths[w * (int64_t)a.stride + len] = nxt;
-                    if (back) {                   // next == previous: sample = cur
-                        a.path_len[w] = len + 1;
-                        a.samples[w] = cur0;
-                        alive = false;
-                    } else {
-                        a.st_len[w] = len + 1;
-                        a.st_prev[w] = cur0;
-                        father = cur0;
-                        cur = nxt;
-                        rank = (int)(pick - tbase);
-                    }
+                    a.st_len[w] = len + 1;
+                    a.st_prev[w] = cur0;
+                    father = cur0;
+                    cur = nxt;
+                    rank = (int)(pick - tbase);
                 }
             }
         }
         if (alive && do_setup) {
             const int32_t *const cs = a.t_cstart + tbase + slot;
             const int cbeg = cs[rank], cend = cs[rank + 1];  // children of cur = ranks [cbeg, cend)
-            if (a.es_mode && a.level > 0) up_edge = a.t_edge[tbase + rank];  // the edge (father -> cur): independent of the loads around it
+            unsigned q3w = 0u;
+            if (a.level == 1) q3w = a.t_q3[q3off + ((rank - 1) >> 5)];
+            if (a.es_mode) {
+                if (a.level > 0) up_edge = a.t_edge[tbase + rank];  // the edge (father -> cur)
+                e0 = a.rowptr[cur];
+                e1 = a.rowptr[cur + 1];
+                st = __hip_atomic_load(&a.es_stamp[cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (up_edge >= 0) fe = a.rev[up_edge];  // s(cur, father) sits at the reverse of that edge, inside adj(cur)
+            }
             const int nchild = cend - cbeg;
             // list of cur (graph_gan.py:250): the root's is children only (tree[root][1:]); any other node's is
             // [father] ++ children unless D-mode removed the father entry of this depth-1 child earlier (Q3)
             hf = 1;
             if (a.level == 0) hf = 0;
-            else if (a.level == 1 && ((a.t_q3[a.t_q3off[slot] + ((rank - 1) >> 5)] >> ((rank - 1) & 31)) & 1u)) hf = 0;
+            else if (a.level == 1 && ((q3w >> ((rank - 1) & 31)) & 1u)) hf = 0;
             k = nchild + hf;
             bool aborted = false;
             if (k == 0) {                          // "the tree only has a root" (:252-253)
@@ -449,11 +494,11 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         }
         slot_w = slot;
         rank_w = rank;
-        a.st_alive[w] = alive ? 1 : 0;
         // the sync-free launch ran only as many levels as earlier launches needed: a walk that is
         // still going after the last one sends the launch to the sized rerun
         if (alive && !do_setup && write_desc == 2) a.ctr[3] = 2ull;
     }
+    if (in_range) a.st_alive[w] = alive ? 1 : 0;
     if (do_sample) {
         const unsigned long long bal = __ballot(sampled);
 #pragma unroll
@@ -481,37 +526,34 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     int64_t cached_off = 0;
     if (alive && a.dc_mode == 2) {
         const unsigned long long key = dc_key(slot_w, rank_w, hf);
-        uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & a.dc_mask;
+        uint32_t h = dc_hash(key, a.dc_mask);
         for (int tries = 0; tries < 64; ++tries) {
-            const unsigned long long kk = a.dc_keys[h];
-            if (kk == key) {
-                const unsigned long long v = a.dc_vals[h];
-                if ((int)(v & 0xffffffffull) == k) { cached = true; cached_off = (int64_t)(v >> 32); }
+            const ulonglong2 ent = a.dc_tab[h];  // {key, value}: one 16-byte read per probe
+            if (ent.x == key) {
+                if ((int)(ent.y & 0xffffffffull) == k) { cached = true; cached_off = (int64_t)(ent.y >> 32); }
                 break;
             }
-            if (kk == ~0ull) break;
+            if (ent.x == ~0ull) break;
             h = (h + 1) & a.dc_mask;
         }
     }
-    // dedup inside the workgroup (256 consecutive walks): the first walk with the same (item, cur) owns the
-    // distribution.  Walks of one root are consecutive, so a walk scans backwards over its root's walks only
-    // (finished walks are skipped, the first live walk of another root ends the scan).
-    __shared__ long long blk_keys[256];
-    __shared__ long long blk_coff[256];
-    __shared__ long long blk_lbase;
-    if (threadIdx.x == 0) blk_lbase = level_chunk_base(a);
+    // dedup inside the workgroup (256 consecutive walks): the walk with the smallest index among those with the same
+    // (item, cur) owns the distribution -- an LDS hash (insert with compare-and-swap, owner with atomic-min).
     const long long key = (alive && !cached) ? (((long long)item << 32) | (unsigned)cur) : -1ll;
-    blk_keys[threadIdx.x] = key;
-    __syncthreads();
-    int owner = (int)threadIdx.x;
-    if (alive && !cached) {
-        for (int jj = (int)threadIdx.x - 1; jj >= 0; --jj) {
-            const long long kj = blk_keys[jj];
-            if (kj == key) owner = jj;
-            else if (kj >= 0 && (int)(kj >> 32) != item) break;
+    int hs = -1;
+    if (key >= 0) {
+        int s = (int)(((unsigned long long)key * 0x9E3779B97F4A7C15ull) >> 55);  // 9 bits
+        for (;;) {
+            const long long old = (long long)atomicCAS((unsigned long long *)&hk[s], ~0ull, (unsigned long long)key);
+            if (old == -1ll || old == key) break;
+            s = (s + 1) & 511;
         }
+        atomicMin(&ho[s], tid);
+        hs = s;
     }
-    const bool owns = alive && !cached && owner == (int)threadIdx.x;
+    __syncthreads();
+    const int owner = hs >= 0 ? ho[hs] : tid;
+    const bool owns = alive && !cached && owner == tid;
     // ---- where do this distribution's scores come from?  (edge-score cache, see WalkArgs)
     //   gather : adj(cur) has been scored since the generator last changed (this level by another root, an earlier level,
     //            or the D launch of the step) -> no rows at all, the weights kernel gathers k four-byte scores;
@@ -521,12 +563,9 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     //            candidates only, as before.
     // Which of two racing owners wins a node only decides WHO scores it: the scores (spec S1) and therefore the walks are
     // the same in every outcome.
-    int mode = 0, deg = 0, fe = -1;
-    int64_t e0 = 0;
+    int mode = 0;
+    const int deg = (int)(e1 - e0);
     if (owns && a.es_mode) {
-        e0 = a.rowptr[cur];
-        deg = (int)(a.rowptr[cur + 1] - e0);
-        const long long st = __hip_atomic_load(&a.es_stamp[cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (st >= a.es_valid_from) {
             // scored (or about to be, by a score kernel that is ordered before this level's weights kernel): gather.  A stamp
             // from the FUTURE belongs to the other half of a split launch (its later score kernel): score privately.
@@ -535,17 +574,16 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
             const long long old = (long long)atomicCAS((unsigned long long *)&a.es_stamp[cur], (unsigned long long)st, (unsigned long long)a.es_now);
             mode = old == st ? 2 : ((old >= a.es_valid_from && old <= a.es_now) ? 1 : 0);
         }
-        if (mode && hf) fe = a.rev[up_edge];  // s(cur, father) sits at the reverse of the edge (father -> cur), inside adj(cur)
     }
     const int p_chunks = owns ? (k + CHUNK - 1) / CHUNK : 0;                                       // prefix region
     const int s_chunks = !owns ? 0 : (mode == 0 ? p_chunks : (mode == 2 ? (deg + CHUNK - 1) / CHUNK : 0));  // score chunks
     const bool big = owns && k > BIG_TASK;
     const bool small = owns && p_chunks > 1 && !big;  // 16 < k <= BIG_TASK: a 16-lane group of the weights kernel
     const bool tiny = owns && mode != 0 && p_chunks == 1;  // gather, k <= 16 (private ones are finished by the score kernel)
-    // chunk offsets and task slots: in-wave exclusive scans, per-block totals through LDS, and ONE returning atomic per
-    // block and counter word (a single word serves only ~88 returning atomics per us); the order of the blocks' regions
-    // in the buffers is irrelevant
-    __shared__ int wv_pch[4], wv_sch[4], wv_big[4], wv_own[4], wv_small[4], wv_tiny[4], wv_gat[4], wv_node[4];
+    // chunk offsets and task slots: in-wave exclusive scans, per-block totals through LDS, and the block's returning
+    // atomics issued by three lanes AT ONCE (a single word serves only ~88 returning atomics per us, and three of them one
+    // after the other were three round trips); the order of the blocks' regions in the buffers is irrelevant
+    __shared__ int wv_pch[4], wv_sch[4], wv_big[4], wv_own[4], wv_small[4], wv_tiny[4], wv_gat[4], wv_node[4], wv_alive[4];
     __shared__ unsigned long long blk_base[3];
     int inc_p = p_chunks, inc_s = s_chunks;
 #pragma unroll
@@ -553,36 +591,29 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         const int op = __shfl_up(inc_p, off, 64), os = __shfl_up(inc_s, off, 64);
         if (lane >= off) { inc_p += op; inc_s += os; }
     }
-    const unsigned long long big_bal = __ballot(big);
-    const int wv = threadIdx.x >> 6;
-    if (lane == 63) { wv_pch[wv] = inc_p; wv_sch[wv] = inc_s; }
-    if (lane == 0) wv_big[wv] = __popcll(big_bal);
-    const unsigned long long small_bal = __ballot(small);
-    if (lane == 0) wv_small[wv] = __popcll(small_bal);
-    const unsigned long long tiny_bal = __ballot(tiny);
-    if (lane == 0) wv_tiny[wv] = __popcll(tiny_bal);
+    const int wv = tid >> 6;
+    const unsigned long long big_bal = __ballot(big), small_bal = __ballot(small), tiny_bal = __ballot(tiny);
     const unsigned long long own_bal = __ballot(owns && mode != 1);  // tasks that read a current row: private owners + node scorings
-    if (lane == 0) wv_own[wv] = __popcll(own_bal);
-    const unsigned long long gat_bal = __ballot(owns && mode != 0);
-    if (lane == 0) wv_gat[wv] = __popcll(gat_bal);
-    const unsigned long long node_bal = __ballot(owns && mode == 2);
-    if (lane == 0) wv_node[wv] = __popcll(node_bal);
+    const unsigned long long gat_bal = __ballot(owns && mode != 0), node_bal = __ballot(owns && mode == 2), alive_bal = __ballot(alive);
+    if (lane == 63) { wv_pch[wv] = inc_p; wv_sch[wv] = inc_s; }
+    if (lane == 0) {
+        wv_big[wv] = __popcll(big_bal); wv_small[wv] = __popcll(small_bal); wv_tiny[wv] = __popcll(tiny_bal);
+        wv_own[wv] = __popcll(own_bal); wv_gat[wv] = __popcll(gat_bal); wv_node[wv] = __popcll(node_bal); wv_alive[wv] = __popcll(alive_bal);
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const int tp = wv_pch[0] + wv_pch[1] + wv_pch[2] + wv_pch[3];
-        const int tsc = wv_sch[0] + wv_sch[1] + wv_sch[2] + wv_sch[3];
-        const int tb = wv_big[0] + wv_big[1] + wv_big[2] + wv_big[3];
-        blk_base[0] = (tp | tsc) ? atomicAdd(&a.lc[CTR_CHUNKS + a.level], (unsigned long long)tp | ((unsigned long long)tsc << 32)) : 0ull;
-        const int ts = wv_small[0] + wv_small[1] + wv_small[2] + wv_small[3];
-        blk_base[1] = (tb | ts) ? atomicAdd(&a.lc[CTR_BIG + a.level], (unsigned long long)tb | ((unsigned long long)ts << 32)) : 0ull;
-        const int tt = wv_tiny[0] + wv_tiny[1] + wv_tiny[2] + wv_tiny[3];
-        blk_base[2] = tt ? atomicAdd(&a.lc[CTR_TINY + a.level], (unsigned long long)tt) : 0ull;
-        const int to = wv_own[0] + wv_own[1] + wv_own[2] + wv_own[3];
-        if (to) atomicAdd(&a.lc[CTR_DISTS + (blockIdx.x & 63)], (unsigned long long)to);
-        const int tg = wv_gat[0] + wv_gat[1] + wv_gat[2] + wv_gat[3];
-        if (tg) atomicAdd(&a.lc[CTR_GATHER + (blockIdx.x & 63)], (unsigned long long)tg);
-        const int tn = wv_node[0] + wv_node[1] + wv_node[2] + wv_node[3];
-        if (tn) atomicAdd(&a.lc[CTR_NODES + (blockIdx.x & 63)], (unsigned long long)tn);
+    if (tid < 7) {
+        auto tot = [&](const int *v) { return (unsigned long long)(v[0] + v[1] + v[2] + v[3]); };
+        unsigned long long *word = nullptr;
+        unsigned long long val = 0;
+        if (tid == 0) { word = &a.lc[CTR_CHUNKS + a.level]; val = tot(wv_pch) | (tot(wv_sch) << 32); }
+        else if (tid == 1) { word = &a.lc[CTR_BIG + a.level]; val = tot(wv_big) | (tot(wv_small) << 32); }
+        else if (tid == 2) { word = &a.lc[CTR_TINY + a.level]; val = tot(wv_tiny); }
+        else if (tid == 3) { word = &a.lc[CTR_DISTS + (blockIdx.x & 63)]; val = tot(wv_own); }
+        else if (tid == 4) { word = &a.lc[CTR_GATHER + (blockIdx.x & 63)]; val = tot(wv_gat); }
+        else if (tid == 5) { word = &a.lc[CTR_NODES + (blockIdx.x & 63)]; val = tot(wv_node); }
+        else { word = &a.lc[CTR_ALIVE + a.level]; val = tot(wv_alive); }  // walks still alive at this hop
+        if (tid < 3) blk_base[tid] = val ? atomicAdd(word, val) : 0ull;
+        else if (val) atomicAdd(word, val);
     }
     __syncthreads();
     int pch_before = 0, sch_before = 0, big_before = 0, small_before = 0, tiny_before = 0, blk_pch = 0, blk_sch = 0;
@@ -595,31 +626,30 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     const int64_t base_p = (int64_t)(blk_base[0] & 0xffffffffull), base_s = (int64_t)(blk_base[0] >> 32);
     const int64_t coff_p_own = base_p + pch_before + inc_p - p_chunks;
     const int64_t coff_s = base_s + sch_before + inc_s - s_chunks;
-    blk_coff[threadIdx.x] = coff_p_own;
+    blk_coff[tid] = coff_p_own;
     __syncthreads();
     const int64_t coff_p = blk_coff[owner];  // non-owners sample from their owner's region
     const int64_t lbase = blk_lbase;
     const bool fits = base_s + blk_sch <= cap_chunks && lbase + base_p + blk_pch <= a.cap_total;
-    if (write_desc == 1 && !fits && threadIdx.x == 0) a.ctr[3] = 2ull;  // speculative capacity exceeded: the host reruns in sized mode
+    if (write_desc == 1 && !fits && tid == 0) a.ctr[3] = 2ull;  // speculative capacity exceeded: the host reruns in sized mode
     if (in_range) {
         a.lv_beg[w] = beg_abs;
         a.lv_k[w] = k | (hf << 31) | (mode != 0 ? LVK_GATHER : 0) | (mode == 2 ? LVK_NODE : 0);
         a.lv_chunks[w] = s_chunks;
         a.lv_coff[w] = coff_s;
         a.lv_pfx[w] = cached ? cached_off : lbase + coff_p;
-        if (mode != 0) a.lv_fe[w] = fe;
+        if (mode != 0) a.lv_fe[w] = hf ? fe : -1;
         if (owns && a.dc_mode == 1 && (fits || write_desc == 0)) {  // D launch: register the distribution for the G launch of the step (sized mode: the buffers are sized after this kernel)
             const unsigned long long key2 = dc_key(slot_w, rank_w, hf);
-            uint32_t h = (uint32_t)((key2 * 0x9E3779B97F4A7C15ull) >> 40) & a.dc_mask;
+            uint32_t h = dc_hash(key2, a.dc_mask);
             for (int tries = 0; tries < 64; ++tries) {
-                const unsigned long long old = atomicCAS(&a.dc_keys[h], ~0ull, key2);
-                if (old == ~0ull) { a.dc_vals[h] = ((unsigned long long)(lbase + coff_p) << 32) | (unsigned long long)(unsigned)k; break; }
+                const unsigned long long old = atomicCAS(&a.dc_tab[h].x, ~0ull, key2);
+                if (old == ~0ull) { a.dc_tab[h].y = ((unsigned long long)(lbase + coff_p) << 32) | (unsigned long long)(unsigned)k; break; }
                 if (old == key2) break;  // another workgroup registered the same distribution: one copy is enough
                 h = (h + 1) & a.dc_mask;
             }
         }
-        // the task lists of the weights kernel: big tasks from the front of the first half of lv_big, small ones from its back,
-        // tiny gather tasks in the second half
+        // the task lists of the weights kernel: big tasks from the front of lv_big, small ones from its back, tiny gather tasks in lv_tiny
         if (big) a.lv_big[(blk_base[1] & 0xffffffffull) + big_before + __popcll(big_bal & ((1ull << lane) - 1ull))] = (int32_t)w;
         if (small) a.lv_big[a.lv_big_cap - 1 - (int64_t)((blk_base[1] >> 32) + small_before + __popcll(small_bal & ((1ull << lane) - 1ull)))] = (int32_t)w;
         if (tiny) a.lv_tiny[(int64_t)blk_base[2] + tiny_before + __popcll(tiny_bal & ((1ull << lane) - 1ull))] = (int32_t)w;
@@ -629,15 +659,6 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
             else
                 for (int i = 0; i < s_chunks; ++i) write_chunk_desc(a.lv_chunk_desc, coff_s + i, cur, k, hf, father, beg_abs, i, lbase + coff_p);
         }
-    }
-    // walks still alive at this hop: one atomic per block
-    __shared__ int wv_alive[4];
-    const unsigned long long bal = __ballot(alive);
-    if (lane == 0) wv_alive[wv] = __popcll(bal);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int ta = wv_alive[0] + wv_alive[1] + wv_alive[2] + wv_alive[3];
-        if (ta) atomicAdd(&a.lc[CTR_ALIVE + a.level], (unsigned long long)ta);
     }
 }
 
@@ -684,7 +705,10 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const
     __syncthreads();
     const unsigned long long cw = a.lc[CTR_CHUNKS + a.level];
     const int64_t total_chunks = (int64_t)(cw >> 32);  // score chunks
-    if (total_chunks > cap_chunks || level_chunk_base(a) + (int64_t)(cw & 0xffffffffull) > a.cap_total) return;
+    const int64_t lbase_now = level_chunk_base(a);
+    // the next hop's prefix base (this hop's chunk counts are final: its advance kernel has finished)
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.lc[CTR_BASE + a.level + 1] = (unsigned long long)(lbase_now + (int64_t)(cw & 0xffffffffull));
+    if (total_chunks > cap_chunks || lbase_now + (int64_t)(cw & 0xffffffffull) > a.cap_total) return;
     const int t = threadIdx.x & 15;
     const int nblk = gridDim.x;
     // consecutive chunks (same task / same root) -> consecutive logical blocks -> one XCD's L2.  (Giving every XCD
@@ -1093,7 +1117,7 @@ __global__ void walk_d_postpass_kernel(const WalkArgs a) {
 // the region(s) it uses; a single-stream launch uses one region behind everything.
 __global__ void walk_reset_kernel(unsigned long long *ctr, int n_words, int64_t *dc_words, int append, int split, int64_t S) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_words) ctr[i] = 0ull;
+    if (i < n_words && i != CTR_BASE && i != CTR_WORDS + CTR_BASE) ctr[i] = 0ull;
     if (i == 0) {
         if (!append) dc_words[1] = dc_words[3] = 0;
         const int64_t e0 = dc_words[1], e1 = dc_words[3];
@@ -1103,6 +1127,8 @@ __global__ void walk_reset_kernel(unsigned long long *ctr, int n_words, int64_t 
         } else {
             dc_words[0] = append ? (e0 > e1 ? e0 : e1) : 0;
         }
+        ctr[CTR_BASE] = (unsigned long long)dc_words[0];                        // prefix base of hop 0 (first half)
+        ctr[CTR_WORDS + CTR_BASE] = (unsigned long long)(split ? dc_words[2] : 0);  // ... second half of a split launch
     }
 }
 
@@ -1151,9 +1177,7 @@ __global__ __launch_bounds__(256) void fill_ones_kernel(uint4 *p, int64_t n16) {
 // end of a D launch that registered its distributions: chunks now in the prefix buffer = where the G launch appends
 __global__ void dc_finish_kernel(const WalkArgs a, int64_t *words, int n_levels) {
     if (a.ctr[3] == 2ull) { words[1] = 0; return; }  // the launch is being rerun
-    int64_t b = words[0];
-    for (int l = 0; l < n_levels; ++l) b += (int64_t)(a.lc[CTR_CHUNKS + l] & 0xffffffffull);
-    words[1] = b;
+    words[1] = (int64_t)a.lc[CTR_BASE + n_levels];  // (written by the score kernel of hop n_levels - 1)
 }
 
 // Levels 0 .. n_levels-1 through the streaming kernels.  sized == true: one 16-byte read-back
@@ -1236,7 +1260,7 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
                 if (alive == 0) {  // every walk has finished
                     *any_alive = false;
                     ctx->w_levels_run = level + 1;
-                    if (a.dc_mode == 1) hipLaunchKernelGGL(dc_finish_kernel, dim3(1), dim3(1), 0, ctx->walk_stream, x, ctx->dc_words.as<int64_t>(), level + 1);
+                    if (a.dc_mode == 1) hipLaunchKernelGGL(dc_finish_kernel, dim3(1), dim3(1), 0, ctx->walk_stream, x, ctx->dc_words.as<int64_t>(), level);  // (hop `level` set nothing up)
                     return GG_OK;
                 }
                 if (level + 1 > ctx->lv_levels_learned) ctx->lv_levels_learned = level + 1;
@@ -1324,12 +1348,14 @@ static int run_levels_and_finish(gg_ctx *ctx, WalkArgs &a, int64_t total_walks) 
         GG_HIP(ctx, ctx->lv_coff.reserve(sizeof(int64_t) * (total_walks + 1)));
         GG_HIP(ctx, ctx->lv_pfx.reserve(sizeof(int64_t) * (total_walks + 1)));
         GG_HIP(ctx, ctx->st_item.reserve(sizeof(int4) * total_walks));
+        GG_HIP(ctx, ctx->st_item2.reserve(sizeof(int4) * total_walks));
         a.st_cur = ctx->st_cur.as<int32_t>();
         a.st_prev = ctx->st_prev.as<int32_t>();
         a.st_len = ctx->st_len.as<int32_t>();
         a.st_alive = ctx->st_alive.as<int32_t>();
         a.st_rank = ctx->st_rank.as<int32_t>();
         a.st_const = ctx->st_item.as<int4>();
+        a.st_const2 = ctx->st_item2.as<int4>();
         a.lv_beg = ctx->lv_beg.as<int64_t>();
         a.lv_k = ctx->lv_k.as<int32_t>();
         a.lv_chunks = ctx->lv_chunks.as<int32_t>();
@@ -1425,15 +1451,13 @@ int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int fo
         size_t want = 1u << 16;
         while (want < (size_t)total_walks * 8 && want < (1u << 24)) want <<= 1;  // distributions of a launch <= a few per walk
         if (want > ctx->dc_size) {
-            GG_HIP(ctx, ctx->dc_keys.reserve(sizeof(unsigned long long) * want));
-            GG_HIP(ctx, ctx->dc_vals.reserve(sizeof(unsigned long long) * want));
+            GG_HIP(ctx, ctx->dc_keys.reserve(sizeof(ulonglong2) * want));  // {key, value} entries
             ctx->dc_size = want;
         }
         // (hipMemsetAsync of these 16 MB took ~150 us on the walk stream; a plain store kernel takes a few)
-        hipLaunchKernelGGL(fill_ones_kernel, dim3(1024), dim3(256), 0, ctx->walk_stream, (uint4 *)ctx->dc_keys.p, (int64_t)(ctx->dc_size / 2));
+        hipLaunchKernelGGL(fill_ones_kernel, dim3(1024), dim3(256), 0, ctx->walk_stream, (uint4 *)ctx->dc_keys.p, (int64_t)ctx->dc_size);
     }
-    a.dc_keys = ctx->dc_keys.as<unsigned long long>();
-    a.dc_vals = ctx->dc_vals.as<unsigned long long>();
+    a.dc_tab = ctx->dc_keys.as<ulonglong2>();
     a.dc_mask = (uint32_t)(ctx->dc_size ? ctx->dc_size - 1 : 0);
     // One small kernel resets the launch's words: the base of its prefix regions (behind the D launch's regions when it
     // looks distributions up, else 0) and every counter word -- they belong to ONE launch (the host accumulates,
