@@ -809,69 +809,87 @@ __device__ __forceinline__ TaskScores task_scores(const WalkArgs &a, const int64
 }
 
 // Small owner tasks (k <= 16 * PER_LANE): one 16-lane group per walk -- max, exact fixed-point weights
-// (spec S2, S3) and their inclusive prefix sums, computed once per (root, node).  All of the task's
-// scores are fetched with independent loads up front (<= PER_LANE per lane; gather tasks: the edge indices first,
-// then the scores): the kernel used to be two dependent passes of k/16 load -> use steps each.
-template <int PER_LANE>
-__device__ __forceinline__ void weights_small_task(const WalkArgs &a, const int64_t w, const int t) {
-    const TaskScores ts = task_scores(a, w);
-    const int k = ts.k;
-    uint64_t *const pf = a.lv_prefix + a.lv_pfx[w] * CHUNK;  // (an owner's prefix region)
-    float v[PER_LANE];
-    if (ts.gather) {
-        int e[PER_LANE];
+// (spec S2, S3) and their inclusive prefix sums, computed once per (root, node).  The kernel is latency bound -- list entry
+// -> task words -> (edge indices ->) scores -> store, a few thousand groups resident -- so a group works on NT tasks AT ONCE:
+// every stage's loads of all NT tasks are in flight together (and all of a task's scores are fetched with independent loads,
+// <= PER_LANE per lane).
+template <int PER_LANE, int NT>
+__device__ __forceinline__ void weights_small_tasks(const WalkArgs &a, const int32_t *list, const int64_t i0, const int64_t n_tasks, const int64_t stride_sign,
+                                                    const int t) {
+    int64_t w[NT];
+    TaskScores ts[NT];
+    uint64_t *pf[NT];
 #pragma unroll
-        for (int i = 0; i < PER_LANE; ++i) {
-            const int jj = i * 16 + t;
-            e[i] = (jj < k) ? ((jj == 0 && ts.hf) ? ts.fe : ts.edges[jj]) : -1;
-        }
+    for (int u = 0; u < NT; ++u) w[u] = (i0 + u < n_tasks) ? (int64_t)list[stride_sign * (i0 + u)] : -1;
 #pragma unroll
-        for (int i = 0; i < PER_LANE; ++i) v[i] = (e[i] >= 0) ? a.es[e[i]] : -INFINITY;
-    } else {
-#pragma unroll
-        for (int i = 0; i < PER_LANE; ++i) {
-            const int jj = i * 16 + t;
-            v[i] = (jj < k) ? ts.sc[jj] : -INFINITY;
-        }
+    for (int u = 0; u < NT; ++u) {
+        const int64_t ww = w[u] >= 0 ? w[u] : 0;  // (a padding slot repeats walk 0's loads; nothing is stored for it)
+        ts[u] = task_scores(a, ww);
+        pf[u] = a.lv_prefix + a.lv_pfx[ww] * CHUNK;
+        if (w[u] < 0) ts[u].k = 0;
     }
-    float mx = v[0];
+    float v[NT][PER_LANE];
+    int e[NT][PER_LANE];
 #pragma unroll
-    for (int i = 1; i < PER_LANE; ++i) mx = fmaxf(mx, v[i]);
+    for (int u = 0; u < NT; ++u)
 #pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 16));
-    uint64_t carry = 0;
-#pragma unroll
-    for (int i = 0; i < PER_LANE; ++i) {
-        if (i * 16 < k) {  // uniform inside the 16-lane group
+        for (int i = 0; i < PER_LANE; ++i) {
             const int jj = i * 16 + t;
-            const uint64_t wgt = (jj < k) ? weight_fix40(exp_spec(v[i] - mx)) : 0ull;
-            const uint64_t C = carry + group16_incl_scan_u64(wgt, t);
-            if (jj < k) pf[jj] = C;
-            carry = __shfl(C, 15, 16);
+            e[u][i] = (ts[u].gather && jj < ts[u].k) ? ((jj == 0 && ts[u].hf) ? ts[u].fe : ts[u].edges[jj]) : -1;
+        }
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int i = 0; i < PER_LANE; ++i) {
+            const int jj = i * 16 + t;
+            v[u][i] = ts[u].gather ? (e[u][i] >= 0 ? a.es[e[u][i]] : -INFINITY) : (jj < ts[u].k ? ts[u].sc[jj] : -INFINITY);
+        }
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int k = ts[u].k;
+        if (k == 0) continue;
+        float mx = v[u][0];
+#pragma unroll
+        for (int i = 1; i < PER_LANE; ++i) mx = fmaxf(mx, v[u][i]);
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 16));
+        uint64_t carry = 0;
+#pragma unroll
+        for (int i = 0; i < PER_LANE; ++i) {
+            if (i * 16 < k) {  // uniform inside the 16-lane group
+                const int jj = i * 16 + t;
+                const uint64_t wgt = (jj < k) ? weight_fix40(exp_spec(v[u][i] - mx)) : 0ull;
+                const uint64_t C = carry + group16_incl_scan_u64(wgt, t);
+                if (jj < k) pf[u][jj] = C;
+                if (PER_LANE > 1) carry = __shfl(C, 15, 16);
+            }
         }
     }
 }
 
-constexpr int SMALL_BLOCKS = 2048;  // workgroups of the weights launch that serve the small-task list (16 tasks each per round)
+constexpr int SMALL_BLOCKS = 2048;  // workgroups of the weights launch that serve the small-task list
 constexpr int TINY_BLOCKS = 2048;   // ... and the tiny-task list (gather tasks with <= 16 candidates)
+constexpr int SMALL_NT = 1, TINY_NT = 4;  // tasks a 16-lane group has in flight
 __device__ __forceinline__ void weights_small_blocks(const WalkArgs &a, const int block) {
     const int t = threadIdx.x & 15;
     const int64_t n_small = (int64_t)(a.lc[CTR_BIG + a.level] >> 32);
-    for (int64_t i = (int64_t)block * 16 + (threadIdx.x >> 4); i < n_small; i += (int64_t)SMALL_BLOCKS * 16)
-        weights_small_task<BIG_TASK / 16>(a, a.lv_big[a.lv_big_cap - 1 - i], t);
+    for (int64_t i = ((int64_t)block * 16 + (threadIdx.x >> 4)) * SMALL_NT; i < n_small; i += (int64_t)SMALL_BLOCKS * 16 * SMALL_NT)
+        weights_small_tasks<BIG_TASK / 16, SMALL_NT>(a, a.lv_big + a.lv_big_cap - 1, i, n_small, -1, t);  // (the small list grows down from the end of lv_big)
 }
 __device__ __forceinline__ void weights_tiny_blocks(const WalkArgs &a, const int block) {
     const int t = threadIdx.x & 15;
     const int64_t n_tiny = (int64_t)a.lc[CTR_TINY + a.level];
-    for (int64_t i = (int64_t)block * 16 + (threadIdx.x >> 4); i < n_tiny; i += (int64_t)TINY_BLOCKS * 16)
-        weights_small_task<1>(a, a.lv_tiny[i], t);
+    for (int64_t i = ((int64_t)block * 16 + (threadIdx.x >> 4)) * TINY_NT; i < n_tiny; i += (int64_t)TINY_BLOCKS * 16 * TINY_NT)
+        weights_small_tasks<1, TINY_NT>(a, a.lv_tiny, i, n_tiny, 1, t);
 }
 
-// Big owner tasks (hubs): one 256-thread workgroup per task, from the level's big-task list.  Tasks of up to
-// BIG_REG candidates keep their scores in registers between the max and the scan pass (one round of
-// independent loads); larger ones re-read them.  (Measured and not kept: one WAVEFRONT per task of up to 1 024 candidates --
-// no barriers, four tasks per workgroup in flight -- the kernel's 18-20 us per level did not move.)
-constexpr int BIG_REG = 4096;
+// Big owner tasks (hubs): one 256-thread workgroup per task, from the level's big-task list, in tiles of BIG_TILE candidates.
+// A thread owns BIG_PT CONSECUTIVE candidates of the tile: the max and the scan need one block-wide combination each (two
+// barrier pairs per tile; lane-strided rows of 256 cost a barrier pair per row, sixteen per tile), the thread's own prefix
+// is a register loop, and it stores 64 contiguous bytes.  A task of up to one tile keeps its scores in registers between
+// the max and the scan pass; larger ones read them twice.
+constexpr int BIG_PT = 8;
+constexpr int BIG_TILE = 256 * BIG_PT;
 constexpr int BIG_BLOCKS = 2048;  // workgroups of the weights launch that serve the big-task list
 __device__ __forceinline__ void weights_big_blocks(const WalkArgs &a) {
     __shared__ float red[4];
@@ -882,25 +900,26 @@ __device__ __forceinline__ void weights_big_blocks(const WalkArgs &a) {
         const int64_t w = a.lv_big[b];
         const TaskScores ts = task_scores(a, w);
         const int k = ts.k;
-        auto score_at = [&](int jj) -> float {  // jj < k
-            if (!ts.gather) return ts.sc[jj];
-            return a.es[(jj == 0 && ts.hf) ? ts.fe : ts.edges[jj]];
-        };
         uint64_t *const pf = a.lv_prefix + a.lv_pfx[w] * CHUNK;
-        constexpr int PER_THREAD = BIG_REG / 256;
-        const bool in_regs = k <= BIG_REG;  // uniform in the workgroup
-        float v[PER_THREAD];
-        float mx = -INFINITY;
-        if (in_regs) {
+        auto load_tile = [&](int j0, float (&v)[BIG_PT]) {  // candidates j0 + 16 * thread + [0, 16)
+            const int jb = j0 + BIG_PT * (int)threadIdx.x;
+            if (ts.gather) {
+                int e[BIG_PT];
 #pragma unroll
-            for (int i = 0; i < PER_THREAD; ++i) {
-                const int jj = i * 256 + threadIdx.x;
-                v[i] = (jj < k) ? score_at(jj) : -INFINITY;
+                for (int i = 0; i < BIG_PT; ++i) e[i] = (jb + i < k) ? ((jb + i == 0 && ts.hf) ? ts.fe : ts.edges[jb + i]) : -1;
+#pragma unroll
+                for (int i = 0; i < BIG_PT; ++i) v[i] = e[i] >= 0 ? a.es[e[i]] : -INFINITY;
+            } else {
+#pragma unroll
+                for (int i = 0; i < BIG_PT; ++i) v[i] = (jb + i < k) ? ts.sc[jb + i] : -INFINITY;
             }
+        };
+        float v[BIG_PT];
+        float mx = -INFINITY;
+        for (int j0 = 0; j0 < k; j0 += BIG_TILE) {
+            load_tile(j0, v);
 #pragma unroll
-            for (int i = 0; i < PER_THREAD; ++i) mx = fmaxf(mx, v[i]);
-        } else {
-            for (int jj = threadIdx.x; jj < k; jj += 256) mx = fmaxf(mx, score_at(jj));
+            for (int i = 0; i < BIG_PT; ++i) mx = fmaxf(mx, v[i]);
         }
         mx = wave_max_f32(mx);
         __syncthreads();
@@ -908,28 +927,29 @@ __device__ __forceinline__ void weights_big_blocks(const WalkArgs &a) {
         __syncthreads();
         mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
         uint64_t carry = 0;
-        auto scan_block = [&](int j0, float x) {
-            const int jj = j0 + threadIdx.x;
-            const uint64_t wgt = (jj < k) ? weight_fix40(exp_spec(x - mx)) : 0ull;
-            const uint64_t inc = wave_incl_scan_u64(wgt, lane);
+        for (int j0 = 0; j0 < k; j0 += BIG_TILE) {
+            if (k > BIG_TILE) load_tile(j0, v);  // (a single tile is still in registers)
+            const int jb = j0 + BIG_PT * (int)threadIdx.x;
+            uint64_t c[BIG_PT], run = 0;
+#pragma unroll
+            for (int i = 0; i < BIG_PT; ++i) {
+                run += (jb + i < k) ? weight_fix40(exp_spec(v[i] - mx)) : 0ull;
+                c[i] = run;
+            }
+            const uint64_t inc = wave_incl_scan_u64(run, lane);
             __syncthreads();
             if (lane == 63) wave_tot[wv] = inc;
             __syncthreads();
-            uint64_t pre = carry, tot = 0;
+            uint64_t pre = carry + inc - run, tot = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (i < wv) pre += wave_tot[i];
                 tot += wave_tot[i];
             }
-            if (jj < k) pf[jj] = pre + inc;
-            carry += tot;
-        };
-        if (in_regs) {
 #pragma unroll
-            for (int i = 0; i < PER_THREAD; ++i)
-                if (i * 256 < k) scan_block(i * 256, v[i]);
-        } else {
-            for (int j0 = 0; j0 < k; j0 += 256) scan_block(j0, (j0 + threadIdx.x < k) ? score_at(j0 + threadIdx.x) : 0.f);
+            for (int i = 0; i < BIG_PT; ++i)
+                if (jb + i < k) pf[jb + i] = pre + c[i];
+            carry += tot;
         }
     }
 }
