@@ -57,7 +57,7 @@ struct BfsArgs {
     uint32_t *gbitmap;       // [grid][bm_words]  (graphs too large for the LDS bitmap)
     uint32_t *gkey;          // [grid][n_node]    all-ones between uses (duplicate-list overflow path)
     int bm_words;
-    int exp;                   // GG_BFS_EXPERIMENT: timing ablations (results are then WRONG): 1 = no cstart stores, 2 = synthetic targets instead of adjacency loads, 4 = no queue stores beyond level 1
+    int exp;                   // GG_BFS_EXPERIMENT: timing ablations (results are then WRONG): 1 = no cstart stores, 2 = synthetic targets instead of adjacency loads, 4 = no queue stores beyond level 1, 8 = no early exit when the component is complete (results stay right)
     unsigned long long *prof;  // GG_BFS_PROFILE: [16] shader-clock cycles of wave 0 per phase + event counts (NULL: off)
 };
 
@@ -368,6 +368,16 @@ __global__ __launch_bounds__(BFS_T) void bfs_order_kernel(const BfsArgs a) {
             if (tail > expect) break;
             head += nb;
             __syncthreads();
+            // Every node of the root's component is on the queue (its size is known from the component sweep): no edge of
+            // the nodes still waiting can discover anything.  On a small-world graph that is the bulk of the stream -- the
+            // last two levels hold most nodes and found nothing in half of all chunks -- so their adjacency is not read at
+            // all: they are leaves of the tree (their child ranges are empty, at the end of the queue).
+            if (tail == expect && head < tail && !(INSTR && (a.exp & 8))) {
+                for (int i = head + tid; i < expect; i += BFS_T) cstart[i + 1] = expect;
+                if (level_end < tail) ++depth;  // the nodes behind level_end are one level deeper than the one being popped
+                __syncthreads();                // (the child-count sweep below reads these entries)
+                break;
+            }
         }
         if (INSTR && a.prof && tid == 0)
             for (int k = 0; k < 12; ++k) atomicAdd(&a.prof[k], pc[k]);
@@ -478,10 +488,10 @@ extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t 
     cleanup();
     if (e != hipSuccess) return fail(ctx, GG_EHIP, "gg_build_trees_device: %s", hipGetErrorString(e));
     if (a.exp) fprintf(stderr, "[bfs experiment %d] kernel %.1f ms for %d roots (results invalid)\n", a.exp, ms, n_roots);
-    GG_CHECK(ctx, stats[2] == 0 || a.exp, GG_EINVAL, "gg_build_trees_device: a BFS reached a different number of nodes than the component sweep of the graph");
+    GG_CHECK(ctx, stats[2] == 0 || (a.exp & ~8), GG_EINVAL, "gg_build_trees_device: a BFS reached a different number of nodes than the component sweep of the graph");
     ctx->tree_max_depth = stats[0];
     ctx->tree_max_list = stats[1];
-    ctx->t_edge_valid = a.exp == 0;
+    ctx->t_edge_valid = (a.exp & ~8) == 0;
     ctx->ctr.bfs_kernel_ms += ms;
     ctx->ctr.bfs_trees += n_roots;
     return GG_OK;

@@ -175,6 +175,122 @@ __global__ __launch_bounds__(256) void pair_grad_kernel(const StepArgs a) {
     flush_u(p1 - 1);
 }
 
+// The same step for LARGE fused batches (ppg = 16: a group owns 16 consecutive pairs), rebuilt around the memory latency that
+// bounded the loop above (SQ_WAIT 90 %: per pair a chain ids -> rows -> dot -> sigmoid -> stores, sixteen times in a row):
+// the group's 16 (u, v, x) triples and stage slots arrive with ONE coalesced load each and live in its lanes (shuffles, no
+// loads and no branches between a row prefetch and its use), and the rows of pair j + 2 are in flight -- raw, from clamped
+// addresses -- while pair j is evaluated.  Arithmetic and accumulation order per row are those of pair_grad_kernel (the
+// staged sums are order-free anyway; the atomic path adds the same values).
+template <int NF, bool STAGED>
+__global__ __launch_bounds__(256) void pair_grad16_kernel(const StepArgs a) {
+    const int t = threadIdx.x & 15;
+    const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int64_t p0 = g * 16;
+    if (p0 >= a.n) return;
+    const int np = (int)min((int64_t)16, (int64_t)a.n - p0);
+    const float inv_n = a.n_glob ? 1.0f / (float)(*a.n_glob) : a.inv_n;
+    const bool mine = t < np;
+    const int myu = mine ? a.u[p0 + t] : 0, myv = mine ? a.v[p0 + t] : 0;
+    const float myx = mine ? a.x[p0 + t] : 0.f;
+    const int my_sv = (STAGED && mine) ? a.slot_v[p0 + t] : -1;
+    const int my_su = (STAGED && mine) ? a.slot_u[p0 + t] : -1;
+    const float mybv = a.b[myv];
+    // end of a run of equal centres (the u-side gradient of the run is flushed there): as pair_occ_count_kernel defines it
+    const int nextu = __shfl(myu, (t + 1) & 15, 16);
+    const bool my_end = mine && (t == np - 1 || nextu != myu);
+    auto fetch = [&](int j, float (&ru)[NF], float (&rv)[NF]) {  // rows of pair j (clamped: pairs behind the group's end re-read pair 0)
+        const int jj = j < np ? j : 0;
+        const float *su = a.E + (int64_t)__shfl(myu, jj, 16) * a.ld, *sv = a.E + (int64_t)__shfl(myv, jj, 16) * a.ld;
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int f = t + 16 * i;
+            const int fc = f < a.ld ? f : a.ld - 1;
+            ru[i] = su[fc];
+            rv[i] = sv[fc];
+        }
+    };
+    float U[3][NF], V[3][NF], accu[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) accu[i] = 0.f;
+    fetch(0, U[0], V[0]);
+    fetch(1, U[1], V[1]);
+#pragma unroll 1
+    for (int j0 = 0; j0 < np; j0 += 3) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {  // buffer r holds pair j0 + r; the fetch of pair j + 2 goes to buffer (r + 2) % 3
+            const int j = j0 + r;
+            if (j >= np) break;
+            fetch(j + 2, U[(r + 2) % 3], V[(r + 2) % 3]);
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const bool in = t + 16 * i < a.ld;
+                const float x = in ? U[r][i] : 0.f, y = in ? V[r][i] : 0.f;
+                U[r][i] = x; V[r][i] = y;
+                acc = __builtin_fmaf(x, y, acc);
+            }
+            acc += __shfl_xor(acc, 8, 64);
+            acc += __shfl_xor(acc, 4, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            acc += __shfl_xor(acc, 1, 64);
+            const float bv = __shfl(mybv, j, 16), xj = __shfl(myx, j, 16);
+            const float s = acc + bv;
+            const float sg = 1.0f / (1.0f + expf(-s));
+            float ds;
+            if (a.is_d) {
+                ds = sg - xj;
+            } else {
+                const bool inside = (sg >= 1e-5f) && (sg <= 1.0f);
+                ds = inside ? -(xj * inv_n) * (1.0f - sg) : 0.0f;
+            }
+            const int iv = __shfl(myv, j, 16), iu = __shfl(myu, j, 16);
+            const int slv = __shfl(my_sv, j, 16), slu = __shfl(my_su, j, 16);
+            const bool st = STAGED && slv >= 0;
+            float *gv = st ? a.stage + (int64_t)slv * a.ld : a.gE + (int64_t)iv * a.ld;
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const int f = t + 16 * i;
+                if (f < a.ld) {
+                    accu[i] += ds * V[r][i] + a.lambda * U[r][i];
+                    const float gval = ds * U[r][i] + a.lambda * V[r][i];
+                    if (st) gv[f] = gval;
+                    else atomicAdd(gv + f, gval);
+                }
+            }
+            if (t == 0) {
+                const float gbv = a.is_d ? ds + a.lambda * bv : ds;
+                if (st) {
+                    a.stage_b[slv] = gbv;
+                } else {
+                    atomicAdd(a.gb + iv, gbv);
+                    if (a.track) a.touched[iv] = 1;
+                }
+            }
+            if (__shfl((int)my_end, j, 16)) {  // the run of equal centres ends at this pair
+                if (STAGED && slu >= 0) {
+                    float *gu = a.stage + (int64_t)slu * a.ld;
+#pragma unroll
+                    for (int i = 0; i < NF; ++i) {
+                        const int f = t + 16 * i;
+                        if (f < a.ld) gu[f] = accu[i];
+                    }
+                    if (t == 0) a.stage_b[slu] = 0.f;
+                } else {
+                    float *gu = a.gE + (int64_t)iu * a.ld;
+#pragma unroll
+                    for (int i = 0; i < NF; ++i) {
+                        const int f = t + 16 * i;
+                        if (f < a.ld) atomicAdd(gu + f, accu[i]);
+                    }
+                    if (t == 0 && a.track) a.touched[iu] = 1;
+                }
+#pragma unroll
+                for (int i = 0; i < NF; ++i) accu[i] = 0.f;
+            }
+        }
+    }
+}
+
 // Deterministic variant for the reference's small batches (n <= DET_MAX_PAIRS; GG_DETERMINISTIC=1):
 // ONE workgroup, no atomics.  Pair coefficients go to LDS; every distinct row of the batch is
 // owned by the first slot that names it (slots = [u_0..u_{n-1}, v_0..v_{n-1}]) and its owner sums
@@ -980,14 +1096,18 @@ int run_step(gg_ctx *ctx, int which, const int32_t *d_u, const int32_t *d_v, con
                            ctx->sg_key.as<int32_t>());
         s.slot_v = slot_v; s.slot_u = slot_u;
         s.stage = ctx->sg_rows.as<float>(); s.stage_b = ctx->sg_bias.as<float>();
-        if (nf <= 4) hipLaunchKernelGGL((pair_grad_kernel<4, true>), dim3(blocks), dim3(256), 0, ctx->stream, s);
-        else if (nf <= 8) hipLaunchKernelGGL((pair_grad_kernel<8, true>), dim3(blocks), dim3(256), 0, ctx->stream, s);
-        else if (nf <= 16) hipLaunchKernelGGL((pair_grad_kernel<16, true>), dim3(blocks), dim3(256), 0, ctx->stream, s);
-        else hipLaunchKernelGGL((pair_grad_kernel<32, true>), dim3(blocks), dim3(256), 0, ctx->stream, s);
+        // (staged implies ppg = 16 and ld <= 256)
+        if (nf <= 4) hipLaunchKernelGGL((pair_grad16_kernel<4, true>), dim3(blocks), dim3(256), 0, ctx->stream, s);
+        else if (nf <= 8) hipLaunchKernelGGL((pair_grad16_kernel<8, true>), dim3(blocks), dim3(256), 0, ctx->stream, s);
+        else hipLaunchKernelGGL((pair_grad16_kernel<16, true>), dim3(blocks), dim3(256), 0, ctx->stream, s);
         if (ctx->tm_cur >= 0) GG_HIP(ctx, hipEventRecord(ctx->tm_ev[ctx->tm_cur][1], ctx->stream));  // gradient | optimizer
         return staged_finish(ctx, which, n, 2 * (int64_t)n);
     }
-    if (nf <= 4) hipLaunchKernelGGL((pair_grad_kernel<4, false>), dim3(blocks), dim3(256), 0, ctx->stream, s);
+    if (s.ppg == PAIRS_PER_GROUP && nf <= 16 && !getenv("GG_OLD_PAIR_GRAD")) {  // large fused batch on the atomic path (replicas, dense Adam, wide rows excluded)
+        if (nf <= 4) hipLaunchKernelGGL((pair_grad16_kernel<4, false>), dim3(blocks), dim3(256), 0, ctx->stream, s);
+        else if (nf <= 8) hipLaunchKernelGGL((pair_grad16_kernel<8, false>), dim3(blocks), dim3(256), 0, ctx->stream, s);
+        else hipLaunchKernelGGL((pair_grad16_kernel<16, false>), dim3(blocks), dim3(256), 0, ctx->stream, s);
+    } else if (nf <= 4) hipLaunchKernelGGL((pair_grad_kernel<4, false>), dim3(blocks), dim3(256), 0, ctx->stream, s);
     else if (nf <= 8) hipLaunchKernelGGL((pair_grad_kernel<8, false>), dim3(blocks), dim3(256), 0, ctx->stream, s);
     else if (nf <= 16) hipLaunchKernelGGL((pair_grad_kernel<16, false>), dim3(blocks), dim3(256), 0, ctx->stream, s);
     else hipLaunchKernelGGL((pair_grad_kernel<32, false>), dim3(blocks), dim3(256), 0, ctx->stream, s);

@@ -102,6 +102,7 @@ struct WalkArgs {
     int32_t es_ratio, es_hub;
     int32_t *lv_fe;          // [total_walks] es index of the father candidate's score (gather tasks with a father entry)
     int32_t *lv_tiny;        // [walks of this half] third task list of the weights kernel: gather tasks with <= 16 candidates
+    int32_t exp;             // GG_WALK_EXPERIMENT: timing ablations (results are then WRONG): 1 / 2 / 4 = the weights kernel skips its big / small / tiny tasks
 };
 
 __device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, int lane) {
@@ -961,9 +962,9 @@ __global__ __launch_bounds__(256) void level_weights_kernel(const WalkArgs a, co
     const unsigned long long cw = a.lc[CTR_CHUNKS + a.level];
     const int64_t pch = (int64_t)(cw & 0xffffffffull), sch = (int64_t)(cw >> 32);
     if (sch > cap_chunks || pch == 0 || level_chunk_base(a) + pch > a.cap_total) return;
-    if (blockIdx.x < BIG_BLOCKS) weights_big_blocks(a);
-    else if (blockIdx.x < BIG_BLOCKS + SMALL_BLOCKS) weights_small_blocks(a, (int)blockIdx.x - BIG_BLOCKS);
-    else weights_tiny_blocks(a, (int)blockIdx.x - BIG_BLOCKS - SMALL_BLOCKS);
+    if (blockIdx.x < BIG_BLOCKS) { if (!(a.exp & 1)) weights_big_blocks(a); }
+    else if (blockIdx.x < BIG_BLOCKS + SMALL_BLOCKS) { if (!(a.exp & 2)) weights_small_blocks(a, (int)blockIdx.x - BIG_BLOCKS); }
+    else if (!(a.exp & 4)) weights_tiny_blocks(a, (int)blockIdx.x - BIG_BLOCKS - SMALL_BLOCKS);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1458,6 +1459,10 @@ int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int fo
     a.es_ratio = ctx->es_ratio_num;
     a.es_hub = ctx->es_hub;
     a.es_mode = 0;  // set below
+    {
+        static const int exp_env = getenv("GG_WALK_EXPERIMENT") ? atoi(getenv("GG_WALK_EXPERIMENT")) : 0;
+        a.exp = exp_env;
+    }
     a.w0 = 0;
     a.w_end = total_walks;
     a.lv_big_cap = total_walks;

@@ -13,8 +13,12 @@
  *     (ctx == NULL: the last gg_create / host-only failure of the calling thread).
  *   - the caller owns every host buffer it passes (C-contiguous; int32 node ids - the
  *     reference's placeholders are tf.int32, generator.py:17-18; fp32 values; int64
- *     offsets).  Inputs are copied; outputs are written before the call returns (every
- *     call is synchronous: it returns after the context's HIP stream is idle).
+ *     offsets).  Inputs are copied; outputs are written before the call returns.  By default
+ *     every call is synchronous (it returns after the context's HIP stream is idle).  The one
+ *     exception is opt-in: after gg_set_profiling(ctx, k) with k != 1, gg_d_pass / gg_g_pass
+ *     return once their kernels are ENQUEUED (stream-ordered behind everything issued before;
+ *     they have no host outputs) -- errors of such a pass surface at the next call that
+ *     synchronises (gg_prepare_*, gg_get_*, gg_synchronize).
  *   - a gg_ctx owns all device memory (embedding tables, Adam slots, graph CSR, tree CSR,
  *     prepared sample buffers, scratch) and one HIP stream on one device; it is not
  *     re-entrant.  Multi-GPU = one process and one context per GPU (gg_comm_*).
