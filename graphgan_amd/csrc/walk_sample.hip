@@ -101,8 +101,7 @@ struct WalkArgs {
     int32_t es_mode;         // 0 = off, 1 = a stale node is scored whole when the asking distribution needs most of it, 2 = always
     int32_t es_ratio, es_hub;
     int32_t *lv_fe;          // [total_walks] es index of the father candidate's score (gather tasks with a father entry)
-    int32_t *lv_tiny;        // [walks of this half] third task list of the weights kernel: gather tasks with <= 16 candidates
-    int32_t exp;             // GG_WALK_EXPERIMENT: timing ablations (results are then WRONG): 1 / 2 / 4 = the weights kernel skips its big / small / tiny tasks
+    int32_t exp;             // GG_WALK_EXPERIMENT: timing ablations (results are then WRONG): 1 / 2 = the weights kernel skips its big / small tasks
 };
 
 __device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, int lane) {
@@ -250,7 +249,7 @@ constexpr int CTR_ROWS = 200;   // ctr[CTR_ROWS + (block & 63)]: candidate rows 
 constexpr int CTR_HOPS_V = 264;  // ctr[CTR_HOPS_V + (block & 63)]: hop counts of the level pipeline, spread over 64 words
 constexpr int CTR_READS_V = 328; // (same-address atomics serialise at ~12 ns each); summed by the host
 constexpr int CTR_DISTS = 392;   // ctr[CTR_DISTS + (block & 63)]: (root, node) distributions set up by the level pipeline (owners), spread words
-constexpr int CTR_TINY = 456;    // ctr[CTR_TINY + level]: gather tasks with <= 16 candidates (third task list of the weights kernel)
+constexpr int CTR_TINY = 456;    // (64 spare words)
 constexpr int CTR_GATHER = 520;  // ctr[CTR_GATHER + (block & 63)]: owner distributions that gather their scores from the edge-score cache, spread words
 constexpr int CTR_NODES = 584;   // ctr[CTR_NODES + (block & 63)]: nodes whose adjacency this launch scored into the cache, spread words
 constexpr int CTR_BASE = 648;    // ctr[CTR_BASE + level]: global chunk offset of the first PREFIX chunk of hop `level` (launch base + the prefix chunks
@@ -260,7 +259,8 @@ static_assert(CTR_WORDS == gg_ctx::CTR_WORDS, "counter layout");
 constexpr int MAX_LEVELS = 64;
 constexpr int LVK_GATHER = 1 << 30;  // lv_k flag: the distribution's scores come from the edge-score cache
 constexpr int LVK_NODE = 1 << 29;    // lv_k flag: ... and this owner scores the node's adjacency (its score chunks are node chunks)
-constexpr int LVK_MASK = (1 << 29) - 1;
+constexpr int LVK_SELF = 1 << 28;    // lv_k flag: <= 16 candidates on a scored node: the WALK gathers the scores itself when it samples (no owner, no task, no prefix sums)
+constexpr int LVK_MASK = (1 << 28) - 1;
 
 // Global chunk offset of the first prefix chunk of hop a.level (one word; it used to be a loop over the earlier levels'
 // counters -- up to `level` dependent reads at the head of every level kernel).
@@ -314,12 +314,13 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     __shared__ long long hk[512];   // dedup hash: key (item, cur) -> ...
     __shared__ int ho[512];         // ... smallest thread index that holds it
     __shared__ long long blk_coff[256];
+    __shared__ unsigned char blk_self[256];
     const int tid = (int)threadIdx.x;
     const int64_t w = a.w0 + (int64_t)blockIdx.x * blockDim.x + tid;
     const int lane = tid & 63;
     const bool in_range = w < a.w_end;
     // ---- loads that need nothing but the walk index (issued before the block learns whether it runs at all)
-    int alive_w = 1, kraw = 0, len = 0, cur0 = -1, prev0 = -1;
+    int alive_w = 1, kraw = 0, len = 0, cur0 = -1, prev0 = -1, fe0 = -1;
     int4 sc = make_int4(0, 0, 0, 0), sc2 = make_int4(0, 0, 0, 0);
     int64_t pfx0 = 0, beg0 = 0;
     if (in_range && do_sample) {
@@ -332,6 +333,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         len = a.st_len[w];
         cur0 = a.st_cur[w];
         prev0 = a.st_prev[w];
+        if (a.es_mode) fe0 = a.lv_fe[w];
     }
     // Block-uniform early exit: other blocks of this very launch may raise flag 2 (speculative overflow below, a walk
     // still alive after the last level), so every thread testing the global word itself could split a workgroup in
@@ -387,11 +389,40 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
             sampled = true;
             const int kk = kraw & LVK_MASK, hf0 = (int)((unsigned)kraw >> 31);
             my_k = (unsigned long long)kk;
+            int lo = 0;
+            if (kraw & LVK_SELF) {
+                // <= 16 candidates on a node whose adjacency is in the edge-score cache: gather the scores through the tree's
+                // edge indices and evaluate the distribution right here -- max, exact fixed-point weights, running sum, first
+                // j whose sum exceeds the threshold (spec S2-S5: the same integers as a search in stored prefix sums)
+                const int32_t *const edges = a.t_edge + beg0 - hf0;
+                int e[CHUNK];
+                float v[CHUNK];
+#pragma unroll
+                for (int i = 0; i < CHUNK; ++i) e[i] = (i < kk) ? ((i == 0 && hf0) ? fe0 : edges[i]) : -1;
+#pragma unroll
+                for (int i = 0; i < CHUNK; ++i) v[i] = (e[i] >= 0) ? a.es[e[i]] : -INFINITY;
+                float mx = v[0];
+#pragma unroll
+                for (int i = 1; i < CHUNK; ++i) mx = fmaxf(mx, v[i]);
+                uint64_t Wtot = 0;
+#pragma unroll
+                for (int i = 0; i < CHUNK; ++i) Wtot += (i < kk) ? weight_fix40(exp_spec(v[i] - mx)) : 0ull;
+                if (Wtot == 0ull) a.ctr[CTR_NONFINITE] = 1ull;
+                const uint64_t thr = threshold(uniform53(a.seed, a.stream, (uint32_t)root, (uint32_t)j, (uint32_t)(a.level - 1)), Wtot);
+                uint64_t C = 0;
+                int cnt = 0;  // candidates whose inclusive sum is <= thr: the pick is the first one above
+#pragma unroll
+                for (int i = 0; i < CHUNK; ++i) {
+                    C += (i < kk) ? weight_fix40(exp_spec(v[i] - mx)) : 0ull;
+                    cnt += (i < kk && C <= thr) ? 1 : 0;
+                }
+                lo = min(cnt, kk - 1);
+            } else {
             const uint64_t *const pf = a.lv_prefix + pfx0 * CHUNK;
             // first j with C_j > thr by a 16-ary search: 15 independent pivot loads per round, ceil(log16 k)
             // dependent rounds instead of log2 k (a hub hop was a chain of 12+ dependent random reads); the
             // first round's pivots do not depend on the threshold and fly together with W = C_{k-1}
-            int lo = 0, n = kk;  // invariant: the answer lies in [lo, lo + n) and C_{lo+n-1} > thr
+            int n = kk;  // invariant: the answer lies in [lo, lo + n) and C_{lo+n-1} > thr
             int step = (n + 15) >> 4;
             uint64_t piv[15];
 #pragma unroll
@@ -419,6 +450,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
                 for (int i = 0; i < 15; ++i) seg += (piv[i] <= thr) ? 1 : 0;
                 lo += seg * step;
                 n = min(step, n - seg * step);
+            }
             }
             // Candidate 0 of a list with a father entry IS the previous node (walks only move down the tree until
             // their back-step), so the terminating condition (:264-266) needs no load: the walk ends iff it picked
@@ -521,11 +553,14 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         }
         return;
     }
+    // <= 16 candidates on a node whose adjacency is (or is being) scored into the edge-score cache: the walk evaluates its
+    // distribution itself when it samples (LVK_SELF) -- no owner, no chunks, no prefix sums, nothing for the weights kernel
+    const bool self_early = alive && a.es_mode && k <= CHUNK && st >= a.es_valid_from && st <= a.es_now;
     // G launch: was this very distribution evaluated by the D launch of the step?  (Same slot, same node, same
     // father flag => same candidate list; same generator tables => same prefix sums, bit for bit.)
     bool cached = false;
     int64_t cached_off = 0;
-    if (alive && a.dc_mode == 2) {
+    if (alive && a.dc_mode == 2 && !self_early) {
         const unsigned long long key = dc_key(slot_w, rank_w, hf);
         uint32_t h = dc_hash(key, a.dc_mask);
         for (int tries = 0; tries < 64; ++tries) {
@@ -540,7 +575,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     }
     // dedup inside the workgroup (256 consecutive walks): the walk with the smallest index among those with the same
     // (item, cur) owns the distribution -- an LDS hash (insert with compare-and-swap, owner with atomic-min).
-    const long long key = (alive && !cached) ? (((long long)item << 32) | (unsigned)cur) : -1ll;
+    const long long key = (alive && !cached && !self_early) ? (((long long)item << 32) | (unsigned)cur) : -1ll;
     int hs = -1;
     if (key >= 0) {
         int s = (int)(((unsigned long long)key * 0x9E3779B97F4A7C15ull) >> 55);  // 9 bits
@@ -554,7 +589,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     }
     __syncthreads();
     const int owner = hs >= 0 ? ho[hs] : tid;
-    const bool owns = alive && !cached && owner == tid;
+    const bool owns = alive && !cached && !self_early && owner == tid;
     // ---- where do this distribution's scores come from?  (edge-score cache, see WalkArgs)
     //   gather : adj(cur) has been scored since the generator last changed (this level by another root, an earlier level,
     //            or the D launch of the step) -> no rows at all, the weights kernel gathers k four-byte scores;
@@ -576,15 +611,17 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
             mode = old == st ? 2 : ((old >= a.es_valid_from && old <= a.es_now) ? 1 : 0);
         }
     }
-    const int p_chunks = owns ? (k + CHUNK - 1) / CHUNK : 0;                                       // prefix region
+    // an owner that gathers <= 16 candidates needs nothing but (mode 2) the node chunks: its walks evaluate the distribution themselves
+    const bool self_owner = owns && mode != 0 && k <= CHUNK;
+    blk_self[tid] = self_owner ? 1 : 0;
+    const int p_chunks = (owns && !self_owner) ? (k + CHUNK - 1) / CHUNK : 0;                      // prefix region
     const int s_chunks = !owns ? 0 : (mode == 0 ? p_chunks : (mode == 2 ? (deg + CHUNK - 1) / CHUNK : 0));  // score chunks
     const bool big = owns && k > BIG_TASK;
-    const bool small = owns && p_chunks > 1 && !big;  // 16 < k <= BIG_TASK: a 16-lane group of the weights kernel
-    const bool tiny = owns && mode != 0 && p_chunks == 1;  // gather, k <= 16 (private ones are finished by the score kernel)
+    const bool small = owns && p_chunks > 1 && !big;  // 16 < k <= BIG_TASK: a 16-lane group of the weights kernel (private single chunks are finished by the score kernel)
     // chunk offsets and task slots: in-wave exclusive scans, per-block totals through LDS, and the block's returning
     // atomics issued by three lanes AT ONCE (a single word serves only ~88 returning atomics per us, and three of them one
     // after the other were three round trips); the order of the blocks' regions in the buffers is irrelevant
-    __shared__ int wv_pch[4], wv_sch[4], wv_big[4], wv_own[4], wv_small[4], wv_tiny[4], wv_gat[4], wv_node[4], wv_alive[4];
+    __shared__ int wv_pch[4], wv_sch[4], wv_big[4], wv_own[4], wv_small[4], wv_gat[4], wv_node[4], wv_alive[4];
     __shared__ unsigned long long blk_base[3];
     int inc_p = p_chunks, inc_s = s_chunks;
 #pragma unroll
@@ -593,12 +630,14 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         if (lane >= off) { inc_p += op; inc_s += os; }
     }
     const int wv = tid >> 6;
-    const unsigned long long big_bal = __ballot(big), small_bal = __ballot(small), tiny_bal = __ballot(tiny);
+    const unsigned long long big_bal = __ballot(big), small_bal = __ballot(small);
     const unsigned long long own_bal = __ballot(owns && mode != 1);  // tasks that read a current row: private owners + node scorings
-    const unsigned long long gat_bal = __ballot(owns && mode != 0), node_bal = __ballot(owns && mode == 2), alive_bal = __ballot(alive);
+    // distributions served from the cache: gather tasks of the weights kernel + walks that will gather themselves (counted per
+    // walk: nothing dedups them; the walks behind a self-gathering owner are not counted)
+    const unsigned long long gat_bal = __ballot((owns && mode != 0) || self_early), node_bal = __ballot(owns && mode == 2), alive_bal = __ballot(alive);
     if (lane == 63) { wv_pch[wv] = inc_p; wv_sch[wv] = inc_s; }
     if (lane == 0) {
-        wv_big[wv] = __popcll(big_bal); wv_small[wv] = __popcll(small_bal); wv_tiny[wv] = __popcll(tiny_bal);
+        wv_big[wv] = __popcll(big_bal); wv_small[wv] = __popcll(small_bal);
         wv_own[wv] = __popcll(own_bal); wv_gat[wv] = __popcll(gat_bal); wv_node[wv] = __popcll(node_bal); wv_alive[wv] = __popcll(alive_bal);
     }
     __syncthreads();
@@ -608,7 +647,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         unsigned long long val = 0;
         if (tid == 0) { word = &a.lc[CTR_CHUNKS + a.level]; val = tot(wv_pch) | (tot(wv_sch) << 32); }
         else if (tid == 1) { word = &a.lc[CTR_BIG + a.level]; val = tot(wv_big) | (tot(wv_small) << 32); }
-        else if (tid == 2) { word = &a.lc[CTR_TINY + a.level]; val = tot(wv_tiny); }
+        else if (tid == 2) { word = &a.lc[CTR_TINY + a.level]; val = 0; }  // (spare)
         else if (tid == 3) { word = &a.lc[CTR_DISTS + (blockIdx.x & 63)]; val = tot(wv_own); }
         else if (tid == 4) { word = &a.lc[CTR_GATHER + (blockIdx.x & 63)]; val = tot(wv_gat); }
         else if (tid == 5) { word = &a.lc[CTR_NODES + (blockIdx.x & 63)]; val = tot(wv_node); }
@@ -617,10 +656,10 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         else if (val) atomicAdd(word, val);
     }
     __syncthreads();
-    int pch_before = 0, sch_before = 0, big_before = 0, small_before = 0, tiny_before = 0, blk_pch = 0, blk_sch = 0;
+    int pch_before = 0, sch_before = 0, big_before = 0, small_before = 0, blk_pch = 0, blk_sch = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        if (i < wv) { pch_before += wv_pch[i]; sch_before += wv_sch[i]; big_before += wv_big[i]; small_before += wv_small[i]; tiny_before += wv_tiny[i]; }
+        if (i < wv) { pch_before += wv_pch[i]; sch_before += wv_sch[i]; big_before += wv_big[i]; small_before += wv_small[i]; }
         blk_pch += wv_pch[i];
         blk_sch += wv_sch[i];
     }
@@ -630,17 +669,18 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     blk_coff[tid] = coff_p_own;
     __syncthreads();
     const int64_t coff_p = blk_coff[owner];  // non-owners sample from their owner's region
+    const bool self = self_early || (alive && !cached && blk_self[owner]);
     const int64_t lbase = blk_lbase;
     const bool fits = base_s + blk_sch <= cap_chunks && lbase + base_p + blk_pch <= a.cap_total;
     if (write_desc == 1 && !fits && tid == 0) a.ctr[3] = 2ull;  // speculative capacity exceeded: the host reruns in sized mode
     if (in_range) {
         a.lv_beg[w] = beg_abs;
-        a.lv_k[w] = k | (hf << 31) | (mode != 0 ? LVK_GATHER : 0) | (mode == 2 ? LVK_NODE : 0);
+        a.lv_k[w] = k | (hf << 31) | (mode != 0 ? LVK_GATHER : 0) | (mode == 2 ? LVK_NODE : 0) | (self ? LVK_SELF : 0);
         a.lv_chunks[w] = s_chunks;
         a.lv_coff[w] = coff_s;
         a.lv_pfx[w] = cached ? cached_off : lbase + coff_p;
-        if (mode != 0) a.lv_fe[w] = hf ? fe : -1;
-        if (owns && a.dc_mode == 1 && (fits || write_desc == 0)) {  // D launch: register the distribution for the G launch of the step (sized mode: the buffers are sized after this kernel)
+        if (mode != 0 || self) a.lv_fe[w] = hf ? fe : -1;
+        if (owns && !self_owner && a.dc_mode == 1 && (fits || write_desc == 0)) {  // D launch: register the distribution for the G launch of the step (sized mode: the buffers are sized after this kernel)
             const unsigned long long key2 = dc_key(slot_w, rank_w, hf);
             uint32_t h = dc_hash(key2, a.dc_mask);
             for (int tries = 0; tries < 64; ++tries) {
@@ -650,10 +690,9 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
                 h = (h + 1) & a.dc_mask;
             }
         }
-        // the task lists of the weights kernel: big tasks from the front of lv_big, small ones from its back, tiny gather tasks in lv_tiny
+        // the task lists of the weights kernel: big tasks from the front of lv_big, small ones from its back
         if (big) a.lv_big[(blk_base[1] & 0xffffffffull) + big_before + __popcll(big_bal & ((1ull << lane) - 1ull))] = (int32_t)w;
         if (small) a.lv_big[a.lv_big_cap - 1 - (int64_t)((blk_base[1] >> 32) + small_before + __popcll(small_bal & ((1ull << lane) - 1ull)))] = (int32_t)w;
-        if (tiny) a.lv_tiny[(int64_t)blk_base[2] + tiny_before + __popcll(tiny_bal & ((1ull << lane) - 1ull))] = (int32_t)w;
         if (write_desc == 1 && fits) {
             if (mode == 2)
                 for (int i = 0; i < s_chunks; ++i) write_node_desc(a.lv_chunk_desc, coff_s + i, cur, deg, e0, i);
@@ -869,21 +908,13 @@ __device__ __forceinline__ void weights_small_tasks(const WalkArgs &a, const int
 }
 
 constexpr int SMALL_BLOCKS = 2048;  // workgroups of the weights launch that serve the small-task list
-constexpr int TINY_BLOCKS = 2048;   // ... and the tiny-task list (gather tasks with <= 16 candidates)
-constexpr int SMALL_NT = 1, TINY_NT = 4;  // tasks a 16-lane group has in flight
+constexpr int SMALL_NT = 1;  // tasks a 16-lane group has in flight
 __device__ __forceinline__ void weights_small_blocks(const WalkArgs &a, const int block) {
     const int t = threadIdx.x & 15;
     const int64_t n_small = (int64_t)(a.lc[CTR_BIG + a.level] >> 32);
     for (int64_t i = ((int64_t)block * 16 + (threadIdx.x >> 4)) * SMALL_NT; i < n_small; i += (int64_t)SMALL_BLOCKS * 16 * SMALL_NT)
         weights_small_tasks<BIG_TASK / 16, SMALL_NT>(a, a.lv_big + a.lv_big_cap - 1, i, n_small, -1, t);  // (the small list grows down from the end of lv_big)
 }
-__device__ __forceinline__ void weights_tiny_blocks(const WalkArgs &a, const int block) {
-    const int t = threadIdx.x & 15;
-    const int64_t n_tiny = (int64_t)a.lc[CTR_TINY + a.level];
-    for (int64_t i = ((int64_t)block * 16 + (threadIdx.x >> 4)) * TINY_NT; i < n_tiny; i += (int64_t)TINY_BLOCKS * 16 * TINY_NT)
-        weights_small_tasks<1, TINY_NT>(a, a.lv_tiny, i, n_tiny, 1, t);
-}
-
 // Big owner tasks (hubs): one 256-thread workgroup per task, from the level's big-task list, in tiles of BIG_TILE candidates.
 // A thread owns BIG_PT CONSECUTIVE candidates of the tile: the max and the scan need one block-wide combination each (two
 // barrier pairs per tile; lane-strided rows of 256 cost a barrier pair per row, sixteen per tile), the thread's own prefix
@@ -956,15 +987,14 @@ __device__ __forceinline__ void weights_big_blocks(const WalkArgs &a) {
 }
 
 // One launch per level for all task classes: the first BIG_BLOCKS workgroups walk the big-task list (they run
-// longest, so they are dispatched first), the next SMALL_BLOCKS take 16 small tasks each per round, the rest the tiny gather
-// tasks.  As back-to-back launches the classes cost the sum of their latency-bound run times; together, the longest.
+// longest, so they are dispatched first), the others take 16 small tasks each per round.  As back-to-back launches the
+// classes cost the sum of their latency-bound run times; together, the longest.
 __global__ __launch_bounds__(256) void level_weights_kernel(const WalkArgs a, const int64_t cap_chunks) {
     const unsigned long long cw = a.lc[CTR_CHUNKS + a.level];
     const int64_t pch = (int64_t)(cw & 0xffffffffull), sch = (int64_t)(cw >> 32);
     if (sch > cap_chunks || pch == 0 || level_chunk_base(a) + pch > a.cap_total) return;
     if (blockIdx.x < BIG_BLOCKS) { if (!(a.exp & 1)) weights_big_blocks(a); }
-    else if (blockIdx.x < BIG_BLOCKS + SMALL_BLOCKS) { if (!(a.exp & 2)) weights_small_blocks(a, (int)blockIdx.x - BIG_BLOCKS); }
-    else if (!(a.exp & 4)) weights_tiny_blocks(a, (int)blockIdx.x - BIG_BLOCKS - SMALL_BLOCKS);
+    else if (!(a.exp & 2)) weights_small_blocks(a, (int)blockIdx.x - BIG_BLOCKS);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1249,7 +1279,6 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
         for (int k = 0; k < 2; ++k) {
             h[k].lc = ctx->dev_ctr + (size_t)k * CTR_WORDS;
             h[k].lv_big = a.lv_big + h[k].w0;
-            h[k].lv_tiny = a.lv_tiny + h[k].w0;
             h[k].lv_big_cap = h[k].w_end - h[k].w0;
             h[k].lv_scores = a.lv_scores + (size_t)k * cap * CHUNK;
             h[k].lv_chunk_desc = a.lv_chunk_desc + (size_t)k * cap;
@@ -1319,9 +1348,7 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
             }
             if (split) GG_HIP(ctx, hipEventRecord(ctx->ev_score[k], hs[k]));
             const int64_t half_walks = x.w_end - x.w0;
-            const unsigned wgrid = x.es_mode ? (unsigned)(BIG_BLOCKS + SMALL_BLOCKS + std::min<int64_t>(TINY_BLOCKS, cdiv(half_walks * 16, 256)))
-                                             : (unsigned)(BIG_BLOCKS + std::min<int64_t>(SMALL_BLOCKS, cdiv(half_walks * 16, 256)));
-            hipLaunchKernelGGL(level_weights_kernel, dim3(wgrid), dim3(256), 0, hs[k], x, cap);
+            hipLaunchKernelGGL(level_weights_kernel, dim3((unsigned)(BIG_BLOCKS + std::min<int64_t>(SMALL_BLOCKS, cdiv(half_walks * 16, 256)))), dim3(256), 0, hs[k], x, cap);
         }
     }
     // finish the last prepared hop
@@ -1364,7 +1391,7 @@ static int run_levels_and_finish(gg_ctx *ctx, WalkArgs &a, int64_t total_walks) 
         GG_HIP(ctx, ctx->lv_beg.reserve(sizeof(int64_t) * total_walks));
         GG_HIP(ctx, ctx->lv_k.reserve(sizeof(int32_t) * total_walks));
         GG_HIP(ctx, ctx->lv_chunks.reserve(sizeof(int32_t) * total_walks));
-        GG_HIP(ctx, ctx->lv_big.reserve(sizeof(int32_t) * 2 * total_walks));  // [0, W): big / small task lists, [W, 2W): tiny gather tasks
+        GG_HIP(ctx, ctx->lv_big.reserve(sizeof(int32_t) * total_walks));
         GG_HIP(ctx, ctx->lv_fe.reserve(sizeof(int32_t) * total_walks));
         GG_HIP(ctx, ctx->lv_coff.reserve(sizeof(int64_t) * (total_walks + 1)));
         GG_HIP(ctx, ctx->lv_pfx.reserve(sizeof(int64_t) * (total_walks + 1)));
@@ -1381,7 +1408,6 @@ static int run_levels_and_finish(gg_ctx *ctx, WalkArgs &a, int64_t total_walks) 
         a.lv_k = ctx->lv_k.as<int32_t>();
         a.lv_chunks = ctx->lv_chunks.as<int32_t>();
         a.lv_big = ctx->lv_big.as<int32_t>();
-        a.lv_tiny = a.lv_big + total_walks;
         a.lv_fe = ctx->lv_fe.as<int32_t>();
         a.lv_coff = ctx->lv_coff.as<int64_t>();
         a.lv_pfx = ctx->lv_pfx.as<int64_t>();
