@@ -157,6 +157,58 @@ def test_powerlaw_100k_fused_passes_match_oracle(ga):
         assert np.quantile(diff[moved], 0.999) < 2e-5 and diff.max() <= 2.5e-3 and diff[~moved].max() == 0.0
 
 
+def test_scale_mode_epochs_on_the_100k_split_match_the_oracle_trainer(ga):
+    """SURVEY 8d config 3 in full -- the 100k-node power-law graph with 10 % of its edges held out and one negative per test
+    edge (src/utils.py:96-128 semantics) -- through two outer epochs of the scale-mode schedule (fused batches, lazy Adam,
+    2 + 2 inner passes per epoch, D prepare -> D passes -> G prepare -> G passes as graph_gan.py:144-176) over 512 sampled
+    roots, engine against the ORACLE TRAINER in the same mode: both tables to float noise, and the link-prediction accuracy
+    of the reference's evaluator on the held-out edges within +-0.5 % (the "pre-trained" rows of this config are noise,
+    so both sit near chance: the gate checks the evaluator path and the split, the tables carry the parity)."""
+    from graphgan_amd import workloads
+    n, d, inner, seed = 100_000, 128, 2, 7
+    w = workloads.powerlaw_split_workload(n, 10, d)
+    rowptr, col, emb = w["rowptr"], w["col"], w["emb"]
+    assert len(w["test"]) == len(w["test_neg"]) == 99990 and w["n_train_edges"] == 899910
+    nbrs = set(zip(np.repeat(np.arange(n), np.diff(rowptr)).tolist(), col.tolist()))
+    assert not any((int(a), int(b)) in nbrs or a == b for a, b in w["test_neg"][:2000])   # negatives are non-neighbours
+    roots = workloads.bench_roots(rowptr, 512, 0, 1, 6)
+    slots = np.arange(len(roots), dtype=np.int32)
+    big = 1 << 30
+    eng = ga.Engine(emb, emb, optimizer=ga.GG_OPT_ADAM_LAZY)
+    eng.set_graph_csr(rowptr, col)
+    eng.build_trees(roots, device=True)
+    eng.set_profiling(3)
+    for epoch in range(2):
+        eng.prepare_d(slots, seed, 2 * (epoch * inner) + 0, fetch=False)
+        for _ in range(inner):
+            eng.d_pass([0], big)
+        eng.prepare_g(slots, 20, seed, 2 * (epoch * inner) + 1, fetch=False)
+        for _ in range(inner):
+            eng.g_pass([0], big)
+    Eg, Ed = eng.get_embeddings(0), eng.get_embeddings(1)
+    c = eng.counters()
+    eng.close()
+    assert c["es_gathers"] > 0 and c["es_nodes"] > 0   # the edge-score cache was in use
+    graph = {v: col[rowptr[v]:rowptr[v + 1]].tolist() for v in range(n)}
+    cfg = orc.Config()
+    cfg.n_epochs_dis = cfg.n_epochs_gen = cfg.dis_interval = cfg.gen_interval = inner
+    cfg.batch_size_gen = cfg.batch_size_dis = big
+    cfg.n_emb = d
+    o = orc.GraphGANOracle(n, graph, emb, emb, cfg=cfg, rng="counter", arith="spec", seed=seed, lazy_adam=True)
+    o.root_nodes = [int(r) for r in roots]
+    for epoch in range(2):
+        o.train_epoch(epoch)
+    test, neg = w["test"].tolist(), w["test_neg"].tolist()
+    for got, want in ((Eg, o.generator.E), (Ed, o.discriminator.E)):
+        diff = np.abs(got - want)
+        moved = np.abs(want - emb) > 0
+        assert moved.sum() > 100_000 and diff[~moved].max() == 0.0
+        assert diff[moved].mean() < 2e-5 and np.quantile(diff[moved], 0.999) < 5e-4
+        acc_e = orc.eval_link_prediction(got.astype(np.float64), test, neg)
+        acc_o = orc.eval_link_prediction(want.astype(np.float64), test, neg)
+        assert abs(acc_e - acc_o) <= 0.005, (acc_e, acc_o)
+
+
 def _compare_walks(got, want, item_ptr, sel, stride_w, tag):
     """walks of the selected roots: got = engine launch over all roots (walk_ptr = item_ptr), want = oracle over sel"""
     o = 0
