@@ -139,9 +139,19 @@ def pmc_traffic(kernel_substr):
         return None, None
     data = json.load(open(files[-1]))
     for name, v in data.items():
-        if kernel_substr in name:
+        if kernel_substr in name and not name.startswith("_"):
             return v["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
     return None, None
+
+
+def pmc_same_run():
+    """Algorithmic bytes per launch of the dominant kernel as counted by the bench run the PMC pass itself profiled
+    (profiles/summarize.py stores that run's own bench line next to its traffic): traffic / algorithmic inside ONE run."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
+    if not files:
+        return None
+    return json.load(open(files[-1])).get("_same_run")
 
 
 def delta(c1, c0):
@@ -409,10 +419,13 @@ def main():
                        "resident_bytes_per_tree": 12.0 * n},
         "roofline": {"kernel": "level_score_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": frac(achieved), "traffic": traffic, "traffic_source": traffic_src,
+                     "traffic_same_run": (dict(pmc_same_run(), traffic=traffic, traffic_over_algorithmic=traffic / pmc_same_run()["algorithmic_bytes_per_launch"])
+                                          if big_default and traffic and pmc_same_run() else None),
                      "algorithmic_bytes_per_launch": sc_bytes / max(sc_launches, 1), "avg_launch_ms": c["score_kernel_ms"] / max(sc_launches, 1),
                      "launches": int(sc_launches), "rows_per_launch": c["score_rows"] / max(sc_launches, 1),
                      "distributions_per_launch": c["score_dists"] / max(sc_launches, 1),
-                     "bytes_model": "SURVEY 8d: 4(d+2) per candidate row + (4d+12) per (root, node) distribution",
+                     "bytes_model": "SURVEY 8d: 4(d+2) per candidate row scored + (4d+12) per scoring task that reads a current row (a private (root, node) "
+                                    "distribution, or a node whose whole adjacency is scored once into the edge-score cache for every root)",
                      "timed": "HIP events on the engine's stream around every level_score_kernel launch of every %s walk call of the timed region, "
                               "as it runs in production: the G-mode launches share the chip with the discriminator update on the other stream" % (
                                   "" if args.profile_every == 1 else "%d-th" % args.profile_every),

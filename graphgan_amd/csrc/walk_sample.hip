@@ -101,7 +101,8 @@ struct WalkArgs {
     int32_t es_mode;         // 0 = off, 1 = a stale node is scored whole when the asking distribution needs most of it, 2 = always
     int32_t es_ratio, es_hub;
     int32_t *lv_fe;          // [total_walks] es index of the father candidate's score (gather tasks with a father entry)
-    int32_t exp;             // GG_WALK_EXPERIMENT: timing ablations (results are then WRONG): 1 / 2 = the weights kernel skips its big / small tasks
+    int32_t *lv_s64;         // [walks of this half] third task list of the weights kernel: tasks with 17 .. 64 candidates (several in flight per group)
+    int32_t exp;             // GG_WALK_EXPERIMENT: timing ablations (results are then WRONG): 1 / 2 / 4 = the weights kernel skips its big / small / 17..64-candidate tasks
 };
 
 __device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, int lane) {
@@ -249,7 +250,7 @@ constexpr int CTR_ROWS = 200;   // ctr[CTR_ROWS + (block & 63)]: candidate rows 
 constexpr int CTR_HOPS_V = 264;  // ctr[CTR_HOPS_V + (block & 63)]: hop counts of the level pipeline, spread over 64 words
 constexpr int CTR_READS_V = 328; // (same-address atomics serialise at ~12 ns each); summed by the host
 constexpr int CTR_DISTS = 392;   // ctr[CTR_DISTS + (block & 63)]: (root, node) distributions set up by the level pipeline (owners), spread words
-constexpr int CTR_TINY = 456;    // (64 spare words)
+constexpr int CTR_TINY = 456;    // ctr[CTR_TINY + level]: owner tasks with 17 .. 64 candidates (third task list of the weights kernel)
 constexpr int CTR_GATHER = 520;  // ctr[CTR_GATHER + (block & 63)]: owner distributions that gather their scores from the edge-score cache, spread words
 constexpr int CTR_NODES = 584;   // ctr[CTR_NODES + (block & 63)]: nodes whose adjacency this launch scored into the cache, spread words
 constexpr int CTR_BASE = 648;    // ctr[CTR_BASE + level]: global chunk offset of the first PREFIX chunk of hop `level` (launch base + the prefix chunks
@@ -617,11 +618,12 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     const int p_chunks = (owns && !self_owner) ? (k + CHUNK - 1) / CHUNK : 0;                      // prefix region
     const int s_chunks = !owns ? 0 : (mode == 0 ? p_chunks : (mode == 2 ? (deg + CHUNK - 1) / CHUNK : 0));  // score chunks
     const bool big = owns && k > BIG_TASK;
-    const bool small = owns && p_chunks > 1 && !big;  // 16 < k <= BIG_TASK: a 16-lane group of the weights kernel (private single chunks are finished by the score kernel)
+    const bool small = owns && p_chunks > 4 && !big;  // 64 < k <= BIG_TASK: a 16-lane group of the weights kernel
+    const bool s64 = owns && p_chunks > 1 && p_chunks <= 4;  // 16 < k <= 64: four of them in flight per group (private single chunks are finished by the score kernel)
     // chunk offsets and task slots: in-wave exclusive scans, per-block totals through LDS, and the block's returning
     // atomics issued by three lanes AT ONCE (a single word serves only ~88 returning atomics per us, and three of them one
     // after the other were three round trips); the order of the blocks' regions in the buffers is irrelevant
-    __shared__ int wv_pch[4], wv_sch[4], wv_big[4], wv_own[4], wv_small[4], wv_gat[4], wv_node[4], wv_alive[4];
+    __shared__ int wv_pch[4], wv_sch[4], wv_big[4], wv_own[4], wv_small[4], wv_s64[4], wv_gat[4], wv_node[4], wv_alive[4];
     __shared__ unsigned long long blk_base[3];
     int inc_p = p_chunks, inc_s = s_chunks;
 #pragma unroll
@@ -630,14 +632,14 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         if (lane >= off) { inc_p += op; inc_s += os; }
     }
     const int wv = tid >> 6;
-    const unsigned long long big_bal = __ballot(big), small_bal = __ballot(small);
+    const unsigned long long big_bal = __ballot(big), small_bal = __ballot(small), s64_bal = __ballot(s64);
     const unsigned long long own_bal = __ballot(owns && mode != 1);  // tasks that read a current row: private owners + node scorings
     // distributions served from the cache: gather tasks of the weights kernel + walks that will gather themselves (counted per
     // walk: nothing dedups them; the walks behind a self-gathering owner are not counted)
     const unsigned long long gat_bal = __ballot((owns && mode != 0) || self_early), node_bal = __ballot(owns && mode == 2), alive_bal = __ballot(alive);
     if (lane == 63) { wv_pch[wv] = inc_p; wv_sch[wv] = inc_s; }
     if (lane == 0) {
-        wv_big[wv] = __popcll(big_bal); wv_small[wv] = __popcll(small_bal);
+        wv_big[wv] = __popcll(big_bal); wv_small[wv] = __popcll(small_bal); wv_s64[wv] = __popcll(s64_bal);
         wv_own[wv] = __popcll(own_bal); wv_gat[wv] = __popcll(gat_bal); wv_node[wv] = __popcll(node_bal); wv_alive[wv] = __popcll(alive_bal);
     }
     __syncthreads();
@@ -647,7 +649,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         unsigned long long val = 0;
         if (tid == 0) { word = &a.lc[CTR_CHUNKS + a.level]; val = tot(wv_pch) | (tot(wv_sch) << 32); }
         else if (tid == 1) { word = &a.lc[CTR_BIG + a.level]; val = tot(wv_big) | (tot(wv_small) << 32); }
-        else if (tid == 2) { word = &a.lc[CTR_TINY + a.level]; val = 0; }  // (spare)
+        else if (tid == 2) { word = &a.lc[CTR_TINY + a.level]; val = tot(wv_s64); }
         else if (tid == 3) { word = &a.lc[CTR_DISTS + (blockIdx.x & 63)]; val = tot(wv_own); }
         else if (tid == 4) { word = &a.lc[CTR_GATHER + (blockIdx.x & 63)]; val = tot(wv_gat); }
         else if (tid == 5) { word = &a.lc[CTR_NODES + (blockIdx.x & 63)]; val = tot(wv_node); }
@@ -656,10 +658,10 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         else if (val) atomicAdd(word, val);
     }
     __syncthreads();
-    int pch_before = 0, sch_before = 0, big_before = 0, small_before = 0, blk_pch = 0, blk_sch = 0;
+    int pch_before = 0, sch_before = 0, big_before = 0, small_before = 0, s64_before = 0, blk_pch = 0, blk_sch = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        if (i < wv) { pch_before += wv_pch[i]; sch_before += wv_sch[i]; big_before += wv_big[i]; small_before += wv_small[i]; }
+        if (i < wv) { pch_before += wv_pch[i]; sch_before += wv_sch[i]; big_before += wv_big[i]; small_before += wv_small[i]; s64_before += wv_s64[i]; }
         blk_pch += wv_pch[i];
         blk_sch += wv_sch[i];
     }
@@ -693,6 +695,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         // the task lists of the weights kernel: big tasks from the front of lv_big, small ones from its back
         if (big) a.lv_big[(blk_base[1] & 0xffffffffull) + big_before + __popcll(big_bal & ((1ull << lane) - 1ull))] = (int32_t)w;
         if (small) a.lv_big[a.lv_big_cap - 1 - (int64_t)((blk_base[1] >> 32) + small_before + __popcll(small_bal & ((1ull << lane) - 1ull)))] = (int32_t)w;
+        if (s64) a.lv_s64[(int64_t)blk_base[2] + s64_before + __popcll(s64_bal & ((1ull << lane) - 1ull))] = (int32_t)w;
         if (write_desc == 1 && fits) {
             if (mode == 2)
                 for (int i = 0; i < s_chunks; ++i) write_node_desc(a.lv_chunk_desc, coff_s + i, cur, deg, e0, i);
@@ -909,6 +912,13 @@ __device__ __forceinline__ void weights_small_tasks(const WalkArgs &a, const int
 
 constexpr int SMALL_BLOCKS = 2048;  // workgroups of the weights launch that serve the small-task list
 constexpr int SMALL_NT = 1;  // tasks a 16-lane group has in flight
+constexpr int S64_BLOCKS = 2048, S64_NT = 4;
+__device__ __forceinline__ void weights_s64_blocks(const WalkArgs &a, const int block) {
+    const int t = threadIdx.x & 15;
+    const int64_t n = (int64_t)a.lc[CTR_TINY + a.level];
+    for (int64_t i = ((int64_t)block * 16 + (threadIdx.x >> 4)) * S64_NT; i < n; i += (int64_t)S64_BLOCKS * 16 * S64_NT)
+        weights_small_tasks<4, S64_NT>(a, a.lv_s64, i, n, 1, t);
+}
 __device__ __forceinline__ void weights_small_blocks(const WalkArgs &a, const int block) {
     const int t = threadIdx.x & 15;
     const int64_t n_small = (int64_t)(a.lc[CTR_BIG + a.level] >> 32);
@@ -987,14 +997,16 @@ __device__ __forceinline__ void weights_big_blocks(const WalkArgs &a) {
 }
 
 // One launch per level for all task classes: the first BIG_BLOCKS workgroups walk the big-task list (they run
-// longest, so they are dispatched first), the others take 16 small tasks each per round.  As back-to-back launches the
-// classes cost the sum of their latency-bound run times; together, the longest.
+// longest, so they are dispatched first), the next SMALL_BLOCKS take 16 tasks of 65 .. 256 candidates each per round, the rest
+// the 17 .. 64-candidate tasks, four per 16-lane group at a time.  As back-to-back launches the classes cost the sum of their
+// latency-bound run times; together, the longest.
 __global__ __launch_bounds__(256) void level_weights_kernel(const WalkArgs a, const int64_t cap_chunks) {
     const unsigned long long cw = a.lc[CTR_CHUNKS + a.level];
     const int64_t pch = (int64_t)(cw & 0xffffffffull), sch = (int64_t)(cw >> 32);
     if (sch > cap_chunks || pch == 0 || level_chunk_base(a) + pch > a.cap_total) return;
     if (blockIdx.x < BIG_BLOCKS) { if (!(a.exp & 1)) weights_big_blocks(a); }
-    else if (!(a.exp & 2)) weights_small_blocks(a, (int)blockIdx.x - BIG_BLOCKS);
+    else if (blockIdx.x < BIG_BLOCKS + SMALL_BLOCKS) { if (!(a.exp & 2)) weights_small_blocks(a, (int)blockIdx.x - BIG_BLOCKS); }
+    else if (!(a.exp & 4)) weights_s64_blocks(a, (int)blockIdx.x - BIG_BLOCKS - SMALL_BLOCKS);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1279,6 +1291,7 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
         for (int k = 0; k < 2; ++k) {
             h[k].lc = ctx->dev_ctr + (size_t)k * CTR_WORDS;
             h[k].lv_big = a.lv_big + h[k].w0;
+            h[k].lv_s64 = a.lv_s64 + h[k].w0;
             h[k].lv_big_cap = h[k].w_end - h[k].w0;
             h[k].lv_scores = a.lv_scores + (size_t)k * cap * CHUNK;
             h[k].lv_chunk_desc = a.lv_chunk_desc + (size_t)k * cap;
@@ -1348,7 +1361,7 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
             }
             if (split) GG_HIP(ctx, hipEventRecord(ctx->ev_score[k], hs[k]));
             const int64_t half_walks = x.w_end - x.w0;
-            hipLaunchKernelGGL(level_weights_kernel, dim3((unsigned)(BIG_BLOCKS + std::min<int64_t>(SMALL_BLOCKS, cdiv(half_walks * 16, 256)))), dim3(256), 0, hs[k], x, cap);
+            hipLaunchKernelGGL(level_weights_kernel, dim3((unsigned)(BIG_BLOCKS + SMALL_BLOCKS + std::min<int64_t>(S64_BLOCKS, cdiv(half_walks * 4, 256)))), dim3(256), 0, hs[k], x, cap);
         }
     }
     // finish the last prepared hop
@@ -1391,7 +1404,7 @@ static int run_levels_and_finish(gg_ctx *ctx, WalkArgs &a, int64_t total_walks) 
         GG_HIP(ctx, ctx->lv_beg.reserve(sizeof(int64_t) * total_walks));
         GG_HIP(ctx, ctx->lv_k.reserve(sizeof(int32_t) * total_walks));
         GG_HIP(ctx, ctx->lv_chunks.reserve(sizeof(int32_t) * total_walks));
-        GG_HIP(ctx, ctx->lv_big.reserve(sizeof(int32_t) * total_walks));
+        GG_HIP(ctx, ctx->lv_big.reserve(sizeof(int32_t) * 2 * total_walks));  // [0, W): big / small task lists, [W, 2W): tasks with 17 .. 64 candidates
         GG_HIP(ctx, ctx->lv_fe.reserve(sizeof(int32_t) * total_walks));
         GG_HIP(ctx, ctx->lv_coff.reserve(sizeof(int64_t) * (total_walks + 1)));
         GG_HIP(ctx, ctx->lv_pfx.reserve(sizeof(int64_t) * (total_walks + 1)));
@@ -1408,6 +1421,7 @@ static int run_levels_and_finish(gg_ctx *ctx, WalkArgs &a, int64_t total_walks) 
         a.lv_k = ctx->lv_k.as<int32_t>();
         a.lv_chunks = ctx->lv_chunks.as<int32_t>();
         a.lv_big = ctx->lv_big.as<int32_t>();
+        a.lv_s64 = a.lv_big + total_walks;
         a.lv_fe = ctx->lv_fe.as<int32_t>();
         a.lv_coff = ctx->lv_coff.as<int64_t>();
         a.lv_pfx = ctx->lv_pfx.as<int64_t>();

@@ -42,9 +42,19 @@ def main():
         wm = sum(w) / len(w) if w else 0.0
         out[name] = {"launches_sampled": len(f), "FETCH_SIZE_KiB_mean": fm, "WRITE_SIZE_KiB_mean": wm,
                      "hbm_bytes_per_launch": (2.0 * fm + wm) * 1024.0}
+    # the bench line printed by the FETCH_SIZE pass itself (tools/profile_round.sh): algorithmic bytes per launch of the SAME run
+    same = os.path.join(os.path.dirname(os.path.normpath(fd)), "%s_fetch_bench.json" % tag)
+    if os.path.isfile(same):
+        try:
+            line = [ln for ln in open(same).read().splitlines() if ln.startswith("{")][-1]
+            r = json.loads(line)["roofline"]
+            out["_same_run"] = {"kernel": r["kernel"], "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
+                                "rows_per_launch": r["rows_per_launch"], "launches": r["launches"]}
+        except (IndexError, KeyError, ValueError):
+            pass
     with open(os.path.join(here, "%s_pmc_hbm_traffic.json" % tag), "w") as fjs:
         json.dump(out, fjs, indent=1, sort_keys=True)
-    for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_sampled"])[:6]:
+    for k, v in sorted(((k, v) for k, v in out.items() if not k.startswith("_")), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_sampled"])[:6]:
         print("%-60s %4d launches  %.1f MB/launch" % (k[:60], v["launches_sampled"], v["hbm_bytes_per_launch"] / 1e6))
     if len(sys.argv) > 5:  # optional: directory of the `--pmc TCC_HIT_sum TCC_MISS_sum` pass
         hit = pmc(os.path.join(sys.argv[5], "l_counter_collection.csv"), "TCC_HIT_sum")

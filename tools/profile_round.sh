@@ -4,7 +4,7 @@
 #   python profiles/summarize.py r2 gpurun_out/r2_kt gpurun_out/r2_fetch gpurun_out/r2_write [gpurun_out/r2_l2 [gpurun_out/r2_sq [gpurun_out/r2_tl]]]
 # GPU tests + smoke, rocprofv3 kernel trace of the default bench, separate PMC passes (FETCH_SIZE, WRITE_SIZE,
 # TCC hit / miss; never combined with trace domains), un-profiled bench with the CPU baseline.  "quick": no tests, no L2 pass.
-T=${1:-r2}
+T=${1:-r3}
 Q=${2:-full}
 R=$GRAFT_REPO_ROOT
 if [ "$Q" != "quick" ]; then
@@ -14,7 +14,8 @@ fi
 cd /tmp && export TMPDIR=/tmp
 PB="--no-cpu-baseline --no-strict --fresh-batches 1 --overlap-steps 3"  # (the 3 extra steps measure the side-stream launches solo)
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${T}_kt -o b -- python $R/bench.py $PB > $R/gpurun_out/${T}_kt.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${T}_fetch -o f -- python $R/bench.py --steps 3 --warmup 1 $PB > $R/gpurun_out/${T}_fetch.log 2>&1
+# (the bench line of the FETCH_SIZE pass is kept: its algorithmic bytes per launch are what the PMC traffic of the same run is compared with)
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${T}_fetch -o f -- python $R/bench.py --steps 3 --warmup 1 $PB > $R/gpurun_out/${T}_fetch_bench.json 2> $R/gpurun_out/${T}_fetch.log
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${T}_write -o w -- python $R/bench.py --steps 3 --warmup 1 $PB > $R/gpurun_out/${T}_write.log 2>&1
 if [ "$Q" != "quick" ]; then
   rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $R/gpurun_out/${T}_l2 -o l -- python $R/bench.py --steps 3 --warmup 1 $PB > $R/gpurun_out/${T}_l2.log 2>&1
