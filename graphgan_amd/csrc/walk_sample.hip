@@ -925,26 +925,26 @@ __device__ __forceinline__ void weights_small_blocks(const WalkArgs &a, const in
     for (int64_t i = ((int64_t)block * 16 + (threadIdx.x >> 4)) * SMALL_NT; i < n_small; i += (int64_t)SMALL_BLOCKS * 16 * SMALL_NT)
         weights_small_tasks<BIG_TASK / 16, SMALL_NT>(a, a.lv_big + a.lv_big_cap - 1, i, n_small, -1, t);  // (the small list grows down from the end of lv_big)
 }
-// Big owner tasks (hubs): one 256-thread workgroup per task, from the level's big-task list, in tiles of BIG_TILE candidates.
-// A thread owns BIG_PT CONSECUTIVE candidates of the tile: the max and the scan need one block-wide combination each (two
-// barrier pairs per tile; lane-strided rows of 256 cost a barrier pair per row, sixteen per tile), the thread's own prefix
-// is a register loop, and it stores 64 contiguous bytes.  A task of up to one tile keeps its scores in registers between
-// the max and the scan pass; larger ones read them twice.
-constexpr int BIG_PT = 8;
-constexpr int BIG_TILE = 256 * BIG_PT;
+// Big owner tasks (hubs, k > BIG_TASK): one WAVEFRONT per task, from the level's big-task list, in tiles of BIG_TILE candidates.
+// A lane owns BIG_PT CONSECUTIVE candidates of the tile (its own prefix is a register loop, it stores 128 contiguous bytes);
+// the max and the scan need one wave-wide combination each (shuffles) -- no LDS, no barriers, and four tasks per workgroup
+// in flight: the class is bound by how many tasks the chip holds at once times the two dependent gathers per tile (a
+// workgroup per task with a barrier pair per 256 candidates kept 1 280 tasks in flight: 3.5 rounds for the 4 500 hub
+// distributions of the bench's third level).  A task of up to one tile keeps its scores in registers between the max and the
+// scan pass; larger ones read them twice.
+constexpr int BIG_PT = 16;
+constexpr int BIG_TILE = 64 * BIG_PT;
 constexpr int BIG_BLOCKS = 2048;  // workgroups of the weights launch that serve the big-task list
 __device__ __forceinline__ void weights_big_blocks(const WalkArgs &a) {
-    __shared__ float red[4];
-    __shared__ uint64_t wave_tot[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int n_big = (int)(a.lc[CTR_BIG + a.level] & 0xffffffffull);
-    for (int b = blockIdx.x; b < n_big; b += BIG_BLOCKS) {
+    for (int b = (int)blockIdx.x * 4 + wv; b < n_big; b += BIG_BLOCKS * 4) {
         const int64_t w = a.lv_big[b];
         const TaskScores ts = task_scores(a, w);
         const int k = ts.k;
         uint64_t *const pf = a.lv_prefix + a.lv_pfx[w] * CHUNK;
-        auto load_tile = [&](int j0, float (&v)[BIG_PT]) {  // candidates j0 + 16 * thread + [0, 16)
-            const int jb = j0 + BIG_PT * (int)threadIdx.x;
+        auto load_tile = [&](int j0, float (&v)[BIG_PT]) {  // candidates j0 + 16 * lane + [0, 16)
+            const int jb = j0 + BIG_PT * lane;
             if (ts.gather) {
                 int e[BIG_PT];
 #pragma unroll
@@ -964,14 +964,10 @@ __device__ __forceinline__ void weights_big_blocks(const WalkArgs &a) {
             for (int i = 0; i < BIG_PT; ++i) mx = fmaxf(mx, v[i]);
         }
         mx = wave_max_f32(mx);
-        __syncthreads();
-        if (lane == 0) red[wv] = mx;
-        __syncthreads();
-        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
         uint64_t carry = 0;
         for (int j0 = 0; j0 < k; j0 += BIG_TILE) {
             if (k > BIG_TILE) load_tile(j0, v);  // (a single tile is still in registers)
-            const int jb = j0 + BIG_PT * (int)threadIdx.x;
+            const int jb = j0 + BIG_PT * lane;
             uint64_t c[BIG_PT], run = 0;
 #pragma unroll
             for (int i = 0; i < BIG_PT; ++i) {
@@ -979,19 +975,11 @@ __device__ __forceinline__ void weights_big_blocks(const WalkArgs &a) {
                 c[i] = run;
             }
             const uint64_t inc = wave_incl_scan_u64(run, lane);
-            __syncthreads();
-            if (lane == 63) wave_tot[wv] = inc;
-            __syncthreads();
-            uint64_t pre = carry + inc - run, tot = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (i < wv) pre += wave_tot[i];
-                tot += wave_tot[i];
-            }
+            const uint64_t pre = carry + inc - run;
 #pragma unroll
             for (int i = 0; i < BIG_PT; ++i)
                 if (jb + i < k) pf[jb + i] = pre + c[i];
-            carry += tot;
+            carry += __shfl(inc, 63, 64);
         }
     }
 }
