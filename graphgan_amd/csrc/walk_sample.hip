@@ -914,9 +914,9 @@ __device__ __forceinline__ void weights_small_tasks(const WalkArgs &a, const int
     }
 }
 
-constexpr int SMALL_BLOCKS = 2048;  // workgroups of the weights launch that serve the small-task list
+constexpr int SMALL_BLOCKS = 1024;  // workgroups of the weights launch that serve the small-task list (= WEIGHTS_BLOCKS)
 constexpr int SMALL_NT = 1;  // tasks a 16-lane group has in flight
-constexpr int S64_BLOCKS = 2048, S64_NT = 4;
+constexpr int S64_BLOCKS = 1024, S64_NT = 4;
 __device__ __forceinline__ void weights_s64_blocks(const WalkArgs &a, const int block) {
     const int t = threadIdx.x & 15;
     const int64_t n = (int64_t)(a.lc[CTR_TINY + a.level] & 0xffffffffull);
@@ -1004,30 +1004,32 @@ __device__ __forceinline__ void weights_wide_task(const WalkArgs &a, const int64
     }
 }
 
-constexpr int GIANT_BLOCKS = 512;  // workgroups of the weights launch that serve the giant-task list (dispatched first)
-constexpr int BIG_BLOCKS = 1536;   // ... and the big-task list, one task per wavefront
-__device__ __forceinline__ void weights_giant_blocks(const WalkArgs &a) {
+constexpr int WEIGHTS_BLOCKS = 1024;  // workgroups per class of the weights launch (4 classes, interleaved over the block index)
+__device__ __forceinline__ void weights_giant_blocks(const WalkArgs &a, const int block) {
     const int n_giant = (int)(a.lc[CTR_TINY + a.level] >> 32);
-    for (int b = blockIdx.x; b < n_giant; b += GIANT_BLOCKS) weights_wide_task<256>(a, a.lv_s64[a.lv_big_cap - 1 - b], (int)threadIdx.x);
+    for (int b = block; b < n_giant; b += WEIGHTS_BLOCKS) weights_wide_task<256>(a, a.lv_s64[a.lv_big_cap - 1 - b], (int)threadIdx.x);
 }
-__device__ __forceinline__ void weights_big_blocks(const WalkArgs &a, const int block) {
+__device__ __forceinline__ void weights_big_blocks(const WalkArgs &a, const int block) {  // block in [0, 2 * WEIGHTS_BLOCKS): two classes' worth
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int n_big = (int)(a.lc[CTR_BIG + a.level] & 0xffffffffull);
-    for (int b = block * 4 + wv; b < n_big; b += BIG_BLOCKS * 4) weights_wide_task<64>(a, a.lv_big[b], lane);
+    for (int b = block * 4 + wv; b < n_big; b += 2 * WEIGHTS_BLOCKS * 4) weights_wide_task<64>(a, a.lv_big[b], lane);
 }
 
-// One launch per level for all task classes: the giants' workgroups first (the longest single tasks), then the big-task list
-// (a task per wavefront), SMALL_BLOCKS with 16 tasks of 65 .. 256 candidates each per round, the rest the 17 .. 64-candidate
-// tasks, four per 16-lane group at a time.  As back-to-back launches the classes cost the sum of their
+// One launch per level for all task classes: giants (a workgroup per task) + big tasks (a wavefront per task), 16-lane groups
+// for the tasks of 65 .. 256 candidates, and the 17 .. 64-candidate tasks four per group at a time.  As back-to-back launches the classes cost the sum of their
 // latency-bound run times; together, the longest.
 __global__ __launch_bounds__(256) void level_weights_kernel(const WalkArgs a, const int64_t cap_chunks) {
     const unsigned long long cw = a.lc[CTR_CHUNKS + a.level];
     const int64_t pch = (int64_t)(cw & 0xffffffffull), sch = (int64_t)(cw >> 32);
     if (sch > cap_chunks || pch == 0 || level_chunk_base(a) + pch > a.cap_total) return;
-    if (blockIdx.x < GIANT_BLOCKS) { if (!(a.exp & 1)) weights_giant_blocks(a); }
-    else if (blockIdx.x < GIANT_BLOCKS + BIG_BLOCKS) { if (!(a.exp & 1)) weights_big_blocks(a, (int)blockIdx.x - GIANT_BLOCKS); }
-    else if (blockIdx.x < GIANT_BLOCKS + BIG_BLOCKS + SMALL_BLOCKS) { if (!(a.exp & 2)) weights_small_blocks(a, (int)blockIdx.x - GIANT_BLOCKS - BIG_BLOCKS); }
-    else if (!(a.exp & 4)) weights_s64_blocks(a, (int)blockIdx.x - GIANT_BLOCKS - BIG_BLOCKS - SMALL_BLOCKS);
+    // The classes are INTERLEAVED over the block index (block b serves class b % 4): workgroups are dispatched in index order,
+    // so with one class after the other the small tasks only started once the big tasks' workgroups had drained -- the
+    // classes' latency-bound run times added up instead of overlapping.
+    const int cls = (int)(blockIdx.x & 3u), blk = (int)(blockIdx.x >> 2);
+    if (cls == 0) { if (!(a.exp & 1)) { weights_giant_blocks(a, blk); weights_big_blocks(a, blk); } }
+    else if (cls == 1) { if (!(a.exp & 1)) weights_big_blocks(a, WEIGHTS_BLOCKS + blk); }
+    else if (cls == 2) { if (!(a.exp & 2)) weights_small_blocks(a, blk); }
+    else if (!(a.exp & 4)) weights_s64_blocks(a, blk);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1381,8 +1383,7 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
                 ctx->lv_ev_used = level + 1;
             }
             if (split) GG_HIP(ctx, hipEventRecord(ctx->ev_score[k], hs[k]));
-            const int64_t half_walks = x.w_end - x.w0;
-            hipLaunchKernelGGL(level_weights_kernel, dim3((unsigned)(GIANT_BLOCKS + BIG_BLOCKS + SMALL_BLOCKS + std::min<int64_t>(S64_BLOCKS, cdiv(half_walks * 4, 256)))), dim3(256), 0, hs[k], x, cap);
+            hipLaunchKernelGGL(level_weights_kernel, dim3(4u * 1024u), dim3(256), 0, hs[k], x, cap);
         }
     }
     // finish the last prepared hop
