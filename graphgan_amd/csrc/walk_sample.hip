@@ -101,8 +101,7 @@ struct WalkArgs {
     int32_t es_mode;         // 0 = off, 1 = a stale node is scored whole when the asking distribution needs most of it, 2 = always
     int32_t es_ratio, es_hub;
     int32_t *lv_fe;          // [total_walks] es index of the father candidate's score (gather tasks with a father entry)
-    int32_t *lv_s64;         // [walks of this half] third task list of the weights kernel: tasks with 17 .. 64 candidates (several in flight per group)
-    int32_t exp;             // GG_WALK_EXPERIMENT: timing ablations (results are then WRONG): 1 / 2 / 4 = the weights kernel skips its big / small / 17..64-candidate tasks
+    int32_t exp;             // GG_WALK_EXPERIMENT: timing ablations (results are then WRONG): 1 / 2 = the weights kernel skips its big / small tasks
 };
 
 __device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, int lane) {
@@ -237,9 +236,7 @@ static int score_blocks() {
     }();
     return v;
 }
-constexpr int BIG_TASK = 256;   // owner tasks with more candidates get a wavefront (or, the giants, a workgroup) of the weights kernel
-constexpr int WIDE_PT = 16;     // candidates a thread of a big / giant task owns
-constexpr int BIG_WAVE_MAX = 64 * WIDE_PT;  // candidates one wavefront takes in one shot: larger tasks are "giant"
+constexpr int BIG_TASK = 256;   // owner tasks with more candidates get a whole workgroup for their prefix sums
 constexpr int CTR_NONFINITE = 6; // ctr[6]: a distribution had total weight 0 (non-finite generator scores) -> GG_EINVAL
 constexpr int CTR_FIN = 7;      // ctr[7]: walks still alive behind the last streamed level = entries of the finisher's walk list
 constexpr int CTR_ALIVE = 8;    // ctr[CTR_ALIVE + level]: walks alive when hop `level` was set up
@@ -252,7 +249,7 @@ constexpr int CTR_ROWS = 200;   // ctr[CTR_ROWS + (block & 63)]: candidate rows 
 constexpr int CTR_HOPS_V = 264;  // ctr[CTR_HOPS_V + (block & 63)]: hop counts of the level pipeline, spread over 64 words
 constexpr int CTR_READS_V = 328; // (same-address atomics serialise at ~12 ns each); summed by the host
 constexpr int CTR_DISTS = 392;   // ctr[CTR_DISTS + (block & 63)]: (root, node) distributions set up by the level pipeline (owners), spread words
-constexpr int CTR_TINY = 456;    // ctr[CTR_TINY + level]: owner tasks with 17 .. 64 candidates (low 32 bits) and giant ones (> 1 024: high 32 bits): lists in lv_s64
+constexpr int CTR_TINY = 456;    // (64 spare words)
 constexpr int CTR_GATHER = 520;  // ctr[CTR_GATHER + (block & 63)]: owner distributions that gather their scores from the edge-score cache, spread words
 constexpr int CTR_NODES = 584;   // ctr[CTR_NODES + (block & 63)]: nodes whose adjacency this launch scored into the cache, spread words
 constexpr int CTR_BASE = 648;    // ctr[CTR_BASE + level]: global chunk offset of the first PREFIX chunk of hop `level` (launch base + the prefix chunks
@@ -619,14 +616,12 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     blk_self[tid] = self_owner ? 1 : 0;
     const int p_chunks = (owns && !self_owner) ? (k + CHUNK - 1) / CHUNK : 0;                      // prefix region
     const int s_chunks = !owns ? 0 : (mode == 0 ? p_chunks : (mode == 2 ? (deg + CHUNK - 1) / CHUNK : 0));  // score chunks
-    const bool giant = owns && k > BIG_WAVE_MAX;       // a workgroup of the weights kernel
-    const bool big = owns && k > BIG_TASK && !giant;   // a wavefront
-    const bool small = owns && p_chunks > 4 && k <= BIG_TASK;  // 64 < k <= BIG_TASK: a 16-lane group
-    const bool s64 = owns && p_chunks > 1 && p_chunks <= 4;  // 16 < k <= 64: four of them in flight per group (private single chunks are finished by the score kernel)
+    const bool big = owns && k > BIG_TASK;
+    const bool small = owns && p_chunks > 1 && !big;  // 16 < k <= BIG_TASK: a 16-lane group of the weights kernel (private single chunks are finished by the score kernel)
     // chunk offsets and task slots: in-wave exclusive scans, per-block totals through LDS, and the block's returning
     // atomics issued by three lanes AT ONCE (a single word serves only ~88 returning atomics per us, and three of them one
     // after the other were three round trips); the order of the blocks' regions in the buffers is irrelevant
-    __shared__ int wv_pch[4], wv_sch[4], wv_big[4], wv_own[4], wv_small[4], wv_s64[4], wv_giant[4], wv_gat[4], wv_node[4], wv_alive[4];
+    __shared__ int wv_pch[4], wv_sch[4], wv_big[4], wv_own[4], wv_small[4], wv_gat[4], wv_node[4], wv_alive[4];
     __shared__ unsigned long long blk_base[3];
     int inc_p = p_chunks, inc_s = s_chunks;
 #pragma unroll
@@ -635,14 +630,14 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         if (lane >= off) { inc_p += op; inc_s += os; }
     }
     const int wv = tid >> 6;
-    const unsigned long long big_bal = __ballot(big), small_bal = __ballot(small), s64_bal = __ballot(s64), giant_bal = __ballot(giant);
+    const unsigned long long big_bal = __ballot(big), small_bal = __ballot(small);
     const unsigned long long own_bal = __ballot(owns && mode != 1);  // tasks that read a current row: private owners + node scorings
     // distributions served from the cache: gather tasks of the weights kernel + walks that will gather themselves (counted per
     // walk: nothing dedups them; the walks behind a self-gathering owner are not counted)
     const unsigned long long gat_bal = __ballot((owns && mode != 0) || self_early), node_bal = __ballot(owns && mode == 2), alive_bal = __ballot(alive);
     if (lane == 63) { wv_pch[wv] = inc_p; wv_sch[wv] = inc_s; }
     if (lane == 0) {
-        wv_big[wv] = __popcll(big_bal); wv_small[wv] = __popcll(small_bal); wv_s64[wv] = __popcll(s64_bal); wv_giant[wv] = __popcll(giant_bal);
+        wv_big[wv] = __popcll(big_bal); wv_small[wv] = __popcll(small_bal);
         wv_own[wv] = __popcll(own_bal); wv_gat[wv] = __popcll(gat_bal); wv_node[wv] = __popcll(node_bal); wv_alive[wv] = __popcll(alive_bal);
     }
     __syncthreads();
@@ -652,7 +647,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         unsigned long long val = 0;
         if (tid == 0) { word = &a.lc[CTR_CHUNKS + a.level]; val = tot(wv_pch) | (tot(wv_sch) << 32); }
         else if (tid == 1) { word = &a.lc[CTR_BIG + a.level]; val = tot(wv_big) | (tot(wv_small) << 32); }
-        else if (tid == 2) { word = &a.lc[CTR_TINY + a.level]; val = tot(wv_s64) | (tot(wv_giant) << 32); }
+        else if (tid == 2) { word = &a.lc[CTR_TINY + a.level]; val = 0; }  // (spare)
         else if (tid == 3) { word = &a.lc[CTR_DISTS + (blockIdx.x & 63)]; val = tot(wv_own); }
         else if (tid == 4) { word = &a.lc[CTR_GATHER + (blockIdx.x & 63)]; val = tot(wv_gat); }
         else if (tid == 5) { word = &a.lc[CTR_NODES + (blockIdx.x & 63)]; val = tot(wv_node); }
@@ -661,10 +656,10 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         else if (val) atomicAdd(word, val);
     }
     __syncthreads();
-    int pch_before = 0, sch_before = 0, big_before = 0, small_before = 0, s64_before = 0, giant_before = 0, blk_pch = 0, blk_sch = 0;
+    int pch_before = 0, sch_before = 0, big_before = 0, small_before = 0, blk_pch = 0, blk_sch = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        if (i < wv) { pch_before += wv_pch[i]; sch_before += wv_sch[i]; big_before += wv_big[i]; small_before += wv_small[i]; s64_before += wv_s64[i]; giant_before += wv_giant[i]; }
+        if (i < wv) { pch_before += wv_pch[i]; sch_before += wv_sch[i]; big_before += wv_big[i]; small_before += wv_small[i]; }
         blk_pch += wv_pch[i];
         blk_sch += wv_sch[i];
     }
@@ -698,8 +693,6 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         // the task lists of the weights kernel: big tasks from the front of lv_big, small ones from its back
         if (big) a.lv_big[(blk_base[1] & 0xffffffffull) + big_before + __popcll(big_bal & ((1ull << lane) - 1ull))] = (int32_t)w;
         if (small) a.lv_big[a.lv_big_cap - 1 - (int64_t)((blk_base[1] >> 32) + small_before + __popcll(small_bal & ((1ull << lane) - 1ull)))] = (int32_t)w;
-        if (s64) a.lv_s64[(int64_t)(blk_base[2] & 0xffffffffull) + s64_before + __popcll(s64_bal & ((1ull << lane) - 1ull))] = (int32_t)w;
-        if (giant) a.lv_s64[a.lv_big_cap - 1 - (int64_t)((blk_base[2] >> 32) + giant_before + __popcll(giant_bal & ((1ull << lane) - 1ull)))] = (int32_t)w;
         if (write_desc == 1 && fits) {
             if (mode == 2)
                 for (int i = 0; i < s_chunks; ++i) write_node_desc(a.lv_chunk_desc, coff_s + i, cur, deg, e0, i);
@@ -914,122 +907,94 @@ __device__ __forceinline__ void weights_small_tasks(const WalkArgs &a, const int
     }
 }
 
-constexpr int SMALL_BLOCKS = 1024;  // workgroups of the weights launch that serve the small-task list (= WEIGHTS_BLOCKS)
+constexpr int SMALL_BLOCKS = 2048;  // workgroups of the weights launch that serve the small-task list
 constexpr int SMALL_NT = 1;  // tasks a 16-lane group has in flight
-constexpr int S64_BLOCKS = 1024, S64_NT = 4;
-__device__ __forceinline__ void weights_s64_blocks(const WalkArgs &a, const int block) {
-    const int t = threadIdx.x & 15;
-    const int64_t n = (int64_t)(a.lc[CTR_TINY + a.level] & 0xffffffffull);
-    for (int64_t i = ((int64_t)block * 16 + (threadIdx.x >> 4)) * S64_NT; i < n; i += (int64_t)S64_BLOCKS * 16 * S64_NT)
-        weights_small_tasks<4, S64_NT>(a, a.lv_s64, i, n, 1, t);
-}
 __device__ __forceinline__ void weights_small_blocks(const WalkArgs &a, const int block) {
     const int t = threadIdx.x & 15;
     const int64_t n_small = (int64_t)(a.lc[CTR_BIG + a.level] >> 32);
     for (int64_t i = ((int64_t)block * 16 + (threadIdx.x >> 4)) * SMALL_NT; i < n_small; i += (int64_t)SMALL_BLOCKS * 16 * SMALL_NT)
         weights_small_tasks<BIG_TASK / 16, SMALL_NT>(a, a.lv_big + a.lv_big_cap - 1, i, n_small, -1, t);  // (the small list grows down from the end of lv_big)
 }
-// Big owner tasks (hubs, k > BIG_TASK).  What bounds them is the LATENCY of the longest one -- a hub distribution of 8 000
-// candidates handled 2 048 at a time was eight serial rounds of two dependent gathers (edge index -> score) plus barriers,
-// ~60 us, and that single task was the critical path of the whole weights launch -- and, for the thousands of mid-size ones,
-// how many tasks the chip holds at once.  So a thread owns WIDE_PT = 16 CONSECUTIVE candidates (all of its gathers in flight
-// together, its scores kept in registers between the max and the scan pass, the fixed-point weights recomputed instead of
-// stored, 128 contiguous bytes written), and the unit that shares a task is sized by it:
-//   257 .. 1 024 candidates: one WAVEFRONT per task (one shot, no LDS, no barriers, four tasks per workgroup),
-//   larger ("giant")       : one WORKGROUP per task, 4 096 candidates per round; their workgroups are dispatched first.
-template <int NTHREADS>
-__device__ __forceinline__ void weights_wide_task(const WalkArgs &a, const int64_t w, const int tix) {
+// Big owner tasks (hubs): one 256-thread workgroup per task, from the level's big-task list, in tiles of BIG_TILE candidates.
+// A thread owns BIG_PT CONSECUTIVE candidates of the tile: the max and the scan need one block-wide combination each (two
+// barrier pairs per tile; lane-strided rows of 256 cost a barrier pair per row, sixteen per tile), the thread's own prefix
+// is a register loop, and it stores 64 contiguous bytes.  A task of up to one tile keeps its scores in registers between
+// the max and the scan pass; larger ones read them twice.
+constexpr int BIG_PT = 8;
+constexpr int BIG_TILE = 256 * BIG_PT;
+constexpr int BIG_BLOCKS = 2048;  // workgroups of the weights launch that serve the big-task list
+__device__ __forceinline__ void weights_big_blocks(const WalkArgs &a) {
     __shared__ float red[4];
     __shared__ uint64_t wave_tot[4];
-    constexpr int TILE = NTHREADS * WIDE_PT;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const TaskScores ts = task_scores(a, w);
-    const int k = ts.k;
-    uint64_t *const pf = a.lv_prefix + a.lv_pfx[w] * CHUNK;
-    auto load_tile = [&](int j0, float (&v)[WIDE_PT]) {  // candidates j0 + 32 * tix + [0, 32)
-        const int jb = j0 + WIDE_PT * tix;
-        if (ts.gather) {
-            int e[WIDE_PT];
+    const int n_big = (int)(a.lc[CTR_BIG + a.level] & 0xffffffffull);
+    for (int b = blockIdx.x; b < n_big; b += BIG_BLOCKS) {
+        const int64_t w = a.lv_big[b];
+        const TaskScores ts = task_scores(a, w);
+        const int k = ts.k;
+        uint64_t *const pf = a.lv_prefix + a.lv_pfx[w] * CHUNK;
+        auto load_tile = [&](int j0, float (&v)[BIG_PT]) {  // candidates j0 + 16 * thread + [0, 16)
+            const int jb = j0 + BIG_PT * (int)threadIdx.x;
+            if (ts.gather) {
+                int e[BIG_PT];
 #pragma unroll
-            for (int i = 0; i < WIDE_PT; ++i) e[i] = (jb + i < k) ? ((jb + i == 0 && ts.hf) ? ts.fe : ts.edges[jb + i]) : -1;
+                for (int i = 0; i < BIG_PT; ++i) e[i] = (jb + i < k) ? ((jb + i == 0 && ts.hf) ? ts.fe : ts.edges[jb + i]) : -1;
 #pragma unroll
-            for (int i = 0; i < WIDE_PT; ++i) v[i] = e[i] >= 0 ? a.es[e[i]] : -INFINITY;
-        } else {
+                for (int i = 0; i < BIG_PT; ++i) v[i] = e[i] >= 0 ? a.es[e[i]] : -INFINITY;
+            } else {
 #pragma unroll
-            for (int i = 0; i < WIDE_PT; ++i) v[i] = (jb + i < k) ? ts.sc[jb + i] : -INFINITY;
+                for (int i = 0; i < BIG_PT; ++i) v[i] = (jb + i < k) ? ts.sc[jb + i] : -INFINITY;
+            }
+        };
+        float v[BIG_PT];
+        float mx = -INFINITY;
+        for (int j0 = 0; j0 < k; j0 += BIG_TILE) {
+            load_tile(j0, v);
+#pragma unroll
+            for (int i = 0; i < BIG_PT; ++i) mx = fmaxf(mx, v[i]);
         }
-    };
-    float v[WIDE_PT];
-    float mx = -INFINITY;
-    for (int j0 = 0; j0 < k; j0 += TILE) {
-        load_tile(j0, v);
-#pragma unroll
-        for (int i = 0; i < WIDE_PT; ++i) mx = fmaxf(mx, v[i]);
-    }
-    mx = wave_max_f32(mx);
-    if (NTHREADS > 64) {
+        mx = wave_max_f32(mx);
         __syncthreads();
         if (lane == 0) red[wv] = mx;
         __syncthreads();
         mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    }
-    uint64_t carry = 0;
-    for (int j0 = 0; j0 < k; j0 += TILE) {
-        if (k > TILE) load_tile(j0, v);  // (a single tile is still in registers)
-        const int jb = j0 + WIDE_PT * tix;
-        uint64_t tot = 0;
+        uint64_t carry = 0;
+        for (int j0 = 0; j0 < k; j0 += BIG_TILE) {
+            if (k > BIG_TILE) load_tile(j0, v);  // (a single tile is still in registers)
+            const int jb = j0 + BIG_PT * (int)threadIdx.x;
+            uint64_t c[BIG_PT], run = 0;
 #pragma unroll
-        for (int i = 0; i < WIDE_PT; ++i) tot += (jb + i < k) ? weight_fix40(exp_spec(v[i] - mx)) : 0ull;
-        const uint64_t inc = wave_incl_scan_u64(tot, lane);
-        uint64_t run = carry + inc - tot, all = __shfl(inc, 63, 64);
-        if (NTHREADS > 64) {
+            for (int i = 0; i < BIG_PT; ++i) {
+                run += (jb + i < k) ? weight_fix40(exp_spec(v[i] - mx)) : 0ull;
+                c[i] = run;
+            }
+            const uint64_t inc = wave_incl_scan_u64(run, lane);
             __syncthreads();
             if (lane == 63) wave_tot[wv] = inc;
             __syncthreads();
-            all = 0;
+            uint64_t pre = carry + inc - run, tot = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (i < wv) run += wave_tot[i];
-                all += wave_tot[i];
+                if (i < wv) pre += wave_tot[i];
+                tot += wave_tot[i];
             }
-        }
 #pragma unroll
-        for (int i = 0; i < WIDE_PT; ++i) {
-            if (jb + i < k) {
-                run += weight_fix40(exp_spec(v[i] - mx));
-                pf[jb + i] = run;
-            }
+            for (int i = 0; i < BIG_PT; ++i)
+                if (jb + i < k) pf[jb + i] = pre + c[i];
+            carry += tot;
         }
-        carry += all;
     }
 }
 
-constexpr int WEIGHTS_BLOCKS = 1024;  // workgroups per class of the weights launch (4 classes, interleaved over the block index)
-__device__ __forceinline__ void weights_giant_blocks(const WalkArgs &a, const int block) {
-    const int n_giant = (int)(a.lc[CTR_TINY + a.level] >> 32);
-    for (int b = block; b < n_giant; b += WEIGHTS_BLOCKS) weights_wide_task<256>(a, a.lv_s64[a.lv_big_cap - 1 - b], (int)threadIdx.x);
-}
-__device__ __forceinline__ void weights_big_blocks(const WalkArgs &a, const int block) {  // block in [0, 2 * WEIGHTS_BLOCKS): two classes' worth
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int n_big = (int)(a.lc[CTR_BIG + a.level] & 0xffffffffull);
-    for (int b = block * 4 + wv; b < n_big; b += 2 * WEIGHTS_BLOCKS * 4) weights_wide_task<64>(a, a.lv_big[b], lane);
-}
-
-// One launch per level for all task classes: giants (a workgroup per task) + big tasks (a wavefront per task), 16-lane groups
-// for the tasks of 65 .. 256 candidates, and the 17 .. 64-candidate tasks four per group at a time.  As back-to-back launches the classes cost the sum of their
-// latency-bound run times; together, the longest.
+// One launch per level for all task classes: the first BIG_BLOCKS workgroups walk the big-task list (they run
+// longest, so they are dispatched first), the others take 16 small tasks each per round.  As back-to-back launches the
+// classes cost the sum of their latency-bound run times; together, the longest.
 __global__ __launch_bounds__(256) void level_weights_kernel(const WalkArgs a, const int64_t cap_chunks) {
     const unsigned long long cw = a.lc[CTR_CHUNKS + a.level];
     const int64_t pch = (int64_t)(cw & 0xffffffffull), sch = (int64_t)(cw >> 32);
     if (sch > cap_chunks || pch == 0 || level_chunk_base(a) + pch > a.cap_total) return;
-    // The classes are INTERLEAVED over the block index (block b serves class b % 4): workgroups are dispatched in index order,
-    // so with one class after the other the small tasks only started once the big tasks' workgroups had drained -- the
-    // classes' latency-bound run times added up instead of overlapping.
-    const int cls = (int)(blockIdx.x & 3u), blk = (int)(blockIdx.x >> 2);
-    if (cls == 0) { if (!(a.exp & 1)) { weights_giant_blocks(a, blk); weights_big_blocks(a, blk); } }
-    else if (cls == 1) { if (!(a.exp & 1)) weights_big_blocks(a, WEIGHTS_BLOCKS + blk); }
-    else if (cls == 2) { if (!(a.exp & 2)) weights_small_blocks(a, blk); }
-    else if (!(a.exp & 4)) weights_s64_blocks(a, blk);
+    if (blockIdx.x < BIG_BLOCKS) { if (!(a.exp & 1)) weights_big_blocks(a); }
+    else if (!(a.exp & 2)) weights_small_blocks(a, (int)blockIdx.x - BIG_BLOCKS);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1314,7 +1279,6 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
         for (int k = 0; k < 2; ++k) {
             h[k].lc = ctx->dev_ctr + (size_t)k * CTR_WORDS;
             h[k].lv_big = a.lv_big + h[k].w0;
-            h[k].lv_s64 = a.lv_s64 + h[k].w0;
             h[k].lv_big_cap = h[k].w_end - h[k].w0;
             h[k].lv_scores = a.lv_scores + (size_t)k * cap * CHUNK;
             h[k].lv_chunk_desc = a.lv_chunk_desc + (size_t)k * cap;
@@ -1383,7 +1347,8 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
                 ctx->lv_ev_used = level + 1;
             }
             if (split) GG_HIP(ctx, hipEventRecord(ctx->ev_score[k], hs[k]));
-            hipLaunchKernelGGL(level_weights_kernel, dim3(4u * 1024u), dim3(256), 0, hs[k], x, cap);
+            const int64_t half_walks = x.w_end - x.w0;
+            hipLaunchKernelGGL(level_weights_kernel, dim3((unsigned)(BIG_BLOCKS + std::min<int64_t>(SMALL_BLOCKS, cdiv(half_walks * 16, 256)))), dim3(256), 0, hs[k], x, cap);
         }
     }
     // finish the last prepared hop
@@ -1426,7 +1391,7 @@ static int run_levels_and_finish(gg_ctx *ctx, WalkArgs &a, int64_t total_walks) 
         GG_HIP(ctx, ctx->lv_beg.reserve(sizeof(int64_t) * total_walks));
         GG_HIP(ctx, ctx->lv_k.reserve(sizeof(int32_t) * total_walks));
         GG_HIP(ctx, ctx->lv_chunks.reserve(sizeof(int32_t) * total_walks));
-        GG_HIP(ctx, ctx->lv_big.reserve(sizeof(int32_t) * 2 * total_walks));  // [0, W): big / small task lists, [W, 2W): tasks with 17 .. 64 candidates
+        GG_HIP(ctx, ctx->lv_big.reserve(sizeof(int32_t) * total_walks));
         GG_HIP(ctx, ctx->lv_fe.reserve(sizeof(int32_t) * total_walks));
         GG_HIP(ctx, ctx->lv_coff.reserve(sizeof(int64_t) * (total_walks + 1)));
         GG_HIP(ctx, ctx->lv_pfx.reserve(sizeof(int64_t) * (total_walks + 1)));
@@ -1443,7 +1408,6 @@ static int run_levels_and_finish(gg_ctx *ctx, WalkArgs &a, int64_t total_walks) 
         a.lv_k = ctx->lv_k.as<int32_t>();
         a.lv_chunks = ctx->lv_chunks.as<int32_t>();
         a.lv_big = ctx->lv_big.as<int32_t>();
-        a.lv_s64 = a.lv_big + total_walks;
         a.lv_fe = ctx->lv_fe.as<int32_t>();
         a.lv_coff = ctx->lv_coff.as<int64_t>();
         a.lv_pfx = ctx->lv_pfx.as<int64_t>();
