@@ -440,9 +440,9 @@ def main():
         "roofline_k34": {"bound": "hbm (fp32 atomics in L2)", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "bytes_model": "gradient kernel 16d + 20 per pair; whole step (gradient + optimizer) 48d + 36 per pair (SURVEY 8d, lazy Adam); "
                                         "traffic_* = HBM bytes of the PMC passes / the same event time: what the atomics really move",
-                         "d": dict({"kernel": "pair_grad_kernel (+ count / segment / slot kernels when staged)", "staged": bool(staged), "achieved": kd_g, "frac": frac(kd_g), "step_achieved": kd_s, "step_frac": frac(kd_s),
+                         "d": dict({"kernel": "pair_grad16_kernel (+ count / segment / slot kernels when staged)", "staged": bool(staged), "achieved": kd_g, "frac": frac(kd_g), "step_achieved": kd_s, "step_frac": frac(kd_s),
                                     "pairs": int(c["d_pairs_timed"]), "grad_ms": c["d_grad_ms"], "passes": int(c["d_passes_timed"])},
-                                   **by_traffic("pair_grad_kernel", c["d_grad_ms"], c["d_passes_timed"])),
+                                   **by_traffic("pair_grad16_kernel", c["d_grad_ms"], c["d_passes_timed"])),
                          "g": dict({"kernel": "path_grad_kernel (+ count / segment / slot kernels when staged): reads every path node once and emits one gradient row per node",
                                     "bytes_model": "8d + 16 per path node (row read + gradient row written)", "path_nodes": int(g_nodes),
                                     "achieved": kg_nodes, "frac": frac(kg_nodes), "pairs": int(c["g_pairs_timed"]),
