@@ -267,8 +267,8 @@ int gg::walk_finalize(gg_ctx *ctx, bool *retried) {
             ctx->ctr.score_launches += n_half;
             ctx->ctr.score_chunks += (int64_t)(c[136 + i] >> 32);
             if (getenv("GG_WALK_DEBUG"))
-                fprintf(stderr, "[walk] for_d=%d level %d alive %llu score chunks %llu prefix chunks %llu big %llu small %llu score %.1f us\n", ctx->w_args.for_d, i,
-                        c[8 + i], c[136 + i] >> 32, c[136 + i] & 0xffffffffull, c[72 + i] & 0xffffffffull, c[72 + i] >> 32, lms * 1e3);
+                fprintf(stderr, "[walk] for_d=%d level %d alive %llu score chunks %llu prefix chunks %llu big %llu small %llu rows %llu score %.1f us\n", ctx->w_args.for_d, i,
+                        c[8 + i], c[136 + i] >> 32, c[136 + i] & 0xffffffffull, c[72 + i] & 0xffffffffull, c[72 + i] >> 32, c[456 + i], lms * 1e3);
         }
         if (ctx->lv_ev_used) {
             ctx->ctr.score_rows += (int64_t)(rows - c[5]);  // rows of the timed score launches

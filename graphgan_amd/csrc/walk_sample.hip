@@ -390,7 +390,13 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
             const int kk = kraw & LVK_MASK, hf0 = (int)((unsigned)kraw >> 31);
             my_k = (unsigned long long)kk;
             int lo = 0;
-            if (kraw & LVK_SELF) {
+            if (kk == 1) {
+                // ONE candidate (a leaf of the tree: its list is [father]; or an only child): it is picked whatever its score
+                // and the uniform are -- weight 2^40 of 2^40 -- so nothing was scored for it (at the deep levels of a
+                // small-world tree most walks stand on leaves: 47 k one-row score chunks per level-4 launch of the bench).
+                // (A non-finite score of such a candidate no longer raises GG_EINVAL by itself; any distribution with two
+                // candidates still does.)
+            } else if (kraw & LVK_SELF) {
                 // <= 16 candidates on a node whose adjacency is in the edge-score cache: gather the scores through the tree's
                 // edge indices and evaluate the distribution right here -- max, exact fixed-point weights, running sum, first
                 // j whose sum exceeds the threshold (spec S2-S5: the same integers as a search in stored prefix sums)
@@ -555,7 +561,8 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     }
     // <= 16 candidates on a node whose adjacency is (or is being) scored into the edge-score cache: the walk evaluates its
     // distribution itself when it samples (LVK_SELF) -- no owner, no chunks, no prefix sums, nothing for the weights kernel
-    const bool self_early = alive && a.es_mode && k <= CHUNK && st >= a.es_valid_from && st <= a.es_now;
+    // (and a distribution with ONE candidate needs nothing at all: see the sampling branch above)
+    const bool self_early = alive && (k == 1 || (a.es_mode && k <= CHUNK && st >= a.es_valid_from && st <= a.es_now));
     // G launch: was this very distribution evaluated by the D launch of the step?  (Same slot, same node, same
     // father flag => same candidate list; same generator tables => same prefix sums, bit for bit.)
     bool cached = false;
@@ -634,7 +641,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     const unsigned long long own_bal = __ballot(owns && mode != 1);  // tasks that read a current row: private owners + node scorings
     // distributions served from the cache: gather tasks of the weights kernel + walks that will gather themselves (counted per
     // walk: nothing dedups them; the walks behind a self-gathering owner are not counted)
-    const unsigned long long gat_bal = __ballot((owns && mode != 0) || self_early), node_bal = __ballot(owns && mode == 2), alive_bal = __ballot(alive);
+    const unsigned long long gat_bal = __ballot((owns && mode != 0) || (self_early && k > 1)), node_bal = __ballot(owns && mode == 2), alive_bal = __ballot(alive);
     if (lane == 63) { wv_pch[wv] = inc_p; wv_sch[wv] = inc_s; }
     if (lane == 0) {
         wv_big[wv] = __popcll(big_bal); wv_small[wv] = __popcll(small_bal);
@@ -826,6 +833,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const
     if (t == 0 && rows) atomicAdd(&blk_rows, rows);
     __syncthreads();
     if (threadIdx.x == 0 && blk_rows) atomicAdd(&a.lc[CTR_ROWS + (blockIdx.x & 63)], blk_rows);
+    if ((a.exp & 8) && threadIdx.x == 0 && blk_rows) atomicAdd(&a.lc[CTR_TINY + a.level], blk_rows);  // GG_WALK_EXPERIMENT & 8: rows per LEVEL (same-address atomics: a ~20 us tail)
 }
 
 // Where the scores of owner walk w's distribution are: its private score region, or (gather) the edge-score cache through
