@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     ho[tid] = 0x7fffffff; ho[tid + 256] = 0x7fffffff;
     __syncthreads();
     if (blk_skip) return;
-    bool alive = false, sampled = false;
+    bool alive = false, sampled = false, forced = false;
     int item = 0, cur = -1, k = 0, hf = 0, father = -1, slot_w = 0, rank_w = 0, up_edge = -1;
     unsigned long long my_k = 0;
     int64_t beg_abs = 0;
@@ -525,6 +525,25 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
                 a.path_len[w] = 0;
                 a.samples[w] = -1;
             }
+            // A LEAF: the list is [father] alone, so the next hop is the back-step and the walk ends (:264-266) -- finished right
+            // here instead of in another round of level kernels (at the deep levels of a small-world tree that is nearly every
+            // walk: 59 k of the bench's walks were alive at hop 4 only to step back).  The hop's uniform is not needed (counter
+            // RNG: nothing to consume); the hop and its one candidate are counted like a sampled hop.
+            if (alive && k == 1 && hf) {
+                const int len_now = a.level == 0 ? 1 : len + 1;  // entries in the path so far
+                if (len_now >= a.stride) {
+                    a.ctr[3] = 1ull;
+                    a.path_len[w] = 0;
+                    a.samples[w] = -1;
+                } else {
+                    a.paths[w * (int64_t)a.stride + len_now] = father;
+                    a.path_len[w] = len_now + 1;
+                    a.samples[w] = cur;
+                }
+                alive = false;
+                k = 0;
+                forced = true;
+            }
             beg_abs = tbase + cbeg;
         }
         if (alive) {
@@ -538,12 +557,13 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         if (alive && !do_setup && write_desc == 2) a.ctr[3] = 2ull;
     }
     if (in_range) a.st_alive[w] = alive ? 1 : 0;
-    if (do_sample) {
-        const unsigned long long bal = __ballot(sampled);
+    {
+        const unsigned long long bal = __ballot(sampled), fbal = __ballot(forced);  // hops sampled here + leaf back-steps finished here
+        my_k += forced ? 1ull : 0ull;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) my_k += __shfl_xor(my_k, off, 64);
-        if (lane == 0 && bal) {
-            atomicAdd(&a.lc[CTR_HOPS_V + (blockIdx.x & 63)], (unsigned long long)__popcll(bal));
+        if (lane == 0 && (bal | fbal)) {
+            atomicAdd(&a.lc[CTR_HOPS_V + (blockIdx.x & 63)], (unsigned long long)(__popcll(bal) + __popcll(fbal)));
             atomicAdd(&a.lc[CTR_READS_V + (blockIdx.x & 63)], my_k);
         }
     }
