@@ -297,6 +297,8 @@ __device__ __forceinline__ void write_node_desc(int4 *desc, int64_t c, int cur, 
 //   do_setup : prepare hop (level) -- tree list of (root, cur) with the reference's hop rules
 //              (root-only-children, Q2 abort, Q3 father removal) and the in-workgroup dedup: walks of
 //              one root standing on the same node need the SAME distribution -> one owner.
+//              do_setup == 2 (the launch's last advance): the hop rules only -- a walk that has just reached a leaf
+//              steps back and ends right there, like in every other round -- no distributions are set up.
 // The kernel is ONE CHAIN OF DEPENDENT RANDOM READS per walk at two to three wavefronts per SIMD: its run time is the length
 // of that chain (a level with 1 800 live walks took as long as one with 160 000: ~35 us = 16 round trips).  So every load
 // is issued as early as its address is known, independent of the branches around it -- per-walk state before the liveness
@@ -554,7 +556,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         rank_w = rank;
         // the sync-free launch ran only as many levels as earlier launches needed: a walk that is
         // still going after the last one sends the launch to the sized rerun
-        if (alive && !do_setup && write_desc == 2) a.ctr[3] = 2ull;
+        if (alive && do_setup != 1 && write_desc == 2) a.ctr[3] = 2ull;
     }
     if (in_range) a.st_alive[w] = alive ? 1 : 0;
     {
@@ -567,7 +569,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
             atomicAdd(&a.lc[CTR_READS_V + (blockIdx.x & 63)], my_k);
         }
     }
-    if (!do_setup) {
+    if (do_setup != 1) {
         // behind the last streamed level: the walks that are still going, as a compact list for the finisher (it used to
         // draw one ticket per WALK, finished or not: 160 k same-address atomics, ~2 ms, to find a few thousand live walks)
         const unsigned long long abal = __ballot(alive);
@@ -1384,7 +1386,7 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
         WalkArgs &x = h[k];
         x.level = level;
         const unsigned wblocks = (unsigned)cdiv(x.w_end - x.w0, 256);
-        hipLaunchKernelGGL(level_advance_kernel, dim3(wblocks), dim3(256), 0, hs[k], x, 1, 0, (!sized && all_levels && !finisher_follows) ? 2 : 0, 0);
+        hipLaunchKernelGGL(level_advance_kernel, dim3(wblocks), dim3(256), 0, hs[k], x, 1, 2, (!sized && all_levels && !finisher_follows) ? 2 : 0, 0);
         if (a.dc_mode == 1) hipLaunchKernelGGL(dc_finish_kernel, dim3(1), dim3(1), 0, hs[k], x, ctx->dc_words.as<int64_t>() + 2 * k, level);
     }
     if (split) {
