@@ -409,6 +409,7 @@ def main():
         "hops_per_step_rank0": hops / args.steps,
         "mean_k": reads / max(hops, 1),
         "rows_scored_per_step_rank0": rows_scored / args.steps,
+        "walk_reruns_in_timed_region": c["walk_reruns"],  # sync-free launches repeated in sized mode (0 in steady state)
         "edge_score_cache": {"distributions_gathered_per_step": c["es_gathers"] / args.steps, "nodes_scored_whole_per_step": c["es_nodes"] / args.steps,
                              "what": "s(u, v) of a graph edge does not depend on the root: a node's adjacency is scored once per generator state "
                                      "and shared by the (root, node) distributions of all roots, levels and both walk launches of a step"},

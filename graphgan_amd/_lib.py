@@ -41,7 +41,8 @@ class GGCounters(ctypes.Structure):
                 ("g_grad_ms", ctypes.c_double), ("g_opt_ms", ctypes.c_double), ("g_pairs_timed", ctypes.c_int64), ("g_rows_timed", ctypes.c_int64),
                 ("d_passes_timed", ctypes.c_int64), ("g_passes_timed", ctypes.c_int64),
                 ("g_walk_nodes_timed", ctypes.c_int64),
-                ("es_gathers", ctypes.c_int64), ("es_nodes", ctypes.c_int64), ("score_gathers", ctypes.c_int64), ("score_nodes", ctypes.c_int64)]
+                ("es_gathers", ctypes.c_int64), ("es_nodes", ctypes.c_int64), ("score_gathers", ctypes.c_int64), ("score_nodes", ctypes.c_int64),
+                ("walk_reruns", ctypes.c_int64)]
 
 
 class GGGraph(ctypes.Structure):

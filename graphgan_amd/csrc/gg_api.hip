@@ -222,6 +222,7 @@ int gg::walk_finalize(gg_ctx *ctx, bool *retried) {
         // nothing the overflowed launch wrote or counted is final (the D-mode post-pass is gated by the same flag,
         // the counter words are zeroed again by the new launch)
         ctx->walk_force_sized = true;
+        ctx->ctr.walk_reruns += 1;
         generator_changed(ctx);  // nodes the aborted launch claimed were never scored: no stamp of it may stay valid
         int rc = launch_and_join(ctx, ctx->w_nslots, total, ctx->w_args.for_d, ctx->w_args.seed, ctx->w_args.stream, ctx->w_stride);
         ctx->walk_force_sized = false;

@@ -114,6 +114,8 @@ typedef struct gg_counters {
     int64_t es_nodes;       /* nodes whose whole adjacency was scored into the cache */
     int64_t score_gathers;  /* ... of the timed launches (the cadence of score_rows / score_dists) */
     int64_t score_nodes;
+    int64_t walk_reruns;    /* sync-free walk launches that overflowed their learned buffer capacity / level count and were
+                               repeated in sized mode (expected: the first launches of a workload, then none) */
 } gg_counters;
 
 typedef struct gg_ctx gg_ctx;

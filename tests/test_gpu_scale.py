@@ -209,6 +209,38 @@ def test_scale_mode_epochs_on_the_100k_split_match_the_oracle_trainer(ga):
         assert abs(acc_e - acc_o) <= 0.005, (acc_e, acc_o)
 
 
+def test_steady_state_steps_need_no_rerun_and_reuse_the_cache(ga):
+    """Performance contract of the sync-free walk launches (a bug here is invisible to the parity tests: a rerun gives the
+    same walks): after the first steps have sized the level buffers and learned how many levels the walks need, NO launch is
+    repeated in sized mode -- in particular a walk that reaches a leaf in the launch's last round ends there instead of
+    counting as "still alive" -- and the G-mode launch of a step scores far fewer rows than its D-mode launch (it gathers
+    from the edge-score cache the D launch filled: a rerun would invalidate it)."""
+    from graphgan_amd import workloads
+    n, d = 50_000, 64
+    rowptr, col, emb, _ = workloads.powerlaw_workload(n, 10, d)
+    roots = workloads.bench_roots(rowptr, 2048, 0, 1, 6)
+    slots = np.arange(len(roots), dtype=np.int32)
+    eng = ga.Engine(emb, emb, optimizer=ga.GG_OPT_ADAM_LAZY)
+    eng.set_graph_csr(rowptr, col)
+    eng.build_trees(roots, device=True)
+    eng.set_profiling(0)
+    reruns, d_rows, g_rows = [], [], []
+    for i in range(8):
+        c0 = eng.counters()
+        eng.prepare_d(slots, 6, 2 * i, fetch=False)
+        c1 = eng.counters()
+        eng.d_pass([0], 1 << 30)
+        eng.prepare_g(slots, 20, 6, 2 * i + 1, fetch=False)
+        c2 = eng.counters()
+        eng.g_pass([0], 1 << 30)
+        reruns.append(c2["walk_reruns"])
+        d_rows.append(c1["rows_scored"] - c0["rows_scored"])
+        g_rows.append(c2["rows_scored"] - c1["rows_scored"])
+    eng.close()
+    assert reruns[-1] == reruns[3], reruns            # nothing repeated from the fifth step on
+    assert all(g < 0.6 * dd for g, dd in zip(g_rows[4:], d_rows[4:])), (d_rows, g_rows)
+
+
 def _compare_walks(got, want, item_ptr, sel, stride_w, tag):
     """walks of the selected roots: got = engine launch over all roots (walk_ptr = item_ptr), want = oracle over sel"""
     o = 0
