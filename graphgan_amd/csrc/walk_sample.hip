@@ -101,7 +101,7 @@ struct WalkArgs {
     int32_t es_mode;         // 0 = off, 1 = a stale node is scored whole when the asking distribution needs most of it, 2 = always
     int32_t es_ratio, es_hub;
     int32_t *lv_fe;          // [total_walks] es index of the father candidate's score (gather tasks with a father entry)
-    int32_t exp;             // GG_WALK_EXPERIMENT: timing ablations (results are then WRONG): 1 / 2 = the weights kernel skips its big / small tasks, 64 / 32 = runs them twice (results stay right), 8 = per-level row counts
+    int32_t exp;             // GG_WALK_EXPERIMENT: timing ablations (results are then WRONG): 1 / 2 = the weights kernel skips its big / small tasks
 };
 
 __device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, int lane) {
@@ -945,97 +945,74 @@ __device__ __forceinline__ void weights_small_blocks(const WalkArgs &a, const in
     for (int64_t i = ((int64_t)block * 16 + (threadIdx.x >> 4)) * SMALL_NT; i < n_small; i += (int64_t)SMALL_BLOCKS * 16 * SMALL_NT)
         weights_small_tasks<BIG_TASK / 16, SMALL_NT>(a, a.lv_big + a.lv_big_cap - 1, i, n_small, -1, t);  // (the small list grows down from the end of lv_big)
 }
-// Big owner tasks (hubs, k > BIG_TASK), from the level's big-task list.  `GG_WALK_EXPERIMENT=64` (the class run twice) puts them
-// at about half of the weights kernel's time: with a workgroup per task the chip holds 1 280 of them at a time, 3.5 rounds for
-// the 4 500 hub distributions of the bench's third level, each round two dependent gathers (edge index -> score) plus two
-// barrier pairs.  So the unit that shares a task is sized by it: up to BIG_WAVE_MAX candidates a WAVEFRONT takes the task in one
-// shot (a lane owns WIDE_PT consecutive candidates: all its gathers in flight together, scores kept in registers between the
-// max and the scan pass, 128 contiguous bytes written; no LDS, no barriers, four tasks per workgroup in flight); larger
-// ("giant") tasks -- the longest single ones, and the critical path when a wavefront had to loop over them alone -- keep the
-// whole workgroup, 256 x WIDE_PT candidates per round.  Both kinds sit in one list: the workgroups first serve the giants they
-// find (entries blockIdx, blockIdx + BIG_BLOCKS, ...), then their wavefronts the others.
-constexpr int WIDE_PT = 16;
-constexpr int BIG_WAVE_MAX = 64 * WIDE_PT;
+// Big owner tasks (hubs): one 256-thread workgroup per task, from the level's big-task list, in tiles of BIG_TILE candidates.
+// A thread owns BIG_PT CONSECUTIVE candidates of the tile: the max and the scan need one block-wide combination each (two
+// barrier pairs per tile; lane-strided rows of 256 cost a barrier pair per row, sixteen per tile), the thread's own prefix
+// is a register loop, and it stores 64 contiguous bytes.  A task of up to one tile keeps its scores in registers between
+// the max and the scan pass; larger ones read them twice.
+constexpr int BIG_PT = 8;
+constexpr int BIG_TILE = 256 * BIG_PT;
 constexpr int BIG_BLOCKS = 2048;  // workgroups of the weights launch that serve the big-task list
-template <int NTHREADS>
-__device__ __forceinline__ void weights_wide_task(const WalkArgs &a, const TaskScores &ts, uint64_t *const pf, const int tix, float *red, uint64_t *wave_tot) {
-    constexpr int TILE = NTHREADS * WIDE_PT;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int k = ts.k;
-    auto load_tile = [&](int j0, float (&v)[WIDE_PT]) {  // candidates j0 + WIDE_PT * tix + [0, WIDE_PT)
-        const int jb = j0 + WIDE_PT * tix;
-        if (ts.gather) {
-            int e[WIDE_PT];
-#pragma unroll
-            for (int i = 0; i < WIDE_PT; ++i) e[i] = (jb + i < k) ? ((jb + i == 0 && ts.hf) ? ts.fe : ts.edges[jb + i]) : -1;
-#pragma unroll
-            for (int i = 0; i < WIDE_PT; ++i) v[i] = e[i] >= 0 ? a.es[e[i]] : -INFINITY;
-        } else {
-#pragma unroll
-            for (int i = 0; i < WIDE_PT; ++i) v[i] = (jb + i < k) ? ts.sc[jb + i] : -INFINITY;
-        }
-    };
-    float v[WIDE_PT];
-    float mx = -INFINITY;
-    for (int j0 = 0; j0 < k; j0 += TILE) {
-        load_tile(j0, v);
-#pragma unroll
-        for (int i = 0; i < WIDE_PT; ++i) mx = fmaxf(mx, v[i]);
-    }
-    mx = wave_max_f32(mx);
-    if (NTHREADS > 64) {
-        __syncthreads();
-        if (lane == 0) red[wv] = mx;
-        __syncthreads();
-        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    }
-    uint64_t carry = 0;
-    for (int j0 = 0; j0 < k; j0 += TILE) {
-        if (k > TILE) load_tile(j0, v);  // (a single tile is still in registers)
-        const int jb = j0 + WIDE_PT * tix;
-        uint64_t tot = 0;
-#pragma unroll
-        for (int i = 0; i < WIDE_PT; ++i) tot += (jb + i < k) ? weight_fix40(exp_spec(v[i] - mx)) : 0ull;
-        const uint64_t inc = wave_incl_scan_u64(tot, lane);
-        uint64_t run = carry + inc - tot, all = __shfl(inc, 63, 64);
-        if (NTHREADS > 64) {
-            __syncthreads();
-            if (lane == 63) wave_tot[wv] = inc;
-            __syncthreads();
-            all = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (i < wv) run += wave_tot[i];
-                all += wave_tot[i];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < WIDE_PT; ++i) {
-            if (jb + i < k) {
-                run += weight_fix40(exp_spec(v[i] - mx));  // (recomputed: cheaper than 16 64-bit partial sums kept alive)
-                pf[jb + i] = run;
-            }
-        }
-        carry += all;
-    }
-}
-
 __device__ __forceinline__ void weights_big_blocks(const WalkArgs &a) {
     __shared__ float red[4];
     __shared__ uint64_t wave_tot[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int n_big = (int)(a.lc[CTR_BIG + a.level] & 0xffffffffull);
-    for (int b = blockIdx.x; b < n_big; b += BIG_BLOCKS) {  // the giants among this workgroup's entries
+    for (int b = blockIdx.x; b < n_big; b += BIG_BLOCKS) {
         const int64_t w = a.lv_big[b];
-        if ((a.lv_k[w] & LVK_MASK) <= BIG_WAVE_MAX) continue;  // (uniform in the workgroup)
         const TaskScores ts = task_scores(a, w);
-        weights_wide_task<256>(a, ts, a.lv_prefix + a.lv_pfx[w] * CHUNK, (int)threadIdx.x, red, wave_tot);
-    }
-    for (int b = (int)blockIdx.x * 4 + wv; b < n_big; b += BIG_BLOCKS * 4) {  // the others: a task per wavefront
-        const int64_t w = a.lv_big[b];
-        if ((a.lv_k[w] & LVK_MASK) > BIG_WAVE_MAX) continue;
-        const TaskScores ts = task_scores(a, w);
-        weights_wide_task<64>(a, ts, a.lv_prefix + a.lv_pfx[w] * CHUNK, lane, red, wave_tot);
+        const int k = ts.k;
+        uint64_t *const pf = a.lv_prefix + a.lv_pfx[w] * CHUNK;
+        auto load_tile = [&](int j0, float (&v)[BIG_PT]) {  // candidates j0 + 16 * thread + [0, 16)
+            const int jb = j0 + BIG_PT * (int)threadIdx.x;
+            if (ts.gather) {
+                int e[BIG_PT];
+#pragma unroll
+                for (int i = 0; i < BIG_PT; ++i) e[i] = (jb + i < k) ? ((jb + i == 0 && ts.hf) ? ts.fe : ts.edges[jb + i]) : -1;
+#pragma unroll
+                for (int i = 0; i < BIG_PT; ++i) v[i] = e[i] >= 0 ? a.es[e[i]] : -INFINITY;
+            } else {
+#pragma unroll
+                for (int i = 0; i < BIG_PT; ++i) v[i] = (jb + i < k) ? ts.sc[jb + i] : -INFINITY;
+            }
+        };
+        float v[BIG_PT];
+        float mx = -INFINITY;
+        for (int j0 = 0; j0 < k; j0 += BIG_TILE) {
+            load_tile(j0, v);
+#pragma unroll
+            for (int i = 0; i < BIG_PT; ++i) mx = fmaxf(mx, v[i]);
+        }
+        mx = wave_max_f32(mx);
+        __syncthreads();
+        if (lane == 0) red[wv] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        uint64_t carry = 0;
+        for (int j0 = 0; j0 < k; j0 += BIG_TILE) {
+            if (k > BIG_TILE) load_tile(j0, v);  // (a single tile is still in registers)
+            const int jb = j0 + BIG_PT * (int)threadIdx.x;
+            uint64_t c[BIG_PT], run = 0;
+#pragma unroll
+            for (int i = 0; i < BIG_PT; ++i) {
+                run += (jb + i < k) ? weight_fix40(exp_spec(v[i] - mx)) : 0ull;
+                c[i] = run;
+            }
+            const uint64_t inc = wave_incl_scan_u64(run, lane);
+            __syncthreads();
+            if (lane == 63) wave_tot[wv] = inc;
+            __syncthreads();
+            uint64_t pre = carry + inc - run, tot = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i < wv) pre += wave_tot[i];
+                tot += wave_tot[i];
+            }
+#pragma unroll
+            for (int i = 0; i < BIG_PT; ++i)
+                if (jb + i < k) pf[jb + i] = pre + c[i];
+            carry += tot;
+        }
     }
 }
 
@@ -1046,13 +1023,8 @@ __global__ __launch_bounds__(256) void level_weights_kernel(const WalkArgs a, co
     const unsigned long long cw = a.lc[CTR_CHUNKS + a.level];
     const int64_t pch = (int64_t)(cw & 0xffffffffull), sch = (int64_t)(cw >> 32);
     if (sch > cap_chunks || pch == 0 || level_chunk_base(a) + pch > a.cap_total) return;
-    if (blockIdx.x < BIG_BLOCKS) {
-        if (!(a.exp & 1)) weights_big_blocks(a);
-        if (a.exp & 64) { __syncthreads(); weights_big_blocks(a); }    // timing ablation: the class twice (idempotent, results stay right)
-    } else {
-        if (!(a.exp & 2)) weights_small_blocks(a, (int)blockIdx.x - BIG_BLOCKS);
-        if (a.exp & 32) weights_small_blocks(a, (int)blockIdx.x - BIG_BLOCKS);
-    }
+    if (blockIdx.x < BIG_BLOCKS) { if (!(a.exp & 1)) weights_big_blocks(a); }
+    else if (!(a.exp & 2)) weights_small_blocks(a, (int)blockIdx.x - BIG_BLOCKS);
 }
 
 // ------------------------------------------------------------------------------------------
