@@ -62,6 +62,22 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_tile_offsets(int64_t *tile_
     if (threadIdx.x == 0) *total_out = carry;
 }
 
+// two independent tile-sum arrays in one launch (workgroup 0 / 1): the segment scan has two of them
+__global__ __launch_bounds__(SCAN_THREADS) void scan_tile_offsets2(int64_t *tile_sum_a, int64_t *tile_sum_b, int64_t n_tiles, int64_t *total_a, int64_t *total_b) {
+    __shared__ int64_t sh[SCAN_THREADS / 64];
+    int64_t *const tile_sum = blockIdx.x == 0 ? tile_sum_a : tile_sum_b;
+    int64_t carry = 0;
+    for (int64_t t0 = 0; t0 < n_tiles; t0 += SCAN_THREADS) {
+        const int64_t i = t0 + threadIdx.x;
+        const int64_t v = i < n_tiles ? tile_sum[i] : 0;
+        int64_t tot;
+        const int64_t ex = block_excl_scan(v, &tot, sh);
+        if (i < n_tiles) tile_sum[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *(blockIdx.x == 0 ? total_a : total_b) = carry;
+}
+
 __global__ __launch_bounds__(SCAN_THREADS) void scan_apply(const int32_t *cnt, int64_t n, const int64_t *tile_off, int64_t *ptr) {
     __shared__ int64_t sh[SCAN_THREADS / 64];
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
@@ -193,8 +209,7 @@ int device_segment_rows(gg_ctx *ctx, const int32_t *cnt, int64_t n, int T, int32
     GG_HIP(ctx, ctx->scan_tmp.reserve(sizeof(int64_t) * (2 * tiles + 4)));
     int64_t *tr = ctx->scan_tmp.as<int64_t>(), *to = tr + tiles + 1;
     hipLaunchKernelGGL(seg_tile_sums, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, ctx->stream, cnt, n, T, tr, to);
-    hipLaunchKernelGGL(scan_tile_offsets, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, tr, tiles, totals);
-    hipLaunchKernelGGL(scan_tile_offsets, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, to, tiles, totals + 1);
+    hipLaunchKernelGGL(scan_tile_offsets2, dim3(2), dim3(SCAN_THREADS), 0, ctx->stream, tr, to, tiles, totals, totals + 1);
     hipLaunchKernelGGL(seg_apply, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, ctx->stream, cnt, n, T, tr, to, off, list);
     GG_HIP(ctx, hipGetLastError());
     return GG_OK;

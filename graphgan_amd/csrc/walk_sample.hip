@@ -101,7 +101,7 @@ struct WalkArgs {
     int32_t es_mode;         // 0 = off, 1 = a stale node is scored whole when the asking distribution needs most of it, 2 = always
     int32_t es_ratio, es_hub;
     int32_t *lv_fe;          // [total_walks] es index of the father candidate's score (gather tasks with a father entry)
-    int32_t exp;             // GG_WALK_EXPERIMENT: timing ablations (results are then WRONG): 1 / 2 = the weights kernel skips its big / small tasks
+    int32_t exp;             // GG_WALK_EXPERIMENT: timing ablations (results are then WRONG): 1 / 2 = the weights kernel skips its big / small tasks, 64 / 32 = runs them twice (results stay right), 8 = per-level row counts
 };
 
 __device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, int lane) {
@@ -1023,8 +1023,13 @@ __global__ __launch_bounds__(256) void level_weights_kernel(const WalkArgs a, co
     const unsigned long long cw = a.lc[CTR_CHUNKS + a.level];
     const int64_t pch = (int64_t)(cw & 0xffffffffull), sch = (int64_t)(cw >> 32);
     if (sch > cap_chunks || pch == 0 || level_chunk_base(a) + pch > a.cap_total) return;
-    if (blockIdx.x < BIG_BLOCKS) { if (!(a.exp & 1)) weights_big_blocks(a); }
-    else if (!(a.exp & 2)) weights_small_blocks(a, (int)blockIdx.x - BIG_BLOCKS);
+    if (blockIdx.x < BIG_BLOCKS) {
+        if (!(a.exp & 1)) weights_big_blocks(a);
+        if (a.exp & 64) { __syncthreads(); weights_big_blocks(a); }    // timing ablation: the class twice (idempotent, results stay right)
+    } else {
+        if (!(a.exp & 2)) weights_small_blocks(a, (int)blockIdx.x - BIG_BLOCKS);
+        if (a.exp & 32) weights_small_blocks(a, (int)blockIdx.x - BIG_BLOCKS);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
