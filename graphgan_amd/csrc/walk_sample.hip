@@ -5,21 +5,24 @@
 // utils.softmax (src/utils.py:131-133) and np.random.choice (:262).
 //
 // Structure: all walks of a launch advance one hop at a time.
-//   level_advance_kernel        one thread per walk: finish hop h-1 (Philox uniform, threshold,
-//                               binary search in the shared prefix sums, path append,
-//                               termination), prepare hop h (tree list + the reference's hop
-//                               rules, in-workgroup dedup of identical (root, node) distributions,
-//                               chunk offsets, chunk descriptors)
-//   level_score_kernel          one 16-lane group per <= 16-candidate chunk: neighbour rows as
-//                               float4 (256 B contiguous per row per load), fmaf chain, xor
-//                               butterfly (spec S1), + bias -> score buffer.  Dominant, HBM-bound.
-//   level_weights_kernel        max, exact fixed-point weights, uint64 prefix sums (S2, S3), once
-//                               per distribution: 16-lane groups for 16 < k <= 256, workgroups for hubs
+//   level_advance_kernel        one thread per walk: finish hop h-1 (Philox uniform, threshold, search in the owner's
+//                               prefix sums -- or, for <= 16 candidates on a scored node, the distribution evaluated in
+//                               registers from the edge-score cache -- path append, termination), prepare hop h (tree list +
+//                               the reference's hop rules; a leaf ends the walk right there; in-workgroup dedup of identical
+//                               (root, node) distributions; where the scores come from: gather / score the node / private;
+//                               chunk offsets, chunk descriptors, task lists)
+//   level_score_kernel          one 16-lane group per <= 16-row chunk -- the candidates of a private (root, node)
+//                               distribution, or 16 neighbours of a node whose whole adjacency goes into the edge-score
+//                               cache once for all roots: rows as float4 (256 B contiguous per row per load), fmaf chain,
+//                               xor butterfly (spec S1), + bias.  Dominant, HBM-bound.
+//   level_weights_kernel        max, exact fixed-point weights, uint64 prefix sums (S2, S3), once per distribution with more
+//                               than 16 candidates: 16-lane groups up to 256, workgroups for hubs; scores from the task's
+//                               private region or gathered from the cache through the tree's edge indices
 //   walk_sample_kernel          "finisher": one wavefront per walk runs the remaining hops
 //                               (GG_WALK_LEVELS < tree depth + 2; = 0: the whole walk)
-// Scores follow S1 and everything after them is exact integer arithmetic, so the decomposition
-// cannot change a sampled node.  Algorithmic bytes of the score kernel: 4(d+3) per candidate row
-// + 4d+16 per chunk.
+// Scores follow S1 and everything after them is exact integer arithmetic, so neither the decomposition nor WHO scored a
+// shared node can change a sampled node.  Algorithmic bytes of the score kernel: 4(d+2) per candidate row +
+// 4d+12 per scoring task (one current row).
 #include <algorithm>
 
 #include "gg_arith.h"
