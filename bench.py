@@ -10,7 +10,8 @@ G-step pairs/sec beside it.  One *step* = one epoch body of the reference's ``tr
 
 ``value`` = sampled edges (hops of both walk launches, all ranks) / wall time of the K timed
 steps, inputs resident in HBM.  Workload at N=1: synthetic power-law graph, 1M nodes / 10M
-edges, n_emb = 128 (the configuration the north-star target is quoted on), R roots per step.
+edges, n_emb = 128 (the configuration the north-star target is quoted on), R = 16 384 roots per step
+(197 GB of resident trees; the 8 192-root batch of rounds 1-2 is reported beside it).
 Weak scaling: every rank walks its own R roots; replicas exchange gradients through RCCL.
 
     python bench.py [--gpus N --steps K --warmup W]              (N > 1: spawns its own N ranks, one per GPU)
@@ -39,7 +40,9 @@ def parse():
     p.add_argument("--nodes", type=int, default=1_000_000)
     p.add_argument("--m", type=int, default=10)
     p.add_argument("--emb", type=int, default=128)
-    p.add_argument("--roots", type=int, default=8192, help="root slots per rank per step (8192 trees of the 1M-node graph = 64 GB of the 288 GB HBM)")
+    p.add_argument("--roots", type=int, default=16384, help="root slots per rank per step (16 384 trees of the 1M-node graph = 197 GB of the 288 GB HBM; "
+                                                                "rounds 1-2 ran 8 192: that batch is reported beside it as `batch_of_rounds_1_2`)")
+    p.add_argument("--continuity-roots", type=int, default=8192, help="behind the timed region: the same steps over this many of the resident roots (0 = skip)")
     p.add_argument("--n-sample-gen", type=int, default=20)
     p.add_argument("--optimizer", default="adam_lazy", choices=["adam_dense", "adam_lazy", "sgd"])
     p.add_argument("--threads", type=int, default=0, help="host BFS threads (0 = min(64, cores))")
@@ -290,6 +293,33 @@ def main():
 
     # ---- behind the timed region (every rank takes part: the steps contain collectives) -------------------------
     nxt = args.warmup + args.steps
+    # (0) continuity with rounds 1-2: the same step over the 8 192-root sample those rounds benched (a subset of the resident
+    #     roots: bench_roots takes a prefix of one seeded permutation), so that the numbers of all rounds stay comparable
+    cont = None
+    if 0 < args.continuity_roots < R and world == 1:
+        sub = workloads.bench_roots(rowptr, args.continuity_roots, rank, world, args.seed)
+        slot_of = {int(r): i for i, r in enumerate(roots)}
+        sub_slots = np.array([slot_of[int(r)] for r in sub], dtype=np.int32)
+
+        def sub_step(i):
+            rows = eng.prepare_d(sub_slots, args.seed, 2 * i, fetch=False)
+            eng.d_pass(np.zeros(1, np.int64), max(int(rows), 1))
+            pairs = eng.prepare_g(sub_slots, args.n_sample_gen, args.seed, 2 * i + 1, fetch=False)
+            eng.g_pass(np.zeros(1, np.int64), max(int(pairs), 1))
+        for i in range(nxt, nxt + 3):
+            sub_step(i)
+        barrier()
+        cc0 = eng.counters()
+        tc = time.perf_counter()
+        for i in range(nxt + 3, nxt + 3 + args.steps):
+            sub_step(i)
+        barrier()
+        dtc = time.perf_counter() - tc
+        cc = delta(eng.counters(), cc0)
+        cont = {"roots_per_step": int(len(sub)), "value": cc["hops"] / dtc, "unit": "edges/s", "ms_per_step": 1e3 * dtc / args.steps,
+                "rows_scored_per_step": cc["rows_scored"] / args.steps,
+                "what": "the same step over the %d-root sample rounds 1-2 benched (a subset of the resident roots)" % len(sub)}
+        nxt += 3 + args.steps
     # (1) the same kernel events with the profiled side-stream launches ISOLATED (they first wait for the main stream): the
     #     kernel alone on the chip.  Not part of the timed region: isolating a launch serialises that step.
     eng.set_profiling_solo(True)
@@ -349,7 +379,7 @@ def main():
     # The reference evaluates every hop's distribution from scratch (4k(d+2) + 4d + 12 per hop);
     # the engine evaluates each distinct (root, node) distribution of a launch once.
     ref_bytes = 4.0 * (d + 2) * reads + (4.0 * d + 12.0) * hops
-    big_default = args.workload == "powerlaw" and args.nodes == 1_000_000 and args.emb == 128 and args.roots == 8192  # what the committed PMC passes ran
+    big_default = args.workload == "powerlaw" and args.nodes == 1_000_000 and args.emb == 128 and args.roots == 16384  # what the committed PMC passes ran
     traffic, traffic_src = pmc_traffic("level_score_kernel") if big_default else (None, None)
     # K2 pair_reward: 8d + 16 per pair.  K3 / K4 (fast mode, lazy Adam) per section 8d: gradient kernel 16d + 20 per pair
     # (two rows read, two rows of gradient added), whole step 48d + 36 per pair; K5 optimizer kernel per touched row:
@@ -462,6 +492,8 @@ def main():
                        "reference_equivalent_GBs": (ref_bytes / calls) / (walk_ms / launches * 1e-3) / 1e9 if walk_ms > 0 and launches else None,
                        "distributions_shared": reads / max(rows_scored, 1)},
     }
+    if cont:
+        out["batch_of_rounds_1_2"] = cont
     if comm:
         out["comm"] = dict(comm, what="rank 0's gradient exchanges up to the end of the timed region (RCCL over xGMI): optimizer steps that exchanged "
                                       "fixed-capacity row packs (sparse) / reduce-scatter + all-gather of the accumulators (dense), bytes sent")

@@ -51,6 +51,11 @@ def powerlaw_split_workload(n_node, m=10, n_emb=128, test_frac=0.1, seed_graph=1
     return dict(rowptr=rowptr, col=col, emb=emb, n_train_edges=len(train), test=test, test_neg=test_neg)
 
 
+# roots per GPU and step of the default bench: 16 384 trees of the 1M-node graph = 197 GB of the 288 GB HBM (12 B per tree node)
+BENCH_ROOTS = 16384
+BENCH_ROOTS_ROUND2 = 8192  # rounds 1-2 ran 8 192 roots per step: bench.py reports that batch too (same graph, same kernels)
+
+
 def bench_roots(rowptr, roots_per_rank, rank=0, world=1, seed=6):
     """The roots a rank walks per bench step: a seeded random sample of the nodes with train edges, this rank's
     contiguous share, longest (hub) roots first (LPT order for the walk scheduler)."""

@@ -12,6 +12,8 @@ def test_defaults_and_faithful_baseline(monkeypatch):
     import bench
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = bench.parse()
+    from graphgan_amd import workloads
+    assert a.roots == workloads.BENCH_ROOTS and a.continuity_roots == workloads.BENCH_ROOTS_ROUND2
     assert a.gpus == 1 and 1 <= a.steps <= 50 and a.warmup >= 1 and a.nodes == 1_000_000 and a.emb == 128
     r = bench.cpu_baseline_faithful(2)  # two all_score recomputations on CA-GrQc + the C oracle's walks
     assert r["value"] > 0 and r["unit"] == "edges/s" and r["kind"] == "port" and "faithful" in r["flavour"]

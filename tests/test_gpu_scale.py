@@ -264,7 +264,7 @@ def test_bench_workload_walks_bit_exact_inside_the_timed_step(ga):
     degree-sorted list.  The oracle follows the engine's generator tables step by step (they change with every
     g_pass; fp32 atomics make them non-reproducible on the CPU) and carries its own copy of the Q3 tree mutations."""
     from graphgan_amd import workloads
-    n, d, R, seed = 1_000_000, 128, 8192, 6
+    n, d, R, seed = 1_000_000, 128, workloads.BENCH_ROOTS, 6   # bench.py's defaults
     rowptr, col, emb, _ = workloads.powerlaw_workload(n, 10, d)
     roots = workloads.bench_roots(rowptr, R, 0, 1, seed)
     deg = (rowptr[1:] - rowptr[:-1]).astype(np.int64)
