@@ -12,7 +12,7 @@ if [ "$Q" != "quick" ]; then
   python -c "import __graft_entry__ as g; g.smoke()" > $R/gpurun_out/${T}_smoke.txt 2>&1
 fi
 cd /tmp && export TMPDIR=/tmp
-PB="--no-cpu-baseline --no-strict --fresh-batches 1 --overlap-steps 3"  # (the 3 extra steps measure the side-stream launches solo)
+PB="--no-cpu-baseline --no-strict --fresh-batches 1 --overlap-steps 3 --continuity-roots 0"  # (the 3 extra steps measure the side-stream launches solo)
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${T}_kt -o b -- python $R/bench.py $PB > $R/gpurun_out/${T}_kt.log 2>&1
 # (the bench line of the FETCH_SIZE pass is kept: its algorithmic bytes per launch are what the PMC traffic of the same run is compared with)
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${T}_fetch -o f -- python $R/bench.py --steps 3 --warmup 1 $PB > $R/gpurun_out/${T}_fetch_bench.json 2> $R/gpurun_out/${T}_fetch.log
@@ -21,7 +21,7 @@ if [ "$Q" != "quick" ]; then
   rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $R/gpurun_out/${T}_l2 -o l -- python $R/bench.py --steps 3 --warmup 1 $PB > $R/gpurun_out/${T}_l2.log 2>&1
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $R/gpurun_out/${T}_sq -o s -- python $R/bench.py --steps 3 --warmup 1 $PB > $R/gpurun_out/${T}_sq.log 2>&1
   # kernel timeline of a few steps (start / end of every kernel on both streams): summarize.py condenses one step
-  rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${T}_tl -o b -- python $R/bench.py --no-cpu-baseline --no-strict --fresh-batches 0 --overlap-steps 0 --steps 6 --warmup 3 > $R/gpurun_out/${T}_tl.log 2>&1
+  rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${T}_tl -o b -- python $R/bench.py --no-cpu-baseline --no-strict --fresh-batches 0 --overlap-steps 0 --continuity-roots 0 --steps 6 --warmup 3 > $R/gpurun_out/${T}_tl.log 2>&1
 fi
 cd $R
 python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
