@@ -141,3 +141,30 @@ def test_native_edge_ingest_matches_read_edges(ga, tmp_path):
     with pytest.raises(ga.GraphGANHipError) as ei:
         ga.read_edges_csr(tmp_path / "missing.txt")
     assert ei.value.code == -6
+
+
+def test_powerlaw_split_workload_follows_the_survey_recipe():
+    """10 % of the edges held out (seed 3), one negative per test edge that is neither the edge's first
+    endpoint nor one of its neighbours in train + test (src/utils.py:96-128 semantics, seed 4), train adjacency in file order of
+    the remaining edges; the generator is seeded: two calls give the same split."""
+    import numpy as np
+    from graphgan_amd import workloads, engine
+    n = 3000
+    w = workloads.powerlaw_split_workload(n, 10, 16)
+    w2 = workloads.powerlaw_split_workload(n, 10, 16)
+    for k in ("rowptr", "col", "test", "test_neg", "emb"):
+        assert np.array_equal(w[k], w2[k]), k
+    edges = engine.synth_powerlaw(n, 10, 1, 2)
+    assert len(w["test"]) == round(0.1 * len(edges)) and w["n_train_edges"] == len(edges) - len(w["test"])
+    assert w["rowptr"][-1] == 2 * w["n_train_edges"] and w["emb"].shape == (n, 16) and w["emb"].dtype == np.float32
+    es = set(map(tuple, edges.tolist())) | set((b, a) for a, b in edges.tolist())
+    ts = set(map(tuple, w["test"].tolist()))
+    assert ts <= set(map(tuple, edges.tolist()))
+    # the train CSR holds exactly the other edges, both directions
+    src = np.repeat(np.arange(n), np.diff(w["rowptr"]))
+    train_dir = set(zip(src.tolist(), w["col"].tolist()))
+    assert all((a, b) not in train_dir and (b, a) not in train_dir for a, b in w["test"].tolist())
+    assert len(train_dir) == 2 * w["n_train_edges"]
+    # negatives: same first endpoint as their test edge, never a neighbour (train or test) nor the node itself
+    assert np.array_equal(w["test_neg"][:, 0], w["test"][:, 0])
+    assert all(a != b and (a, b) not in es for a, b in w["test_neg"].tolist())
