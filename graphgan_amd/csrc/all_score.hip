@@ -285,10 +285,18 @@ __global__ __launch_bounds__(256) void all_score_reduce_bf16_kernel(const uint4 
 // of each other: one of them misses, the others hit the CU's vector cache.  No cross-wave merge: a wave owns its rows.
 // With one wavefront per SIMD the kernel runs at (bytes in flight) / (memory latency) until the matrix cores saturate: one
 // 16 KB tile per wave at d = 256 -- two row blocks per wave (RB = 2) double the work per byte in flight.
-template <int KS, int RB>
+// Round 3: (a) ONE set of B fragments -- the k-slice s of the next tile is loaded into b[s] right behind the matrix instructions
+// that read the current tile's b[s]: a rolling prefetch one tile deep without the 64 register copies per tile of a double
+// buffer; (b) a 7-instruction consumer instead of ~12: the log-sum-exp is accumulated WITHOUT a running reference,
+// s += exp2(x log2 e) -- one fused multiply-add and one exponential per score, no rescale, no select -- and brought to the
+// (max, sum exp(x - max)) form once, at the end; max / argmax compare the scores themselves (bit-identical to the other
+// kernels).  The reference-free sum is finite and accurate while the scores stay inside (-85, 85) -- embedding dot products are
+// a few units --; a cell whose sum overflows, or underflows to 0, raises `overflow` and the host repeats the call with the
+// narrow kernel above (running maximum).
+template <int KS, int RB, bool LSE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void all_score_reduce_bf16_rows_kernel(const uint4 *Eb, const float *bias, int n_node, const int32_t *rows,
-                                                                         int n_rows, int cols_per_split, int lse, float *part_max,
-                                                                         int32_t *part_arg, float *part_sum) {
+                                                                         int n_rows, int cols_per_split, float *part_max,
+                                                                         int32_t *part_arg, float *part_sum, int32_t *overflow) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, half = lane >> 5;
     const int split = blockIdx.x, r0 = blockIdx.y * (128 * RB) + wv * (32 * RB);
     union Frag { uint4 u; bf16x8 v; };
@@ -300,7 +308,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int s = 0; s < KS; ++s) afrag[rb][s].u = node >= 0 ? Eb[(int64_t)node * (2 * KS) + 2 * s + half] : make_uint4(0u, 0u, 0u, 0u);
     }
-    // (three scalar arrays instead of one array of structs: 64 x 12 bytes is more than the compiler promotes to registers)
+    // (scalar arrays instead of one array of structs: 64 x 12 bytes is more than the compiler promotes to registers)
     float rm[RB][16], rs[RB][16];
     int ra[RB][16];
 #pragma unroll
@@ -308,20 +316,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int i = 0; i < 16; ++i) { rm[rb][i] = -INFINITY; rs[rb][i] = 0.f; ra[rb][i] = 0x7fffffff; }
     const int cbeg = split * cols_per_split, cend = min(n_node, cbeg + cols_per_split);
-    auto load_tile = [&](Frag (&dst)[KS], int c0t) {
+    auto brow_of = [&](int c0t) -> const uint4 * {
         const int colt = c0t + (lane & 31);
-        const uint4 *brow = Eb + (int64_t)((c0t < cend && colt < cend) ? colt : cbeg) * (2 * KS) + half;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) dst[s].u = brow[2 * s];
+        return Eb + (int64_t)((c0t < cend && colt < cend) ? colt : cbeg) * (2 * KS) + half;
     };
-    // B fragments double buffered in registers (as above).  Measured and not kept: three buffers (two tiles in flight) with the
-    // loop unrolled over them -- the unrolled consumer bodies cost more than the extra tile in flight brings (390 -> 309 TFLOP/s).
-    Frag bcur[KS], bnxt[KS];
-    load_tile(bcur, cbeg);
+    constexpr float LOG2E = 1.44269504088896341f;
+    Frag b[KS];
+    {
+        const uint4 *const first = brow_of(cbeg);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) b[s].u = first[2 * s];
+    }
+    // Measured and not kept (round 2): three B buffers (two tiles in flight) with the loop unrolled over them -- the unrolled
+    // consumer bodies cost more than the extra tile in flight brings (390 -> 309 TFLOP/s).
     for (int c0 = cbeg; c0 < cend; c0 += 32) {
         const int col = c0 + (lane & 31);
-        const bool ok = col < cend;
-        load_tile(bnxt, c0 + 32);
+        const uint4 *const nxt = brow_of(c0 + 32);
         f32x16 acc[RB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
@@ -330,33 +340,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[rb][s].v, bcur[s].v, acc[rb], 0, 0, 0);
+            for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[rb][s].v, b[s].v, acc[rb], 0, 0, 0);
+            b[s].u = nxt[2 * s];
         }
+        // a column behind the split's end: bias -inf -> score -inf, its exponential 0, the compare false (no branch)
+        const float bj = col < cend ? bias[col] : -INFINITY;
+        const float bj2 = bj * LOG2E;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) bcur[s] = bnxt[s];
-        if (ok) {
-            const float bj = bias[col];
+        for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    Running x{rm[rb][reg], rs[rb][reg], ra[rb][reg]};
-                    run_update(x, acc[rb][reg] + bj, col, lse != 0);
-                    rm[rb][reg] = x.m; rs[rb][reg] = x.s; ra[rb][reg] = x.arg;
-                }
-        }
+            for (int reg = 0; reg < 16; ++reg) {
+                const float a = acc[rb][reg];
+                const float x = a + bj;
+                if (LSE) rs[rb][reg] += __builtin_amdgcn_exp2f(__builtin_fmaf(a, LOG2E, bj2));
+                const bool up = x > rm[rb][reg];
+                rm[rb][reg] = up ? x : rm[rb][reg];
+                ra[rb][reg] = up ? col : ra[rb][reg];
+            }
     }
-    // merge a row's 32 column lanes; lanes 0 and 32 then hold the wave's rows: row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    // (max, sum exp(x - max)) per cell; merge a row's 32 column lanes; lanes 0 and 32 then hold the wave's rows:
+    // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-            Running x{rm[rb][reg], rs[rb][reg], ra[rb][reg]};
+            float sx = rs[rb][reg];
+            if (LSE) {
+                // inf / nan, or 0 although the cell saw a column: the scores left the range a reference-free sum can hold
+                if (!(sx <= 3.0e38f) || (sx == 0.f && rm[rb][reg] > -INFINITY)) atomicOr(overflow, 1);
+                sx = rm[rb][reg] > -INFINITY ? sx * __builtin_amdgcn_exp2f(-rm[rb][reg] * LOG2E) : 0.f;
+            }
+            Running x{rm[rb][reg], sx, ra[rb][reg]};
 #pragma unroll
             for (int off = 16; off >= 1; off >>= 1) {
-                const float m = __shfl_xor(x.m, off, 64), sx = __shfl_xor(x.s, off, 64);
+                const float m = __shfl_xor(x.m, off, 64), so = __shfl_xor(x.s, off, 64);
                 const int ar = __shfl_xor(x.arg, off, 64);
-                run_merge(x, m, sx, ar, lse != 0);
+                run_merge(x, m, so, ar, LSE);
             }
             if ((lane & 31) == 0) {
                 const int row = r0 + rb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
@@ -422,7 +441,8 @@ extern "C" int gg_all_score_reduce(gg_ctx *ctx, const int32_t *rows, int32_t n_r
     const int ld16 = 16 * KS;
     const int RB = (precision == 1 && KS <= 8) ? 2 : 1;
     // bf16, many rows: a workgroup's four wavefronts take four row blocks and share the table sweep (all_score_reduce_bf16_rows_kernel)
-    const bool wide = precision == 1 && n_rows >= 512 && !getenv("GG_ALLPAIRS_NARROW");
+    static thread_local bool force_narrow = false;  // set for the repeat of a call whose wide kernel reported an overflowing sum
+    const bool wide = precision == 1 && n_rows >= 512 && !getenv("GG_ALLPAIRS_NARROW") && !force_narrow;
     const int RBW = KS <= 8 ? 4 : (KS <= 16 ? 2 : 1);  // row blocks per wavefront of the wide kernel: as many as the registers of ONE wave per SIMD hold
     const int tile_rows = wide ? 128 * RBW : 32 * RB;
     const int row_tiles = cdiv(n_rows, tile_rows);
@@ -430,15 +450,17 @@ extern "C" int gg_all_score_reduce(gg_ctx *ctx, const int32_t *rows, int32_t n_r
     int splits = std::max(1, std::min(cdiv(n, 128), cdiv(wide ? 1024 : 2048, row_tiles)));
     int cps = cdiv(cdiv(n, splits), 128) * 128;
     splits = cdiv(n, cps);
-    DevBuf d_rows, d_pm, d_pa, d_ps, d_bf;
-    auto rel = [&]() { d_rows.release(); d_pm.release(); d_pa.release(); d_ps.release(); d_bf.release(); };
+    DevBuf d_rows, d_pm, d_pa, d_ps, d_bf, d_ovf;
+    auto rel = [&]() { d_rows.release(); d_pm.release(); d_pa.release(); d_ps.release(); d_bf.release(); d_ovf.release(); };
     const size_t np = (size_t)n_rows * splits;
     hipError_t e = d_pm.reserve(sizeof(float) * np);
     if (e == hipSuccess) e = d_pa.reserve(sizeof(int32_t) * np);
     if (e == hipSuccess) e = d_ps.reserve(sizeof(float) * np);
     if (e == hipSuccess && rows) e = d_rows.reserve(sizeof(int32_t) * n_rows);
     if (e == hipSuccess && precision == 1) e = d_bf.reserve(sizeof(uint16_t) * (size_t)n * ld16);
+    if (e == hipSuccess) e = d_ovf.reserve(sizeof(int32_t) * 4);
     if (e != hipSuccess) { rel(); return fail(ctx, GG_ENOMEM, "gg_all_score_reduce: %s", hipGetErrorString(e)); }
+    (void)hipMemsetAsync(d_ovf.p, 0, sizeof(int32_t) * 4, ctx->stream);
     if (rows) (void)hipMemcpyAsync(d_rows.p, rows, sizeof(int32_t) * n_rows, hipMemcpyHostToDevice, ctx->stream);
     const Model &G = ctx->model[0];
     const int32_t *dr = rows ? d_rows.as<int32_t>() : nullptr;
@@ -458,9 +480,13 @@ extern "C" int gg_all_score_reduce(gg_ctx *ctx, const int32_t *rows, int32_t n_r
 #define GG_BF16_LAUNCH(KSV, RBV)                                                                                                    \
     hipLaunchKernelGGL((all_score_reduce_bf16_kernel<KSV, RBV>), grid, dim3(256), 0, ctx->stream, Eb, G.b, n, dr, n_rows, cps, want_lse, \
                        d_pm.as<float>(), d_pa.as<int32_t>(), d_ps.as<float>())
-#define GG_BF16_ROWS(KSV, RBV)                                                                                                           \
-    hipLaunchKernelGGL((all_score_reduce_bf16_rows_kernel<KSV, RBV>), grid, dim3(256), 0, ctx->stream, Eb, G.b, n, dr, n_rows, cps, want_lse, \
-                       d_pm.as<float>(), d_pa.as<int32_t>(), d_ps.as<float>())
+#define GG_BF16_ROWS(KSV, RBV)                                                                                                                            \
+    do {                                                                                                                                                 \
+        if (want_lse) hipLaunchKernelGGL((all_score_reduce_bf16_rows_kernel<KSV, RBV, true>), grid, dim3(256), 0, ctx->stream, Eb, G.b, n, dr, n_rows, cps, \
+                                         d_pm.as<float>(), d_pa.as<int32_t>(), d_ps.as<float>(), d_ovf.as<int32_t>());                                     \
+        else hipLaunchKernelGGL((all_score_reduce_bf16_rows_kernel<KSV, RBV, false>), grid, dim3(256), 0, ctx->stream, Eb, G.b, n, dr, n_rows, cps,        \
+                                d_pm.as<float>(), d_pa.as<int32_t>(), d_ps.as<float>(), d_ovf.as<int32_t>());                                             \
+    } while (0)
         if (wide) {
             if (KS <= 4) { GG_BF16_ROWS(4, 4); }
             else if (KS <= 8) { GG_BF16_ROWS(8, 4); }
@@ -480,7 +506,16 @@ extern "C" int gg_all_score_reduce(gg_ctx *ctx, const int32_t *rows, int32_t n_r
     if (e == hipSuccess) e = hipMemcpyAsync(pm.data(), d_pm.p, sizeof(float) * np, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(pa.data(), d_pa.p, sizeof(int32_t) * np, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(ps.data(), d_ps.p, sizeof(float) * np, hipMemcpyDeviceToHost, ctx->stream);
+    int32_t h_ovf = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_ovf, d_ovf.p, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && h_ovf && wide) {  // scores outside the range of the wide kernel's reference-free sum: running-max kernel
+        rel();
+        force_narrow = true;
+        const int rc = gg_all_score_reduce(ctx, rows, rows ? n_rows : 0, precision, want_lse, row_max, row_argmax, row_lse, kernel_ms_out);
+        force_narrow = false;
+        return rc;
+    }
     float ms = 0.f;
     if (e == hipSuccess) (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     rel();

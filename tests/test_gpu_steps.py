@@ -755,6 +755,34 @@ def test_all_score_streamed_consumer(ga, n, d, precision):
     eng.close()
 
 
+def test_all_score_wide_consumer_falls_back_when_its_sum_leaves_the_fp32_range(ga):
+    """The wide bf16 consumer accumulates sum_j exp(S[i, j]) without a running reference (cheaper per score); scores beyond
+    +-85 overflow / underflow that fp32 sum: the kernel raises a flag and the call is repeated with the running-max kernel --
+    same max / argmax / log-sum-exp as the narrow path asked for directly."""
+    n, d = 1200, 64
+    rs = np.random.RandomState(12)
+    Eg = (rs.randn(n, d) * 2.0).astype(np.float32)         # scores ~ N(0, 32): the row maxima are far beyond 85
+    bg = (rs.randn(n) * 0.1).astype(np.float32)
+    eng = engine_with(ga, Eg, Eg, bg, bg)
+    wide = eng.all_score_reduce(None, precision="bf16")
+    os.environ["GG_ALLPAIRS_NARROW"] = "1"
+    try:
+        narrow = eng.all_score_reduce(None, precision="bf16")
+    finally:
+        del os.environ["GG_ALLPAIRS_NARROW"]
+    assert wide["max"].max() > 120.0
+    assert np.array_equal(wide["max"], narrow["max"]) and np.array_equal(wide["argmax"], narrow["argmax"])
+    assert np.isfinite(wide["logsumexp"]).all() and np.allclose(wide["logsumexp"], narrow["logsumexp"], rtol=1e-6, atol=1e-5)
+    # very negative scores: the reference-free sum underflows to 0 -> same fall-back
+    eng.set_bias(0, np.full(n, -400.0, np.float32))
+    low = eng.all_score_reduce(None, precision="bf16")
+    ref = _bf16_round(Eg)
+    S = ref.astype(np.float64) @ ref.T.astype(np.float64) - 400.0
+    lse = S.max(1) + np.log(np.exp(S - S.max(1, keepdims=True)).sum(1))
+    assert np.isfinite(low["logsumexp"]).all() and np.max(np.abs(low["logsumexp"] - lse)) <= 2e-3 * np.abs(S).max()
+    eng.close()
+
+
 def test_evaluator_scores_on_the_device_and_binary_sidecar(ga, tmp_path):
     """src/evaluation/link_prediction.py:19-38 with the per-edge dots computed by gg_edge_scores: the accuracy of the shipped
     pre-trained embeddings is the reference's 0.7598343685300207 to the digit, scores equal np.dot to 1e-12, and the
