@@ -209,13 +209,21 @@ __global__ __launch_bounds__(256) void all_score_reduce_f32_kernel(const float *
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// fp32 table -> bf16 copy [n][ld16] (ld16 = n_emb rounded up to 16, zero padded), round to nearest even
-__global__ void to_bf16_kernel(const float *E, int64_t n, int ld, int ld16, __bf16 *out) {
+// fp32 table -> bf16 copy (round to nearest even, k zero padded to ld16 = 16 KS, rows zero padded to a multiple of 32), TILED for
+// the matrix instruction's B operand: the 16-byte piece {k = 16 s + 8 h .. + 8} of row r sits at piece index
+//     ((r / 32) * KS + s) * 64 + 32 h + r % 32,
+// i.e. the 64 lanes of a wavefront that loads k-step s of a 32-column tile (lane = 32 h + column) read ONE CONTIGUOUS KILOBYTE.
+// (Row-major, every such load touched 32 different cache lines for 32 bytes each: 4 wavefronts x 16 loads x 32 line look-ups per
+// tile and CU were what the wide consumer waited for, not the HBM and not the matrix pipe.)
+__device__ __forceinline__ int64_t bf16_piece(int64_t r, int s, int h, int KS) { return ((r >> 5) * KS + s) * 64 + 32 * h + (r & 31); }
+
+__global__ void to_bf16_kernel(const float *E, int64_t n, int64_t n_pad, int ld, int ld16, __bf16 *out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * ld16) return;
+    if (i >= n_pad * ld16) return;
     const int64_t r = i / ld16;
     const int k = (int)(i % ld16);
-    out[i] = (__bf16)(k < ld ? E[r * ld + k] : 0.0f);
+    const float v = (r < n && k < ld) ? E[r * ld + k] : 0.0f;
+    out[bf16_piece(r, k >> 4, (k >> 3) & 1, ld16 / 16) * 8 + (k & 7)] = (__bf16)v;
 }
 
 // KS = ld16 / 16 k-steps, RB row blocks of 32 rows per workgroup.  No LDS for the operands: the A fragments of the
@@ -235,7 +243,7 @@ __global__ __launch_bounds__(256) void all_score_reduce_bf16_kernel(const uint4 
         const int r = r0 + rb * 32 + (lane & 31);
         const int node = r < n_rows ? (rows ? rows[r] : r) : -1;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) afrag[rb][s].u = node >= 0 ? Eb[(int64_t)node * (2 * KS) + 2 * s + half] : make_uint4(0u, 0u, 0u, 0u);
+        for (int s = 0; s < KS; ++s) afrag[rb][s].u = node >= 0 ? Eb[bf16_piece(node, s, half, KS)] : make_uint4(0u, 0u, 0u, 0u);
     }
     Running run[16 * RB];
 #pragma unroll
@@ -245,10 +253,11 @@ __global__ __launch_bounds__(256) void all_score_reduce_bf16_kernel(const uint4 
     // instructions and the consumer of the current one, so that memory latency hides behind them (two waves per SIMD).
     Frag bcur[KS], bnxt[KS];
     auto load_tile = [&](Frag (&dst)[KS], int c0t) {
-        const int colt = c0t + (lane & 31);
-        const uint4 *brow = Eb + (int64_t)((c0t < cend && colt < cend) ? colt : cbeg) * (2 * KS) + half;
+        // (tiles start at multiples of 32 columns; the padded rows behind the table's end are zeros; a prefetch behind the
+        // split's end re-reads its first tile)
+        const uint4 *brow = Eb + (int64_t)((c0t < cend ? c0t : cbeg) >> 5) * KS * 64 + lane;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) dst[s].u = brow[2 * s];
+        for (int s = 0; s < KS; ++s) dst[s].u = brow[64 * s];
     };
     load_tile(bcur, cbeg + wv * 32);
     for (int c0 = cbeg + wv * 32; c0 < cend; c0 += 128) {
@@ -306,7 +315,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int r = r0 + rb * 32 + (lane & 31);
         const int node = r < n_rows ? (rows ? rows[r] : r) : -1;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) afrag[rb][s].u = node >= 0 ? Eb[(int64_t)node * (2 * KS) + 2 * s + half] : make_uint4(0u, 0u, 0u, 0u);
+        for (int s = 0; s < KS; ++s) afrag[rb][s].u = node >= 0 ? Eb[bf16_piece(node, s, half, KS)] : make_uint4(0u, 0u, 0u, 0u);
     }
     // (scalar arrays instead of one array of structs: 64 x 12 bytes is more than the compiler promotes to registers)
     float rm[RB][16], rs[RB][16];
@@ -316,16 +325,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int i = 0; i < 16; ++i) { rm[rb][i] = -INFINITY; rs[rb][i] = 0.f; ra[rb][i] = 0x7fffffff; }
     const int cbeg = split * cols_per_split, cend = min(n_node, cbeg + cols_per_split);
-    auto brow_of = [&](int c0t) -> const uint4 * {
-        const int colt = c0t + (lane & 31);
-        return Eb + (int64_t)((c0t < cend && colt < cend) ? colt : cbeg) * (2 * KS) + half;
+    auto brow_of = [&](int c0t) -> const uint4 * {  // (tiles start at multiples of 32 columns; a prefetch behind the split's end re-reads its first tile)
+        return Eb + (int64_t)((c0t < cend ? c0t : cbeg) >> 5) * KS * 64 + lane;
     };
     constexpr float LOG2E = 1.44269504088896341f;
     Frag b[KS];
     {
         const uint4 *const first = brow_of(cbeg);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) b[s].u = first[2 * s];
+        for (int s = 0; s < KS; ++s) b[s].u = first[64 * s];
     }
     // Measured and not kept (round 2): three B buffers (two tiles in flight) with the loop unrolled over them -- the unrolled
     // consumer bodies cost more than the extra tile in flight brings (390 -> 309 TFLOP/s).
@@ -341,7 +349,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int s = 0; s < KS; ++s) {
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[rb][s].v, b[s].v, acc[rb], 0, 0, 0);
-            b[s].u = nxt[2 * s];
+            b[s].u = nxt[64 * s];
         }
         // a column behind the split's end: bias -inf -> score -inf, its exponential 0, the compare false (no branch)
         const float bj = col < cend ? bias[col] : -INFINITY;
@@ -457,7 +465,8 @@ extern "C" int gg_all_score_reduce(gg_ctx *ctx, const int32_t *rows, int32_t n_r
     if (e == hipSuccess) e = d_pa.reserve(sizeof(int32_t) * np);
     if (e == hipSuccess) e = d_ps.reserve(sizeof(float) * np);
     if (e == hipSuccess && rows) e = d_rows.reserve(sizeof(int32_t) * n_rows);
-    if (e == hipSuccess && precision == 1) e = d_bf.reserve(sizeof(uint16_t) * (size_t)n * ld16);
+    const int64_t n_pad = ((int64_t)n + 31) / 32 * 32;  // the bf16 copy is tiled by 32 rows
+    if (e == hipSuccess && precision == 1) e = d_bf.reserve(sizeof(uint16_t) * (size_t)n_pad * ld16);
     if (e == hipSuccess) e = d_ovf.reserve(sizeof(int32_t) * 4);
     if (e != hipSuccess) { rel(); return fail(ctx, GG_ENOMEM, "gg_all_score_reduce: %s", hipGetErrorString(e)); }
     (void)hipMemsetAsync(d_ovf.p, 0, sizeof(int32_t) * 4, ctx->stream);
@@ -466,8 +475,8 @@ extern "C" int gg_all_score_reduce(gg_ctx *ctx, const int32_t *rows, int32_t n_r
     const int32_t *dr = rows ? d_rows.as<int32_t>() : nullptr;
     const dim3 grid(splits, row_tiles);
     if (precision == 1) {
-        const int64_t tot = (int64_t)n * ld16;
-        hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, G.E, (int64_t)n, ld, ld16, (__bf16 *)d_bf.p);
+        const int64_t tot = n_pad * ld16;
+        hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, G.E, (int64_t)n, n_pad, ld, ld16, (__bf16 *)d_bf.p);
     }
     (void)hipEventRecord(ctx->ev0, ctx->stream);
     if (precision == 0) {
