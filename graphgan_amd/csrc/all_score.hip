@@ -325,21 +325,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int i = 0; i < 16; ++i) { rm[rb][i] = -INFINITY; rs[rb][i] = 0.f; ra[rb][i] = 0x7fffffff; }
     const int cbeg = split * cols_per_split, cend = min(n_node, cbeg + cols_per_split);
-    auto brow_of = [&](int c0t) -> const uint4 * {  // (tiles start at multiples of 32 columns; a prefetch behind the split's end re-reads its first tile)
-        return Eb + (int64_t)((c0t < cend ? c0t : cbeg) >> 5) * KS * 64 + lane;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    union FragB { u32x4 q; bf16x8 v; };
+    // The B fragments are loaded and awaited BY HAND (inline assembly): where these loads sit decides everything here -- one
+    // wavefront per SIMD, nothing to switch to -- and the compiler moved them with every edit of the loop (to the top of the next
+    // iteration = no prefetch at all; into a second register set = 64 copies per tile; behind a bias load whose wait drained
+    // the whole queue).  The order is: slice s of the NEXT tile is requested into b[s] right behind the matrix instructions
+    // that read the current b[s]; the memory counter retires in order and every request has exactly 15 younger ones when its
+    // slice is needed, so `s_waitcnt vmcnt(15)` in front of a slice's matrix instructions is exact.  Each b[s] is a
+    // read-write operand of both statements: it stays in one physical register quadruple, and neither the matrix
+    // instructions nor a register copy can move across the wait.  (The bias refill below is the only compiler-issued
+    // load inside the loop; its compiler-placed wait drains the queue: over-waiting is safe.)
+    auto tile_of = [&](int c0t) -> const char * {  // (tiles start at multiples of 32 columns; the prefetch behind the split's end re-reads its first tile)
+        return (const char *)(Eb + (int64_t)((c0t < cend ? c0t : cbeg) >> 5) * KS * 64);
     };
     constexpr float LOG2E = 1.44269504088896341f;
-    Frag b[KS];
-    {
-        const uint4 *const first = brow_of(cbeg);
+    int voff[(KS + 3) / 4];  // byte offset of this lane's 16 bytes in slices 4k .. 4k+3 (the instruction's immediate reaches 4 KB)
 #pragma unroll
-        for (int s = 0; s < KS; ++s) b[s].u = first[64 * s];
+    for (int k = 0; k < (KS + 3) / 4; ++k) voff[k] = lane * 16 + 4096 * k;
+    FragB b[KS];
+#define GG_B_LOAD(S, BASE, CONSTRAINT)                                                                                            \
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : CONSTRAINT(b[S].q) : "v"(voff[(S) >> 2]), "s"(BASE), "n"(((S) & 3) * 1024))
+    {
+        // (the A fragments are used once here, so that their compiler-placed wait stands in front of the loop and not -- merged over
+        // the back edge -- as a drain of the queue inside every iteration)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) asm volatile("" ::"v"(afrag[rb][s].u.x), "v"(afrag[rb][s].u.w));
+        const char *const first = tile_of(cbeg);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) GG_B_LOAD(s, first, "=v");
     }
+    // The bias of the columns comes through LDS, 2 048 columns at a time and private to the wave: a global bias load per tile sits
+    // in the same in-order memory counter as the B prefetch.  An LDS read has its own counter; the refill stalls once per 64 tiles.
+    constexpr int BIAS_CHUNK = 2048;
+    __shared__ float bias_lds[4][BIAS_CHUNK];
+    float *const wb = bias_lds[wv];
     // Measured and not kept (round 2): three B buffers (two tiles in flight) with the loop unrolled over them -- the unrolled
     // consumer bodies cost more than the extra tile in flight brings (390 -> 309 TFLOP/s).
     for (int c0 = cbeg; c0 < cend; c0 += 32) {
         const int col = c0 + (lane & 31);
-        const uint4 *const nxt = brow_of(c0 + 32);
+        const int within = (c0 - cbeg) & (BIAS_CHUNK - 1);
+        if (within == 0) {
+#pragma unroll
+            for (int i = 0; i < BIAS_CHUNK / 64; ++i) {
+                const int c = c0 + i * 64 + lane;
+                wb[i * 64 + lane] = c < cend ? bias[c] : -INFINITY;
+            }
+        }
+        const float bj = wb[within + (lane & 31)];
+        const char *const nxt = tile_of(c0 + 32);
         f32x16 acc[RB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
@@ -347,12 +383,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int i = 0; i < 16; ++i) acc[rb][i] = 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(b[s].q) : "n"(KS - 1));
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[rb][s].v, b[s].v, acc[rb], 0, 0, 0);
-            b[s].u = nxt[64 * s];
+            GG_B_LOAD(s, nxt, "+v");
         }
-        // a column behind the split's end: bias -inf -> score -inf, its exponential 0, the compare false (no branch)
-        const float bj = col < cend ? bias[col] : -INFINITY;
+        // (a column behind the split's end: bias -inf -> score -inf, its exponential 0, the compare false: no branch)
         const float bj2 = bj * LOG2E;
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
@@ -366,6 +402,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 ra[rb][reg] = up ? col : ra[rb][reg];
             }
     }
+    // (the last tile's prefetch is still in flight INTO b[]: drain it before the registers are anyone else's)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[s].q));
+#undef GG_B_LOAD
     // (max, sum exp(x - max)) per cell; merge a row's 32 column lanes; lanes 0 and 32 then hold the wave's rows:
     // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
