@@ -287,146 +287,198 @@ __global__ __launch_bounds__(256) void all_score_reduce_bf16_kernel(const uint4 
     tile_finish<16 * RB>(run, lse != 0, r0, n_rows, split, gridDim.x, part_max, part_arg, part_sum, sh_m, sh_s, sh_a);
 }
 
-// The same consumer for MANY rows: the 4 wavefronts of a workgroup take 4 DIFFERENT row blocks (RB x 32 rows each) and walk the
-// SAME 32-column tiles, so one sweep of the table serves 128 x RB rows instead of 32 x RB -- in the variant above every
-// 32 x RB rows re-stream the whole bf16 table from HBM (4 096 rows x 10^7 nodes: 128 sweeps of 5 GB = 8.3 TB/s at 266 TFLOP/s:
-// it ran at the HBM roofline, not the matrix cores').  The four wavefronts load the same B fragments within a few cycles
-// of each other: one of them misses, the others hit the CU's vector cache.  No cross-wave merge: a wave owns its rows.
-// With one wavefront per SIMD the kernel runs at (bytes in flight) / (memory latency) until the matrix cores saturate: one
-// 16 KB tile per wave at d = 256 -- two row blocks per wave (RB = 2) double the work per byte in flight.
-// Round 3: (a) ONE set of B fragments -- the k-slice s of the next tile is loaded into b[s] right behind the matrix instructions
-// that read the current tile's b[s]: a rolling prefetch one tile deep without the 64 register copies per tile of a double
-// buffer; (b) a 7-instruction consumer instead of ~12: the log-sum-exp is accumulated WITHOUT a running reference,
-// s += exp2(x log2 e) -- one fused multiply-add and one exponential per score, no rescale, no select -- and brought to the
-// (max, sum exp(x - max)) form once, at the end; max / argmax compare the scores themselves (bit-identical to the other
-// kernels).  The reference-free sum is finite and accurate while the scores stay inside (-85, 85) -- embedding dot products are
-// a few units --; a cell whose sum overflows, or underflows to 0, raises `overflow` and the host repeats the call with the
-// narrow kernel above (running maximum).
-template <int KS, int RB, bool LSE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void all_score_reduce_bf16_rows_kernel(const uint4 *Eb, const float *bias, int n_node, const int32_t *rows,
-                                                                         int n_rows, int cols_per_split, float *part_max,
-                                                                         int32_t *part_arg, float *part_sum, int32_t *overflow) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, half = lane >> 5;
-    const int split = blockIdx.x, r0 = blockIdx.y * (128 * RB) + wv * (32 * RB);
-    union Frag { uint4 u; bf16x8 v; };
-    Frag afrag[RB][KS];
+// The same consumer for MANY rows (>= 512): the 4 wavefronts of a workgroup take 4 DIFFERENT row blocks (16 NRB rows each) and walk
+// the SAME 32-column tiles, so one sweep of the table serves 64 NRB rows instead of 32 or 64 -- in the kernel above every
+// row tile re-streams the whole bf16 table from HBM (4 096 rows x 10^7 nodes: 128 sweeps of 5 GB = 8.3 TB/s at 266 TFLOP/s:
+// it ran at the HBM roofline, not the matrix cores').  No cross-wave merge: a wave owns its rows.  One wavefront per SIMD
+// (all 512 registers), so everything below is about what that single instruction stream looks like:
+//  - v_mfma_f32_16x16x32_bf16: a wavefront owns NRB blocks of 16 rows x 2 halves of the 32-column tile = 2 NRB independent
+//    16x16 accumulators (4 registers each), walked k-step by k-step (32 k): 2 NRB instructions between two uses of one
+//    accumulator.  A 16 x 32 fragment is 4 runs of 256 bytes of the table's 32-row tiles (to_bf16_kernel).  The running state
+//    is 4 NRB cells per lane (lane = column, registers = rows; both column halves of a tile feed the same row cells).
+//  - the A fragments live in ACCUMULATION registers (a matrix instruction reads A from either file).  As ordinary values
+//    they overflow the 256 architectural registers together with b[] and the running state, and the compiler's way out is to
+//    park them in accumulation registers anyway and COPY four registers back in front of every second matrix instruction.
+//  - the B fragments are requested and awaited BY HAND (inline assembly): where these loads sit decides everything with one
+//    wavefront per SIMD, and the compiler moved them with every edit of the loop (to the top of the next iteration = no
+//    prefetch; into a second register set = 64 copies per tile; behind a bias load whose wait drained the whole queue).
+//    ONE set of B registers: step t of the NEXT tile is requested into b[t] right behind the matrix instructions that read
+//    the current b[t]; the memory counter retires in order and a request pair has exactly KS - 2 younger requests when its
+//    step is multiplied, so `s_waitcnt vmcnt(KS - 2)` there is exact.  Each b[t] is a read-write operand of both
+//    statements: it stays in one register quadruple and nothing moves across the wait.  THE KERNEL MUST NOT SPILL: a spilled
+//    b[t] would be copied while its data is in flight (csrc/check_no_scratch.sh fails the build on any scratch use here).
+//  - the bias of the columns comes through LDS, 2 048 columns at a time and private to the wave: a global bias load per tile
+//    sits in the same in-order memory counter as the B prefetch.  The refill is the only compiler-issued load in the loop;
+//    its compiler-placed wait drains the queue (over-waiting is safe), once per 64 tiles, all 32 requests in flight at once.
+//  - software pipeline over TWO accumulator sets: the iteration that multiplies tile t consumes the finished accumulators
+//    of tile t - 1 between its matrix instructions (8 NRB / KT scores behind each k-step, pinned with scheduling barriers: left
+//    alone the scheduler lumps the consumer behind the matrix instructions).  One extra iteration drains the pipe;
+//    iterations in front of the first / behind the last tile of the split see a bias of -inf and change nothing (their
+//    matrix instructions re-read the split's first tile: finite numbers).
+//  - a 7-instruction consumer: the log-sum-exp is accumulated WITHOUT a running reference, s += exp2(x log2 e) -- one fused
+//    multiply-add and one exponential per score, no rescale, no select -- and brought to the (max, sum exp(x - max)) form
+//    once, at the end; max / argmax compare the scores themselves (bit-identical to the other kernels).  The reference-free
+//    sum is finite and accurate while the scores stay inside (-85, 85) -- embedding dot products are a few units --; a
+//    cell whose sum overflows, or underflows to 0, raises `overflow` and the host repeats the call with the kernel above.
+// Measured at 4 096 rows x 10^7 nodes x d = 256 (ms per call on one box; DESIGN.md section 5 has the table): this kernel 21.1
+// (max / argmax only: 18.3); without the software pipeline, 32x32x16 instructions: 22.2; the same before the A fragments
+// moved to accumulation registers and the refill issued its 32 loads one by one: 25.3; before the hand-placed loads: 30.6.
+// Its matrix instructions alone (no loads, no consumer) take 13.4 ms = 1.56 PFLOP/s: the clocks this chip sustains under
+// dense matrix work, not the 2.5 PFLOP/s of the data sheet, are what "1.0" would be.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int KS, int NRB, bool LSE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void all_score_reduce_bf16_x16_kernel(const uint4 *Eb, const float *bias, int n_node, const int32_t *rows,
+                                                                        int n_rows, int cols_per_split, float *part_max,
+                                                                        int32_t *part_arg, float *part_sum, int32_t *overflow) {
+    constexpr int KT = KS / 2;  // k-steps of 32
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kg = lane >> 4;
+    const int split = blockIdx.x, r0 = blockIdx.y * (64 * NRB) + wv * (16 * NRB);
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    union FragA { u32x4 q; bf16x8 v; };
+    union FragB { u32x4 q; bf16x8 v; };
+    // lane (row l15, k-group kg) of a 16 x 32 fragment: 8 consecutive k = 16-slice 2t + (kg >> 1), half kg & 1 of the table
+    FragA afrag[NRB][KT];
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-        const int r = r0 + rb * 32 + (lane & 31);
+    for (int rbk = 0; rbk < NRB; ++rbk) {
+        const int r = r0 + 16 * rbk + l15;
         const int node = r < n_rows ? (rows ? rows[r] : r) : -1;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) afrag[rb][s].u = node >= 0 ? Eb[bf16_piece(node, s, half, KS)] : make_uint4(0u, 0u, 0u, 0u);
+        for (int t = 0; t < KT; ++t) {
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            afrag[rbk][t].q = node >= 0 ? *(const u32x4 *)&Eb[bf16_piece(node, 2 * t + (kg >> 1), kg & 1, KS)] : z;
+        }
     }
-    // (scalar arrays instead of one array of structs: 64 x 12 bytes is more than the compiler promotes to registers)
-    float rm[RB][16], rs[RB][16];
-    int ra[RB][16];
+    float rm[NRB][4], rs[NRB][4];
+    int ra[NRB][4];
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
+    for (int rbk = 0; rbk < NRB; ++rbk)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { rm[rb][i] = -INFINITY; rs[rb][i] = 0.f; ra[rb][i] = 0x7fffffff; }
+        for (int i = 0; i < 4; ++i) { rm[rbk][i] = -INFINITY; rs[rbk][i] = 0.f; ra[rbk][i] = 0x7fffffff; }
     const int cbeg = split * cols_per_split, cend = min(n_node, cbeg + cols_per_split);
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    union FragB { u32x4 q; bf16x8 v; };
-    // The B fragments are loaded and awaited BY HAND (inline assembly): where these loads sit decides everything here -- one
-    // wavefront per SIMD, nothing to switch to -- and the compiler moved them with every edit of the loop (to the top of the next
-    // iteration = no prefetch at all; into a second register set = 64 copies per tile; behind a bias load whose wait drained
-    // the whole queue).  The order is: slice s of the NEXT tile is requested into b[s] right behind the matrix instructions
-    // that read the current b[s]; the memory counter retires in order and every request has exactly 15 younger ones when its
-    // slice is needed, so `s_waitcnt vmcnt(15)` in front of a slice's matrix instructions is exact.  Each b[s] is a
-    // read-write operand of both statements: it stays in one physical register quadruple, and neither the matrix
-    // instructions nor a register copy can move across the wait.  (The bias refill below is the only compiler-issued
-    // load inside the loop; its compiler-placed wait drains the queue: over-waiting is safe.)
-    auto tile_of = [&](int c0t) -> const char * {  // (tiles start at multiples of 32 columns; the prefetch behind the split's end re-reads its first tile)
+    auto tile_of = [&](int c0t) -> const char * {  // (the prefetch behind the split's end re-reads its first tile)
         return (const char *)(Eb + (int64_t)((c0t < cend ? c0t : cbeg) >> 5) * KS * 64);
     };
     constexpr float LOG2E = 1.44269504088896341f;
-    int voff[(KS + 3) / 4];  // byte offset of this lane's 16 bytes in slices 4k .. 4k+3 (the instruction's immediate reaches 4 KB)
+    // B fragments by hand, as above: step t, column half h at byte (t & 1) * 2048 + h * 256 behind voff[t >> 1]; every request
+    // pair has KS - 2 younger requests when its step is multiplied
+    int voff[(KT + 1) / 2];
 #pragma unroll
-    for (int k = 0; k < (KS + 3) / 4; ++k) voff[k] = lane * 16 + 4096 * k;
-    FragB b[KS];
-#define GG_B_LOAD(S, BASE, CONSTRAINT)                                                                                            \
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : CONSTRAINT(b[S].q) : "v"(voff[(S) >> 2]), "s"(BASE), "n"(((S) & 3) * 1024))
+    for (int k = 0; k < (KT + 1) / 2; ++k) voff[k] = (((kg >> 1) * 64 + 32 * (kg & 1) + l15) << 4) + 4096 * k;
+    FragB b[KT][2];
+#define GG_B16_LOAD(T, H, BASE, CONSTRAINT)                                                                                       \
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : CONSTRAINT(b[T][H].q) : "v"(voff[(T) >> 1]), "s"(BASE), "n"(((T) & 1) * 2048 + (H) * 256))
     {
-        // (the A fragments are used once here, so that their compiler-placed wait stands in front of the loop and not -- merged over
-        // the back edge -- as a drain of the queue inside every iteration)
+        // The A fragments live in ACCUMULATION registers from here on (a matrix instruction reads its A operand from either file).
+        // As ordinary values they overflow the 256 architectural registers together with b[] and the running state, and the
+        // compiler's way out is to park them in accumulation registers anyway and COPY four registers back in front of every
+        // second matrix instruction: 128 extra vector instructions per tile, each pair a write-after-read on the operand the
+        // matrix core is still reading.  (It also puts their compiler-placed wait in front of the loop.)
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
+        for (int rbk = 0; rbk < NRB; ++rbk)
 #pragma unroll
-            for (int s = 0; s < KS; ++s) asm volatile("" ::"v"(afrag[rb][s].u.x), "v"(afrag[rb][s].u.w));
+            for (int t = 0; t < KT; ++t) asm volatile("" : "+a"(afrag[rbk][t].q));
         const char *const first = tile_of(cbeg);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) GG_B_LOAD(s, first, "=v");
+        for (int t = 0; t < KT; ++t) {
+            GG_B16_LOAD(t, 0, first, "=v");
+            GG_B16_LOAD(t, 1, first, "=v");
+        }
     }
-    // The bias of the columns comes through LDS, 2 048 columns at a time and private to the wave: a global bias load per tile sits
-    // in the same in-order memory counter as the B prefetch.  An LDS read has its own counter; the refill stalls once per 64 tiles.
     constexpr int BIAS_CHUNK = 2048;
     __shared__ float bias_lds[4][BIAS_CHUNK];
     float *const wb = bias_lds[wv];
-    // Measured and not kept (round 2): three B buffers (two tiles in flight) with the loop unrolled over them -- the unrolled
-    // consumer bodies cost more than the extra tile in flight brings (390 -> 309 TFLOP/s).
-    for (int c0 = cbeg; c0 < cend; c0 += 32) {
-        const int col = c0 + (lane & 31);
-        const int within = (c0 - cbeg) & (BIAS_CHUNK - 1);
-        if (within == 0) {
+    f32x4 acc[2][NRB][2];
 #pragma unroll
-            for (int i = 0; i < BIAS_CHUNK / 64; ++i) {
-                const int c = c0 + i * 64 + lane;
-                wb[i * 64 + lane] = c < cend ? bias[c] : -INFINITY;
+    for (int rbk = 0; rbk < NRB; ++rbk)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[1][rbk][h][i] = 0.f;
+    constexpr int VALS = NRB * 8;  // scores per lane and tile: consumed VALS / KT behind each k-step of the next tile
+    for (int cc = cbeg; cc < cend + 32; cc += 64) {
+        // bias of the two tiles consumed in this iteration (cc - 32 and cc): only the second can open a new LDS chunk (refilled
+        // after the first one's read), and the two halves below stay one basic block
+        float bjs[2][2];
+        const int wprev = (cc - 32 - cbeg) & (BIAS_CHUNK - 1);
+        bjs[0][0] = cc > cbeg ? wb[wprev + l15] : -INFINITY;
+        bjs[0][1] = cc > cbeg ? wb[wprev + 16 + l15] : -INFINITY;
+        const int within = (cc - cbeg) & (BIAS_CHUNK - 1);
+        if (within == 0) {  // (all requests first, clamped instead of predicated: one memory latency per refill, not 32)
+            float bv[BIAS_CHUNK / 64];
+#pragma unroll
+            for (int i = 0; i < BIAS_CHUNK / 64; ++i) bv[i] = bias[min(cc + i * 64 + lane, cend - 1)];
+#pragma unroll
+            for (int i = 0; i < BIAS_CHUNK / 64; ++i) wb[i * 64 + lane] = cc + i * 64 + lane < cend ? bv[i] : -INFINITY;
+        }
+        bjs[1][0] = wb[within + l15];
+        bjs[1][1] = wb[within + 16 + l15];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int c0 = cc + 32 * p, cprev = c0 - 32;  // multiplied now / consumed now
+            const int col0 = cprev + l15;
+            const float bj2[2] = {bjs[p][0] * LOG2E, bjs[p][1] * LOG2E};
+            const char *const nxt = tile_of(c0 + 32);
+#pragma unroll
+            for (int rbk = 0; rbk < NRB; ++rbk)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[p][rbk][h][i] = 0.f;
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b[t][0].q), "+v"(b[t][1].q) : "n"(KS - 2));
+#pragma unroll
+                for (int rbk = 0; rbk < NRB; ++rbk)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        acc[p][rbk][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[rbk][t].v, b[t][h].v, acc[p][rbk][h], 0, 0, 0);
+                GG_B16_LOAD(t, 0, nxt, "+v");
+                GG_B16_LOAD(t, 1, nxt, "+v");
+#pragma unroll
+                for (int v = t * VALS / KT; v < (t + 1) * VALS / KT; ++v) {
+                    // (column half 0 of every row cell before half 1: ties keep the lower column)
+                    const int h = v / (NRB * 4), rbk = (v >> 2) % NRB, i = v & 3;
+                    const float a = acc[p ^ 1][rbk][h][i];
+                    const float x = a + bjs[p][h];
+                    if (LSE) rs[rbk][i] += __builtin_amdgcn_exp2f(__builtin_fmaf(a, LOG2E, bj2[h]));
+                    const bool up = x > rm[rbk][i];
+                    rm[rbk][i] = up ? x : rm[rbk][i];
+                    ra[rbk][i] = up ? col0 + 16 * h : ra[rbk][i];
+                }
+                // one matrix instruction, then the vector instructions that fit beside it (a wave issues in order: 2 NRB matrix
+                // instructions back to back hold the issue port until the last one is accepted, and the consumer runs after them)
+#pragma unroll
+                for (int k = 0; k < 2 * NRB; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // (left alone, the scheduler lumps the consumer behind the matrix instructions)
             }
         }
-        const float bj = wb[within + (lane & 31)];
-        const char *const nxt = tile_of(c0 + 32);
-        f32x16 acc[RB];
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[rb][i] = 0.f;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(b[s].q) : "n"(KS - 1));
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[rb][s].v, b[s].v, acc[rb], 0, 0, 0);
-            GG_B_LOAD(s, nxt, "+v");
-        }
-        // (a column behind the split's end: bias -inf -> score -inf, its exponential 0, the compare false: no branch)
-        const float bj2 = bj * LOG2E;
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const float a = acc[rb][reg];
-                const float x = a + bj;
-                if (LSE) rs[rb][reg] += __builtin_amdgcn_exp2f(__builtin_fmaf(a, LOG2E, bj2));
-                const bool up = x > rm[rb][reg];
-                rm[rb][reg] = up ? x : rm[rb][reg];
-                ra[rb][reg] = up ? col : ra[rb][reg];
-            }
     }
-    // (the last tile's prefetch is still in flight INTO b[]: drain it before the registers are anyone else's)
+    // (the last prefetch is still in flight INTO b[]: drain it before the registers are anyone else's)
 #pragma unroll
-    for (int s = 0; s < KS; ++s) asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[s].q));
-#undef GG_B_LOAD
-    // (max, sum exp(x - max)) per cell; merge a row's 32 column lanes; lanes 0 and 32 then hold the wave's rows:
-    // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    for (int t = 0; t < KT; ++t) asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[t][0].q), "+v"(b[t][1].q));
+#undef GG_B16_LOAD
+    // merge a row's 16 column lanes; lanes with l15 == 0 then hold rows 16 rbk + 4 kg + i
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
+    for (int rbk = 0; rbk < NRB; ++rbk) {
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            float sx = rs[rb][reg];
+        for (int i = 0; i < 4; ++i) {
+            float sx = rs[rbk][i];
             if (LSE) {
-                // inf / nan, or 0 although the cell saw a column: the scores left the range a reference-free sum can hold
-                if (!(sx <= 3.0e38f) || (sx == 0.f && rm[rb][reg] > -INFINITY)) atomicOr(overflow, 1);
-                sx = rm[rb][reg] > -INFINITY ? sx * __builtin_amdgcn_exp2f(-rm[rb][reg] * LOG2E) : 0.f;
+                if (!(sx <= 3.0e38f) || (sx == 0.f && rm[rbk][i] > -INFINITY)) atomicOr(overflow, 1);
+                sx = rm[rbk][i] > -INFINITY ? sx * __builtin_amdgcn_exp2f(-rm[rbk][i] * LOG2E) : 0.f;
             }
-            Running x{rm[rb][reg], sx, ra[rb][reg]};
+            Running x{rm[rbk][i], sx, ra[rbk][i]};
 #pragma unroll
-            for (int off = 16; off >= 1; off >>= 1) {
+            for (int off = 8; off >= 1; off >>= 1) {
                 const float m = __shfl_xor(x.m, off, 64), so = __shfl_xor(x.s, off, 64);
                 const int ar = __shfl_xor(x.arg, off, 64);
                 run_merge(x, m, so, ar, LSE);
             }
-            if ((lane & 31) == 0) {
-                const int row = r0 + rb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+            if (l15 == 0) {
+                const int row = r0 + 16 * rbk + 4 * kg + i;
                 if (row < n_rows) {
                     const int64_t o = (int64_t)row * gridDim.x + split;
                     part_max[o] = x.m;
@@ -488,11 +540,12 @@ extern "C" int gg_all_score_reduce(gg_ctx *ctx, const int32_t *rows, int32_t n_r
     const int KS = ks_need <= 4 ? 4 : ks_need <= 8 ? 8 : ks_need <= 16 ? 16 : 32;
     const int ld16 = 16 * KS;
     const int RB = (precision == 1 && KS <= 8) ? 2 : 1;
-    // bf16, many rows: a workgroup's four wavefronts take four row blocks and share the table sweep (all_score_reduce_bf16_rows_kernel)
+    // bf16, many rows: a workgroup's four wavefronts take four row blocks and share the table sweep (all_score_reduce_bf16_x16_kernel)
     static thread_local bool force_narrow = false;  // set for the repeat of a call whose wide kernel reported an overflowing sum
     const bool wide = precision == 1 && n_rows >= 512 && !getenv("GG_ALLPAIRS_NARROW") && !force_narrow;
-    const int RBW = KS <= 8 ? 4 : (KS <= 16 ? 2 : 1);  // row blocks per wavefront of the wide kernel: as many as the registers of ONE wave per SIMD hold
-    const int tile_rows = wide ? 128 * RBW : 32 * RB;
+    // 16-row blocks per wavefront of the wide kernel: as many as the registers of ONE wave per SIMD hold without a spill
+    const int NRBW = KS <= 8 ? 6 : (KS <= 16 ? 4 : 2);
+    const int tile_rows = wide ? 64 * NRBW : 32 * RB;
     const int row_tiles = cdiv(n_rows, tile_rows);
     // enough workgroups for the chip: split the columns when there are few row tiles (multiples of 128 columns)
     int splits = std::max(1, std::min(cdiv(n, 128), cdiv(wide ? 1024 : 2048, row_tiles)));
@@ -529,24 +582,24 @@ extern "C" int gg_all_score_reduce(gg_ctx *ctx, const int32_t *rows, int32_t n_r
 #define GG_BF16_LAUNCH(KSV, RBV)                                                                                                    \
     hipLaunchKernelGGL((all_score_reduce_bf16_kernel<KSV, RBV>), grid, dim3(256), 0, ctx->stream, Eb, G.b, n, dr, n_rows, cps, want_lse, \
                        d_pm.as<float>(), d_pa.as<int32_t>(), d_ps.as<float>())
-#define GG_BF16_ROWS(KSV, RBV)                                                                                                                            \
-    do {                                                                                                                                                 \
-        if (want_lse) hipLaunchKernelGGL((all_score_reduce_bf16_rows_kernel<KSV, RBV, true>), grid, dim3(256), 0, ctx->stream, Eb, G.b, n, dr, n_rows, cps, \
-                                         d_pm.as<float>(), d_pa.as<int32_t>(), d_ps.as<float>(), d_ovf.as<int32_t>());                                     \
-        else hipLaunchKernelGGL((all_score_reduce_bf16_rows_kernel<KSV, RBV, false>), grid, dim3(256), 0, ctx->stream, Eb, G.b, n, dr, n_rows, cps,        \
-                                d_pm.as<float>(), d_pa.as<int32_t>(), d_ps.as<float>(), d_ovf.as<int32_t>());                                             \
+#define GG_BF16_WIDE(KSV, NRBV)                                                                                                                         \
+    do {                                                                                                                                               \
+        if (want_lse) hipLaunchKernelGGL((all_score_reduce_bf16_x16_kernel<KSV, NRBV, true>), grid, dim3(256), 0, ctx->stream, Eb, G.b, n, dr, n_rows, cps, \
+                                         d_pm.as<float>(), d_pa.as<int32_t>(), d_ps.as<float>(), d_ovf.as<int32_t>());                                   \
+        else hipLaunchKernelGGL((all_score_reduce_bf16_x16_kernel<KSV, NRBV, false>), grid, dim3(256), 0, ctx->stream, Eb, G.b, n, dr, n_rows, cps,        \
+                                d_pm.as<float>(), d_pa.as<int32_t>(), d_ps.as<float>(), d_ovf.as<int32_t>());                                           \
     } while (0)
-        if (wide) {
-            if (KS <= 4) { GG_BF16_ROWS(4, 4); }
-            else if (KS <= 8) { GG_BF16_ROWS(8, 4); }
-            else if (KS <= 16) { GG_BF16_ROWS(16, 2); }
-            else { GG_BF16_ROWS(32, 1); }
+        if (wide) {  // (NRBW above)
+            if (KS <= 4) { GG_BF16_WIDE(4, 6); }
+            else if (KS <= 8) { GG_BF16_WIDE(8, 6); }
+            else if (KS <= 16) { GG_BF16_WIDE(16, 4); }
+            else { GG_BF16_WIDE(32, 2); }
         } else if (KS <= 4) { GG_BF16_LAUNCH(4, 2); }
         else if (KS <= 8) { GG_BF16_LAUNCH(8, 2); }
         else if (KS <= 16) { GG_BF16_LAUNCH(16, 1); }
         else { GG_BF16_LAUNCH(32, 1); }
 #undef GG_BF16_LAUNCH
-#undef GG_BF16_ROWS
+#undef GG_BF16_WIDE
     }
     (void)hipEventRecord(ctx->ev1, ctx->stream);
     std::vector<float> pm(np), ps(np);

@@ -713,7 +713,7 @@ def _bf16_round(x):
     return r.astype(np.uint32).view(np.float32)
 
 
-@pytest.mark.parametrize("n,d", [(700, 50), (3000, 128), (1029, 256), (300, 8)])
+@pytest.mark.parametrize("n,d", [(700, 50), (3000, 128), (1029, 256), (300, 8), (600, 300)])
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_all_score_streamed_consumer(ga, n, d, precision):
     """generator.all_score (generator.py:21) streamed through the fused consumer (max, argmax, log-sum-exp per row; nothing
