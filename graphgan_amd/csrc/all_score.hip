@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void all_score_reduce_bf16_kernel(const uint4 
 //    sum is finite and accurate while the scores stay inside (-85, 85) -- embedding dot products are a few units --; a
 //    cell whose sum overflows, or underflows to 0, raises `overflow` and the host repeats the call with the kernel above.
 // Measured at 4 096 rows x 10^7 nodes x d = 256 (ms per call on one box; DESIGN.md section 5 has the table): this kernel 21.1
-// (max / argmax only: 18.3); without the software pipeline, 32x32x16 instructions: 22.2; the same before the A fragments
+// (max / argmax only: 17.5; both with the accumulators in architectural registers, Makefile); without the software pipeline, 32x32x16 instructions: 22.2; the same before the A fragments
 // moved to accumulation registers and the refill issued its 32 loads one by one: 25.3; before the hand-placed loads: 30.6.
 // Its matrix instructions alone (no loads, no consumer) take 13.4 ms = 1.56 PFLOP/s: the clocks this chip sustains under
 // dense matrix work, not the 2.5 PFLOP/s of the data sheet, are what "1.0" would be.
@@ -544,7 +544,7 @@ extern "C" int gg_all_score_reduce(gg_ctx *ctx, const int32_t *rows, int32_t n_r
     static thread_local bool force_narrow = false;  // set for the repeat of a call whose wide kernel reported an overflowing sum
     const bool wide = precision == 1 && n_rows >= 512 && !getenv("GG_ALLPAIRS_NARROW") && !force_narrow;
     // 16-row blocks per wavefront of the wide kernel: as many as the registers of ONE wave per SIMD hold without a spill
-    const int NRBW = KS <= 8 ? 6 : (KS <= 16 ? 4 : 2);
+    const int NRBW = KS <= 4 ? 6 : (KS <= 8 ? 5 : (KS <= 16 ? 4 : 2));
     const int tile_rows = wide ? 64 * NRBW : 32 * RB;
     const int row_tiles = cdiv(n_rows, tile_rows);
     // enough workgroups for the chip: split the columns when there are few row tiles (multiples of 128 columns)
@@ -591,7 +591,7 @@ extern "C" int gg_all_score_reduce(gg_ctx *ctx, const int32_t *rows, int32_t n_r
     } while (0)
         if (wide) {  // (NRBW above)
             if (KS <= 4) { GG_BF16_WIDE(4, 6); }
-            else if (KS <= 8) { GG_BF16_WIDE(8, 6); }
+            else if (KS <= 8) { GG_BF16_WIDE(8, 5); }
             else if (KS <= 16) { GG_BF16_WIDE(16, 4); }
             else { GG_BF16_WIDE(32, 2); }
         } else if (KS <= 4) { GG_BF16_LAUNCH(4, 2); }
