@@ -23,6 +23,22 @@ if [ "$Q" != "quick" ]; then
   # kernel timeline of a few steps (start / end of every kernel on both streams): summarize.py condenses one step
   rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${T}_tl -o b -- python $R/bench.py --no-cpu-baseline --no-strict --fresh-batches 0 --overlap-steps 0 --continuity-roots 0 --steps 6 --warmup 3 > $R/gpurun_out/${T}_tl.log 2>&1
 fi
+if [ "$Q" != "quick" ]; then
+  # K7 (all-pairs consumer on the matrix cores, configs[4] size): kernel stats + the matrix pipe's busy cycles (own PMC pass)
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${T}_k7 -o a -- python $R/tools/allpairs_bench.py 10000000 256 4096 > $R/gpurun_out/${T}_k7_bench.json 2> $R/gpurun_out/${T}_k7.log
+  rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_INST_ANY --output-format csv -d $R/gpurun_out/${T}_k7pmc -o s -- python $R/tools/allpairs_bench.py 10000000 256 4096 > /dev/null 2> $R/gpurun_out/${T}_k7pmc.log
+  python - <<PY
+import csv, collections, glob, json
+out = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("$R/gpurun_out/${T}_k7pmc/**/s_counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        if "all_score_reduce" in k: out[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+res = {k: {c: {"launches": len(x), "mean": sum(x) / len(x)} for c, x in v.items()} for k, v in out.items()}
+json.dump({"what": "SQ counters of the all-pairs consumer kernels, tools/allpairs_bench.py 10000000 256 4096 (sum over the chip's SEs per launch; SQ_BUSY_CYCLES / SQ_VALU_MFMA_BUSY_CYCLES count cycles, SQ_WAVE_CYCLES / SQ_WAIT_INST_ANY quad-cycles)", "kernels": res}, open("$R/gpurun_out/${T}_k7_pmc.json", "w"), indent=1)
+PY
+  rm -rf $R/gpurun_out/${T}_k7pmc $R/gpurun_out/${T}_k7/a_kernel_trace.csv
+fi
 cd $R
 python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
 # the raw traces are large: keep the summaries
