@@ -305,8 +305,10 @@ __global__ __launch_bounds__(256) void all_score_reduce_bf16_kernel(const uint4 
 //    ONE set of B registers: step t of the NEXT tile is requested into b[t] right behind the matrix instructions that read
 //    the current b[t]; the memory counter retires in order and a request pair has exactly KS - 2 younger requests when its
 //    step is multiplied, so `s_waitcnt vmcnt(KS - 2)` there is exact.  Each b[t] is a read-write operand of both
-//    statements: it stays in one register quadruple and nothing moves across the wait.  THE KERNEL MUST NOT SPILL: a spilled
-//    b[t] would be copied while its data is in flight (csrc/check_no_scratch.sh fails the build on any scratch use here).
+//    statements: it stays in one register quadruple and nothing moves across the wait.  THE KERNEL MUST NOT SPILL OR COPY them: a b[t] moved
+//    while its data is in flight is stale.  The build checks both on the generated code: csrc/check_no_scratch.sh (no scratch,
+//    no spill in any instantiation) and csrc/audit_inflight_regs.py (no instruction names a destination register between a
+//    load statement and the wait that covers it, around the loop and from the prologue).
 //  - the bias of the columns comes through LDS, 2 048 columns at a time and private to the wave: a global bias load per tile
 //    sits in the same in-order memory counter as the B prefetch.  The refill is the only compiler-issued load in the loop;
 //    its compiler-placed wait drains the queue (over-waiting is safe), once per 64 tiles, all 32 requests in flight at once.
