@@ -50,6 +50,7 @@ def parse():
     p.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--seed", type=int, default=6)
+    p.add_argument("--no-g-head-start", action="store_true", help="do not call gg_prepare_g_begin before the D pass (the G-mode walks then start once the host has enqueued the D pass)")
     p.add_argument("--overlap-steps", type=int, default=6, help="steps behind the timed region whose profiled side-stream launches ARE isolated (solo roofline figure)")
     p.add_argument("--fresh-batches", type=int, default=2, help="behind the timed region: root batches whose trees are built first (end-to-end figure); 0 = skip")
     p.add_argument("--no-strict", action="store_true", help="skip the strict-mode (batch 64, dense TF1-Adam, CA-GrQc) pairs/s line")
@@ -268,6 +269,8 @@ def main():
     def step(i):
         # every rank issues both passes (they contain the replicas' gradient exchange), even with no rows
         rows = eng.prepare_d(slots, args.seed, 2 * i, fetch=False)
+        if not args.no_g_head_start:  # the G-mode walks need the generator only: enqueued before the host enqueues the D pass
+            eng.prepare_g_begin(slots, args.n_sample_gen, args.seed, 2 * i + 1)
         eng.d_pass(np.zeros(1, np.int64), max(int(rows), 1))
         pairs = eng.prepare_g(slots, args.n_sample_gen, args.seed, 2 * i + 1, fetch=False)
         eng.g_pass(np.zeros(1, np.int64), max(int(pairs), 1))
@@ -303,6 +306,8 @@ def main():
 
         def sub_step(i):
             rows = eng.prepare_d(sub_slots, args.seed, 2 * i, fetch=False)
+            if not args.no_g_head_start:
+                eng.prepare_g_begin(sub_slots, args.n_sample_gen, args.seed, 2 * i + 1)
             eng.d_pass(np.zeros(1, np.int64), max(int(rows), 1))
             pairs = eng.prepare_g(sub_slots, args.n_sample_gen, args.seed, 2 * i + 1, fetch=False)
             eng.g_pass(np.zeros(1, np.int64), max(int(pairs), 1))
@@ -428,7 +433,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": wl_name, "roots_per_gpu_per_step": int(R), "n_sample_gen": args.n_sample_gen,
-                   "optimizer": args.optimizer, "step": "prepare_d + d_pass + prepare_g + g_pass (graph_gan.py:144-176, one inner pass each)",
+                   "optimizer": args.optimizer, "step": "prepare_d + d_pass + prepare_g + g_pass (graph_gan.py:144-176, one inner pass each)" + ("" if args.no_g_head_start else "; the walks of prepare_g are enqueued before d_pass (gg_prepare_g_begin)"),
                    "parallelism": "roots sharded x%d, replicated tables, RCCL sparse gradient all-gather per pass" % world if world > 1 else "single GPU"},
         # pairs through the update kernels / HIP-event time of those kernels (gradient + optimizer) on the profiled passes
         "d_step_pairs_per_sec": c["d_pairs_timed"] / ((c["d_grad_ms"] + c["d_opt_ms"]) * 1e-3) if c["d_grad_ms"] > 0 else None,

@@ -82,6 +82,7 @@ SIGNATURES = {
     "gg_prepare_d": (ctypes.c_int, [_P, _P, _i32, _u64, _u32, _P, _P]),
     "gg_get_d_data": (ctypes.c_int, [_P, _P, _P, _P]),
     "gg_prepare_g": (ctypes.c_int, [_P, _P, _i32, _i32, _u64, _u32, _P, _P]),
+    "gg_prepare_g_begin": (ctypes.c_int, [_P, _P, _i32, _i32, _u64, _u32]),
     "gg_get_g_data": (ctypes.c_int, [_P, _P, _P, _P]),
     "gg_d_pass": (ctypes.c_int, [_P, _P, _i64, _i32]),
     "gg_g_pass": (ctypes.c_int, [_P, _P, _i64, _i32]),
@@ -125,7 +126,7 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.gg_abi_version() != 3:
+    if lib.gg_abi_version() != 4:
         raise ImportError("graphgan_amd: ABI version mismatch")
     return lib
 

@@ -29,6 +29,7 @@ int fail(gg_ctx *ctx, int code, const char *fmt, ...) {
 }
 
 static void free_trees(gg_ctx *ctx) {
+    discard_begun_walk(ctx);
     void *ps[] = {ctx->t_root, ctx->t_order, ctx->t_cstart, ctx->t_base, ctx->t_q3, ctx->t_q3off, ctx->t_edge};
     for (void *p : ps)
         if (p) (void)hipFree(p);
@@ -48,6 +49,7 @@ static void free_trees(gg_ctx *ctx) {
 // Device arrays for the BFS-order trees of `roots`: node counts C_r (NULL: component sizes from a cached host sweep of
 // the graph), Q3 bit rows sized by the roots' child counts (NULL: their degrees, an upper bound), zero-initialised.
 int alloc_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int64_t *node_counts, const int64_t *root_children) {
+    discard_begun_walk(ctx);
     (void)hipDeviceSynchronize();  // walks of calls that returned early may still read the old trees
     ctx->dc_valid = false;
     ctx->t_edge_valid = false;  // set by whoever fills the arrays (GPU BFS: in the same pass; otherwise derive_tree_edges)
@@ -124,7 +126,7 @@ using namespace gg;
 
 // One walk launch on ctx->walk_stream; a side-stream launch is ordered behind the last generator update and
 // hands its completion back to the main stream, where everything that follows the walk is enqueued.
-static int launch_and_join(gg_ctx *ctx, int32_t n_slots, int64_t total, int32_t for_d, uint64_t seed, uint32_t stream, int32_t stride) {
+static int launch_and_join(gg_ctx *ctx, int32_t n_slots, int64_t total, int32_t for_d, uint64_t seed, uint32_t stream, int32_t stride, bool join = true) {
     const bool side = ctx->walk_stream != ctx->stream;
     int rc = launch_walk_sample(ctx, n_slots, total, for_d, seed, stream, stride);
     if (rc != GG_OK) {
@@ -133,15 +135,29 @@ static int launch_and_join(gg_ctx *ctx, int32_t n_slots, int64_t total, int32_t 
     }
     if (side) {
         GG_HIP(ctx, hipEventRecord(ctx->ev_walk_done, ctx->walk_stream));
-        GG_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_walk_done, 0));
+        if (join) GG_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_walk_done, 0));  // (gg_prepare_g_begin: joined by the adopting gg_prepare_g)
     }
     return GG_OK;
+}
+
+// A launch started by gg_prepare_g_begin that no gg_prepare_g adopted: wait for it and forget it.  What it stamped into the
+// edge-score cache is dropped as well (its counter words are never read: whether it completed is unknown).
+void gg::discard_begun_walk(gg_ctx *ctx) {
+    if (!ctx->g_begun) return;
+    (void)hipStreamSynchronize(ctx->stream2);
+    ctx->g_begun = false;
+    ctx->dc_request = 0;
+    ctx->walk_stream = ctx->stream;
+    ctx->w_nslots = 0;
+    ctx->w_total = 0;
+    generator_changed(ctx);
 }
 
 // Shared by gg_walk_sample and gg_prepare_*: stage the launch on device and enqueue it (no host
 // synchronisation).  n_walks == NULL: CSR degree of each slot's root (D-mode, graph_gan.py:190-191).
 int gg::walk_launch_async(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, int32_t uniform_walks, int32_t n_slots,
-                          int32_t for_d, uint64_t seed, uint32_t stream, int32_t stride, bool side_stream) {
+                          int32_t for_d, uint64_t seed, uint32_t stream, int32_t stride, bool side_stream, bool defer_join) {
+    discard_begun_walk(ctx);  // (a launch begun earlier uses the buffers this one is about to fill)
     GG_CHECK(ctx, ctx->n_tree_roots > 0, GG_EINVAL, "walk: no trees loaded (gg_build_trees / gg_set_trees)");
     GG_CHECK(ctx, n_slots >= 0 && (slots || n_slots == 0), GG_EINVAL, "walk: bad slots");
     GG_CHECK(ctx, stride >= 2, GG_ECAPACITY, "walk: stride %d < 2", stride);
@@ -201,7 +217,7 @@ int gg::walk_launch_async(gg_ctx *ctx, const int32_t *slots, const int32_t *n_wa
         ctx->walk_stream = ctx->stream;
         return GG_OK;
     }
-    return launch_and_join(ctx, n_slots, total, for_d, seed, stream, stride);
+    return launch_and_join(ctx, n_slots, total, for_d, seed, stream, stride, !defer_join);
 }
 
 // Wait for the enqueued launch (and whatever the caller enqueued behind it), collect counters,
@@ -411,6 +427,7 @@ int gg_destroy(gg_ctx *ctx) {
     if (!ctx) return GG_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);  // (a launch begun by gg_prepare_g_begin may still run)
     comm_destroy(ctx);
     for (int m = 0; m < 2; ++m) {
         Model &M = ctx->model[m];
@@ -456,6 +473,7 @@ int gg_destroy(gg_ctx *ctx) {
 int gg_set_graph_csr(gg_ctx *ctx, const int64_t *rowptr, const int32_t *col) {
     if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
     GG_CHECK(ctx, rowptr && rowptr[0] == 0, GG_EINVAL, "gg_set_graph_csr: rowptr[0] must be 0");
+    discard_begun_walk(ctx);
     const int n = ctx->n_node;
     const int64_t nnz = rowptr[n];
     GG_CHECK(ctx, nnz >= 0 && (col || nnz == 0), GG_EINVAL, "gg_set_graph_csr: col is NULL");
@@ -826,6 +844,7 @@ int gg_walk_info(const gg_ctx *ctx, int64_t *total_walks, int32_t *stride, int32
 int gg_get_walks(gg_ctx *ctx, int32_t *samples, int32_t *paths, int32_t *path_len, int32_t *root_status) {
     if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
     GG_HIP(ctx, hipSetDevice(ctx->device));
+    discard_begun_walk(ctx);  // (a launch that was only begun has no results to hand out)
     GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int64_t total = ctx->w_total;
     if (samples && total) GG_HIP(ctx, hipMemcpy(samples, ctx->w_samples.p, sizeof(int32_t) * total, hipMemcpyDeviceToHost));
@@ -843,7 +862,7 @@ static int table_io(gg_ctx *ctx, int32_t which, float *out, const float *in, boo
     GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     Model &M = ctx->model[which];
     const int n = ctx->n_node, d = ctx->n_emb, ld = ctx->ld;
-    if (in && which == 0) generator_changed(ctx);
+    if (in && which == 0) { discard_begun_walk(ctx); generator_changed(ctx); }
     if (bias) {
         if (out) GG_HIP(ctx, hipMemcpy(out, M.b, sizeof(float) * n, hipMemcpyDeviceToHost));
         else GG_HIP(ctx, hipMemcpy(M.b, in, sizeof(float) * n, hipMemcpyHostToDevice));
@@ -889,6 +908,7 @@ int gg_synchronize(gg_ctx *ctx) {
     if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
     GG_HIP(ctx, hipSetDevice(ctx->device));
     GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->g_begun) GG_HIP(ctx, hipStreamSynchronize(ctx->stream2));  // (the begun launch stays adoptable)
     harvest_timings(ctx);
     return check_exchange_flag(ctx);
 }
@@ -973,6 +993,7 @@ int state_io(gg_ctx *ctx, const char *path, bool save) {
     GG_CHECK(ctx, path, GG_EINVAL, "state: path is NULL");
     GG_HIP(ctx, hipSetDevice(ctx->device));
     GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!save) discard_begun_walk(ctx);  // (the generator's tables are about to be replaced)
     const bool slots = ctx->cfg.optimizer != GG_OPT_SGD;
     const size_t ne = (size_t)ctx->n_node * ctx->ld, nb = (size_t)ctx->n_node;
     struct Scalars { int64_t t; float b1p, b2p; };

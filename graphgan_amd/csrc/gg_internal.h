@@ -198,6 +198,11 @@ struct gg_ctx {
     gg::DevBuf g_node1, g_node2, g_reward, g_cnt, g_ptr;
     int64_t g_pairs = 0;
     bool g_paths_valid = false;  // w_paths / g_ptr still describe the resident prepare_g data
+    // gg_prepare_g_begin: a G-mode walk launch enqueued on the side stream and NOT yet joined / finalized; adopted by the next
+    // gg_prepare_g with the same arguments, discarded (side stream drained) by anything else that needs the walk buffers, the
+    // trees or the generator's tables
+    bool g_begun = false;
+    struct { int32_t n_slots = 0, n_sample = 0; uint64_t seed = 0; uint32_t stream = 0; } g_begun_args;
     gg::DevBuf touched_ptr;
     gg::DevBuf bfs_key, bfs_bm, bfs_misc;  // scratch of gg_build_trees_device (bfs_gpu.hip)
     int n_cus = 256;                       // compute units of the device (gg_create; hipGetDeviceProperties costs milliseconds)
@@ -271,7 +276,8 @@ int32_t lists_to_order(int32_t n, int32_t root, const int32_t *off, const int32_
 
 // launchers
 int walk_launch_async(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, int32_t uniform_walks, int32_t n_slots,
-                      int32_t for_d, uint64_t seed, uint32_t stream, int32_t stride, bool side_stream = false);
+                      int32_t for_d, uint64_t seed, uint32_t stream, int32_t stride, bool side_stream = false, bool defer_join = false);
+void discard_begun_walk(gg_ctx *ctx);  // gg_api.hip: drain and forget a gg_prepare_g_begin launch nobody adopted
 int walk_finalize(gg_ctx *ctx, bool *retried);
 int timing_slot(gg_ctx *ctx);
 int check_exchange_flag(gg_ctx *ctx);

@@ -6,6 +6,8 @@
 // node lists through the host between the walk kernel and the update passes.
 #include <algorithm>
 
+#include <cstring>
+
 #include "gg_internal.h"
 
 namespace gg {
@@ -476,6 +478,7 @@ int gg_prepare_d(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, uint64_t se
     ctx->d_rows = 0;
     // the distributions these walks evaluate are registered for the G-mode walks of the same step (walk_sample.hip)
     ctx->dc_valid = false;
+    discard_begun_walk(ctx);
     ctx->dc_request = ctx->dc_enabled ? 1 : 0;
     int rc = walk_launch_async(ctx, slots, nullptr, -1, n_slots, 1, seed, stream, stride);
     if (rc != GG_OK) { ctx->dc_request = 0; return rc; }
@@ -566,16 +569,48 @@ static int enqueue_g_pairs(gg_ctx *ctx, int64_t nw, int64_t cap) {
     return GG_OK;
 }
 
+// gg_prepare_g_begin: see include/graphgan_hip.h.  The launch is exactly the one gg_prepare_g would enqueue -- same stream,
+// same arguments, same caches -- only earlier, and without the main stream waiting for it yet.
+int gg_prepare_g_begin(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, int32_t n_sample, uint64_t seed, uint32_t stream) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    GG_CHECK(ctx, n_sample >= 0, GG_EINVAL, "gg_prepare_g_begin: n_sample < 0");
+    const int stride = ctx->tree_max_depth + 3;
+    discard_begun_walk(ctx);
+    ctx->dc_request = ctx->dc_valid ? 2 : 0;
+    int rc = walk_launch_async(ctx, slots, nullptr, n_sample, n_slots, 0, seed, stream, stride, /*side_stream=*/true, /*defer_join=*/true);
+    if (rc != GG_OK) { ctx->dc_request = 0; return rc; }
+    if (n_slots == 0) { ctx->dc_request = 0; return GG_OK; }  // (nothing was enqueued: gg_prepare_g does the whole call)
+    ctx->g_begun = true;
+    ctx->g_begun_args.n_slots = n_slots;
+    ctx->g_begun_args.n_sample = n_sample;
+    ctx->g_begun_args.seed = seed;
+    ctx->g_begun_args.stream = stream;
+    return GG_OK;
+}
+
 int gg_prepare_g(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, int32_t n_sample, uint64_t seed, uint32_t stream,
                  int64_t *n_pairs_out, int32_t *root_status) {
     if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
     GG_CHECK(ctx, n_sample >= 0, GG_EINVAL, "gg_prepare_g: n_sample < 0");
     const int stride = ctx->tree_max_depth + 3;
     ctx->g_pairs = 0;
-    // G walks read the generator's tables and the trees only: beside the discriminator update still in flight
-    ctx->dc_request = ctx->dc_valid ? 2 : 0;  // G-mode walks look their distributions up in what the D launch of the step left
-    int rc = walk_launch_async(ctx, slots, nullptr, n_sample, n_slots, 0, seed, stream, stride, /*side_stream=*/true);
-    if (rc != GG_OK) { ctx->dc_request = 0; return rc; }
+    int rc;
+    const bool adopt = ctx->g_begun && ctx->g_begun_args.n_slots == n_slots && ctx->g_begun_args.n_sample == n_sample &&
+                       ctx->g_begun_args.seed == seed && ctx->g_begun_args.stream == stream && slots &&
+                       ctx->h_slots_m[0].size() == (size_t)n_slots && memcmp(ctx->h_slots_m[0].data(), slots, sizeof(int32_t) * n_slots) == 0;
+    if (adopt) {
+        // the launch gg_prepare_g_begin enqueued IS this call's: the main stream joins it here, everything else as below
+        ctx->g_begun = false;
+        GG_HIP(ctx, hipSetDevice(ctx->device));
+        GG_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_walk_done, 0));
+    } else {
+        // G walks read the generator's tables and the trees only: beside the discriminator update still in flight
+        // (a begun launch with other arguments is drained and dropped inside walk_launch_async)
+        discard_begun_walk(ctx);
+        ctx->dc_request = ctx->dc_valid ? 2 : 0;  // G-mode walks look their distributions up in what the D launch of the step left
+        rc = walk_launch_async(ctx, slots, nullptr, n_sample, n_slots, 0, seed, stream, stride, /*side_stream=*/true);
+        if (rc != GG_OK) { ctx->dc_request = 0; return rc; }
+    }
     const int64_t nw = ctx->w_total;
     // a path of L = len - 1 <= stride - 1 nodes gives at most 2 * window * L pairs
     const int64_t cap = nw * 2 * ctx->cfg.window_size * (stride - 1);
@@ -616,6 +651,7 @@ int gg_prepare_g(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, int32_t n_s
 
 int gg_get_g_data(gg_ctx *ctx, int32_t *node_1, int32_t *node_2, float *reward) {
     if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    discard_begun_walk(ctx);  // (a begun launch overwrote the walks these pairs are expanded from: g_paths_valid is false)
     const int64_t n = ctx->g_pairs;
     if (n == 0) return GG_OK;
     GG_HIP(ctx, hipSetDevice(ctx->device));

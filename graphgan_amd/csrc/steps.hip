@@ -1318,6 +1318,7 @@ using namespace gg;
 
 static int host_step(gg_ctx *ctx, int which, const int32_t *u, const int32_t *v, const float *x, int32_t n) {
     if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    if (which == 0) discard_begun_walk(ctx);  // (walks begun by gg_prepare_g_begin read the tables this step writes)
     GG_CHECK(ctx, n >= 0 && (n == 0 || (u && v && x)), GG_EINVAL, "step: bad argument");
     if (n == 0) return GG_OK;
     for (int i = 0; i < n; ++i)
@@ -1351,6 +1352,7 @@ static int host_step(gg_ctx *ctx, int which, const int32_t *u, const int32_t *v,
 
 static int run_pass(gg_ctx *ctx, int which, const int64_t *starts, int64_t n_batches, int32_t batch_size) {
     if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    if (which == 0) discard_begun_walk(ctx);  // (walks begun by gg_prepare_g_begin read the tables this pass writes)
     GG_CHECK(ctx, batch_size > 0 && n_batches >= 0 && (starts || n_batches == 0), GG_EINVAL, "pass: bad argument");
     const int64_t rows = which == 1 ? ctx->d_rows : ctx->g_pairs;
     const int32_t *u = which == 1 ? ctx->d_center.as<int32_t>() : ctx->g_node1.as<int32_t>();

@@ -274,6 +274,12 @@ class Engine:
         self._ck(lib.gg_get_g_data(self._ctx, _ptr(a), _ptr(b), _ptr(r)))
         return a, b, r, status
 
+    def prepare_g_begin(self, slots, n_sample, seed, stream):
+        """Optional head start: enqueue the walks of the NEXT prepare_g (same arguments) on the side stream now -- before
+        the d_pass that precedes it -- without waiting for anything (gg_prepare_g_begin)."""
+        slots = _i32(slots)
+        self._ck(lib.gg_prepare_g_begin(self._ctx, _ptr(slots), len(slots), n_sample, seed, stream))
+
     def d_pass(self, starts, batch_size):
         """One inner D epoch over the prepared rows (graph_gan.py:149-157)."""
         starts = np.ascontiguousarray(starts, dtype=np.int64)

@@ -218,6 +218,11 @@ class GraphGAN(object):
                 if d_epoch % cfg.dis_interval == 0:
                     self._stream = self.stream_id(epoch, d_epoch, cfg.n_epochs_dis, True)
                     train_size = self._prepare_d_resident()
+                if d_epoch == cfg.n_epochs_dis - 1 and cfg.n_epochs_gen > 0 and cfg.update_ratio >= 1:
+                    # the G-mode walks of the first G epoch read the generator only (reference :204-216): started on the
+                    # engine's side stream before the last D pass is enqueued, adopted by prepare_g below (same arguments; with
+                    # update_ratio < 1 the root draw of that call is not known yet, and nothing is begun)
+                    self.engine.prepare_g_begin(self._select_slots(), cfg.n_sample_gen, self.seed, self.stream_id(epoch, 0, cfg.n_epochs_gen, False))
                 self.engine.d_pass(self._batch_starts(train_size, cfg.batch_size_dis), cfg.batch_size_dis)
 
             # G-steps

@@ -14,11 +14,12 @@
  *   - the caller owns every host buffer it passes (C-contiguous; int32 node ids - the
  *     reference's placeholders are tf.int32, generator.py:17-18; fp32 values; int64
  *     offsets).  Inputs are copied; outputs are written before the call returns.  By default
- *     every call is synchronous (it returns after the context's HIP stream is idle).  The one
- *     exception is opt-in: after gg_set_profiling(ctx, k) with k != 1, gg_d_pass / gg_g_pass
+ *     every call is synchronous (it returns after the context's HIP stream is idle).  The two
+ *     exceptions are opt-in: after gg_set_profiling(ctx, k) with k != 1, gg_d_pass / gg_g_pass
  *     return once their kernels are ENQUEUED (stream-ordered behind everything issued before;
  *     they have no host outputs) -- errors of such a pass surface at the next call that
- *     synchronises (gg_prepare_*, gg_get_*, gg_synchronize).
+ *     synchronises (gg_prepare_*, gg_get_*, gg_synchronize); and gg_prepare_g_begin, which only
+ *     enqueues the walks of the gg_prepare_g that follows (errors surface in that call).
  *   - a gg_ctx owns all device memory (embedding tables, Adam slots, graph CSR, tree CSR,
  *     prepared sample buffers, scratch) and one HIP stream on one device; it is not
  *     re-entrant.  Multi-GPU = one process and one context per GPU (gg_comm_*).
@@ -35,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GG_ABI_VERSION 3  /* round 3: gg_counters extended (edge-score cache) */
+#define GG_ABI_VERSION 4  /* round 3: gg_counters extended (edge-score cache); gg_prepare_g_begin */
 
 enum {
     GG_OK = 0,
@@ -207,6 +208,16 @@ int gg_prepare_d(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, uint64_t se
 int gg_get_d_data(gg_ctx *ctx, int32_t *center, int32_t *neighbor, float *label);
 int gg_prepare_g(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, int32_t n_sample, uint64_t seed,
                  uint32_t stream, int64_t *n_pairs_out, int32_t *root_status);
+/* Optional head start for the gg_prepare_g that follows a discriminator update: enqueue its walks NOW -- on the side stream,
+ * without any host synchronisation -- typically between gg_prepare_d and gg_d_pass, so that they run beside the whole
+ * discriminator pass instead of starting once the host has enqueued it (graph_gan.py:204-216 samples from the generator
+ * only; the rewards of :220-222, which need the updated discriminator, stay in gg_prepare_g).  The next gg_prepare_g with
+ * the SAME (slots, n_sample, seed, stream) adopts the launch and returns exactly what it would have returned without
+ * this call.  Any other call that needs the walk buffers, the trees or the generator's tables -- another walk launch,
+ * gg_get_walks, gg_get_g_data, gg_g_step / gg_g_pass, gg_set_embeddings / gg_set_bias(0), gg_load_state, a tree or graph
+ * call -- first waits for the begun launch and drops it; a later gg_prepare_g then launches anew.  Allowed in between
+ * without losing the head start: gg_d_step / gg_d_pass, gg_get_d_data, the getters and gg_synchronize. */
+int gg_prepare_g_begin(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, int32_t n_sample, uint64_t seed, uint32_t stream);
 /* The (node_1, node_2) arrays of gg_prepare_g are expanded from its walks on first use -- gg_get_g_data, or a gg_g_pass in
  * minibatches -- which must therefore come before the next walk launch of the context (gg_prepare_d / gg_prepare_g /
  * gg_walk_sample); later it is GG_EINVAL.  Rewards, and whole-batch passes over the walks, do not need them. */

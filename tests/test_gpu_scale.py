@@ -241,6 +241,61 @@ def test_steady_state_steps_need_no_rerun_and_reuse_the_cache(ga):
     assert all(g < 0.6 * dd for g, dd in zip(g_rows[4:], d_rows[4:])), (d_rows, g_rows)
 
 
+def test_prepare_g_begin_changes_when_the_walks_start_and_nothing_else(ga):
+    """gg_prepare_g_begin enqueues the walks of the next gg_prepare_g before the discriminator pass that precedes it
+    (graph_gan.py:204-216 reads the generator only).  Same walks, pairs and pair count as the plain call order; rewards and the
+    tables after the step equal up to the run-dependent order of the hub rows' atomic adds; a begun launch that something
+    else overtakes -- other arguments, a read of the walks, an upload of the generator -- is dropped without a trace."""
+    from graphgan_amd import workloads
+    n, d = 30_000, 64
+    rowptr, col, emb, _ = workloads.powerlaw_workload(n, 10, d)
+    roots = workloads.bench_roots(rowptr, 1024, 0, 1, 6)
+    slots = np.arange(len(roots), dtype=np.int32)
+
+    def run(order, steps=3):
+        eng = ga.Engine(emb, emb, optimizer=ga.GG_OPT_ADAM_LAZY)
+        eng.set_graph_csr(rowptr, col)
+        eng.build_trees(roots, device=True)
+        eng.set_profiling(0)          # passes return once they are enqueued
+        out = []
+        for i in range(steps):
+            rows = eng.prepare_d(slots, 6, 2 * i, fetch=False)
+            if order == "begin":
+                eng.prepare_g_begin(slots, 20, 6, 2 * i + 1)
+            elif order == "begin_other_args":       # dropped by the gg_prepare_g below (another stream id)
+                eng.prepare_g_begin(slots, 20, 6, 2 * i + 77)
+            elif order == "begin_then_read":        # dropped by gg_get_walks
+                eng.prepare_g_begin(slots, 20, 6, 2 * i + 1)
+                eng.get_walks()
+            elif order == "begin_then_upload":      # dropped by gg_set_bias(generator); the same bias goes back in
+                eng.prepare_g_begin(slots, 20, 6, 2 * i + 1)
+                eng.set_bias(0, eng.get_bias(0))
+            eng.d_pass([0], 1 << 30)
+            a, b, r, status = eng.prepare_g(slots, 20, 6, 2 * i + 1)
+            w = eng.get_walks()
+            eng.g_pass([0], 1 << 30)
+            out.append((rows, a, b, r, status, w))
+        tabs = [eng.get_embeddings(0), eng.get_embeddings(1), eng.get_bias(0), eng.get_bias(1)]
+        c = eng.counters()
+        eng.close()
+        return out, tabs, c
+
+    ref, ref_tabs, c_ref = run("plain")
+    for order in ("begin", "begin_other_args", "begin_then_read", "begin_then_upload"):
+        got, tabs, c = run(order)
+        for (rows0, a0, b0, r0, s0, w0), (rows1, a1, b1, r1, s1, w1) in zip(ref, got):
+            assert rows0 == rows1 and np.array_equal(s0, s1), order
+            assert np.array_equal(a0, a1) and np.array_equal(b0, b1), order
+            for k in ("samples", "path_len", "root_status"):
+                assert np.array_equal(w0[k], w1[k]), (order, k)
+            assert np.allclose(r0, r1, rtol=1e-5, atol=1e-6), order
+        for t0, t1 in zip(ref_tabs, tabs):
+            assert np.allclose(t0, t1, rtol=1e-4, atol=1e-6), order
+        assert c["hops"] >= c_ref["hops"]   # (a dropped launch is never counted; an adopted one exactly once)
+        if order == "begin":
+            assert c["hops"] == c_ref["hops"] and c["walk_reruns"] == c_ref["walk_reruns"]
+
+
 def _compare_walks(got, want, item_ptr, sel, stride_w, tag):
     """walks of the selected roots: got = engine launch over all roots (walk_ptr = item_ptr), want = oracle over sel"""
     o = 0
@@ -290,6 +345,7 @@ def test_bench_workload_walks_bit_exact_inside_the_timed_step(ga):
         got = eng.get_walks()
         want = orc.c_walk_sample(Eg, bg, off, nbr, base, sroots, oslots, deg[sroots].astype(np.int32), True, seed, 2 * i, stride)
         _compare_walks(got, want, d_ptr, sel, stride, "step %d D" % i)
+        eng.prepare_g_begin(slots, 20, seed, 2 * i + 1)  # as bench.py's step: the G-mode walks are enqueued before the D pass
         eng.d_pass(np.zeros(1, np.int64), max(int(rows), 1))
         pairs = eng.prepare_g(slots, 20, seed, 2 * i + 1, fetch=False)
         got = eng.get_walks()

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(ga):
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert raw.gg_abi_version() == 3
+    assert raw.gg_abi_version() == 4
 
 
 def test_no_gpu_means_loud_failure(ga):

@@ -110,6 +110,7 @@ class _FakeEngine(object):
         self.calls.append(("prepare_g", len(slots), n_sample, seed, stream, fetch))
         self.last_slots = np.array(slots)
         return 333 if len(slots) else 0
+    def prepare_g_begin(self, slots, n_sample, seed, stream): self.calls.append(("prepare_g_begin", len(slots), n_sample, seed, stream))
     def d_pass(self, starts, batch): self.calls.append(("d_pass", list(starts), batch))
     def g_pass(self, starts, batch): self.calls.append(("g_pass", list(starts), batch))
     def get_embeddings(self, which): return self.E[which]
@@ -143,7 +144,8 @@ def test_training_schedule_drives_the_engine_like_the_reference(pkg, tmp_path, m
     assert names[:3] == ["set_profiling", "set_graph_csr", "build_trees"] and calls[2][1] == n and calls[2][2] is True
     assert names[3] == "load_state"                                 # load_model and the checkpoint exists (:124-127)
     assert names[4:6] == ["write_embeddings", "write_embeddings"]  # before training (:129)
-    per_epoch = ["prepare_d", "d_pass", "d_pass", "prepare_d", "d_pass", "d_pass",
+    # (prepare_g_begin: the walks of the epoch's first prepare_g are started before the last D pass is enqueued)
+    per_epoch = ["prepare_d", "d_pass", "d_pass", "prepare_d", "d_pass", "prepare_g_begin", "d_pass",
                  "prepare_g", "g_pass", "g_pass", "g_pass", "prepare_g", "g_pass", "g_pass", "write_embeddings", "write_embeddings"]
     want = per_epoch + per_epoch + ["save_state"] + per_epoch  # save at epoch 2 (epoch > 0 and epoch % save_steps == 0, :136-138)
     assert names[6:] == want
@@ -153,6 +155,10 @@ def test_training_schedule_drives_the_engine_like_the_reference(pkg, tmp_path, m
     assert [c[3] for c in pd] == [2 * (e * 4 + i) for e in range(3) for i in (0, 2)]
     assert [c[4] for c in pg] == [2 * (e * 5 + i) + 1 for e in range(3) for i in (0, 3)]
     assert all(c[1] == n and c[2] == 11 and c[4] is False for c in pd) and all(c[2] == 20 for c in pg)
+    # the head start names exactly the arguments of the prepare_g that adopts it (slots, n_sample, seed, stream)
+    pb = [c for c in calls if c[0] == "prepare_g_begin"]
+    first_pg = [c for c in pg if (c[4] - 1) // 2 % 5 == 0]
+    assert [c[1:] for c in pb] == [c[1:5] for c in first_pg] and len(pb) == 3
     # batches: a permutation of the contiguous starts 0, 64, ... of the prepared size
     for c in calls:
         if c[0] == "d_pass":

@@ -150,6 +150,8 @@ class _ReplicaEngine(object):
         self.rows[1] = int(2 * self.deg[np.asarray(self.tree_roots)[np.asarray(slots)]].sum())  # 2 * deg rows per root
         return self.rows[1]
 
+    def prepare_g_begin(self, slots, n_sample, seed, stream): pass   # (a head start on the device: no collective, no result)
+
     def prepare_g(self, slots, n_sample, seed, stream, fetch=True):
         self.rows[0] = 37 * len(slots) + 5 * self.rank
         return self.rows[0]
