@@ -252,11 +252,12 @@ def test_prepare_g_begin_changes_when_the_walks_start_and_nothing_else(ga):
     roots = workloads.bench_roots(rowptr, 1024, 0, 1, 6)
     slots = np.arange(len(roots), dtype=np.int32)
 
-    def run(order, steps=3):
+    def run(order, steps=3, profiling=0):
         eng = ga.Engine(emb, emb, optimizer=ga.GG_OPT_ADAM_LAZY)
         eng.set_graph_csr(rowptr, col)
         eng.build_trees(roots, device=True)
-        eng.set_profiling(0)          # passes return once they are enqueued
+        eng.set_profiling(profiling)  # 0: passes return once they are enqueued; 1: every launch and pass timed, passes synchronous
+        order = order.replace("_timed", "")
         out = []
         for i in range(steps):
             rows = eng.prepare_d(slots, 6, 2 * i, fetch=False)
@@ -281,8 +282,8 @@ def test_prepare_g_begin_changes_when_the_walks_start_and_nothing_else(ga):
         return out, tabs, c
 
     ref, ref_tabs, c_ref = run("plain")
-    for order in ("begin", "begin_other_args", "begin_then_read", "begin_then_upload"):
-        got, tabs, c = run(order)
+    for order in ("begin", "begin_other_args", "begin_then_read", "begin_then_upload", "begin_timed"):
+        got, tabs, c = run(order, profiling=1 if order.endswith("_timed") else 0)
         for (rows0, a0, b0, r0, s0, w0), (rows1, a1, b1, r1, s1, w1) in zip(ref, got):
             assert rows0 == rows1 and np.array_equal(s0, s1), order
             assert np.array_equal(a0, a1) and np.array_equal(b0, b1), order
@@ -292,7 +293,7 @@ def test_prepare_g_begin_changes_when_the_walks_start_and_nothing_else(ga):
         for t0, t1 in zip(ref_tabs, tabs):
             assert np.allclose(t0, t1, rtol=1e-4, atol=1e-6), order
         assert c["hops"] >= c_ref["hops"]   # (a dropped launch is never counted; an adopted one exactly once)
-        if order == "begin":
+        if order in ("begin", "begin_timed"):
             assert c["hops"] == c_ref["hops"] and c["walk_reruns"] == c_ref["walk_reruns"]
 
 
