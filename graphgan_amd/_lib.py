@@ -12,6 +12,18 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgraphgan_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "graphgan_hip.h")
+ABI_VERSION = 4  # == GG_ABI_VERSION of include/graphgan_hip.h (tests/test_host_cpu.py keeps header, binding and library in step)
+
+
+def header_abi_version(path=HEADER_PATH):
+    """GG_ABI_VERSION as the C header declares it (the one place the number is defined)."""
+    import re
+    with open(path) as f:
+        m = re.search(r"^#define\s+GG_ABI_VERSION\s+(\d+)", f.read(), flags=re.M)
+    if not m:
+        raise RuntimeError("GG_ABI_VERSION not found in %s" % path)
+    return int(m.group(1))
 
 GG_OK, GG_EINVAL, GG_ECAPACITY, GG_EHIP, GG_ECOMM, GG_ENOMEM, GG_EIO = 0, -1, -2, -3, -4, -5, -6
 GG_OPT_ADAM_DENSE, GG_OPT_ADAM_LAZY, GG_OPT_SGD = 0, 1, 2
@@ -126,8 +138,9 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.gg_abi_version() != 4:
-        raise ImportError("graphgan_amd: ABI version mismatch")
+    if lib.gg_abi_version() != ABI_VERSION:
+        raise ImportError("graphgan_amd: %s has ABI version %d, this binding expects %d -- rebuild (make -C graphgan_amd/csrc)"
+                          % (LIB_PATH, lib.gg_abi_version(), ABI_VERSION))
     return lib
 
 

@@ -158,7 +158,9 @@ void gg::discard_begun_walk(gg_ctx *ctx) {
 int gg::walk_launch_async(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, int32_t uniform_walks, int32_t n_slots,
                           int32_t for_d, uint64_t seed, uint32_t stream, int32_t stride, bool side_stream, bool defer_join) {
     discard_begun_walk(ctx);  // (a launch begun earlier uses the buffers this one is about to fill)
-    GG_CHECK(ctx, ctx->n_tree_roots > 0, GG_EINVAL, "walk: no trees loaded (gg_build_trees / gg_set_trees)");
+    // (an EMPTY launch needs no trees: a rank whose update_ratio draw selected no root still makes the call -- it ends with a
+    // collective and resets the resident row count -- possibly before any tree was ever built)
+    GG_CHECK(ctx, ctx->n_tree_roots > 0 || n_slots == 0, GG_EINVAL, "walk: no trees loaded (gg_build_trees / gg_set_trees)");
     GG_CHECK(ctx, n_slots >= 0 && (slots || n_slots == 0), GG_EINVAL, "walk: bad slots");
     GG_CHECK(ctx, stride >= 2, GG_ECAPACITY, "walk: stride %d < 2", stride);
     std::vector<int64_t> &ptr = ctx->h_ptr_new;
@@ -505,13 +507,23 @@ int gg_set_graph_csr(gg_ctx *ctx, const int64_t *rowptr, const int32_t *col) {
     ctx->g_hash = h;
     // edge-score cache of the walk sampler (gg_internal.h): scores, per-node stamps, reverse-edge index
     if (nnz > 0 && nnz < (1ll << 31)) {
-        GG_HIP(ctx, hipMalloc((void **)&ctx->es, sizeof(float) * (size_t)nnz));
-        GG_HIP(ctx, hipMalloc((void **)&ctx->es_stamp, sizeof(long long) * (size_t)n));
-        GG_HIP(ctx, hipMalloc((void **)&ctx->g_rev, sizeof(int32_t) * (size_t)nnz));
-        GG_HIP(ctx, hipMemset(ctx->es_stamp, 0, sizeof(long long) * (size_t)n));
+        // The cache is optional (launch_walk_sample scores privately when the pointers are NULL): if its 8 * nnz + 8 * n bytes
+        // do not fit beside the graph, the graph stays usable without it instead of the call failing.
+        hipError_t e = hipMalloc((void **)&ctx->es, sizeof(float) * (size_t)nnz);
+        if (e == hipSuccess) e = hipMalloc((void **)&ctx->es_stamp, sizeof(long long) * (size_t)n);
+        if (e == hipSuccess) e = hipMalloc((void **)&ctx->g_rev, sizeof(int32_t) * (size_t)nnz);
+        if (e == hipSuccess) e = hipMemset(ctx->es_stamp, 0, sizeof(long long) * (size_t)n);
         generator_changed(ctx);
-        int rc = compute_reverse_edges(ctx);
-        if (rc != GG_OK) return rc;
+        int rc = e == hipSuccess ? compute_reverse_edges(ctx) : GG_ENOMEM;
+        if (rc != GG_OK) {
+            (void)hipGetLastError();
+            for (void *p : {(void *)ctx->es, (void *)ctx->es_stamp, (void *)ctx->g_rev})
+                if (p) (void)hipFree(p);
+            ctx->es = nullptr;
+            ctx->es_stamp = nullptr;
+            ctx->g_rev = nullptr;
+            if (getenv("GG_WALK_DEBUG")) fprintf(stderr, "[graph] edge-score cache not allocated (%s): walks score privately\n", e == hipSuccess ? ctx->err.c_str() : hipGetErrorString(e));
+        }
     }
     return GG_OK;
 }
@@ -844,7 +856,11 @@ int gg_walk_info(const gg_ctx *ctx, int64_t *total_walks, int32_t *stride, int32
 int gg_get_walks(gg_ctx *ctx, int32_t *samples, int32_t *paths, int32_t *path_len, int32_t *root_status) {
     if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
     GG_HIP(ctx, hipSetDevice(ctx->device));
-    discard_begun_walk(ctx);  // (a launch that was only begun has no results to hand out)
+    // A launch that was only begun (gg_prepare_g_begin) has overwritten the walk buffers and has no results to hand out: the
+    // caller asked for walks that no longer exist -- an error, not an empty answer.
+    const bool begun = ctx->g_begun;
+    discard_begun_walk(ctx);
+    GG_CHECK(ctx, !begun, GG_EINVAL, "gg_get_walks: the walks of the last completed launch were overwritten by gg_prepare_g_begin (fetch them before it, or after the gg_prepare_g that adopts it)");
     GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int64_t total = ctx->w_total;
     if (samples && total) GG_HIP(ctx, hipMemcpy(samples, ctx->w_samples.p, sizeof(int32_t) * total, hipMemcpyDeviceToHost));

@@ -1319,7 +1319,7 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
             h[k].lv_big = a.lv_big + h[k].w0;
             h[k].lv_big_cap = h[k].w_end - h[k].w0;
             h[k].lv_scores = a.lv_scores + (size_t)k * cap * CHUNK;
-            h[k].lv_chunk_desc = a.lv_chunk_desc + (size_t)k * cap;
+            h[k].lv_chunk_desc = a.lv_chunk_desc + (size_t)2 * k * cap;  // two int4 per chunk (write_chunk_desc / write_node_desc)
             h[k].dc_words = a.dc_words + 2 * k;
             h[k].cap_total = std::min<int64_t>((k + 1) * S, a.cap_total);
         }

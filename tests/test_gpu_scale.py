@@ -64,6 +64,45 @@ def test_powerlaw_100k_sampled_roots_bit_exact(ga):
     eng.close()
 
 
+def test_powerlaw_10m_device_trees_and_walks_bit_exact(ga):
+    """BASELINE.json configs[4] size on one GPU: 10^7 nodes / 10^8 edges, n_emb = 256.  The visited bitmap of such a graph
+    (1.25 MB) does not fit a CU's LDS, so gg_build_trees_device takes the GLOBAL-MEMORY bitmap instance of bfs_order_kernel by
+    itself -- the code path this configuration runs.  16 roots (the 4 top-degree hubs + 12 random ones): trees equal to the
+    oracle's FIFO BFS (graph_gan.py:84-108), then D / G / D walks bit-exact (graph_gan.py:225-270), Q3 state included."""
+    n, d = 10_000_000, 256
+    rowptr, col, E, b = make(ga, n, d, 7)
+    deg = (rowptr[1:] - rowptr[:-1]).astype(np.int32)
+    rs = np.random.RandomState(3)
+    hubs = np.argpartition(-deg, 4)[:4]
+    roots = np.unique(np.concatenate([hubs, rs.choice(n, 12, replace=False)])).astype(np.int32)
+    eng = ga.Engine(E, E, optimizer=ga.GG_OPT_SGD)  # (no Adam slots: 4 x 10 GB less to allocate; the test is about trees and walks)
+    eng.set_bias(0, b)
+    eng.set_graph_csr(rowptr, col)
+    eng.build_trees(roots, device=True)
+    off, nbr, base, dmax = orc.c_build_trees(n, rowptr, col, roots)
+    toff, tnbr, tbase = eng.get_trees()
+    assert np.array_equal(tbase, base) and np.array_equal(toff, off) and np.array_equal(tnbr, nbr)
+    assert eng.max_depth == dmax
+    del toff, tnbr
+    Ep = orc.pad_rows(E)
+    slots = np.arange(len(roots), dtype=np.int32)
+    stride = dmax + 3
+    nbr = nbr.copy()
+    for rnd, for_d in enumerate((True, False, True)):
+        nw = deg[roots] if for_d else np.full(len(roots), 20, np.int32)
+        want = orc.c_walk_sample(Ep, b, off, nbr, base, roots, slots, nw, for_d, 6, rnd, stride)
+        got = eng.walk_sample(slots, nw, for_d, 6, rnd, stride=stride)
+        assert np.array_equal(got["root_status"], want["root_status"])
+        assert np.array_equal(got["path_len"], want["path_len"])
+        assert np.array_equal(got["samples"], want["samples"])
+        m = np.arange(stride)[None, :] < want["path_len"][:, None]
+        assert np.array_equal(got["paths"][m], want["paths"][m])
+    assert want["hops"] > 1000
+    _, tnbr, _ = eng.get_trees()
+    assert np.array_equal(tnbr, nbr)  # Q3 mutation state
+    eng.close()
+
+
 def test_powerlaw_1m_walk_invariants(ga):
     n, d = 1_000_000, 128
     rowptr, col, E, b = make(ga, n, d, 5)
@@ -265,9 +304,11 @@ def test_prepare_g_begin_changes_when_the_walks_start_and_nothing_else(ga):
                 eng.prepare_g_begin(slots, 20, 6, 2 * i + 1)
             elif order == "begin_other_args":       # dropped by the gg_prepare_g below (another stream id)
                 eng.prepare_g_begin(slots, 20, 6, 2 * i + 77)
-            elif order == "begin_then_read":        # dropped by gg_get_walks
-                eng.prepare_g_begin(slots, 20, 6, 2 * i + 1)
-                eng.get_walks()
+            elif order == "begin_then_read":        # dropped by gg_get_walks -- which has nothing to return: the D-mode walks
+                eng.prepare_g_begin(slots, 20, 6, 2 * i + 1)   # were overwritten by the begun launch (GG_EINVAL, not 0 walks)
+                with pytest.raises(ga.GraphGANHipError) as ei:
+                    eng.get_walks()
+                assert ei.value.code == ga.GG_EINVAL and "gg_prepare_g_begin" in str(ei.value)
             elif order == "begin_then_upload":      # dropped by gg_set_bias(generator); the same bias goes back in
                 eng.prepare_g_begin(slots, 20, 6, 2 * i + 1)
                 eng.set_bias(0, eng.get_bias(0))

@@ -16,14 +16,14 @@ def ga():
     return graphgan_amd
 
 
-def run_both(ga, n, rowptr, col, roots, E, b, rounds, seed, n_sample=20, stride=None):
+def run_both(ga, n, rowptr, col, roots, E, b, rounds, seed, n_sample=20, stride=None, device_bfs=False):
     """D, G, D, G ... on engine and oracle; returns nothing, asserts equality."""
     roots = np.asarray(roots, dtype=np.int32)
     deg = (rowptr[1:] - rowptr[:-1]).astype(np.int32)
     eng = ga.Engine(E, E)
     eng.set_bias(0, b)
     eng.set_graph_csr(rowptr, col)
-    eng.build_trees(roots)
+    eng.build_trees(roots, device=device_bfs)
     off, nbr, base, dmax = orc.c_build_trees(n, rowptr, col, roots)
     toff, tnbr, tbase = eng.get_trees()
     assert np.array_equal(toff, off) and np.array_equal(tnbr, nbr) and np.array_equal(tbase, base)
@@ -217,11 +217,40 @@ def test_speculative_level_buffers_overflow_is_retried(ga, monkeypatch):
     eng.close()
 
 
-@pytest.mark.parametrize("case", ["small0", "small3", "star", "ca_grqc", "powerlaw"])
-def test_gpu_bfs_builds_the_reference_trees(ga, case):
+def dense_layers_edges(widths=(1, 120, 150, 90), seed=3):
+    """Layered graph whose consecutive layers are COMPLETELY connected, edges in a shuffled file order: a BFS from the
+    single top node finds every node of layer l + 1 from every node of layer l -- 120 x 150 = 18 000 edges into 150 new nodes
+    inside two consecutive chunks of the GPU BFS's edge stream, i.e. thousands of in-chunk duplicates: the overflow branch of
+    its duplicate list (resolved through the per-workgroup key array)."""
+    ids, nxt = [], 0
+    for w in widths:
+        ids.append(np.arange(nxt, nxt + w))
+        nxt += w
+    edges = np.concatenate([np.stack(np.meshgrid(a, b, indexing="ij"), -1).reshape(-1, 2) for a, b in zip(ids[:-1], ids[1:])])
+    edges = edges[np.random.RandomState(seed).permutation(len(edges))]
+    return edges.astype(np.int32), nxt
+
+
+@pytest.fixture(params=["lds_bitmap", "global_bitmap"])
+def bfs_bitmap(request, monkeypatch):
+    """Both instances of bfs_order_kernel: the visited bitmap in LDS (graphs up to ~1.1 M nodes) and in global memory
+    (GG_BFS_GLOBAL_BITMAP=1 forces what larger graphs -- BASELINE.json configs[4], 10^7 nodes -- take by themselves)."""
+    if request.param == "global_bitmap":
+        monkeypatch.setenv("GG_BFS_GLOBAL_BITMAP", "1")
+    else:
+        monkeypatch.delenv("GG_BFS_GLOBAL_BITMAP", raising=False)
+    return request.param
+
+
+@pytest.mark.parametrize("case", ["small0", "small3", "star", "ca_grqc", "powerlaw", "dense_layers"])
+def test_gpu_bfs_builds_the_reference_trees(ga, case, bfs_bitmap):
     """gg_build_trees_device == the host builder == reference construct_trees (pop order, child order,
     self-loops, isolated nodes, several components), offsets / lists / depth / longest list."""
-    if case.startswith("small"):
+    if case == "dense_layers":
+        edges, n = dense_layers_edges()
+        rowptr, col = ga.edges_to_csr(n, edges)
+        roots = np.array([0, 1, 130, n - 1, 200], dtype=np.int32)
+    elif case.startswith("small"):
         g, n, graph = load_small(int(case[-1]))
         rowptr, col = ga.graph_to_csr(n, graph)
         roots = np.arange(n, dtype=np.int32)
@@ -271,6 +300,48 @@ def test_gpu_bfs_builds_the_reference_trees(ga, case):
             adj = col[rowptr[f]:rowptr[f + 1]]
             assert rowptr[f] + int(np.flatnonzero(adj == o[i])[0]) == e[i]
     eng.close()
+
+
+@pytest.mark.parametrize("case", ["small1", "powerlaw"])
+def test_walks_on_device_built_trees_bit_exact(ga, case, bfs_bitmap):
+    """The whole path -- trees from gg_build_trees_device (either bitmap instance), then D / G / D / G walks -- against the
+    oracle's trees and walks (graph_gan.py:84-108,225-270): what a graph above the LDS bitmap's size runs."""
+    if case == "small1":
+        g, n, graph = load_small(1)
+        rowptr, col = ga.graph_to_csr(n, graph)
+        roots, E, b = np.arange(n, dtype=np.int32), g["E"], g["b"]
+    else:
+        n = 20_000
+        rowptr, col = ga.edges_to_csr(n, ga.synth_powerlaw(n, 10, 1, 2))
+        deg = rowptr[1:] - rowptr[:-1]
+        rs = np.random.RandomState(2)
+        roots = np.unique(np.concatenate([np.argsort(-deg)[:4], rs.choice(n, 60, replace=False)])).astype(np.int32)
+        E = (rs.randn(n, 32) * 0.3).astype(np.float32)
+        b = (rs.randn(n) * 0.1).astype(np.float32)
+    hops = run_both(ga, n, rowptr, col, roots, E, b, rounds=4, seed=77, device_bfs=True)
+    assert hops > 500
+
+
+def test_split_launch_with_skewed_halves(ga, monkeypatch):
+    """Two-half launches (GG_WALK_SPLIT=1) whose first half needs nearly ALL the chunks of a level: hub roots first, then
+    many low-degree roots, D-mode walks = degree.  Each half may use up to the learned capacity `cap` of score chunks and a
+    chunk descriptor is two int4: the halves' descriptor regions must be 2 * cap int4 apart (round-3 advisor finding: they
+    were cap apart, so a half that used more than cap / 2 chunks overwrote the other half's descriptors)."""
+    monkeypatch.setenv("GG_WALK_LEVELS", "64")
+    monkeypatch.setenv("GG_WALK_SPLIT", "1")
+    monkeypatch.setenv("GG_WALK_SPLIT_MIN", "512")
+    n = 20_000
+    rowptr, col = ga.edges_to_csr(n, ga.synth_powerlaw(n, 10, 1, 2))
+    deg = rowptr[1:] - rowptr[:-1]
+    by_deg = np.argsort(-deg, kind="stable")
+    hubs, small = by_deg[:24], by_deg[-700:]
+    assert deg[hubs].sum() > 0.8 * deg[small].sum()    # the first half of the D-mode walks is hub walks only
+    roots = np.concatenate([hubs, small]).astype(np.int32)
+    rs = np.random.RandomState(4)
+    E = (rs.randn(n, 32) * 0.3).astype(np.float32)
+    b = (rs.randn(n) * 0.1).astype(np.float32)
+    hops = run_both(ga, n, rowptr, col, roots, E, b, rounds=6, seed=31)  # round 0 sized (learns cap), 1.. sync-free = split
+    assert hops > 20000
 
 
 def test_deep_chain_crosses_the_level_cap(ga):

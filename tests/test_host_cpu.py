@@ -33,7 +33,16 @@ def test_library_exports_every_declared_symbol(ga):
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert raw.gg_abi_version() == 4
+    assert raw.gg_abi_version() == _lib.ABI_VERSION == _lib.header_abi_version()
+
+
+def test_graft_entry_build_runs_end_to_end(ga):
+    """The driver's "does it build" check: make (a no-op when everything is up to date), import, and the three ABI
+    numbers -- header, binding, library -- agree.  Round 3's entry point asserted a stale literal and raised."""
+    import __graft_entry__
+    __graft_entry__.build()
+    src = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert not re.search(r"gg_abi_version\(\)\s*==\s*\d", src), "compare against the header, not a literal"
 
 
 def test_no_gpu_means_loud_failure(ga):
