@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgraphgan_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "graphgan_hip.h")
-ABI_VERSION = 4  # == GG_ABI_VERSION of include/graphgan_hip.h (tests/test_host_cpu.py keeps header, binding and library in step)
+ABI_VERSION = 5  # == GG_ABI_VERSION of include/graphgan_hip.h (tests/test_host_cpu.py keeps header, binding and library in step)
 
 
 def header_abi_version(path=HEADER_PATH):
@@ -96,6 +96,11 @@ SIGNATURES = {
     "gg_prepare_g": (ctypes.c_int, [_P, _P, _i32, _i32, _u64, _u32, _P, _P]),
     "gg_prepare_g_begin": (ctypes.c_int, [_P, _P, _i32, _i32, _u64, _u32]),
     "gg_get_g_data": (ctypes.c_int, [_P, _P, _P, _P]),
+    "gg_epoch_begin": (ctypes.c_int, [_P, _i32, _i32]),
+    "gg_epoch_add": (ctypes.c_int, [_P, _P, _i32, _i32, _i32, _i32, _u64, _u32, _u32, _P, _P]),
+    "gg_epoch_commit": (ctypes.c_int, [_P, _i32, _P]),
+    "gg_q3_clear": (ctypes.c_int, [_P]),
+    "gg_q3_get": (ctypes.c_int, [_P, _P, _P]),
     "gg_d_pass": (ctypes.c_int, [_P, _P, _i64, _i32]),
     "gg_g_pass": (ctypes.c_int, [_P, _P, _i64, _i32]),
     "gg_pair_reward": (ctypes.c_int, [_P, _P, _P, _i64, _P]),

@@ -400,6 +400,418 @@ __global__ __launch_bounds__(BFS_T) void bfs_order_kernel(const BfsArgs a) {
     }
 }
 
+
+// ============================================================================================================================
+// Round 4: the same BFS as a SCAN phase and a CLAIM phase per window (bfs_order2_kernel, the default; GG_BFS_V1=1 runs the
+// chunk kernel above).  What the chunk kernel spends per edge -- ~51 vector instructions, five workgroup barriers per 8 192
+// stream positions -- is mostly bookkeeping that only the edges which DISCOVER a node need (1 M of the 19 M a tree of the
+// 1M-node graph inspects): the owner of every stream position, per-position masks, a compaction of all 8 192 positions.  Here
+//   * SCAN: a window = up to 1 024 queue nodes / 4 096 quads of 4 consecutive adjacency entries.  A thread takes quads
+//     (one 16-byte load each, all of a thread's loads in flight together), tests the four targets against the visited bitmap
+//     in LDS and does nothing else unless a target is unseen: such a CANDIDATE {window node, stream position, target} goes to a
+//     short LDS list and sets its bit in a position mask.  No barrier inside a window; nothing is modified, so a window
+//     whose candidates do not fit the list (the growth levels) is simply rescanned shorter (the window length follows the
+//     candidate density of the previous window).
+//   * CLAIM: one thread per candidate.  atomic-or on the bitmap: the hardware winner among the edges into the same new
+//     node; the in-window duplicates (rare) go to the duplicate list and the winner takes the smallest position -- the edge
+//     the sequential BFS appends the node at (graph_gan.py:101-107) -- exactly as in the chunk kernel, overflow path included.
+//     Popcounts over the position mask give every appending candidate its place in stream order (= queue order), a per-node
+//     counter + scan gives cstart.  A window without candidates (most windows of the last levels) costs one barrier.
+// Same outputs, bit for bit (tests/test_gpu_walk.py::test_gpu_bfs_builds_the_reference_trees runs both kernels).
+constexpr int B2_T = 1024;
+constexpr int B2_WAVES = B2_T / 64;
+constexpr int B2_NB = 1024;              // queue nodes per window
+constexpr int B2_SLOTS = 4096;           // quads per window
+constexpr int B2_POS = 4 * B2_SLOTS;     // stream positions per window (14 bits)
+constexpr int B2_CCAP = 1024;            // candidates per window (one claim thread each)
+constexpr int B2_LCAP = 512;             // in-window duplicates resolved through the LDS list
+constexpr int B2_MINSLOTS = 64;          // shortest window the density rule asks for (256 positions < CCAP: cannot overflow)
+
+typedef int32_t int4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load from a 4-byte aligned address
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(v, off, 64);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
+template <bool LDS_BM>
+__global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
+    extern __shared__ uint32_t lds_bm[];              // [bm_words] when LDS_BM
+    __shared__ uint32_t e0s[B2_NB];                   // first CSR entry of each window node (of the segment, for a partial node)
+    __shared__ uint32_t pk[B2_NB + 1];                // (quad offset << 16) | position offset of each window node; [nb] = totals
+    __shared__ uint32_t scratch[B2_SLOTS / 2];        // SCAN: quad -> window node (uint16 x 4 096); CLAIM: duplicate list + child counts
+    __shared__ uint32_t posmask[B2_POS / 32];         // stream positions whose target was unseen
+    __shared__ uint32_t winbits[B2_POS / 32];         // ... that append (only written when the window has in-window duplicates)
+    __shared__ int32_t wpre[B2_POS / 32];             // exclusive popcount prefix over the words of that mask
+    __shared__ uint32_t candK[B2_CCAP];               // (window node << 14) | position
+    __shared__ int32_t candW[B2_CCAP];                // target node
+    __shared__ int32_t wtot[4][B2_WAVES];
+    __shared__ int32_t s_root, s_nC, s_Lcount, s_cap, s_max;
+    __shared__ uint32_t s_e0;
+    __shared__ int32_t s_deg;
+    uint16_t *const emap = reinterpret_cast<uint16_t *>(scratch);
+    int32_t *const L_w = reinterpret_cast<int32_t *>(scratch);            // [B2_LCAP]
+    int32_t *const L_pos = L_w + B2_LCAP;                                 // [B2_LCAP]
+    int32_t *const ccnt = L_w + 2 * B2_LCAP;                              // [B2_NB] children appended per window node
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t *const bm = LDS_BM ? lds_bm : a.gbitmap + (size_t)blockIdx.x * a.bm_words;
+    uint32_t *const gkey = a.gkey + (size_t)blockIdx.x * a.n_node;
+
+    auto seen = [&](int w) -> bool {
+        if (LDS_BM) return (bm[w >> 5] >> (w & 31)) & 1u;
+        return (__hip_atomic_load(&bm[w >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (w & 31)) & 1u;
+    };
+
+    for (;;) {
+        if (tid == 0) {
+            s_root = (int)atomicAdd(a.ticket, 1u);
+            s_nC = 0;
+            s_Lcount = 0;
+            s_max = 0;
+        }
+        for (int i = tid; i < B2_POS / 32; i += B2_T) { posmask[i] = 0u; winbits[i] = 0u; }
+        __syncthreads();
+        const int r = s_root;
+        if (r >= a.n_roots) return;
+        const int root = a.roots[r];
+        int32_t *const order = a.order + a.base[r];
+        int32_t *const cstart = a.cstart + a.base[r] + r;
+        int32_t *const tedge = a.edge + a.base[r];
+        const int expect = (int)(a.base[r + 1] - a.base[r]);
+        for (int i = tid; i < a.bm_words; i += B2_T) bm[i] = 0u;
+        __syncthreads();
+        if (tid == 0) {
+            bm[root >> 5] = 1u << (root & 31);
+            order[0] = root;
+            tedge[0] = -1;
+            cstart[0] = 1;
+        }
+        __syncthreads();
+
+        int head = 0, tail = 1, level_end = 1, depth = 0;
+        unsigned long long st_win = 0, st_rescan = 0, st_cand = 0, st_slots = 0, st_empty = 0, st_dup = 0, st_key = 0;  // GG_BFS_PROFILE
+        int tmax = B2_SLOTS;     // quads the next window may hold (follows the candidate density)
+        int seg_a = 0;           // > 0: the node at `head` is being scanned in segments, this many entries are done
+        int pf_q = -1;           // queue index whose node this thread has prefetched
+        uint32_t pf_e0 = 0;
+        int pf_deg = 0;
+        while (head < tail) {
+            if (head == level_end) {  // the next level starts: everything up to `tail` belongs to it
+                level_end = tail;
+                ++depth;
+            }
+            int nb = 0;      // complete nodes of this window; 0 = one node, entries [seg_a, seg_a + seg_len)
+            int seg_len = 0;
+            if (seg_a == 0) {
+                const int navail = min(B2_NB, level_end - head);
+                uint32_t e0 = 0;
+                int deg = 0;
+                if (tid < navail) {
+                    if (pf_q == head + tid) {
+                        e0 = pf_e0;
+                        deg = pf_deg;
+                    } else {
+                        const int v = __hip_atomic_load(&order[head + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const int64_t b = a.rowptr[v];
+                        e0 = (uint32_t)b;
+                        deg = (int)(a.rowptr[v + 1] - b);
+                    }
+                }
+                const int q = (deg + 3) >> 2;
+                const int incq = wave_incl_scan(q, lane), incd = wave_incl_scan(deg, lane);
+                if (lane == 63) { wtot[0][wv] = incq; wtot[1][wv] = incd; }
+                if (tid == 0) { s_cap = 0; s_e0 = e0; s_deg = deg; }
+                __syncthreads();
+                int preq = 0, pred = 0;
+#pragma unroll
+                for (int i = 0; i < B2_WAVES; ++i)
+                    if (i < wv) { preq += wtot[0][i]; pred += wtot[1][i]; }
+                const int inclq = preq + incq, excq = inclq - q, incld = pred + incd, excd = incld - deg;
+                // window = the longest prefix of the available nodes whose quads fit
+                const unsigned long long okb = __ballot(tid < navail && inclq <= tmax);
+                if (lane == 0 && okb) atomicAdd(&s_cap, (int)__popcll(okb));
+                __syncthreads();
+                nb = s_cap;
+                if (nb > 0) {
+                    if (tid < nb) {
+                        e0s[tid] = e0;
+                        pk[tid] = ((uint32_t)excq << 16) | (uint32_t)excd;
+                        if (tid == nb - 1) pk[nb] = ((uint32_t)inclq << 16) | (uint32_t)incld;
+                        if (q <= 8)
+                            for (int k = 0; k < q; ++k) emap[excq + k] = (uint16_t)tid;
+                    }
+                    unsigned long long wide = __ballot(tid < nb && q > 8);  // their quads are filled by the whole wavefront
+                    while (wide) {
+                        const int l = __ffsll((long long)wide) - 1;
+                        wide &= wide - 1;
+                        const int qq = __shfl(q, l, 64), ss = __shfl(excq, l, 64);
+                        for (int k = lane; k < qq; k += 64) emap[ss + k] = (uint16_t)((wv << 6) + l);
+                    }
+                    // prefetch the next window's nodes (queue entries below `tail` are final)
+                    const int q2 = head + nb + tid;
+                    pf_q = -1;
+                    if (q2 < tail) {
+                        const int v2 = __hip_atomic_load(&order[q2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const int64_t b2 = a.rowptr[v2];
+                        pf_e0 = (uint32_t)b2;
+                        pf_deg = (int)(a.rowptr[v2 + 1] - b2);
+                        pf_q = q2;
+                    }
+                }
+            }
+            if (nb == 0) {  // one node alone (it exceeds the window, or is being continued): the segment [seg_a, seg_a + seg_len)
+                const int deg0 = s_deg;
+                seg_len = min(deg0 - seg_a, 4 * tmax);
+                const int qs = (seg_len + 3) >> 2;
+                for (int k = tid; k < qs; k += B2_T) emap[k] = 0;
+                if (tid == 0) {
+                    e0s[0] = s_e0 + (uint32_t)seg_a;
+                    pk[0] = 0u;
+                    pk[1] = ((uint32_t)qs << 16) | (uint32_t)seg_len;
+                }
+            }
+            __syncthreads();
+            const int nbw = nb > 0 ? nb : 1;  // window nodes (the last entry of pk holds the totals)
+
+            // ---------------- SCAN
+            int T = (int)(pk[nbw] >> 16);
+            int nC;
+            for (;;) {
+                int4u w4[4];
+                int wi[4], wp0[4], wc[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int s = tid + it * B2_T;
+                    wc[it] = 0;
+                    if (s < T) {
+                        const int i = (int)emap[s];
+                        const uint32_t a0 = pk[i], a1 = pk[i + 1];
+                        const int j0 = 4 * (s - (int)(a0 >> 16));
+                        const int d = (int)(a1 & 0xffffu) - (int)(a0 & 0xffffu);
+                        wc[it] = min(4, d - j0);
+                        wi[it] = i;
+                        wp0[it] = (int)(a0 & 0xffffu) + j0;
+                        w4[it] = *reinterpret_cast<const int4u *>(a.col + (e0s[i] + (uint32_t)j0));
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    uint32_t cand = 0;
+                    if (wc[it] > 0) {
+                        if (!seen(w4[it].x)) cand |= 1u;
+                        if (wc[it] > 1 && !seen(w4[it].y)) cand |= 2u;
+                        if (wc[it] > 2 && !seen(w4[it].z)) cand |= 4u;
+                        if (wc[it] > 3 && !seen(w4[it].w)) cand |= 8u;
+                    }
+                    while (__ballot(cand != 0u)) {  // (uniform: rare outside the growth levels)
+                        const bool has = cand != 0u;
+                        const int k = has ? __ffs((int)cand) - 1 : 0;
+                        cand &= cand - 1u;
+                        const unsigned long long m = __ballot(has);
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(&s_nC, (int)__popcll(m));
+                        base = __shfl(base, 0, 64);
+                        if (has) {
+                            const int idx = base + lanes_below(m);
+                            const int p = wp0[it] + k;
+                            const int w = k == 0 ? w4[it].x : k == 1 ? w4[it].y : k == 2 ? w4[it].z : w4[it].w;
+                            if (idx < B2_CCAP) {
+                                candK[idx] = ((uint32_t)wi[it] << 14) | (uint32_t)p;
+                                candW[idx] = w;
+                            }
+                            atomicOr(&posmask[p >> 5], 1u << (p & 31));
+                        }
+                    }
+                }
+                __syncthreads();
+                nC = s_nC;
+                st_slots += (unsigned long long)T;
+                if (nC <= B2_CCAP) break;
+                ++st_rescan;
+                // more candidates than claim threads: rescan a shorter window (nothing was modified).  New length from the
+                // density just seen, with a quarter of slack.
+                const int target = max(B2_MINSLOTS / 2, (int)((long long)T * (B2_CCAP * 3 / 4) / nC));
+                if (tid == 0) { s_nC = 0; s_cap = 0; }
+                for (int i = tid; i < B2_POS / 32; i += B2_T) posmask[i] = 0u;
+                __syncthreads();
+                if (nb > 0) {
+                    const unsigned long long okb = __ballot(tid < nb && (int)(pk[tid + 1] >> 16) <= target);
+                    if (lane == 0 && okb) atomicAdd(&s_cap, (int)__popcll(okb));
+                    __syncthreads();
+                    nb = s_cap;
+                    pf_q = -1;  // (the prefetched nodes no longer follow this window)
+                    if (nb == 0) {  // not even the first node: scan a segment of it
+                        seg_len = min(s_deg, 4 * target);
+                        if (tid == 0) pk[1] = ((uint32_t)((seg_len + 3) >> 2) << 16) | (uint32_t)seg_len;
+                        __syncthreads();  // (emap[s] of its quads is 0 already; e0s[0], pk[0] are the node's)
+                    }
+                } else {
+                    seg_len = min(seg_len, 4 * target);
+                    if (tid == 0) pk[1] = ((uint32_t)((seg_len + 3) >> 2) << 16) | (uint32_t)seg_len;
+                    __syncthreads();
+                }
+                T = (int)(pk[nb > 0 ? nb : 1] >> 16);
+                tmax = max(B2_MINSLOTS, target);
+            }
+            const int nbn = nb > 0 ? nb : 1;
+            ++st_win;
+            st_cand += (unsigned long long)nC;
+            if (nC == 0) ++st_empty;
+            // density rule for the next window: aim at three quarters of the candidate list
+            tmax = nC * 4 <= B2_CCAP ? min(B2_SLOTS, 2 * max(tmax, T)) : max(B2_MINSLOTS, min(B2_SLOTS, (int)((long long)T * (B2_CCAP * 3 / 4) / nC)));
+
+            if (nC == 0) {
+                // nothing new: every node that ends in this window has its children end at `tail`
+                if (nb > 0) {
+                    if (tid < nb) cstart[head + tid + 1] = tail;
+                    head += nb;
+                } else {
+                    seg_a += seg_len;
+                    if (seg_a == s_deg) {
+                        if (tid == 0) cstart[head + 1] = tail;
+                        head += 1;
+                        seg_a = 0;
+                    }
+                }
+            } else {
+                // ---------------- CLAIM: one thread per candidate
+                if (tid < nbn) ccnt[tid] = 0;  // (the quad map is dead: SCAN is over)
+                bool won = false;
+                uint32_t myk = 0;
+                int myw = 0;
+                if (tid < nC) {
+                    myk = candK[tid];
+                    myw = candW[tid];
+                    const uint32_t bit = 1u << (myw & 31);
+                    const uint32_t old = atomicOr(&bm[myw >> 5], bit);
+                    won = !(old & bit);
+                    if (!won) {  // another edge of this window reaches the same new node
+                        const int li = atomicAdd(&s_Lcount, 1);
+                        if (li < B2_LCAP) { L_w[li] = myw; L_pos[li] = (int)(myk & 0x3fffu); }
+                    }
+                }
+                __syncthreads();
+                const int nL = s_Lcount;
+                const uint32_t *wb = posmask;  // without in-window duplicates every candidate appends
+                if (nL > 0) {
+                    ++st_dup;
+                    if (nL > B2_LCAP) ++st_key;
+                    wb = winbits;
+                    if (nL <= B2_LCAP) {
+                        // the sequential BFS appends a node at the FIRST edge that reaches it: smallest position among the
+                        // hardware winner's and the duplicates'
+                        if (won) {
+                            int eff = (int)(myk & 0x3fffu);
+                            for (int i = 0; i < nL; ++i)
+                                if (L_w[i] == myw) eff = min(eff, L_pos[i]);
+                            atomicOr(&winbits[eff >> 5], 1u << (eff & 31));
+                        }
+                    } else {
+                        // too many for the list: smallest position per node through the key array (all-ones between uses)
+                        const uint32_t p = myk & 0x3fffu;
+                        if (tid < nC) atomicMin(&gkey[myw], p);
+                        __syncthreads();
+                        if (tid < nC && atomicMin(&gkey[myw], 0xFFFFFFFFu) == p) atomicOr(&winbits[p >> 5], 1u << (p & 31));
+                        __syncthreads();
+                        if (tid < nC) __hip_atomic_store(&gkey[myw], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    __syncthreads();
+                }
+                // place of every appending position in stream order
+                const int wcnt = tid < B2_POS / 32 ? (int)__popc(wb[tid]) : 0;
+                const int winc = wave_incl_scan(wcnt, lane);
+                if (lane == 63) wtot[2][wv] = winc;
+                __syncthreads();
+                int wpr = 0, total = 0;
+#pragma unroll
+                for (int i = 0; i < B2_POS / 32 / 64; ++i) {
+                    const int c = wtot[2][i];
+                    if (i < wv) wpr += c;
+                    total += c;
+                }
+                if (tid < B2_POS / 32) wpre[tid] = wpr + winc - wcnt;
+                __syncthreads();
+                if (tid < nC) {
+                    const int p = (int)(myk & 0x3fffu);
+                    const uint32_t word = wb[p >> 5];
+                    if ((word >> (p & 31)) & 1u) {
+                        const int rank = tail + wpre[p >> 5] + (int)__popc(word & ((1u << (p & 31)) - 1u));
+                        const int i = (int)(myk >> 14);
+                        if (rank < expect) {
+                            order[rank] = myw;
+                            tedge[rank] = (int32_t)(e0s[i] + (uint32_t)(p - (int)(pk[i] & 0xffffu)));
+                        }
+                        atomicAdd(&ccnt[i], 1);
+                    }
+                }
+                __syncthreads();
+                // reset what the next window's SCAN accumulates into
+                if (tid < B2_POS / 32) {
+                    posmask[tid] = 0u;
+                    if (nL > 0) winbits[tid] = 0u;
+                }
+                if (tid == 0) { s_nC = 0; s_Lcount = 0; }
+                if (nb > 0) {
+                    // children of window node i end behind the appends of nodes 0 .. i
+                    const int x = tid < nb ? ccnt[tid] : 0;
+                    const int xi = wave_incl_scan(x, lane);
+                    if (lane == 63) wtot[3][wv] = xi;
+                    __syncthreads();
+                    int xp = 0;
+#pragma unroll
+                    for (int i = 0; i < B2_WAVES; ++i)
+                        if (i < wv) xp += wtot[3][i];
+                    if (tid < nb) cstart[head + tid + 1] = tail + xp + xi;
+                    tail += total;
+                    head += nb;
+                } else {
+                    tail += total;
+                    seg_a += seg_len;
+                    if (seg_a == s_deg) {
+                        if (tid == 0) cstart[head + 1] = tail;
+                        head += 1;
+                        seg_a = 0;
+                    }
+                }
+                if (tail > expect) break;  // more nodes than the component sweep promised: the graph is not the one set (uniform)
+            }
+            __syncthreads();
+            // Every node of the root's component is on the queue (its size is known from the component sweep): no edge of the
+            // nodes still waiting can discover anything -- they are leaves of the tree (empty child ranges at the end of the queue).
+            if (tail == expect && head < tail && !(a.exp & 8)) {
+                for (int i = head + tid; i < expect; i += B2_T) cstart[i + 1] = expect;
+                if (level_end < tail) ++depth;  // the nodes behind level_end are one level deeper than the one being popped
+                __syncthreads();                // (the child-count sweep below reads these entries)
+                break;
+            }
+        }
+
+        if (a.prof && tid == 0) {
+            atomicAdd(&a.prof[0], st_win); atomicAdd(&a.prof[1], st_rescan); atomicAdd(&a.prof[2], st_cand); atomicAdd(&a.prof[3], st_slots);
+            atomicAdd(&a.prof[4], st_empty); atomicAdd(&a.prof[5], st_dup); atomicAdd(&a.prof[6], st_key);
+        }
+        // ---- per-root results: node count check, depth, longest list (1 + most children)
+        int mc = 0;
+        if (tail == expect)
+            for (int i = tid; i < tail; i += B2_T) mc = max(mc, cstart[i + 1] - cstart[i]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mc = max(mc, __shfl_xor(mc, off, 64));
+        if (lane == 0) atomicMax(&s_max, mc);
+        __syncthreads();
+        if (tid == 0) {
+            if (tail != expect) a.stats[2] = 1;
+            atomicMax(&a.stats[0], depth);
+            atomicMax(&a.stats[1], s_max + 1);
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace gg
 
 using namespace gg;
@@ -419,8 +831,9 @@ extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t 
     const int grid = std::min<int>(n_roots, ctx->n_cus);
     const int bm_words = (n + 31) / 32;
     // static LDS of the kernel (eoff, e0s, duplicate list, mask, counters) ~ 21.5 KB; the CU has 160 KB
+    const bool v1 = getenv("GG_BFS_V1") != nullptr;  // the chunk kernel of rounds 2-3 (kept for A/B timing and as a second witness in the tests)
     hipFuncAttributes fa;
-    GG_HIP(ctx, hipFuncGetAttributes(&fa, (const void *)bfs_order_kernel<true, false>));
+    GG_HIP(ctx, hipFuncGetAttributes(&fa, v1 ? (const void *)bfs_order_kernel<true, false> : (const void *)bfs_order2_kernel<true>));
     const size_t lds_total = 160 * 1024;
     const bool lds_bm = !getenv("GG_BFS_GLOBAL_BITMAP") && fa.sharedSizeBytes + (size_t)bm_words * 4 <= lds_total;
 
@@ -454,7 +867,16 @@ extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t 
     if (gkey.bytes != key_bytes_before)  // new allocation: all-ones; the kernel restores every word it uses
         (void)hipMemsetAsync(gkey.p, 0xFF, sizeof(uint32_t) * (size_t)grid * n, ctx->stream);
     (void)hipEventRecord(ctx->ev0, ctx->stream);
-    if (lds_bm) {
+    if (!v1) {
+        const size_t dyn = lds_bm ? (size_t)bm_words * 4 : 0;
+        if (lds_bm) {
+            e = hipFuncSetAttribute((const void *)bfs_order2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+            if (e != hipSuccess) { cleanup(); return fail(ctx, GG_EHIP, "gg_build_trees_device: %zu bytes of LDS: %s", dyn, hipGetErrorString(e)); }
+            hipLaunchKernelGGL((bfs_order2_kernel<true>), dim3(grid), dim3(B2_T), dyn, ctx->stream, a);
+        } else {
+            hipLaunchKernelGGL((bfs_order2_kernel<false>), dim3(grid), dim3(B2_T), 0, ctx->stream, a);
+        }
+    } else if (lds_bm) {
         const size_t dyn = (size_t)bm_words * 4;
         const bool instr = prof || a.exp != 0;
         const void *fn = instr ? (const void *)bfs_order_kernel<true, true> : (const void *)bfs_order_kernel<true, false>;
@@ -472,7 +894,14 @@ extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t 
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(stats, a.stats, sizeof(stats), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess && prof) {
+    if (e == hipSuccess && prof && !v1) {
+        unsigned long long pc[16];
+        if (hipMemcpy(pc, a.prof, sizeof(pc), hipMemcpyDeviceToHost) == hipSuccess)
+            fprintf(stderr, "[bfs2 profile] %d roots, grid %d: per root %.0f windows (%.0f without a candidate, %.0f with in-window duplicates, %.0f through the key array), "
+                    "%.1f rescans, %.0f candidates, %.0f quads scanned\n", n_roots, grid, (double)pc[0] / n_roots, (double)pc[4] / n_roots, (double)pc[5] / n_roots,
+                    (double)pc[6] / n_roots, (double)pc[1] / n_roots, (double)pc[2] / n_roots, (double)pc[3] / n_roots);
+    }
+    if (e == hipSuccess && prof && v1) {
         unsigned long long pc[16];
         if (hipMemcpy(pc, a.prof, sizeof(pc), hipMemcpyDeviceToHost) == hipSuccess) {
             const char *names[8] = {"nodes+scan", "batch form", "map+load+test", "empty chunk", "claim", "dup resolve", "compaction", "stores"};

@@ -150,6 +150,7 @@ struct gg_ctx {
     int64_t fin_threshold = 0;
     int w_levels_run = 0;
     bool w_fin_follows = false;
+    bool w_net = false;   // the finisher ran as the safety net behind the learned number of levels (walk_sample.hip, run_levels_and_finish)
     const gg::DevBuf &w_slots_buf() const { return w_slots_m[w_mode]; }
     const gg::DevBuf &w_ptr_buf() const { return w_ptr_m[w_mode]; }
     gg::DevBuf w_samples, w_paths, w_len, w_status, w_first, w_abort, w_scratch;
@@ -205,6 +206,16 @@ struct gg_ctx {
     struct { int32_t n_slots = 0, n_sample = 0; uint64_t seed = 0; uint32_t stream = 0; } g_begun_args;
     gg::DevBuf touched_ptr;
     gg::DevBuf bfs_key, bfs_bm, bfs_misc;  // scratch of gg_build_trees_device (bfs_gpu.hip)
+    // epoch over root batches (epoch.hip): persistent Q3 bits of EVERY root -- words [q3s_off[v], q3s_off[v + 1]) for root node v,
+    // ceil(deg(v) / 32) of them, bit (rank - 1) for the child of BFS rank `rank` as in t_q3 -- and the rows / pairs the batches
+    // of the running epoch have produced so far
+    gg::DevBuf q3_store, q3s_off;
+    int64_t q3_words = 0;
+    bool q3_store_ready = false;
+    gg::DevBuf ep_center, ep_neighbor, ep_label, ep_node1, ep_node2, ep_reward;
+    int64_t ep_rows = 0, ep_pairs = 0;
+    std::vector<int32_t> ep_slots;     // 0, 1, 2, ... (the slots of a batch)
+    bool in_epoch_add = false;         // gg_prepare_* inside gg_epoch_add: no per-batch replica collective (the ranks' batch counts differ)
     int n_cus = 256;                       // compute units of the device (gg_create; hipGetDeviceProperties costs milliseconds)
     gg::DevBuf scan_tmp, step_u, step_v, step_x;
     // staged generator gradient (steps.hip, run_path_step): per-row counts / segment offsets, per path node slot, row list,

@@ -506,8 +506,10 @@ int gg_prepare_d(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, uint64_t se
         ctx->dc_valid = ctx->dc_enabled && ctx->walk_levels > 0;
         if (root_status) GG_HIP(ctx, hipMemcpy(root_status, ctx->w_status.p, sizeof(int32_t) * n_slots, hipMemcpyDeviceToHost));
     }
-    rc = exchange_count_max(ctx, ctx->d_rows, &ctx->d_rows_max);  // replicas: capacity rule of the passes' row packs
-    if (rc != GG_OK) return rc;
+    if (!ctx->in_epoch_add) {  // (an epoch over root batches exchanges the totals once, in gg_epoch_commit)
+        rc = exchange_count_max(ctx, ctx->d_rows, &ctx->d_rows_max);  // replicas: capacity rule of the passes' row packs
+        if (rc != GG_OK) return rc;
+    }
     if (n_rows_out) *n_rows_out = ctx->d_rows;
     return GG_OK;
 }
@@ -643,8 +645,10 @@ int gg_prepare_g(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, int32_t n_s
         ctx->g_paths_valid = true;
     }
     if (root_status && n_slots) GG_HIP(ctx, hipMemcpy(root_status, ctx->w_status.p, sizeof(int32_t) * n_slots, hipMemcpyDeviceToHost));
-    rc = exchange_count_max(ctx, ctx->g_pairs, &ctx->g_pairs_max);
-    if (rc != GG_OK) return rc;
+    if (!ctx->in_epoch_add) {
+        rc = exchange_count_max(ctx, ctx->g_pairs, &ctx->g_pairs_max);
+        if (rc != GG_OK) return rc;
+    }
     if (n_pairs_out) *n_pairs_out = ctx->g_pairs;
     return GG_OK;
 }

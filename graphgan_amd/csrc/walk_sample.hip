@@ -1416,10 +1416,11 @@ static int run_levels_and_finish(gg_ctx *ctx, WalkArgs &a, int64_t total_walks) 
     const bool all_levels = n_levels >= ctx->tree_max_depth + 2;
     if (all_levels) n_levels = ctx->tree_max_depth + 2;
     if (n_levels > MAX_LEVELS) n_levels = MAX_LEVELS;
-    bool any_alive = true;
+    bool any_alive = true, small_finisher = false;
     ctx->lv_ev_used = 0;
     ctx->w_levels_run = 0;
     ctx->w_fin_follows = true;
+    ctx->w_net = false;
     if (n_levels > 0) {
         GG_HIP(ctx, ctx->st_cur.reserve(sizeof(int32_t) * total_walks));
         GG_HIP(ctx, ctx->st_prev.reserve(sizeof(int32_t) * total_walks));
@@ -1459,16 +1460,28 @@ static int run_levels_and_finish(gg_ctx *ctx, WalkArgs &a, int64_t total_walks) 
             for (int l = 1; l < n_levels && l < MAX_LEVELS; ++l)
                 if (prof[l] >= 0 && prof[l] < ctx->fin_threshold) { n_levels = l; early = true; break; }
         }
-        ctx->w_fin_follows = early || !all_levels;
-        int rc = run_levels<NCH>(ctx, a, total_walks, n_levels, sized, early, &any_alive);
+        // A sync-free launch streams as many levels as earlier launches found walks alive in.  A walk of THIS launch that is
+        // still going behind them used to send the whole launch to a sized rerun (flag 2: a full walk call, with a host
+        // round trip per level, inside the timed region whenever one walk went a hop deeper than any before it -- the
+        // generator moves, so that never quite stops).  Now the last advance lists such walks and the per-walk finisher
+        // takes them: a safety net that costs one near-empty launch when nobody is left (round 4).
+        bool net = false;
+        if (all_levels && !sized && !early && ctx->lv_levels_learned > 0 && ctx->lv_levels_learned < n_levels && !getenv("GG_WALK_NO_NET")) {
+            n_levels = ctx->lv_levels_learned;
+            net = true;
+        }
+        ctx->w_net = net;
+        ctx->w_fin_follows = early || !all_levels || net;
+        int rc = run_levels<NCH>(ctx, a, total_walks, n_levels, sized, early || net, &any_alive);
         if (rc != GG_OK) return rc;
         ctx->walk_used_speculation = !sized;
-        if (all_levels && !early) any_alive = false;
+        if (all_levels && !early && !net) any_alive = false;
+        if (net) small_finisher = true;
     }
     if (any_alive) {
         a.level = n_levels;
         int64_t blocks = (total_walks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-        const int64_t max_blocks = 256 * 8;
+        const int64_t max_blocks = small_finisher ? 256 : 256 * 8;  // (the safety net expects a handful of walks)
         if (blocks > max_blocks) blocks = max_blocks;
         if (blocks >= 8) blocks -= blocks % 8;
         const int64_t need_stride = ctx->tree_max_list > SCORE_CAP ? ((ctx->tree_max_list + 63) / 64 * 64) : 0;

@@ -39,7 +39,22 @@ def graph_to_csr(n_node, graph):
 def edges_to_csr(n_node, edges):
     """Vectorised ``read_edges`` adjacency for large synthetic graphs: for edge k = (a, b) the
     reference appends b to graph[a] and then a to graph[b] (utils.py:36-37), in file order."""
-    edges = np.asarray(edges, dtype=np.int64).reshape(-1, 2)
+    edges = np.asarray(edges).reshape(-1, 2)
+    if 2 * len(edges) < 2 ** 31 - 1:
+        try:  # one stable counting pass in C (scipy's COO -> CSR kernel, called directly: no duplicate merging, no index sorting)
+            from scipy.sparse import _sparsetools
+            src = np.empty(2 * len(edges), dtype=np.int32)
+            dst = np.empty(2 * len(edges), dtype=np.int32)
+            src[0::2], dst[0::2] = edges[:, 0], edges[:, 1]
+            src[1::2], dst[1::2] = edges[:, 1], edges[:, 0]
+            indptr = np.zeros(n_node + 1, dtype=np.int32)
+            col = np.empty(len(src), dtype=np.int32)
+            nothing = np.zeros(len(src), dtype=np.int8)
+            _sparsetools.coo_tocsr(n_node, n_node, len(src), src, dst, nothing, indptr, col, np.empty_like(nothing))
+            return indptr.astype(np.int64), col
+        except (ImportError, AttributeError):
+            pass
+    edges = edges.astype(np.int64)
     src = np.empty(2 * len(edges), dtype=np.int64)
     dst = np.empty(2 * len(edges), dtype=np.int32)
     src[0::2], dst[0::2] = edges[:, 0], edges[:, 1]
@@ -279,6 +294,59 @@ class Engine:
         the d_pass that precedes it -- without waiting for anything (gg_prepare_g_begin)."""
         slots = _i32(slots)
         self._ck(lib.gg_prepare_g_begin(self._ctx, _ptr(slots), len(slots), n_sample, seed, stream))
+
+    # ------------------------------------------------------------------ an epoch over root batches (trees not all resident)
+    def epoch_begin(self, reset_d=True, reset_g=True):
+        """Empty the accumulated discriminator rows / generator pairs of gg_epoch_add."""
+        self._ck(lib.gg_epoch_begin(self._ctx, int(bool(reset_d)), int(bool(reset_g))))
+
+    def epoch_add(self, roots, do_d=True, do_g=True, n_sample=20, seed=0, stream_d=0, stream_g=1):
+        """prepare_data_for_d / prepare_data_for_g (graph_gan.py:182-223) for one BATCH of roots (node ids): trees built on
+        the GPU, the roots' Q3 bits restored from / saved to the persistent store, rows and pairs appended to the epoch's
+        arrays.  Returns (rows accumulated so far, pairs accumulated so far)."""
+        roots = _i32(roots)
+        rows, pairs = ctypes.c_int64(), ctypes.c_int64()
+        self._ck(lib.gg_epoch_add(self._ctx, _ptr(roots), len(roots), int(bool(do_d)), int(bool(do_g)), int(n_sample), seed, stream_d,
+                                  stream_g, ctypes.byref(rows), ctypes.byref(pairs)))
+        if len(roots) and (do_d or do_g):
+            self._after_trees(roots)
+        return rows.value, pairs.value
+
+    def epoch_commit(self, which):
+        """The accumulated rows (which = 1) / pairs with their rewards (which = 0) become the data of d_pass / g_pass; returns their number."""
+        n = ctypes.c_int64()
+        self._ck(lib.gg_epoch_commit(self._ctx, int(which), ctypes.byref(n)))
+        if which == 1:
+            self.d_rows = n.value
+        else:
+            self.g_pairs = n.value
+        return n.value
+
+    def get_d_data(self):
+        """The resident discriminator rows (center, neighbor, label) -- of the last prepare_d or epoch_commit(1)."""
+        n = self.d_rows
+        c, nb, lab = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.float32)
+        self._ck(lib.gg_get_d_data(self._ctx, _ptr(c), _ptr(nb), _ptr(lab)))
+        return c, nb, lab
+
+    def get_g_data(self):
+        """The resident generator pairs (node_1, node_2, reward) -- of the last prepare_g or epoch_commit(0)."""
+        n = self.g_pairs
+        a, b, r = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.float32)
+        self._ck(lib.gg_get_g_data(self._ctx, _ptr(a), _ptr(b), _ptr(r)))
+        return a, b, r
+
+    def q3_clear(self):
+        """Forget every in-place tree mutation (graph_gan.py:258-259) kept for the root-batched epochs."""
+        self._ck(lib.gg_q3_clear(self._ctx))
+
+    def q3_get(self):
+        """(word_off int64 [N+1], words uint32): bit j of root v's words = the father entry of its (j+1)-th tree child was removed."""
+        off = np.zeros(self.n_node + 1, dtype=np.int64)
+        self._ck(lib.gg_q3_get(self._ctx, _ptr(off), None))
+        words = np.zeros(max(int(off[-1]), 1), dtype=np.uint32)
+        self._ck(lib.gg_q3_get(self._ctx, None, _ptr(words)))
+        return off, words[: int(off[-1])]
 
     def d_pass(self, starts, batch_size):
         """One inner D epoch over the prepared rows (graph_gan.py:149-157)."""

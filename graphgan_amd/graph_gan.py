@@ -24,6 +24,7 @@ use ``numpy.random.RandomState(engine_seed)``, so runs are reproducible.
 """
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -92,15 +93,20 @@ class GraphGAN(object):
 
         # BFS trees live in HBM; like the reference's self.trees (:31-46) every root stays resident for the whole
         # run -- also with update_ratio < 1, where each prepare call only SELECTS a subset of the resident slots, so
-        # the in-place D-mode mutations (Q3, :258-259) persist across epochs exactly as in the reference.  Only when
-        # all N trees cannot fit the budget (config.engine_tree_budget_gb; N^2 storage) and update_ratio < 1 are the
-        # trees of each draw built on demand instead (mutation state then lives for one prepare call).
+        # the in-place D-mode mutations (Q3, :258-259) persist across epochs exactly as in the reference.  When all N
+        # trees cannot fit the budget (config.engine_tree_budget_gb; N^2 storage: 12 TB at 10^6 nodes) the epoch runs
+        # over ROOT BATCHES instead (_prepare_root_batches / gg_epoch_*): the same schedule -- prepare over all (selected)
+        # roots, then the passes over all rows -- with one batch of trees resident at a time and the mutation bits kept
+        # in a store that outlives the trees.
         print("constructing BFS-trees...")
         self.trees = None
         self._slot_of_root = None
         self._all_resident = False
+        self._g_pairs_ready = False
         budget = float(_cfg(cfg, "engine_tree_budget_gb", 160.0)) * 2.0 ** 30
-        if cfg.update_ratio >= 1 or self.engine.tree_bytes_estimate(len(self.root_nodes)) <= budget:
+        # roots per batch of a root-batched epoch (all N trees do not fit: N^2 storage): what the budget holds
+        self._batch_roots = int(_cfg(cfg, "engine_batch_roots", 0)) or max(1, min(16384, int(budget // self.engine.tree_bytes_estimate(1))))
+        if self.engine.tree_bytes_estimate(len(self.root_nodes)) <= budget:
             # construct or read BFS-trees (reference :31-46; the cache is a flat GGTR file instead of a pickle)
             cache = self._tree_cache_path(_cfg(cfg, "cache_filename", None))
             if cache and os.path.isfile(cache) and self._load_tree_cache(cache):
@@ -213,12 +219,24 @@ class GraphGAN(object):
                 self.engine.save_state(self.latest_checkpoint)
 
             # D-steps
+            t_epoch = time.time()
             train_size = 0
+            self._g_pairs_ready = False
             for d_epoch in range(cfg.n_epochs_dis):
                 if d_epoch % cfg.dis_interval == 0:
                     self._stream = self.stream_id(epoch, d_epoch, cfg.n_epochs_dis, True)
-                    train_size = self._prepare_d_resident()
-                if d_epoch == cfg.n_epochs_dis - 1 and cfg.n_epochs_gen > 0 and cfg.update_ratio >= 1:
+                    if self._all_resident:
+                        train_size = self._prepare_d_resident()
+                    else:
+                        # the G-mode walks of the epoch's first generator prepare read the generator, the trees and the Q3 bits
+                        # only (reference :204-216) -- nothing the remaining D passes change: they share the trees of the LAST
+                        # discriminator prepare of the epoch (one BFS per root and outer epoch instead of two).  With
+                        # update_ratio < 1 the two prepares draw their own roots (:189, :209): no sharing.
+                        last = d_epoch + cfg.dis_interval >= cfg.n_epochs_dis
+                        g_too = last and cfg.n_epochs_gen > 0 and cfg.update_ratio >= 1
+                        train_size = self._prepare_root_batches(True, g_too, self._stream, self.stream_id(epoch, 0, cfg.n_epochs_gen, False))
+                        self._g_pairs_ready = g_too
+                if self._all_resident and d_epoch == cfg.n_epochs_dis - 1 and cfg.n_epochs_gen > 0 and cfg.update_ratio >= 1:
                     # the G-mode walks of the first G epoch read the generator only (reference :204-216): started on the
                     # engine's side stream before the last D pass is enqueued, adopted by prepare_g below (same arguments; with
                     # update_ratio < 1 the root draw of that call is not known yet, and nothing is begun)
@@ -230,12 +248,19 @@ class GraphGAN(object):
             for g_epoch in range(cfg.n_epochs_gen):
                 if g_epoch % cfg.gen_interval == 0:
                     self._stream = self.stream_id(epoch, g_epoch, cfg.n_epochs_gen, False)
-                    train_size = self._prepare_g_resident()
+                    if self._all_resident:
+                        train_size = self._prepare_g_resident()
+                    elif g_epoch == 0 and self._g_pairs_ready:
+                        train_size = self.engine.epoch_commit(0)  # pairs sampled beside the last D prepare; rewards evaluated now
+                        self._g_pairs_ready = False
+                    else:
+                        train_size = self._prepare_root_batches(False, True, 0, self._stream)
                 self.engine.g_pass(self._batch_starts(train_size, cfg.batch_size_gen), cfg.batch_size_gen)
 
             if self.rank == 0:
                 self.write_embeddings_to_file()
-                self.evaluation(self)
+                results = self.evaluation(self)
+                self._write_perf_log(epoch, time.time() - t_epoch, results)
         print("training completes")
 
     def _batch_starts(self, train_size, batch_size):
@@ -252,9 +277,10 @@ class GraphGAN(object):
         return start_list
 
     # ------------------------------------------------------------------ sample preparation
-    def _select_slots(self):
+    def _draw_roots(self):
         """``np.random.rand() < update_ratio`` per root (reference :189, :209): one draw per root, in root order
-        (no draws with update_ratio >= 1: every root is taken, and the oracle trainer does the same)."""
+        (no draws with update_ratio >= 1: every root is taken, and the oracle trainer does the same).  Returns indices
+        into ``root_nodes``."""
         cfg = self.config
         if cfg.update_ratio >= 1:
             return np.arange(len(self.root_nodes), dtype=np.int32)
@@ -264,12 +290,25 @@ class GraphGAN(object):
         else:  # one draw per ROOT of the whole graph, keyed by the prepare call: the selection does not depend on the sharding
             draws = np.random.RandomState([self.seed, self._prepare_no]).rand(self.n_node)
             take = np.flatnonzero(draws[np.asarray(self.root_nodes, dtype=np.int64)] < cfg.update_ratio)
-        if self._all_resident:
-            return take.astype(np.int32)  # slot i holds root_nodes[i]
-        if len(take) == 0:
-            return np.zeros(0, dtype=np.int32)
-        self.trees = self.construct_trees([self.root_nodes[i] for i in take])
-        return np.arange(len(take), dtype=np.int32)
+        return take.astype(np.int32)
+
+    def _select_slots(self):
+        """The resident slots of this prepare call's roots (slot i holds root_nodes[i])."""
+        assert self._all_resident
+        return self._draw_roots()
+
+    def _prepare_root_batches(self, do_d, do_g, stream_d, stream_g):
+        """prepare_data_for_d and / or prepare_data_for_g (reference :182-223) over this call's roots when their trees
+        cannot all be resident: batch by batch (gg_epoch_add: BFS trees on the GPU, Q3 bits restored / saved, walks, rows
+        and pairs appended in root order), then the discriminator rows -- or, for a generator-only call, the pairs -- become
+        the prepared data of the passes.  A rank that drew no root still commits (the call holds the replicas' collective)."""
+        cfg = self.config
+        roots = np.asarray(self.root_nodes, dtype=np.int32)[self._draw_roots()]
+        self.engine.epoch_begin(reset_d=do_d, reset_g=do_g)
+        for k in range(0, len(roots), self._batch_roots):
+            self.engine.epoch_add(roots[k:k + self._batch_roots], do_d, do_g, cfg.n_sample_gen, self.seed, stream_d, stream_g)
+        self._slot_of_root = None  # (the resident slots are the last batch's)
+        return self.engine.epoch_commit(1 if do_d else 0)
 
     # An empty draw (update_ratio < 1) still goes through the engine: gg_prepare_* ends with a collective over the replicas
     # (the max of the ranks' row counts) that every rank must join, and it resets the resident row count that the passes and
@@ -287,6 +326,10 @@ class GraphGAN(object):
         returns (center_nodes, neighbor_nodes, labels) and leaves them resident for d_pass"""
         if not hasattr(self, "_stream"):
             self._stream = 0
+        if not self._all_resident:
+            self._prepare_root_batches(True, False, self._stream, 0)
+            center, neighbor, label = self.engine.get_d_data()
+            return center.tolist(), neighbor.tolist(), label.astype(np.int64).tolist()
         slots = self._select_slots()
         if len(slots) == 0:
             return [], [], []
@@ -297,6 +340,10 @@ class GraphGAN(object):
         """sample nodes for the generator (reference :204-223); returns (node_1, node_2, reward)"""
         if not hasattr(self, "_stream"):
             self._stream = 1
+        if not self._all_resident:
+            self._prepare_root_batches(False, True, 0, self._stream)
+            n1, n2, reward = self.engine.get_g_data()
+            return n1.tolist(), n2.tolist(), reward
         slots = self._select_slots()
         if len(slots) == 0:
             return [], [], np.zeros(0, dtype=np.float32)
@@ -343,6 +390,23 @@ class GraphGAN(object):
                 self.engine.write_embeddings(i, cfg.emb_filenames[i])  # native formatter, byte-identical text
             if _cfg(cfg, "engine_emb_sidecar", False):
                 self.engine.write_embeddings_bin(i, cfg.emb_filenames[i] + ".bin")  # same numbers, 4 B each
+
+    def _write_perf_log(self, epoch, wall_s, results):
+        """One JSON line per outer epoch beside the results file (``<result_filename>.perf.jsonl``): wall time, the engine's
+        counters (walks, sampled edges, rows scored, pairs through the passes, optimizer steps, tree builds) and the
+        accuracies just appended to the results file (reference :316-319 writes only those)."""
+        import json
+        cfg = self.config
+        c = self.engine.counters()
+        prev = getattr(self, "_perf_prev", {})
+        delta = {k: c[k] - prev.get(k, 0) for k in ("walks", "hops", "rows_scored", "d_pairs", "g_pairs", "d_steps", "g_steps", "bfs_trees", "bfs_kernel_ms", "walk_reruns")}
+        self._perf_prev = c
+        rec = {"epoch": int(epoch), "wall_s": wall_s, "sampled_edges_per_sec": delta["hops"] / wall_s if wall_s > 0 else None,
+               "trees": "resident" if self._all_resident else "root batches of %d" % self._batch_roots, "world": self.world,
+               "results": [r.strip() for r in (results or [])], **delta}
+        os.makedirs(os.path.dirname(cfg.result_filename) or ".", exist_ok=True)
+        with open(cfg.result_filename + ".perf.jsonl", "a") as f:
+            f.write(json.dumps(rec) + "\n")
 
     @staticmethod
     def evaluation(self):

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GG_ABI_VERSION 4  /* round 3: gg_counters extended (edge-score cache); gg_prepare_g_begin */
+#define GG_ABI_VERSION 5  /* round 4: epoch over root batches (gg_epoch_*, gg_q3_*); round 3: gg_counters extended, gg_prepare_g_begin */
 
 enum {
     GG_OK = 0,
@@ -222,6 +222,35 @@ int gg_prepare_g_begin(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, int32
  * minibatches -- which must therefore come before the next walk launch of the context (gg_prepare_d / gg_prepare_g /
  * gg_walk_sample); later it is GG_EINVAL.  Rewards, and whole-batch passes over the walks, do not need them. */
 int gg_get_g_data(gg_ctx *ctx, int32_t *node_1, int32_t *node_2, float *reward);
+
+/* ---- an epoch over ROOT BATCHES (ABI 5).  The reference keeps the tree of every root resident (self.trees, graph_gan.py:31-46)
+ * and prepare_data_for_d / prepare_data_for_g visit every root (:188, :208) before the passes run over all rows (:149-157,
+ * :168-176).  N trees are N^2 entries (12 TB at 10^6 nodes): where they cannot all be resident, the same schedule runs with
+ * one batch of trees in HBM at a time:
+ *   gg_epoch_begin   empty the accumulated discriminator rows (reset_d) and / or generator pairs (reset_g);
+ *   gg_epoch_add     for the given ROOTS (node ids, not slots): their BFS trees are built on the GPU into slots 0 .. n_roots-1
+ *                    (whatever was resident is replaced), the roots' Q3 bits -- father entries that D-mode walks of EARLIER
+ *                    epochs removed for good, graph_gan.py:258-259 -- are restored from a store that outlives the trees; do_d:
+ *                    gg_prepare_d on them (seed, stream_d), bits saved back, rows appended; do_g: gg_prepare_g (n_sample, seed,
+ *                    stream_g), window pairs appended.  do_d and do_g in one call share the trees: the G-mode walks read only
+ *                    the generator, the trees and the Q3 bits the D-mode walks of the same root have just set -- nothing the
+ *                    discriminator's passes change -- so one BFS per root serves both phases of an outer epoch.  Batches are
+ *                    appended in call order; *rows_total_out / *pairs_total_out = accumulated so far.  gg_get_walks /
+ *                    gg_get_trees afterwards show the batch's last launch / its trees (mutations included).
+ *   gg_epoch_commit  which = 1: the accumulated rows become the resident prepared data of gg_d_pass / gg_get_d_data;
+ *                    which = 0: the rewards of ALL accumulated pairs are evaluated now (graph_gan.py:220-222, with the
+ *                    discriminator as its passes left it) and the pairs become the data of gg_g_pass / gg_get_g_data.
+ *                    With replicas this is where the ranks exchange their counts (once per epoch, not per batch).
+ * Rows / pairs equal those of the all-resident calls over the same roots in the same order (tested bit for bit).
+ * gg_q3_clear forgets all mutations (a fresh process of the reference: its pickle is written before any, :45);
+ * gg_q3_get reads the store: word_off[v] .. word_off[v + 1] = the ceil(deg(v) / 32) words of root v, bit j = the father entry of
+ * its (j + 1)-th tree child was removed.  The store is also what gg_epoch_add leaves in the resident slots' own Q3 rows. */
+int gg_epoch_begin(gg_ctx *ctx, int32_t reset_d, int32_t reset_g);
+int gg_epoch_add(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, int32_t do_d, int32_t do_g, int32_t n_sample, uint64_t seed,
+                 uint32_t stream_d, uint32_t stream_g, int64_t *rows_total_out, int64_t *pairs_total_out);
+int gg_epoch_commit(gg_ctx *ctx, int32_t which, int64_t *n_out);
+int gg_q3_clear(gg_ctx *ctx);
+int gg_q3_get(gg_ctx *ctx, int64_t *word_off /*[n_node + 1] or NULL*/, uint32_t *words /*[word_off[n_node]] or NULL*/);
 
 /* gg_d_pass / gg_g_pass: one inner epoch over the prepared rows = the minibatch loops
  * graph_gan.py:149-157 / :168-176: for each s in starts (the caller's shuffled start_list),

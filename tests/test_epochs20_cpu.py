@@ -33,3 +33,20 @@ def test_final_accuracy_of_the_full_schedule_agrees_within_half_a_percent_on_the
     assert np.all(np.abs(mean) <= 2.0 * sem + 0.1), (np.abs(mean) - 2 * sem).max()
     # and what the comparison is worth: both sides end at chance (a coin flip on 2 898 test edges has sigma = 0.93 %)
     assert np.all(np.abs(O[:, 20].mean(0) - 0.5) < 0.01) and np.all(np.abs(E[:, 20].mean(0) - 0.5) < 0.01)
+
+
+def test_short_schedule_fixture_is_informative():
+    """tests/golden/oracle_epochs_short.json (8 seeds x 5 outer epochs of the 2 + 2 schedule): what the per-seed +-0.5 % gate of
+    tests/test_gpu_e2e.py::test_short_schedule_epochs_match_the_oracle_per_seed rests on -- after epochs 0 and 1 both models sit
+    far from the start AND far from chance, and the seeds agree to a fraction of the gate."""
+    import json
+    import os
+    import numpy as np
+    f = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_epochs_short.json")))
+    a = np.array([f["epochs"][str(s)] for s in range(8)])          # [seed, epoch 0 = before training .. 5, (gen, dis)]
+    assert f["n_inner"] == 2 and a.shape == (8, 6, 2)
+    assert np.all(a[:, 0] == 0.7598343685300207)
+    for ep in (1, 2):
+        assert np.all(a[:, ep, 0] > 0.86) and np.all(np.abs(a[:, ep, 1] - 0.78) < 0.02)   # generator UP by > 0.1, nowhere near 0.5
+        assert a[:, ep].std(0).max() < 0.0025                                              # seed spread: half the gate at most
+    assert 0.62 < a[:, 3, 0].mean() < 0.67 and a[:, 3, 0].std() < 0.01                    # the turn: still informative, looser gate

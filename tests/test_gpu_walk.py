@@ -231,18 +231,20 @@ def dense_layers_edges(widths=(1, 120, 150, 90), seed=3):
     return edges.astype(np.int32), nxt
 
 
-@pytest.fixture(params=["lds_bitmap", "global_bitmap"])
+@pytest.fixture(params=["lds_bitmap", "global_bitmap", "v1_lds_bitmap", "v1_global_bitmap"])
 def bfs_bitmap(request, monkeypatch):
-    """Both instances of bfs_order_kernel: the visited bitmap in LDS (graphs up to ~1.1 M nodes) and in global memory
-    (GG_BFS_GLOBAL_BITMAP=1 forces what larger graphs -- BASELINE.json configs[4], 10^7 nodes -- take by themselves)."""
-    if request.param == "global_bitmap":
-        monkeypatch.setenv("GG_BFS_GLOBAL_BITMAP", "1")
-    else:
-        monkeypatch.delenv("GG_BFS_GLOBAL_BITMAP", raising=False)
+    """Both instances of the BFS kernel: the visited bitmap in LDS (graphs up to ~1.06 M nodes) and in global memory
+    (GG_BFS_GLOBAL_BITMAP=1 forces what larger graphs -- BASELINE.json configs[4], 10^7 nodes -- take by themselves); and both
+    kernels: the scan / claim kernel of round 4 (default) and the chunk kernel of rounds 2-3 (GG_BFS_V1=1)."""
+    for var, on in (("GG_BFS_GLOBAL_BITMAP", "global" in request.param), ("GG_BFS_V1", request.param.startswith("v1"))):
+        if on:
+            monkeypatch.setenv(var, "1")
+        else:
+            monkeypatch.delenv(var, raising=False)
     return request.param
 
 
-@pytest.mark.parametrize("case", ["small0", "small3", "star", "ca_grqc", "powerlaw", "dense_layers"])
+@pytest.mark.parametrize("case", ["small0", "small3", "star", "big_star", "ca_grqc", "powerlaw", "dense_layers"])
 def test_gpu_bfs_builds_the_reference_trees(ga, case, bfs_bitmap):
     """gg_build_trees_device == the host builder == reference construct_trees (pop order, child order,
     self-loops, isolated nodes, several components), offsets / lists / depth / longest list."""
@@ -254,8 +256,10 @@ def test_gpu_bfs_builds_the_reference_trees(ga, case, bfs_bitmap):
         g, n, graph = load_small(int(case[-1]))
         rowptr, col = ga.graph_to_csr(n, graph)
         roots = np.arange(n, dtype=np.int32)
-    elif case == "star":
-        edges, n = star_graph_edges(300)
+    elif case in ("star", "big_star"):
+        # big_star: a hub whose 20 003 adjacency entries exceed one scan window (16 384 positions) -- scanned in segments -- and
+        # are ALL new when the hub is the root: more candidates than claim threads, the window is rescanned shorter
+        edges, n = star_graph_edges(300 if case == "star" else 20000)
         rowptr, col = ga.edges_to_csr(n, edges)
         roots = np.array([0, 1, 5, n - 1, 17], dtype=np.int32)
     elif case == "ca_grqc":

@@ -111,6 +111,11 @@ class _FakeEngine(object):
         self.last_slots = np.array(slots)
         return 333 if len(slots) else 0
     def prepare_g_begin(self, slots, n_sample, seed, stream): self.calls.append(("prepare_g_begin", len(slots), n_sample, seed, stream))
+    def counters(self): return {k: 0 for k in ("walks", "hops", "rows_scored", "d_pairs", "g_pairs", "d_steps", "g_steps", "bfs_trees", "bfs_kernel_ms", "walk_reruns")}
+    def epoch_begin(self, reset_d=True, reset_g=True): self.calls.append(("epoch_begin", bool(reset_d), bool(reset_g)))
+    def epoch_add(self, roots, do_d, do_g, n_sample, seed, stream_d, stream_g):
+        self.calls.append(("epoch_add", [int(r) for r in roots], bool(do_d), bool(do_g), n_sample, seed, stream_d, stream_g))
+    def epoch_commit(self, which): self.calls.append(("epoch_commit", which)); return 200 if which == 1 else 333
     def d_pass(self, starts, batch): self.calls.append(("d_pass", list(starts), batch))
     def g_pass(self, starts, batch): self.calls.append(("g_pass", list(starts), batch))
     def get_embeddings(self, which): return self.E[which]
@@ -172,6 +177,54 @@ def test_training_schedule_drives_the_engine_like_the_reference(pkg, tmp_path, m
     assert open(cfg.emb_filenames[0]).readline() == "5242\t50\n"
 
 
+def test_root_batched_epoch_when_the_trees_do_not_fit(pkg, tmp_path, monkeypatch):
+    """All N trees over the budget (N^2 storage): the mirror runs the reference's schedule (graph_gan.py:133-176) over ROOT
+    BATCHES -- gg_epoch_begin / gg_epoch_add per batch / gg_epoch_commit -- instead of failing: every root of root_nodes in
+    order, the G-mode walks of the epoch's first generator prepare in the same batches as the LAST discriminator prepare (one
+    BFS per root and outer epoch), later generator prepares with batches of their own; passes and streams as before; one
+    JSON line per outer epoch beside the results file."""
+    import json
+    from tests.test_gpu_e2e import make_cfg, write_reference_layout
+    from graphgan_amd import engine as eng_mod, graph_gan
+    base = str(tmp_path)
+    d, n, graph = write_reference_layout(base)
+    monkeypatch.setattr(eng_mod, "Engine", _FakeEngine)
+    per_tree = 8.0 * (n + 1)                        # the fake engine's estimate
+    cfg = make_cfg(base, n_epochs=2, n_epochs_dis=4, n_epochs_gen=5, dis_interval=2, gen_interval=3, engine_seed=11,
+                   engine_tree_budget_gb=1200.5 * per_tree / 2.0 ** 30)  # room for 1 200 of the 5 242 trees
+    g = graph_gan.GraphGAN(cfg)
+    assert not g._all_resident and g._batch_roots == 1200 and g.trees is None
+    g.train()
+    calls = g.engine.calls
+    names = [c[0] for c in calls]
+    assert "build_trees" not in names and "prepare_d" not in names and "prepare_g" not in names and "prepare_g_begin" not in names
+    adds = ["epoch_add"] * 5                        # ceil(5242 / 1200) batches
+    per_epoch = (["epoch_begin"] + adds + ["epoch_commit", "d_pass", "d_pass"]          # D prepare at inner epoch 0
+                 + ["epoch_begin"] + adds + ["epoch_commit", "d_pass", "d_pass"]        # ... at inner epoch 2: with the G walks
+                 + ["epoch_commit", "g_pass", "g_pass", "g_pass"]                       # G epoch 0: the pairs are there already
+                 + ["epoch_begin"] + adds + ["epoch_commit", "g_pass", "g_pass"]        # G prepare at inner epoch 3: own batches
+                 + ["write_embeddings", "write_embeddings"])
+    i0 = names.index("epoch_begin")
+    assert names[i0:] == per_epoch + per_epoch
+    ep = [c for c in calls if c[0] in ("epoch_begin", "epoch_add", "epoch_commit")]
+    begins = [c[1:] for c in ep if c[0] == "epoch_begin"]
+    assert begins == [(True, False), (True, True), (False, True)] * 2
+    commits = [c[1] for c in ep if c[0] == "epoch_commit"]
+    assert commits == [1, 1, 0, 0] * 2
+    a = [c for c in ep if c[0] == "epoch_add"]
+    for k in range(0, len(a), 5):                   # every prepare covers root_nodes once, in order
+        assert sum((c[1] for c in a[k:k + 5]), []) == list(range(n))
+    flags = [(c[2], c[3]) for c in a[::5]]
+    assert flags == [(True, False), (True, True), (False, True)] * 2
+    sd = lambda e, i: 2 * (e * 4 + i)               # noqa: E731  streams as in the resident schedule
+    sg = lambda e, i: 2 * (e * 5 + i) + 1           # noqa: E731
+    assert [(c[6], c[7]) for c in a[::5]] == [(sd(0, 0), sg(0, 0)), (sd(0, 2), sg(0, 0)), (0, sg(0, 3)),
+                                               (sd(1, 0), sg(1, 0)), (sd(1, 2), sg(1, 0)), (0, sg(1, 3))]
+    assert all(c[4] == 20 and c[5] == 11 for c in a)
+    perf = [json.loads(l) for l in open(cfg.result_filename + ".perf.jsonl")]
+    assert [p["epoch"] for p in perf] == [0, 1] and perf[0]["trees"] == "root batches of 1200" and len(perf[0]["results"]) == 2
+
+
 def test_update_ratio_selects_roots_per_prepare(pkg, tmp_path, monkeypatch):
     """``np.random.rand() < update_ratio`` per root (graph_gan.py:189,209).  The reference keeps ALL trees in
     self.trees and only skips roots per prepare, so the D-mode mutations (Q3) persist: the mirror builds every
@@ -200,43 +253,49 @@ def test_update_ratio_selects_roots_per_prepare(pkg, tmp_path, monkeypatch):
     assert np.array_equal(seen[0], first)                          # one draw per root, in root order, before any shuffle
 
 
-def test_update_ratio_with_trees_over_budget_builds_per_draw(pkg, tmp_path, monkeypatch):
-    """When all N trees cannot stay resident (engine_tree_budget_gb) and update_ratio < 1, every prepare builds the
-    trees of its own draw; an empty draw prepares nothing (0 rows) instead of failing; sample() of a root outside
-    the last draw builds that root's tree on demand."""
+def test_update_ratio_with_trees_over_budget_batches_each_draw(pkg, tmp_path, monkeypatch):
+    """When all N trees cannot stay resident (engine_tree_budget_gb) and update_ratio < 1, every prepare runs root batches
+    over ITS OWN draw (graph_gan.py:189,209 draw per prepare: the G-mode walks cannot share the D prepare's trees); an empty
+    draw adds nothing but still commits (0 rows; the commit holds the replicas' collective); sample() of a root builds that
+    root's tree on demand."""
     from tests.test_gpu_e2e import make_cfg, write_reference_layout
     from graphgan_amd import engine as eng_mod, graph_gan
     base = str(tmp_path)
     d, n, graph = write_reference_layout(base)
     monkeypatch.setattr(eng_mod, "Engine", _FakeEngine)
     cfg = make_cfg(base, n_epochs=1, n_epochs_dis=2, n_epochs_gen=2, dis_interval=1, gen_interval=2, update_ratio=0.1, engine_seed=3,
-                   engine_tree_budget_gb=0.0)
+                   engine_tree_budget_gb=0.0, engine_batch_roots=100)
     g = graph_gan.GraphGAN(cfg)
-    assert g.trees is None and not any(c[0] == "build_trees" for c in g.engine.calls)
+    assert g.trees is None and not any(c[0] == "build_trees" for c in g.engine.calls) and g._batch_roots == 100
     g.train()
     calls = g.engine.calls
-    builds = [c for c in calls if c[0] == "build_trees"]
-    prepares = [c for c in calls if c[0] in ("prepare_d", "prepare_g")]
-    assert len(builds) == len(prepares) == 3
-    for b, p in zip(builds, prepares):
-        assert 0.06 * n < b[1] < 0.14 * n and p[1] == b[1]      # ~10 % of the roots, all of their slots
-        assert calls.index(b) + 1 == calls.index(p)             # trees of the subset right before its prepare
-    roots = g.engine.tree_roots
-    assert roots == sorted(roots) and len(set(roots)) == len(roots) and g._slot_of_root[roots[5]] == 5
-    # empty draw: nothing built, zero rows -- but the engine IS called with the empty slot list: gg_prepare_* ends with a
-    # collective every replica must join, and it resets the resident row count the passes read (ADVICE r2)
+    assert not any(c[0] in ("build_trees", "prepare_d", "prepare_g") for c in calls)
+    begins = [i for i, c in enumerate(calls) if c[0] == "epoch_begin"]
+    assert [calls[i][1:] for i in begins] == [(True, False), (True, False), (False, True)]   # D, D, G: three draws
+    drawn = []
+    for i in begins:
+        j = i + 1
+        roots = []
+        while calls[j][0] == "epoch_add":
+            assert len(calls[j][1]) <= 100 and calls[j][2:4] == calls[i][1:]
+            roots += calls[j][1]
+            j += 1
+        assert calls[j][0] == "epoch_commit" and calls[j][1] == (1 if calls[i][1] else 0)
+        assert 0.06 * n < len(roots) < 0.14 * n and roots == sorted(set(roots))   # ~10 % of the roots, in root order
+        drawn.append(roots)
+    assert len({tuple(r) for r in drawn}) == 3                                      # a fresh draw per prepare
+    assert drawn[0] == np.flatnonzero(np.random.RandomState(3).rand(n) < 0.1).tolist()
+    # empty draw: no batch, zero rows -- but begin + commit are issued (the commit is a collective every replica joins)
     g.config.update_ratio = 0.0
-    nb = len([c for c in g.engine.calls if c[0] == "build_trees"])
-    np_ = len([c for c in g.engine.calls if c[0] in ("prepare_d", "prepare_g")])
-    assert g._prepare_d_resident() == 0 and g._prepare_g_resident() == 0
-    assert [c[:2] for c in g.engine.calls if c[0] in ("prepare_d", "prepare_g")][np_:] == [("prepare_d", 0), ("prepare_g", 0)]
+    k = len(g.engine.calls)
+    g.engine.get_d_data = lambda: (np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32))
+    g.engine.epoch_commit = lambda which: (g.engine.calls.append(("epoch_commit", which)), 0)[1]
     assert g.prepare_data_for_d() == ([], [], [])
-    assert len([c for c in g.engine.calls if c[0] == "build_trees"]) == nb
-    # sample() of a root that is not in the last draw: its tree is built on demand
-    other = [r for r in range(n) if r not in set(roots)][0]
+    assert [c[0] for c in g.engine.calls[k:]] == ["epoch_begin", "epoch_commit"]
+    # sample() of a root: its tree is built on demand
     g.engine.walk_sample = lambda slots, nw, for_d, seed, stream: dict(root_status=np.array([1]), paths=None, path_len=None, samples=None)
-    assert g.sample(other, None, 5, False) == (None, None)
-    assert g.engine.tree_roots == [other]
+    assert g.sample(77, None, 5, False) == (None, None)
+    assert g.engine.tree_roots == [77]
 
 
 def test_tree_cache_is_read_or_written_like_the_pickle(pkg, tmp_path, monkeypatch):

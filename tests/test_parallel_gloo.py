@@ -151,6 +151,7 @@ class _ReplicaEngine(object):
         return self.rows[1]
 
     def prepare_g_begin(self, slots, n_sample, seed, stream): pass   # (a head start on the device: no collective, no result)
+    def counters(self): return {k: 0 for k in ("walks", "hops", "rows_scored", "d_pairs", "g_pairs", "d_steps", "g_steps", "bfs_trees", "bfs_kernel_ms", "walk_reruns")}
 
     def prepare_g(self, slots, n_sample, seed, stream, fetch=True):
         self.rows[0] = 37 * len(slots) + 5 * self.rank
