@@ -162,6 +162,38 @@ def delta(c1, c0):
     return {k: c1[k] - c0[k] for k in c1}
 
 
+def exchange_label(comm):
+    """What the replicas' gradient exchanges of this run actually were (gg_comm_stats), not what was planned."""
+    if not comm:
+        return "none (counters unavailable)"
+    sp, de = comm.get("sparse_steps", 0), comm.get("dense_steps", 0)
+    kinds = []
+    if sp:
+        kinds.append("%d x all-gather of fixed-capacity row packs" % sp)
+    if de:
+        kinds.append("%d x dense reduce-scatter + all-gather of the accumulators" % de)
+    return ", ".join(kinds) if kinds else "no exchange ran"
+
+
+def comm_model(n, ld, d_rows_touched, g_rows_touched, d_pairs, g_pairs):
+    """Bytes ONE rank sends per step (D exchange + G exchange) at P = 2 / 4 / 8 under each strategy, from this run's real
+    per-rank counts (touched rows of the two passes, pairs of the two passes).  Weak scaling: every rank brings the same
+    counts.  dense = reduce-scatter + all-gather of the [N, ld + 1] accumulators (+ the int32 row flags);
+    packs = all-gather of fixed-capacity row packs, capacity min(N, 2 * pairs) rows of (ld + 2) words, sent to P - 1 peers;
+    owner = owner-partitioned sparse reduce: each touched row goes to its owner (row mod P), the owner's reduced rows -- the
+    union over ranks, bounded by min(N, P * touched) -- go to the P - 1 peers.  No N > 1 run exists: this is a model."""
+    row_b = 4.0 * (ld + 2)
+    out = {}
+    for P in (2, 4, 8):
+        f = (P - 1.0) / P
+        dense = 2 * (2.0 * f * 4.0 * n * (ld + 1) + 2.0 * f * 4.0 * n)
+        packs = sum((P - 1) * min(n, 2 * pairs) * row_b for pairs in (d_pairs, g_pairs))
+        owner = sum(f * t * row_b + f * min(n, P * t) * row_b for t in (d_rows_touched, g_rows_touched))
+        out["P=%d" % P] = {"dense_rs_ag": dense, "row_packs_allgather": packs, "owner_partitioned_sparse": owner,
+                           "picked_today": "dense_rs_ag" if P * min(n, 2 * max(d_pairs, g_pairs)) >= 1.5 * n else "row_packs_allgather"}
+    return out
+
+
 def strict_mode_line(ga, _lib, seconds=1.5):
     """SURVEY.md section 8d metric 2(i): the reference's own schedule -- batch 64, dense TF1-Adam over the whole table per
     step (graph_gan.py:149-157,168-176) -- on the CA-GrQc fixture (N = 5 242, d = 50), pairs/s through gg_d_pass /
@@ -436,7 +468,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": wl_name, "roots_per_gpu_per_step": int(R), "n_sample_gen": args.n_sample_gen,
                    "optimizer": args.optimizer, "step": "prepare_d + d_pass + prepare_g + g_pass (graph_gan.py:144-176, one inner pass each)" + ("" if args.no_g_head_start else "; the walks of prepare_g are enqueued before d_pass (gg_prepare_g_begin)"),
-                   "parallelism": "roots sharded x%d, replicated tables, RCCL sparse gradient all-gather per pass" % world if world > 1 else "single GPU"},
+                   "parallelism": ("roots sharded x%d, replicated tables, RCCL gradient exchange per pass: %s" % (world, exchange_label(comm))) if world > 1 else "single GPU"},
         # pairs through the update kernels / HIP-event time of those kernels (gradient + optimizer) on the profiled passes
         "d_step_pairs_per_sec": c["d_pairs_timed"] / ((c["d_grad_ms"] + c["d_opt_ms"]) * 1e-3) if c["d_grad_ms"] > 0 else None,
         "g_step_pairs_per_sec": c["g_pairs_timed"] / ((c["g_grad_ms"] + c["g_opt_ms"]) * 1e-3) if c["g_grad_ms"] > 0 else None,
@@ -503,8 +535,25 @@ def main():
                        "reference_equivalent_GBs": (ref_bytes / calls) / (walk_ms / launches * 1e-3) / 1e9 if walk_ms > 0 and launches else None,
                        "distributions_shared": reads / max(rows_scored, 1)},
     }
+    # ---- the tree build, priced like a kernel: algorithmic bytes per tree = the adjacency once (4 B per directed edge) + the
+    # row pointers of every queue node (16 B) + the three output arrays (12 B per node) -- 108 MB at 1M nodes / 10M edges
+    nnz = int(rowptr[-1])
+    bfs_bytes = 4.0 * nnz + 28.0 * n
+    bfs_us = out["tree_build"]["us_per_tree"]
+    out["tree_build"].update({"algorithmic_bytes_per_tree": bfs_bytes,
+                              "achieved_GBs": bfs_bytes / (bfs_us * 1e-6) / 1e9 if bfs_us else None,
+                              "frac_of_hbm_peak": bfs_bytes / (bfs_us * 1e-6) / 1e9 / HBM_PEAK_GBS if bfs_us else None,
+                              "bytes_model": "4 B per directed edge (adjacency read once) + 16 B per node (row pointers) + 12 B per node (pop order, first-child ranks, edge indices)"})
+    # (scalars: the driver's record keeps the scalar members of `roofline` and `config`)
+    out["roofline"]["bfs_us_per_tree"] = bfs_us
+    out["roofline"]["bfs_frac_of_hbm_peak"] = out["tree_build"]["frac_of_hbm_peak"]
     if cont:
         out["batch_of_rounds_1_2"] = cont
+    if c["d_passes_timed"] and c["g_passes_timed"]:
+        out["comm_model"] = dict(comm_model(n, eng.n_emb + (-eng.n_emb) % 4, c["d_rows_timed"] / c["d_passes_timed"], c["g_rows_timed"] / c["g_passes_timed"],
+                                            c["d_pairs"] / args.steps, c["g_pairs"] / args.steps),
+                                 what="bytes one rank would send per step for its two gradient exchanges, from this run's per-rank touched rows / pairs; "
+                                      "unit B; NOT measured (no multi-GPU box)")
     if comm:
         out["comm"] = dict(comm, what="rank 0's gradient exchanges up to the end of the timed region (RCCL over xGMI): optimizer steps that exchanged "
                                       "fixed-capacity row packs (sparse) / reduce-scatter + all-gather of the accumulators (dense), bytes sent")
@@ -514,6 +563,11 @@ def main():
             "what": "%d fresh batches of %d roots per GPU: gg_build_trees_device + one step each (trees not resident)" % (args.fresh_batches, R),
             "s_per_batch": e2e_dt / args.fresh_batches, "bfs_kernel_ms_per_batch": e2e[2] / args.fresh_batches,
             "bfs_us_per_tree": 1e3 * e2e[2] / max(e2e[3], 1)}
+        # the number a user of this configuration sees when the trees are NOT resident (an epoch over all N roots is a
+        # sequence of exactly these batches): beside the resident-trees headline, where the driver's record keeps it
+        out["roofline"]["with_tree_build_edges_per_sec"] = sums[3] / e2e_dt
+        out["config"]["with_tree_build_edges_per_sec"] = sums[3] / e2e_dt
+        out["config"]["with_tree_build_s_per_batch"] = e2e_dt / args.fresh_batches
     if world == 1 and not args.no_strict:
         out["strict_mode"] = strict_mode_line(ga, _lib)
     if world == 1 and not args.no_cpu_baseline:

@@ -403,29 +403,33 @@ __global__ __launch_bounds__(BFS_T) void bfs_order_kernel(const BfsArgs a) {
 
 // ============================================================================================================================
 // Round 4: the same BFS as a SCAN phase and a CLAIM phase per window (bfs_order2_kernel, the default; GG_BFS_V1=1 runs the
-// chunk kernel above).  What the chunk kernel spends per edge -- ~51 vector instructions, five workgroup barriers per 8 192
-// stream positions -- is mostly bookkeeping that only the edges which DISCOVER a node need (1 M of the 19 M a tree of the
-// 1M-node graph inspects): the owner of every stream position, per-position masks, a compaction of all 8 192 positions.  Here
-//   * SCAN: a window = up to 1 024 queue nodes / 4 096 quads of 4 consecutive adjacency entries.  A thread takes quads
-//     (one 16-byte load each, all of a thread's loads in flight together), tests the four targets against the visited bitmap
-//     in LDS and does nothing else unless a target is unseen: such a CANDIDATE {window node, stream position, target} goes to a
-//     short LDS list and sets its bit in a position mask.  No barrier inside a window; nothing is modified, so a window
-//     whose candidates do not fit the list (the growth levels) is simply rescanned shorter (the window length follows the
-//     candidate density of the previous window).
-//   * CLAIM: one thread per candidate.  atomic-or on the bitmap: the hardware winner among the edges into the same new
-//     node; the in-window duplicates (rare) go to the duplicate list and the winner takes the smallest position -- the edge
-//     the sequential BFS appends the node at (graph_gan.py:101-107) -- exactly as in the chunk kernel, overflow path included.
-//     Popcounts over the position mask give every appending candidate its place in stream order (= queue order), a per-node
-//     counter + scan gives cstart.  A window without candidates (most windows of the last levels) costs one barrier.
+// chunk kernel above).  Measured on the chunk kernel and on the first version of this one (profiles/r4_bfs_notes.txt): a unit of
+// ~8 000 stream positions costs ~17 000 cycles either way -- a third of it memory round trips that a workgroup alone on its CU
+// cannot hide (every __syncthreads also waits for the stores and prefetches in flight), the rest ~550 instructions per thread of
+// per-unit bookkeeping (two block scans, a candidate list, a child-count scan).  So, per window of up to 1 024 queue nodes /
+// 4 096 quads (= 16 384 stream positions):
+//   * SCAN: a thread takes quads of 4 consecutive adjacency entries (one 16-byte load each, all of a thread's loads in flight
+//     together), tests the four targets against the visited bitmap in LDS and remembers the unseen ones (CANDIDATES) in a 4-bit
+//     mask per quad -- the targets stay in its registers.  Nothing is written; a window without a candidate (most windows
+//     of the last levels) ends here.
+//   * CLAIM, by the thread that scanned: atomic-or on the bitmap -- the hardware winner among the window's edges into the same
+//     new node; in-window duplicates register their smallest position per node in an LDS hash and the winner takes the minimum of it and its own, i.e. the edge the
+//     sequential BFS appends the node at (graph_gan.py:101-107), exactly as in the chunk kernel, overflow path included.  The
+//     appending positions are bits of a mask over the window's positions (position = 4 * quad + entry: stream order); ONE
+//     popcount prefix over its 512 words gives every appended node its queue rank AND every window node the end of its child
+//     range (cstart): no candidate list, no per-node counters, no second scan.
+//   * barriers wait for LDS only; the one global dependency -- queue entries written by earlier windows and read back as the
+//     next nodes -- is fenced when the reader gets within reach of entries written since the last fence (once per level).
 // Same outputs, bit for bit (tests/test_gpu_walk.py::test_gpu_bfs_builds_the_reference_trees runs both kernels).
 constexpr int B2_T = 1024;
 constexpr int B2_WAVES = B2_T / 64;
 constexpr int B2_NB = 1024;              // queue nodes per window
 constexpr int B2_SLOTS = 4096;           // quads per window
-constexpr int B2_POS = 4 * B2_SLOTS;     // stream positions per window (14 bits)
-constexpr int B2_CCAP = 1024;            // candidates per window (one claim thread each)
-constexpr int B2_LCAP = 512;             // in-window duplicates resolved through the LDS list
-constexpr int B2_MINSLOTS = 64;          // shortest window the density rule asks for (256 positions < CCAP: cannot overflow)
+constexpr int B2_POS = 4 * B2_SLOTS;     // stream positions per window
+constexpr int B2_WORDS = B2_POS / 32;    // words of the position mask (one per thread of the first 8 wavefronts)
+constexpr bool B2_PF_TWO_STAGE = false;  // row pointers of the prefetched nodes issued behind the scan instead of right behind their ids (measured: 48.7 vs 47.2 us per tree)
+constexpr int B2_HASH = 1024;            // in-window duplicates: LDS hash node -> smallest duplicate position ...
+constexpr int B2_DCAP = 768;             // ... for up to this many duplicates per window (more: the key array in global memory)
 
 typedef int32_t int4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load from a 4-byte aligned address
 
@@ -438,25 +442,23 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
     return v;
 }
 
+// workgroup barrier that waits for this wavefront's LDS traffic only: global loads / stores in flight stay in flight
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <bool LDS_BM>
 __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
     extern __shared__ uint32_t lds_bm[];              // [bm_words] when LDS_BM
     __shared__ uint32_t e0s[B2_NB];                   // first CSR entry of each window node (of the segment, for a partial node)
-    __shared__ uint32_t pk[B2_NB + 1];                // (quad offset << 16) | position offset of each window node; [nb] = totals
-    __shared__ uint32_t scratch[B2_SLOTS / 2];        // SCAN: quad -> window node (uint16 x 4 096); CLAIM: duplicate list + child counts
-    __shared__ uint32_t posmask[B2_POS / 32];         // stream positions whose target was unseen
-    __shared__ uint32_t winbits[B2_POS / 32];         // ... that append (only written when the window has in-window duplicates)
-    __shared__ int32_t wpre[B2_POS / 32];             // exclusive popcount prefix over the words of that mask
-    __shared__ uint32_t candK[B2_CCAP];               // (window node << 14) | position
-    __shared__ int32_t candW[B2_CCAP];                // target node
-    __shared__ int32_t wtot[4][B2_WAVES];
-    __shared__ int32_t s_root, s_nC, s_Lcount, s_cap, s_max;
+    __shared__ uint16_t soff[B2_NB + 2];              // first quad of each window node; [nb] = quads of the window
+    __shared__ uint16_t degs[B2_NB];                  // adjacency entries of each window node (of the segment)
+    __shared__ uint32_t scratch[B2_SLOTS / 2];        // quad -> window node (uint16 x 4 096)
+    __shared__ int32_t tkey[B2_HASH], tpos[B2_HASH];  // duplicates of the window: node -> smallest position (open addressing; -1 / INT_MAX when free)
+    __shared__ uint32_t winbits[B2_WORDS + 1];        // positions that append a node ([B2_WORDS] stays 0)
+    __shared__ int32_t wpre[B2_WORDS + 1];            // exclusive popcount prefix over those words; [B2_WORDS] = total
+    __shared__ int32_t wtot[2][B2_WAVES];
+    __shared__ int32_t s_root, s_any, s_Lcount, s_cap, s_max, s_deg;
     __shared__ uint32_t s_e0;
-    __shared__ int32_t s_deg;
     uint16_t *const emap = reinterpret_cast<uint16_t *>(scratch);
-    int32_t *const L_w = reinterpret_cast<int32_t *>(scratch);            // [B2_LCAP]
-    int32_t *const L_pos = L_w + B2_LCAP;                                 // [B2_LCAP]
-    int32_t *const ccnt = L_w + 2 * B2_LCAP;                              // [B2_NB] children appended per window node
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     uint32_t *const bm = LDS_BM ? lds_bm : a.gbitmap + (size_t)blockIdx.x * a.bm_words;
@@ -470,11 +472,12 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
     for (;;) {
         if (tid == 0) {
             s_root = (int)atomicAdd(a.ticket, 1u);
-            s_nC = 0;
+            s_any = 0;
             s_Lcount = 0;
             s_max = 0;
         }
-        for (int i = tid; i < B2_POS / 32; i += B2_T) { posmask[i] = 0u; winbits[i] = 0u; }
+        for (int i = tid; i <= B2_WORDS; i += B2_T) winbits[i] = 0u;
+        for (int i = tid; i < B2_HASH; i += B2_T) { tkey[i] = -1; tpos[i] = 0x7fffffff; }
         __syncthreads();
         const int r = s_root;
         if (r >= a.n_roots) return;
@@ -494,16 +497,32 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
         __syncthreads();
 
         int head = 0, tail = 1, level_end = 1, depth = 0;
-        unsigned long long st_win = 0, st_rescan = 0, st_cand = 0, st_slots = 0, st_empty = 0, st_dup = 0, st_key = 0;  // GG_BFS_PROFILE
-        int tmax = B2_SLOTS;     // quads the next window may hold (follows the candidate density)
+        int fenced = 1;          // queue entries below this index were written before the last full fence
+        unsigned long long st_win = 0, st_fence = 0, st_cand = 0, st_slots = 0, st_empty = 0, st_dup = 0, st_key = 0;  // GG_BFS_PROFILE
+        unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // wave 0's clock per phase: setup, scan, claim, duplicates, prefix, append
+        long long tprev = a.prof ? (long long)clock64() : 0;
+#define B2_TICK(k)                                  \
+    if (a.prof) {                                   \
+        const long long tn = (long long)clock64();  \
+        ph[k] += (unsigned long long)(tn - tprev);  \
+        tprev = tn;                                 \
+    }
         int seg_a = 0;           // > 0: the node at `head` is being scanned in segments, this many entries are done
         int pf_q = -1;           // queue index whose node this thread has prefetched
+        int pf_v = 0, pf_stage = 0;
         uint32_t pf_e0 = 0;
         int pf_deg = 0;
         while (head < tail) {
             if (head == level_end) {  // the next level starts: everything up to `tail` belongs to it
                 level_end = tail;
                 ++depth;
+            }
+            // queue entries are read back from global memory (this window's nodes, the next window's prefetch): entries
+            // written since the last fence must have landed first
+            if (fenced < tail && head + 2 * B2_NB > fenced) {
+                __syncthreads();
+                fenced = tail;
+                ++st_fence;
             }
             int nb = 0;      // complete nodes of this window; 0 = one node, entries [seg_a, seg_a + seg_len)
             int seg_len = 0;
@@ -522,26 +541,29 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
                         deg = (int)(a.rowptr[v + 1] - b);
                     }
                 }
-                const int q = (deg + 3) >> 2;
-                const int incq = wave_incl_scan(q, lane), incd = wave_incl_scan(deg, lane);
-                if (lane == 63) { wtot[0][wv] = incq; wtot[1][wv] = incd; }
+                const int q = min((deg + 3) >> 2, B2_SLOTS + 1);  // (a node above the window size ends the window whatever its size)
+                const int incq = wave_incl_scan(q, lane);
+                if (lane == 63) wtot[0][wv] = incq;
                 if (tid == 0) { s_cap = 0; s_e0 = e0; s_deg = deg; }
-                __syncthreads();
-                int preq = 0, pred = 0;
+                lds_barrier();
+                B2_TICK(0)
+                int preq = 0;
 #pragma unroll
                 for (int i = 0; i < B2_WAVES; ++i)
-                    if (i < wv) { preq += wtot[0][i]; pred += wtot[1][i]; }
-                const int inclq = preq + incq, excq = inclq - q, incld = pred + incd, excd = incld - deg;
+                    if (i < wv) preq += wtot[0][i];
+                const int inclq = preq + incq, excq = inclq - q;
                 // window = the longest prefix of the available nodes whose quads fit
-                const unsigned long long okb = __ballot(tid < navail && inclq <= tmax);
+                const unsigned long long okb = __ballot(tid < navail && inclq <= B2_SLOTS);
                 if (lane == 0 && okb) atomicAdd(&s_cap, (int)__popcll(okb));
-                __syncthreads();
+                lds_barrier();
+                B2_TICK(1)
                 nb = s_cap;
                 if (nb > 0) {
                     if (tid < nb) {
                         e0s[tid] = e0;
-                        pk[tid] = ((uint32_t)excq << 16) | (uint32_t)excd;
-                        if (tid == nb - 1) pk[nb] = ((uint32_t)inclq << 16) | (uint32_t)incld;
+                        soff[tid] = (uint16_t)excq;
+                        degs[tid] = (uint16_t)deg;
+                        if (tid == nb - 1) soff[nb] = (uint16_t)inclq;
                         if (q <= 8)
                             for (int k = 0; k < q; ++k) emap[excq + k] = (uint16_t)tid;
                     }
@@ -552,121 +574,87 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
                         const int qq = __shfl(q, l, 64), ss = __shfl(excq, l, 64);
                         for (int k = lane; k < qq; k += 64) emap[ss + k] = (uint16_t)((wv << 6) + l);
                     }
-                    // prefetch the next window's nodes (queue entries below `tail` are final)
+                    // prefetch the next window's nodes, stage 1: their ids (queue entries below `fenced` have landed).  Stage 2 --
+                    // the row pointers, which need the id -- is issued behind the scan, when the id has long arrived: issued
+                    // here, the dependent pair stalled every thread for a memory round trip per window (a third of the kernel).
                     const int q2 = head + nb + tid;
                     pf_q = -1;
-                    if (q2 < tail) {
-                        const int v2 = __hip_atomic_load(&order[q2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const int64_t b2 = a.rowptr[v2];
-                        pf_e0 = (uint32_t)b2;
-                        pf_deg = (int)(a.rowptr[v2 + 1] - b2);
+                    if (q2 < fenced) {
+                        pf_v = __hip_atomic_load(&order[q2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         pf_q = q2;
+                        pf_stage = 1;
+                        if (!B2_PF_TWO_STAGE) {
+                            const int64_t b2 = a.rowptr[pf_v];
+                            pf_e0 = (uint32_t)b2;
+                            pf_deg = (int)(a.rowptr[pf_v + 1] - b2);
+                            pf_stage = 0;
+                        }
                     }
                 }
             }
             if (nb == 0) {  // one node alone (it exceeds the window, or is being continued): the segment [seg_a, seg_a + seg_len)
-                const int deg0 = s_deg;
-                seg_len = min(deg0 - seg_a, 4 * tmax);
+                seg_len = min(s_deg - seg_a, B2_POS);
                 const int qs = (seg_len + 3) >> 2;
                 for (int k = tid; k < qs; k += B2_T) emap[k] = 0;
                 if (tid == 0) {
                     e0s[0] = s_e0 + (uint32_t)seg_a;
-                    pk[0] = 0u;
-                    pk[1] = ((uint32_t)qs << 16) | (uint32_t)seg_len;
+                    soff[0] = 0;
+                    soff[1] = (uint16_t)qs;
+                    degs[0] = (uint16_t)seg_len;
                 }
             }
-            __syncthreads();
-            const int nbw = nb > 0 ? nb : 1;  // window nodes (the last entry of pk holds the totals)
-
-            // ---------------- SCAN
-            int T = (int)(pk[nbw] >> 16);
-            int nC;
-            for (;;) {
-                int4u w4[4];
-                int wi[4], wp0[4], wc[4];
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int s = tid + it * B2_T;
-                    wc[it] = 0;
-                    if (s < T) {
-                        const int i = (int)emap[s];
-                        const uint32_t a0 = pk[i], a1 = pk[i + 1];
-                        const int j0 = 4 * (s - (int)(a0 >> 16));
-                        const int d = (int)(a1 & 0xffffu) - (int)(a0 & 0xffffu);
-                        wc[it] = min(4, d - j0);
-                        wi[it] = i;
-                        wp0[it] = (int)(a0 & 0xffffu) + j0;
-                        w4[it] = *reinterpret_cast<const int4u *>(a.col + (e0s[i] + (uint32_t)j0));
-                    }
-                }
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    uint32_t cand = 0;
-                    if (wc[it] > 0) {
-                        if (!seen(w4[it].x)) cand |= 1u;
-                        if (wc[it] > 1 && !seen(w4[it].y)) cand |= 2u;
-                        if (wc[it] > 2 && !seen(w4[it].z)) cand |= 4u;
-                        if (wc[it] > 3 && !seen(w4[it].w)) cand |= 8u;
-                    }
-                    while (__ballot(cand != 0u)) {  // (uniform: rare outside the growth levels)
-                        const bool has = cand != 0u;
-                        const int k = has ? __ffs((int)cand) - 1 : 0;
-                        cand &= cand - 1u;
-                        const unsigned long long m = __ballot(has);
-                        int base = 0;
-                        if (lane == 0) base = atomicAdd(&s_nC, (int)__popcll(m));
-                        base = __shfl(base, 0, 64);
-                        if (has) {
-                            const int idx = base + lanes_below(m);
-                            const int p = wp0[it] + k;
-                            const int w = k == 0 ? w4[it].x : k == 1 ? w4[it].y : k == 2 ? w4[it].z : w4[it].w;
-                            if (idx < B2_CCAP) {
-                                candK[idx] = ((uint32_t)wi[it] << 14) | (uint32_t)p;
-                                candW[idx] = w;
-                            }
-                            atomicOr(&posmask[p >> 5], 1u << (p & 31));
-                        }
-                    }
-                }
-                __syncthreads();
-                nC = s_nC;
-                st_slots += (unsigned long long)T;
-                if (nC <= B2_CCAP) break;
-                ++st_rescan;
-                // more candidates than claim threads: rescan a shorter window (nothing was modified).  New length from the
-                // density just seen, with a quarter of slack.
-                const int target = max(B2_MINSLOTS / 2, (int)((long long)T * (B2_CCAP * 3 / 4) / nC));
-                if (tid == 0) { s_nC = 0; s_cap = 0; }
-                for (int i = tid; i < B2_POS / 32; i += B2_T) posmask[i] = 0u;
-                __syncthreads();
-                if (nb > 0) {
-                    const unsigned long long okb = __ballot(tid < nb && (int)(pk[tid + 1] >> 16) <= target);
-                    if (lane == 0 && okb) atomicAdd(&s_cap, (int)__popcll(okb));
-                    __syncthreads();
-                    nb = s_cap;
-                    pf_q = -1;  // (the prefetched nodes no longer follow this window)
-                    if (nb == 0) {  // not even the first node: scan a segment of it
-                        seg_len = min(s_deg, 4 * target);
-                        if (tid == 0) pk[1] = ((uint32_t)((seg_len + 3) >> 2) << 16) | (uint32_t)seg_len;
-                        __syncthreads();  // (emap[s] of its quads is 0 already; e0s[0], pk[0] are the node's)
-                    }
-                } else {
-                    seg_len = min(seg_len, 4 * target);
-                    if (tid == 0) pk[1] = ((uint32_t)((seg_len + 3) >> 2) << 16) | (uint32_t)seg_len;
-                    __syncthreads();
-                }
-                T = (int)(pk[nb > 0 ? nb : 1] >> 16);
-                tmax = max(B2_MINSLOTS, target);
-            }
-            const int nbn = nb > 0 ? nb : 1;
+            lds_barrier();
+            B2_TICK(2)
+            const int nbn = nb > 0 ? nb : 1;  // window nodes
+            const int T = (int)soff[nbn];
             ++st_win;
-            st_cand += (unsigned long long)nC;
-            if (nC == 0) ++st_empty;
-            // density rule for the next window: aim at three quarters of the candidate list
-            tmax = nC * 4 <= B2_CCAP ? min(B2_SLOTS, 2 * max(tmax, T)) : max(B2_MINSLOTS, min(B2_SLOTS, (int)((long long)T * (B2_CCAP * 3 / 4) / nC)));
+            st_slots += (unsigned long long)T;
 
-            if (nC == 0) {
+            // ---------------- SCAN: quads tid, tid + 1024, ...; position of entry k of quad s = 4 s + k (stream order)
+            int4u w4[4];
+            uint32_t we[4];     // CSR index of the quad's first entry
+            uint32_t cand[4];   // entries whose target is unseen
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int s = tid + it * B2_T;
+                cand[it] = 0u;
+                we[it] = 0xffffffffu;  // (no quad)
+                if (s < T) {
+                    const int i = (int)emap[s];
+                    const int j0 = 4 * (s - (int)soff[i]);
+                    const int cnt = (int)degs[i] - j0;  // >= 1
+                    we[it] = e0s[i] + (uint32_t)j0;
+                    w4[it] = *reinterpret_cast<const int4u *>(a.col + we[it]);
+                    cand[it] = cnt >= 4 ? 15u : ((1u << cnt) - 1u);  // valid entries for now
+                }
+            }
+            uint32_t anyc = 0;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                if (we[it] != 0xffffffffu) {
+                    // four independent LDS reads per quad (entries behind the node's end test its first target again: a valid id)
+                    const uint32_t valid = cand[it];
+                    const int wx = w4[it].x, wy = (valid & 2u) ? w4[it].y : wx, wz = (valid & 4u) ? w4[it].z : wx, ww = (valid & 8u) ? w4[it].w : wx;
+                    const uint32_t sx = seen(wx) ? 1u : 0u, sy = seen(wy) ? 2u : 0u, sz = seen(wz) ? 4u : 0u, sw = seen(ww) ? 8u : 0u;
+                    const uint32_t c = valid & ~(sx | sy | sz | sw);
+                    cand[it] = c;
+                    anyc |= c;
+                }
+            }
+            if (__ballot(anyc != 0u) && lane == 0) s_any = 1;
+            B2_TICK(3)
+            lds_barrier();  // every test before any set: a later edge must not hide an earlier one
+            if (pf_stage == 1) {  // prefetch, stage 2: the row pointers of the next window's nodes
+                const int64_t b2 = a.rowptr[pf_v];
+                pf_e0 = (uint32_t)b2;
+                pf_deg = (int)(a.rowptr[pf_v + 1] - b2);
+                pf_stage = 0;
+            }
+            B2_TICK(4)
+
+            if (!s_any) {
                 // nothing new: every node that ends in this window has its children end at `tail`
+                ++st_empty;
                 if (nb > 0) {
                     if (tid < nb) cstart[head + tid + 1] = tail;
                     head += nb;
@@ -679,94 +667,142 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
                     }
                 }
             } else {
-                // ---------------- CLAIM: one thread per candidate
-                if (tid < nbn) ccnt[tid] = 0;  // (the quad map is dead: SCAN is over)
-                bool won = false;
-                uint32_t myk = 0;
-                int myw = 0;
-                if (tid < nC) {
-                    myk = candK[tid];
-                    myw = candW[tid];
-                    const uint32_t bit = 1u << (myw & 31);
-                    const uint32_t old = atomicOr(&bm[myw >> 5], bit);
-                    won = !(old & bit);
-                    if (!won) {  // another edge of this window reaches the same new node
-                        const int li = atomicAdd(&s_Lcount, 1);
-                        if (li < B2_LCAP) { L_w[li] = myw; L_pos[li] = (int)(myk & 0x3fffu); }
+                // ---------------- CLAIM, by the thread that scanned
+                uint32_t won[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    won[it] = 0u;
+                    uint32_t c = cand[it];
+                    while (c) {
+                        const int k = __ffs((int)c) - 1;
+                        c &= c - 1u;
+                        const int w = k == 0 ? w4[it].x : k == 1 ? w4[it].y : k == 2 ? w4[it].z : w4[it].w;
+                        const uint32_t bit = 1u << (w & 31);
+                        const uint32_t old = atomicOr(&bm[w >> 5], bit);
+                        if (old & bit) {  // another edge of this window reaches the same new node: smallest such position per node
+                            const int li = atomicAdd(&s_Lcount, 1);
+                            if (li < B2_DCAP) {
+                                uint32_t h = ((uint32_t)w * 2654435761u) >> 22;
+                                for (;;) {
+                                    const int k0 = atomicCAS(&tkey[h], -1, w);
+                                    if (k0 == -1 || k0 == w) {
+                                        atomicMin(&tpos[h], 4 * (tid + it * B2_T) + k);
+                                        break;
+                                    }
+                                    h = (h + 1) & (B2_HASH - 1);
+                                }
+                            }
+                        } else {
+                            won[it] |= 1u << k;
+                        }
                     }
                 }
-                __syncthreads();
+                lds_barrier();
+                B2_TICK(5)
                 const int nL = s_Lcount;
-                const uint32_t *wb = posmask;  // without in-window duplicates every candidate appends
-                if (nL > 0) {
-                    ++st_dup;
-                    if (nL > B2_LCAP) ++st_key;
-                    wb = winbits;
-                    if (nL <= B2_LCAP) {
-                        // the sequential BFS appends a node at the FIRST edge that reaches it: smallest position among the
-                        // hardware winner's and the duplicates'
-                        if (won) {
-                            int eff = (int)(myk & 0x3fffu);
-                            for (int i = 0; i < nL; ++i)
-                                if (L_w[i] == myw) eff = min(eff, L_pos[i]);
+                if (nL <= B2_DCAP) {
+                    // the sequential BFS appends a node at the FIRST edge that reaches it: smallest position among the hardware
+                    // winner's and the duplicates'
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        uint32_t c = won[it];
+                        while (c) {
+                            const int k = __ffs((int)c) - 1;
+                            c &= c - 1u;
+                            int eff = 4 * (tid + it * B2_T) + k;
+                            if (nL > 0 && !(a.exp & 16)) {
+                                const int w = k == 0 ? w4[it].x : k == 1 ? w4[it].y : k == 2 ? w4[it].z : w4[it].w;
+                                uint32_t h = ((uint32_t)w * 2654435761u) >> 22;
+                                for (;;) {
+                                    const int k0 = tkey[h];
+                                    if (k0 == w) { eff = min(eff, tpos[h]); break; }
+                                    if (k0 == -1) break;
+                                    h = (h + 1) & (B2_HASH - 1);
+                                }
+                            }
                             atomicOr(&winbits[eff >> 5], 1u << (eff & 31));
                         }
-                    } else {
-                        // too many for the list: smallest position per node through the key array (all-ones between uses)
-                        const uint32_t p = myk & 0x3fffu;
-                        if (tid < nC) atomicMin(&gkey[myw], p);
-                        __syncthreads();
-                        if (tid < nC && atomicMin(&gkey[myw], 0xFFFFFFFFu) == p) atomicOr(&winbits[p >> 5], 1u << (p & 31));
-                        __syncthreads();
-                        if (tid < nC) __hip_atomic_store(&gkey[myw], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                } else {
+                    // too many duplicates for the list: smallest position per node through the key array (all-ones between uses)
+                    ++st_key;
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        uint32_t c = cand[it];
+                        while (c) {
+                            const int k = __ffs((int)c) - 1;
+                            c &= c - 1u;
+                            const int w = k == 0 ? w4[it].x : k == 1 ? w4[it].y : k == 2 ? w4[it].z : w4[it].w;
+                            atomicMin(&gkey[w], (uint32_t)(4 * (tid + it * B2_T) + k));
+                        }
                     }
                     __syncthreads();
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        uint32_t c = cand[it];
+                        while (c) {
+                            const int k = __ffs((int)c) - 1;
+                            c &= c - 1u;
+                            const int w = k == 0 ? w4[it].x : k == 1 ? w4[it].y : k == 2 ? w4[it].z : w4[it].w;
+                            const uint32_t p = (uint32_t)(4 * (tid + it * B2_T) + k);
+                            if (atomicMin(&gkey[w], 0xFFFFFFFFu) == p) atomicOr(&winbits[p >> 5], 1u << (p & 31));
+                        }
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        uint32_t c = cand[it];
+                        while (c) {
+                            const int k = __ffs((int)c) - 1;
+                            c &= c - 1u;
+                            const int w = k == 0 ? w4[it].x : k == 1 ? w4[it].y : k == 2 ? w4[it].z : w4[it].w;
+                            __hip_atomic_store(&gkey[w], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
                 }
-                // place of every appending position in stream order
-                const int wcnt = tid < B2_POS / 32 ? (int)__popc(wb[tid]) : 0;
+                if (nL > 0) ++st_dup;
+                lds_barrier();
+                // place of every appending position in stream order = popcount prefix over the mask
+                const int wcnt = tid < B2_WORDS ? (int)__popc(winbits[tid]) : 0;
                 const int winc = wave_incl_scan(wcnt, lane);
-                if (lane == 63) wtot[2][wv] = winc;
-                __syncthreads();
+                if (lane == 63) wtot[1][wv] = winc;
+                lds_barrier();
                 int wpr = 0, total = 0;
 #pragma unroll
-                for (int i = 0; i < B2_POS / 32 / 64; ++i) {
-                    const int c = wtot[2][i];
+                for (int i = 0; i < B2_WORDS / 64; ++i) {
+                    const int c = wtot[1][i];
                     if (i < wv) wpr += c;
                     total += c;
                 }
-                if (tid < B2_POS / 32) wpre[tid] = wpr + winc - wcnt;
-                __syncthreads();
-                if (tid < nC) {
-                    const int p = (int)(myk & 0x3fffu);
-                    const uint32_t word = wb[p >> 5];
-                    if ((word >> (p & 31)) & 1u) {
-                        const int rank = tail + wpre[p >> 5] + (int)__popc(word & ((1u << (p & 31)) - 1u));
-                        const int i = (int)(myk >> 14);
-                        if (rank < expect) {
-                            order[rank] = myw;
-                            tedge[rank] = (int32_t)(e0s[i] + (uint32_t)(p - (int)(pk[i] & 0xffffu)));
+                if (tid < B2_WORDS) wpre[tid] = wpr + winc - wcnt;
+                if (tid == 0) wpre[B2_WORDS] = total;
+                lds_barrier();
+                B2_TICK(6)
+                st_cand += (unsigned long long)total;
+                // append: every candidate (hardware winner or duplicate) whose position carries the bit
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    uint32_t c = cand[it];
+                    while (c) {
+                        const int k = __ffs((int)c) - 1;
+                        c &= c - 1u;
+                        const int p = 4 * (tid + it * B2_T) + k;
+                        const uint32_t word = winbits[p >> 5];
+                        if ((word >> (p & 31)) & 1u) {
+                            const int rank = tail + wpre[p >> 5] + (int)__popc(word & ((1u << (p & 31)) - 1u));
+                            if (rank < expect) {
+                                order[rank] = k == 0 ? w4[it].x : k == 1 ? w4[it].y : k == 2 ? w4[it].z : w4[it].w;
+                                tedge[rank] = (int32_t)(we[it] + (uint32_t)k);
+                            }
                         }
-                        atomicAdd(&ccnt[i], 1);
                     }
                 }
-                __syncthreads();
-                // reset what the next window's SCAN accumulates into
-                if (tid < B2_POS / 32) {
-                    posmask[tid] = 0u;
-                    if (nL > 0) winbits[tid] = 0u;
-                }
-                if (tid == 0) { s_nC = 0; s_Lcount = 0; }
+                // children of window node i end behind the appends of the positions below its last quad's end
                 if (nb > 0) {
-                    // children of window node i end behind the appends of nodes 0 .. i
-                    const int x = tid < nb ? ccnt[tid] : 0;
-                    const int xi = wave_incl_scan(x, lane);
-                    if (lane == 63) wtot[3][wv] = xi;
-                    __syncthreads();
-                    int xp = 0;
-#pragma unroll
-                    for (int i = 0; i < B2_WAVES; ++i)
-                        if (i < wv) xp += wtot[3][i];
-                    if (tid < nb) cstart[head + tid + 1] = tail + xp + xi;
+                    if (tid < nb) {
+                        const int P = 4 * (int)soff[tid + 1];
+                        cstart[head + tid + 1] = tail + wpre[P >> 5] + (int)__popc(winbits[P >> 5] & ((1u << (P & 31)) - 1u));
+                    }
                     tail += total;
                     head += nb;
                 } else {
@@ -778,26 +814,32 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
                         seg_a = 0;
                     }
                 }
+                lds_barrier();  // everyone has read the mask and the prefix
+                if (nL > 0) { tkey[tid] = -1; tpos[tid] = 0x7fffffff; }  // (B2_HASH == B2_T entries: one each)
+                if (tid < B2_WORDS) winbits[tid] = 0u;
+                if (tid == 0) { s_any = 0; s_Lcount = 0; }
                 if (tail > expect) break;  // more nodes than the component sweep promised: the graph is not the one set (uniform)
             }
-            __syncthreads();
+            lds_barrier();
+            B2_TICK(7)
             // Every node of the root's component is on the queue (its size is known from the component sweep): no edge of the
             // nodes still waiting can discover anything -- they are leaves of the tree (empty child ranges at the end of the queue).
             if (tail == expect && head < tail && !(a.exp & 8)) {
                 for (int i = head + tid; i < expect; i += B2_T) cstart[i + 1] = expect;
                 if (level_end < tail) ++depth;  // the nodes behind level_end are one level deeper than the one being popped
-                __syncthreads();                // (the child-count sweep below reads these entries)
                 break;
             }
         }
-
+        __syncthreads();  // (all queue / cstart stores have landed: the child-count sweep below reads cstart)
         if (a.prof && tid == 0) {
-            atomicAdd(&a.prof[0], st_win); atomicAdd(&a.prof[1], st_rescan); atomicAdd(&a.prof[2], st_cand); atomicAdd(&a.prof[3], st_slots);
+            atomicAdd(&a.prof[0], st_win); atomicAdd(&a.prof[1], st_fence); atomicAdd(&a.prof[2], st_cand); atomicAdd(&a.prof[3], st_slots);
             atomicAdd(&a.prof[4], st_empty); atomicAdd(&a.prof[5], st_dup); atomicAdd(&a.prof[6], st_key);
+            for (int k = 0; k < 8; ++k) atomicAdd(&a.prof[8 + k], ph[k]);
         }
+#undef B2_TICK
         // ---- per-root results: node count check, depth, longest list (1 + most children)
         int mc = 0;
-        if (tail == expect)
+        if (tail == expect && !(a.exp & 32))
             for (int i = tid; i < tail; i += B2_T) mc = max(mc, cstart[i + 1] - cstart[i]);
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) mc = max(mc, __shfl_xor(mc, off, 64));
@@ -898,8 +940,16 @@ extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t 
         unsigned long long pc[16];
         if (hipMemcpy(pc, a.prof, sizeof(pc), hipMemcpyDeviceToHost) == hipSuccess)
             fprintf(stderr, "[bfs2 profile] %d roots, grid %d: per root %.0f windows (%.0f without a candidate, %.0f with in-window duplicates, %.0f through the key array), "
-                    "%.1f rescans, %.0f candidates, %.0f quads scanned\n", n_roots, grid, (double)pc[0] / n_roots, (double)pc[4] / n_roots, (double)pc[5] / n_roots,
+                    "%.1f full fences, %.0f nodes appended, %.0f quads scanned\n", n_roots, grid, (double)pc[0] / n_roots, (double)pc[4] / n_roots, (double)pc[5] / n_roots,
                     (double)pc[6] / n_roots, (double)pc[1] / n_roots, (double)pc[2] / n_roots, (double)pc[3] / n_roots);
+        {
+            const char *names[8] = {"setup: node info + scan", "window choice", "quad map", "scan: loads + tests", "scan barrier", "claim", "duplicates + prefix", "append + cstart (empty windows: all behind the scan)"};
+            double tot = 0;
+            for (int k = 0; k < 8; ++k) tot += (double)pc[8 + k];
+            fprintf(stderr, "[bfs2 profile] wave-0 clock per window %.0f:", tot / (double)(pc[0] ? pc[0] : 1));
+            for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.1f%%", names[k], 100.0 * (double)pc[8 + k] / (tot > 0 ? tot : 1));
+            fprintf(stderr, "\n");
+        }
     }
     if (e == hipSuccess && prof && v1) {
         unsigned long long pc[16];
