@@ -23,6 +23,9 @@ typedef int (*fn_AllReduce)(const void *, void *, size_t, int, int, void *, hipS
 typedef int (*fn_AllGather)(const void *, void *, size_t, int, void *, hipStream_t);
 typedef int (*fn_ReduceScatter)(const void *, void *, size_t, int, int, void *, hipStream_t);
 typedef const char *(*fn_GetErrorString)(int);
+typedef int (*fn_Send)(const void *, size_t, int, int, void *, hipStream_t);
+typedef int (*fn_Recv)(void *, size_t, int, int, void *, hipStream_t);
+typedef int (*fn_Group)(void);
 
 struct RcclApi {
     void *handle = nullptr;
@@ -33,6 +36,9 @@ struct RcclApi {
     fn_AllGather AllGather = nullptr;
     fn_ReduceScatter ReduceScatter = nullptr;
     fn_GetErrorString GetErrorString = nullptr;
+    fn_Send Send = nullptr;            // (point-to-point: optional -- without them the owner-partitioned exchange is not offered)
+    fn_Recv Recv = nullptr;
+    fn_Group GroupStart = nullptr, GroupEnd = nullptr;
 };
 
 static RcclApi g_rccl;
@@ -60,6 +66,10 @@ static int load_rccl(gg_ctx *ctx) {
     api.AllGather = (fn_AllGather)dlsym(h, "ncclAllGather");
     api.ReduceScatter = (fn_ReduceScatter)dlsym(h, "ncclReduceScatter");
     api.GetErrorString = (fn_GetErrorString)dlsym(h, "ncclGetErrorString");
+    api.Send = (fn_Send)dlsym(h, "ncclSend");
+    api.Recv = (fn_Recv)dlsym(h, "ncclRecv");
+    api.GroupStart = (fn_Group)dlsym(h, "ncclGroupStart");
+    api.GroupEnd = (fn_Group)dlsym(h, "ncclGroupEnd");
     if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.AllGather || !api.ReduceScatter || !api.GetErrorString)
         return fail(ctx, GG_ECOMM, "librccl is missing a required symbol");
     g_rccl = api;
@@ -130,6 +140,26 @@ int comm_allgather(gg_ctx *ctx, const void *send, void *recv, size_t count, int 
     }
     for (int r = 0; r < ctx->fake_world; ++r)
         GG_HIP(ctx, hipMemcpyAsync((char *)recv + (size_t)r * count * elem_bytes, send, count * elem_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return GG_OK;
+}
+
+bool comm_has_p2p(const gg_ctx *ctx) {
+    return !ctx->comm || (g_rccl.Send && g_rccl.Recv && g_rccl.GroupStart && g_rccl.GroupEnd);
+}
+
+// Personalised exchange of 4-byte words: this rank sends send_cnt[r] words from send + send_off[r] to every peer r and
+// receives recv_cnt[r] words from it at recv + recv_off[r] (one grouped batch of point-to-point calls: xGMI is point to
+// point, every pair has its own link).  The caller handles r == rank itself.
+int comm_exchange_v(gg_ctx *ctx, const float *send, const int64_t *send_off, const int64_t *send_cnt, float *recv, const int64_t *recv_off,
+                    const int64_t *recv_cnt) {
+    if (!ctx->comm) return GG_OK;
+    GG_NCCL(ctx, g_rccl.GroupStart());
+    for (int r = 0; r < ctx->world; ++r) {
+        if (r == ctx->rank) continue;
+        if (send_cnt[r]) GG_NCCL(ctx, g_rccl.Send(send + send_off[r], (size_t)send_cnt[r], NCCL_FLOAT32, r, ctx->comm, ctx->stream));
+        if (recv_cnt[r]) GG_NCCL(ctx, g_rccl.Recv(recv + recv_off[r], (size_t)recv_cnt[r], NCCL_FLOAT32, r, ctx->comm, ctx->stream));
+    }
+    GG_NCCL(ctx, g_rccl.GroupEnd());
     return GG_OK;
 }
 

@@ -244,6 +244,10 @@ struct gg_ctx {
     int32_t fake_world = 0;  // GG_COMM_FAKE_WORLD=k: exercise the k-rank exchange code on one GPU (every rank = this one)
     gg::DevBuf x_cnt, x_send_ids, x_send_rows, x_recv_ids, x_recv_rows;  // sparse gradient exchange
     gg::DevBuf x_nglob;  // pairs of all ranks in the generator step in flight (device word)
+    gg::DevBuf x_own;    // owner-partitioned exchange: per-owner counts / fill cursors / the gathered count matrix (int64 words)
+    int32_t owner_exchange = 1;       // GG_COMM_OWNER=0 switches the owner-partitioned sparse exchange off
+    int64_t owner_min_bound = 4096;   // GG_COMM_OWNER_MIN: steps of fewer pairs never try it (its two host round trips outweigh a minibatch)
+    int64_t comm_steps_owner = 0;     // optimizer steps that took it (gg_comm_stats counts them with the sparse steps)
 
     std::string err;
 };
@@ -308,6 +312,9 @@ int comm_allreduce_max_i64(gg_ctx *ctx, int64_t *buf, size_t count);
 size_t comm_dense_bytes(const gg_ctx *ctx);
 int exchange_count_max(gg_ctx *ctx, int64_t local, int64_t *max_out);  // steps.hip: max over ranks of a prepared row / pair count
 int comm_allgather(gg_ctx *ctx, const void *send, void *recv, size_t count, int elem_bytes);
+bool comm_has_p2p(const gg_ctx *ctx);
+int comm_exchange_v(gg_ctx *ctx, const float *send, const int64_t *send_off, const int64_t *send_cnt, float *recv, const int64_t *recv_off,
+                    const int64_t *recv_cnt);
 void comm_destroy(gg_ctx *ctx);
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

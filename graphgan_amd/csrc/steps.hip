@@ -1198,6 +1198,232 @@ __global__ void scale_grads_kernel(float *gE, float *gb, int64_t nE, int n, floa
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) gb[i] *= k;
 }
 
+// ---- owner-partitioned sparse exchange (round 4; SURVEY.md section 8e "sparse", graph_gan.py:154-157,173-176).
+// A fused pass touches a few 10^5 rows per rank; with P = 8 the ranks' packs together outgrow the row-pack rule
+// (P * cap >= 1.5 N) and the step falls back to the dense exchange: 2 (P-1)/P * 4 N (ld + 1) bytes per rank whatever was
+// touched.  Here every table row has an OWNER, row mod P:
+//   1. the ranks count their touched rows per owner and all-gather the P x P count matrix (16 P^2 bytes, one host round trip:
+//      point-to-point transfers need their sizes);
+//   2. scatter: a rank's touched rows travel to their owners only, each pair of ranks over its own xGMI link;
+//   3. the owner adds what it received to its own contribution IN RANK ORDER (plain adds: a rank names a row once) -- the
+//      sum of a row is formed in one place, so all replicas receive the same bits;
+//   4. gather: the owners' reduced rows -- the union over ranks of the touched rows, not N -- are all-gathered (capacity =
+//      the largest owner's count, from a second 8-byte exchange) and every rank OVERWRITES its accumulator rows with them.
+// Bytes sent per rank: (P-1)/P * own touched rows + (P-1) * (union / P) rows of (ld + 2) words, against N rows twice for the
+// dense path.  Taken when the matrix says it is cheaper (all ranks see the same matrix: same branch everywhere).
+// GG_COMM_FAKE_WORLD = k simulates it on one GPU: this rank plays every owner in turn, each "source rank" is a copy of it.
+__global__ __launch_bounds__(256) void owner_count_kernel(const int32_t *list, const int64_t *cnt_ptr, int world, long long *cnt) {
+    __shared__ int sh[64];
+    if (threadIdx.x < 64) sh[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t n = *cnt_ptr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) atomicAdd(&sh[list[i] % world], 1);
+    __syncthreads();
+    if ((int)threadIdx.x < world && sh[threadIdx.x]) atomicAdd((unsigned long long *)&cnt[threadIdx.x], (unsigned long long)sh[threadIdx.x]);
+}
+
+// touched rows -> per-owner segments of the send buffer (slots inside a segment by arrival: a rank names a row once, so the
+// owner's sum does not depend on the slot order)
+__global__ __launch_bounds__(256) void owner_pack_kernel(const float *gE, const float *gb, const int32_t *list, const int64_t *cnt_ptr, int world,
+                                                         const long long *seg_off, long long *fill, int ld, int32_t *out_ids, float *out_rows) {
+    const int t = threadIdx.x & 15;
+    const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4, ng = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    const int64_t cnt = *cnt_ptr;
+    for (int64_t r = g0; r < cnt; r += ng) {
+        const int row = list[r];
+        const int q = row % world;
+        long long slot = 0;
+        if (t == 0) slot = seg_off[q] + (long long)atomicAdd((unsigned long long *)&fill[q], 1ull);
+        slot = __shfl(slot, (threadIdx.x & 63) & ~15, 64);
+        const float *src = gE + (int64_t)row * ld;
+        float *dst = out_rows + slot * (ld + 1);
+        for (int f = t; f < ld; f += 16) dst[f] = src[f];
+        if (t == 0) { dst[ld] = gb[row]; out_ids[slot] = row; }
+    }
+}
+
+// owner side, after the adds: the flagged rows this rank owns -> gather pack (ids -1 behind them up to the capacity)
+__global__ __launch_bounds__(256) void owner_gather_pack_kernel(const float *gE, const float *gb, const int32_t *list, const int64_t *cnt_ptr, int world,
+                                                                int me, long long *fill, int64_t cap, int ld, int32_t *out_ids, float *out_rows) {
+    const int t = threadIdx.x & 15;
+    const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4, ng = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    const int64_t cnt = *cnt_ptr;
+    for (int64_t r = g0; r < cnt; r += ng) {
+        const int row = list[r];
+        if (row % world != me) continue;
+        long long slot = 0;
+        if (t == 0) slot = (long long)atomicAdd((unsigned long long *)fill, 1ull);
+        slot = __shfl(slot, (threadIdx.x & 63) & ~15, 64);
+        if (slot >= cap) continue;  // (cannot happen: the capacity is the largest owner's count)
+        const float *src = gE + (int64_t)row * ld;
+        float *dst = out_rows + slot * (ld + 1);
+        for (int f = t; f < ld; f += 16) dst[f] = src[f];
+        if (t == 0) { dst[ld] = gb[row]; out_ids[slot] = row; }
+    }
+}
+
+__global__ void owner_count_owned_kernel(const int32_t *list, const int64_t *cnt_ptr, int world, int me, long long *out) {
+    const int64_t n = *cnt_ptr;
+    int c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) c += (list[i] % world == me) ? 1 : 0;
+    for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd((unsigned long long *)out, (unsigned long long)c);
+}
+
+__global__ void fill_ids_kernel(int32_t *ids, int64_t n, int32_t v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) ids[i] = v;
+}
+
+// receivers of the gather: the owner's sum REPLACES whatever this rank had accumulated for the row
+__global__ __launch_bounds__(256) void set_rows_kernel(float *gE, float *gb, int32_t *touched, const int32_t *ids, const float *rows, int64_t cnt, int ld) {
+    const int t = threadIdx.x & 15;
+    const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4, ng = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    for (int64_t r = g0; r < cnt; r += ng) {
+        const int row = ids[r];
+        if (row < 0) continue;
+        float *dst = gE + (int64_t)row * ld;
+        const float *src = rows + r * (ld + 1);
+        for (int f = t; f < ld; f += 16) dst[f] = src[f];
+        if (t == 0) { gb[row] = src[ld]; touched[row] = 1; }
+    }
+}
+
+// returns GG_OK with *taken = true when the exchange was done here; *taken = false: the caller takes the dense path
+static int exchange_owner(gg_ctx *ctx, OptArgs &o, int world, bool *taken) {
+    *taken = false;
+    const int n = ctx->n_node, ld = ctx->ld;
+    const bool fake = !ctx->comm;
+    if (!ctx->owner_exchange || world < 2 || world > 64 || !comm_has_p2p(ctx)) return GG_OK;
+    const size_t row_f = (size_t)ld + 1;
+    // ---- 1. this rank's touched rows, counted per owner; the P x P matrix on every host
+    int rc = device_compact_flags(ctx, ctx->touched, n, ctx->touched_list, ctx->touched_ptr.as<int64_t>() + n);
+    if (rc != GG_OK) return rc;
+    GG_HIP(ctx, ctx->x_own.reserve(sizeof(long long) * (size_t)(3 * world + world * world + 8)));
+    long long *cnt = ctx->x_own.as<long long>(), *fill = cnt + world, *seg = cnt + 2 * world, *mat = cnt + 3 * world, *own = mat + world * world;
+    GG_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(long long) * (size_t)(3 * world + world * world + 8), ctx->stream));
+    hipLaunchKernelGGL(owner_count_kernel, dim3(256), dim3(256), 0, ctx->stream, ctx->touched_list, o.touched_total, world, cnt);
+    rc = comm_allgather(ctx, cnt, mat, (size_t)world, 8);
+    if (rc != GG_OK) return rc;
+    std::vector<long long> M((size_t)world * world);
+    GG_HIP(ctx, hipMemcpyAsync(M.data(), mat, sizeof(long long) * M.size(), hipMemcpyDeviceToHost, ctx->stream));
+    GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int me_real = fake ? 0 : ctx->rank;
+    long long sum_t = 0, max_t = 0;
+    for (int r = 0; r < world; ++r) {
+        long long tr = 0;
+        for (int q = 0; q < world; ++q) tr += M[(size_t)r * world + q];
+        sum_t += tr;
+        max_t = std::max(max_t, tr);
+    }
+    // rows sent: own rows to their owners + the owners' unions to everyone, against the table twice for the dense path
+    const double f = (double)(world - 1) / world;
+    if (f * (double)max_t + f * (double)std::min<long long>(n, sum_t) >= 0.9 * 2.0 * f * (double)n) return GG_OK;  // dense is no worse
+    // ---- 2. pack by owner
+    std::vector<long long> soff(world + 1, 0);
+    for (int q = 0; q < world; ++q) soff[q + 1] = soff[q] + M[(size_t)me_real * world + q];
+    const long long T = soff[world];
+    GG_HIP(ctx, hipMemcpyAsync(seg, soff.data(), sizeof(long long) * world, hipMemcpyHostToDevice, ctx->stream));
+    GG_HIP(ctx, ctx->x_send_ids.reserve(sizeof(int32_t) * (size_t)std::max<long long>(T, 1)));
+    GG_HIP(ctx, ctx->x_send_rows.reserve(sizeof(float) * (size_t)std::max<long long>(T, 1) * row_f));
+    int nb = cdiv(std::max<long long>(T, 1) * 16, 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(owner_pack_kernel, dim3(nb), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, ctx->touched_list, o.touched_total, world, seg, fill, ld,
+                       ctx->x_send_ids.as<int32_t>(), ctx->x_send_rows.as<float>());
+    long long bytes = 0;
+    const int owners = fake ? world : 1;  // simulated ranks: this GPU plays every owner in turn
+    for (int oi = 0; oi < owners; ++oi) {
+        const int me = fake ? oi : ctx->rank;
+        // ---- 3. scatter: what the other ranks have for owner `me`
+        std::vector<int64_t> s_off(world, 0), s_cnt(world, 0), r_off(world, 0), r_cnt(world, 0), si_off(world, 0), si_cnt(world, 0), ri_off(world, 0), ri_cnt(world, 0);
+        long long R = 0;
+        for (int r = 0; r < world; ++r) {
+            if (r == me) continue;
+            const long long in = M[(size_t)r * world + me], out = M[(size_t)me * world + r];
+            ri_off[r] = R; ri_cnt[r] = in;
+            r_off[r] = R * (long long)row_f; r_cnt[r] = in * (long long)row_f;
+            si_off[r] = soff[r]; si_cnt[r] = out;
+            s_off[r] = soff[r] * (long long)row_f; s_cnt[r] = out * (long long)row_f;
+            R += in;
+            bytes += out * (long long)(row_f + 1) * 4;
+        }
+        GG_HIP(ctx, ctx->x_recv_ids.reserve(sizeof(int32_t) * (size_t)std::max<long long>(R, 1)));
+        GG_HIP(ctx, ctx->x_recv_rows.reserve(sizeof(float) * (size_t)std::max<long long>(R, 1) * row_f));
+        if (!fake) {
+            rc = comm_exchange_v(ctx, (const float *)ctx->x_send_ids.p, si_off.data(), si_cnt.data(), (float *)ctx->x_recv_ids.p, ri_off.data(), ri_cnt.data());
+            if (rc == GG_OK) rc = comm_exchange_v(ctx, ctx->x_send_rows.as<float>(), s_off.data(), s_cnt.data(), ctx->x_recv_rows.as<float>(), r_off.data(), r_cnt.data());
+            if (rc != GG_OK) return rc;
+        } else {
+            for (int r = 0; r < world; ++r) {  // every simulated source holds this rank's segment for owner `me`
+                if (r == me || !ri_cnt[r]) continue;
+                GG_HIP(ctx, hipMemcpyAsync(ctx->x_recv_ids.as<int32_t>() + ri_off[r], ctx->x_send_ids.as<int32_t>() + soff[me], sizeof(int32_t) * (size_t)ri_cnt[r], hipMemcpyDeviceToDevice, ctx->stream));
+                GG_HIP(ctx, hipMemcpyAsync(ctx->x_recv_rows.as<float>() + r_off[r], ctx->x_send_rows.as<float>() + soff[me] * (long long)row_f, sizeof(float) * (size_t)r_cnt[r], hipMemcpyDeviceToDevice, ctx->stream));
+            }
+        }
+        // ---- owner's sum: own contribution (already in the accumulators) + the sources in rank order
+        for (int r = 0; r < world; ++r) {
+            if (r == me || !ri_cnt[r]) continue;
+            int nbr = cdiv(ri_cnt[r] * 16, 256);
+            if (nbr > 4096) nbr = 4096;
+            hipLaunchKernelGGL(add_rows_kernel, dim3(nbr), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, ctx->touched, ctx->x_recv_ids.as<int32_t>() + ri_off[r],
+                               ctx->x_recv_rows.as<float>() + r_off[r], (int64_t)ri_cnt[r], ld);
+        }
+    }
+    // ---- 4. gather the owners' reduced rows
+    rc = device_compact_flags(ctx, ctx->touched, n, ctx->touched_list, ctx->touched_ptr.as<int64_t>() + n);  // (the adds flagged new rows)
+    if (rc != GG_OK) return rc;
+    long long umax = 0;
+    if (!fake) {
+        hipLaunchKernelGGL(owner_count_owned_kernel, dim3(256), dim3(256), 0, ctx->stream, ctx->touched_list, o.touched_total, world, ctx->rank, own);
+        rc = comm_allreduce_max_i64(ctx, (int64_t *)own, 1);
+        if (rc != GG_OK) return rc;
+        GG_HIP(ctx, hipMemcpyAsync(&umax, own, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+        GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const size_t cap = (size_t)std::max<long long>(umax, 1);
+        GG_HIP(ctx, ctx->x_send_ids.reserve(sizeof(int32_t) * cap));
+        GG_HIP(ctx, ctx->x_send_rows.reserve(sizeof(float) * cap * row_f));
+        GG_HIP(ctx, ctx->x_recv_ids.reserve(sizeof(int32_t) * cap * world));
+        GG_HIP(ctx, ctx->x_recv_rows.reserve(sizeof(float) * cap * row_f * world));
+        hipLaunchKernelGGL(fill_ids_kernel, dim3(256), dim3(256), 0, ctx->stream, ctx->x_send_ids.as<int32_t>(), (int64_t)cap, -1);
+        GG_HIP(ctx, hipMemsetAsync(own + 1, 0, sizeof(long long), ctx->stream));
+        int nbg = cdiv((int64_t)cap * 16, 256);
+        if (nbg > 4096) nbg = 4096;
+        hipLaunchKernelGGL(owner_gather_pack_kernel, dim3(nbg), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, ctx->touched_list, o.touched_total, world, ctx->rank,
+                           own + 1, (int64_t)cap, ld, ctx->x_send_ids.as<int32_t>(), ctx->x_send_rows.as<float>());
+        rc = comm_allgather(ctx, ctx->x_send_ids.p, ctx->x_recv_ids.p, cap, 4);
+        if (rc == GG_OK) rc = comm_allgather(ctx, ctx->x_send_rows.p, ctx->x_recv_rows.p, cap * row_f, 4);
+        if (rc != GG_OK) return rc;
+        for (int r = 0; r < world; ++r) {
+            if (r == ctx->rank) continue;
+            hipLaunchKernelGGL(set_rows_kernel, dim3(nbg), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, ctx->touched, ctx->x_recv_ids.as<int32_t>() + (size_t)r * cap,
+                               ctx->x_recv_rows.as<float>() + (size_t)r * cap * row_f, (int64_t)cap, ld);
+        }
+        bytes += (long long)(world - 1) * (long long)cap * (long long)(row_f + 1) * 4;
+    } else {
+        // simulated: every owner's rows are already in this GPU's accumulators; run the pack / overwrite kernels once (owner 0)
+        // so that they are exercised: overwriting a row with itself changes nothing
+        hipLaunchKernelGGL(owner_count_owned_kernel, dim3(256), dim3(256), 0, ctx->stream, ctx->touched_list, o.touched_total, world, 0, own);
+        GG_HIP(ctx, hipMemcpyAsync(&umax, own, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+        GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const size_t cap = (size_t)std::max<long long>(umax, 1);
+        GG_HIP(ctx, ctx->x_send_ids.reserve(sizeof(int32_t) * cap));
+        GG_HIP(ctx, ctx->x_send_rows.reserve(sizeof(float) * cap * row_f));
+        hipLaunchKernelGGL(fill_ids_kernel, dim3(256), dim3(256), 0, ctx->stream, ctx->x_send_ids.as<int32_t>(), (int64_t)cap, -1);
+        GG_HIP(ctx, hipMemsetAsync(own + 1, 0, sizeof(long long), ctx->stream));
+        int nbg = cdiv((int64_t)cap * 16, 256);
+        if (nbg > 4096) nbg = 4096;
+        hipLaunchKernelGGL(owner_gather_pack_kernel, dim3(nbg), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, ctx->touched_list, o.touched_total, world, 0, own + 1,
+                           (int64_t)cap, ld, ctx->x_send_ids.as<int32_t>(), ctx->x_send_rows.as<float>());
+        hipLaunchKernelGGL(set_rows_kernel, dim3(nbg), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, ctx->touched, ctx->x_send_ids.as<int32_t>(),
+                           ctx->x_send_rows.as<float>(), (int64_t)cap, ld);
+    }
+    GG_HIP(ctx, hipGetLastError());
+    ctx->comm_steps_sparse += 1;
+    ctx->comm_steps_owner += 1;
+    if (ctx->comm) ctx->comm_bytes_sent += bytes;
+    *taken = true;
+    return GG_OK;
+}
+
 // Replica exchange of the lazy / sgd modes, WITHOUT host synchronisation.  `bound` = the most pairs any rank brings to
 // this step (known on every host: the batch size of a minibatch step, or the max over ranks of the prepared rows that
 // gg_prepare_* exchanged inside its own synchronisation), so cap = min(N, 2 * bound) rows bound every rank's pack.
@@ -1212,6 +1438,14 @@ static int exchange_sparse(gg_ctx *ctx, OptArgs &o, int world, int64_t bound) {
     const int64_t cap = std::min<int64_t>(n, 2 * std::max<int64_t>(bound, 0));
     if (cap == 0) return GG_OK;  // no rank has a pair in this step
     if ((double)world * (double)cap >= (double)ctx->dense_exchange_ratio * n) {
+        // the packs of all ranks together may outgrow the table: first choice the owner-partitioned exchange of what was
+        // really touched (two small host round trips; a fused pass has one step), else the whole accumulators
+        if (bound >= ctx->owner_min_bound) {
+            bool taken = false;
+            int rc = exchange_owner(ctx, o, world, &taken);
+            if (rc != GG_OK) return rc;
+            if (taken) return GG_OK;
+        }
         if (ctx->comm) {
             int rc = comm_allreduce_grads(ctx);
             if (rc == GG_OK) rc = comm_allreduce_flags(ctx);

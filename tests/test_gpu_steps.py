@@ -632,6 +632,52 @@ def test_sparse_exchange_with_simulated_ranks(ga, mode, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("mode", ["sgd", "lazy"])
+def test_owner_partitioned_exchange_with_simulated_ranks(ga, mode, world, monkeypatch):
+    """The owner-partitioned sparse exchange (round 4): touched rows travel to their owner (row mod P), the owner adds the
+    sources in rank order, the reduced rows are gathered back and OVERWRITE the receivers' accumulator rows.  One GPU here:
+    GG_COMM_FAKE_WORLD = P makes this rank play every owner in turn with P - 1 copies of its own rows as the other sources,
+    so the applied gradient must be exactly P x the local one -- per-owner counting, segment offsets, slot assignment, the
+    rank-order adds, the gather pack and the overwrite kernel all run.  The branch is forced (dense ratio 0: the row packs are
+    ruled out) and must really be taken (statistics)."""
+    monkeypatch.setenv("GG_COMM_FAKE_WORLD", str(world))
+    monkeypatch.setenv("GG_COMM_DENSE_RATIO", "0")
+    monkeypatch.setenv("GG_COMM_OWNER_MIN", "0")
+    n, d = 1200, 64
+    Eg, Ed, bg, bd = make_models(n, d, 33)
+    opt = ga.GG_OPT_SGD if mode == "sgd" else ga.GG_OPT_ADAM_LAZY
+    eng = engine_with(ga, Eg, Ed, bg, bd, optimizer=opt)
+    for k in ("GG_COMM_FAKE_WORLD", "GG_COMM_DENSE_RATIO", "GG_COMM_OWNER_MIN"):
+        monkeypatch.delenv(k)
+    dis = orc.Discriminator(Ed, 1e-3, lazy=True)
+    dis.b[:] = bd
+    rs = np.random.RandomState(world)
+    B = 700
+    for t in range(3):
+        u, v = rs.randint(0, n // 4, B), rs.randint(0, n // 4, B)   # ~ 270 of the 1 200 rows touched: P x that stays below the table
+        lab = (rs.rand(B) < 0.5).astype(np.float32)
+        _, gu, gv, gb = dis.loss_and_grads(u, v, lab, 1e-5)
+        GE, Gb = np.zeros((n, d), np.float64), np.zeros(n)
+        np.add.at(GE, u, gu)
+        np.add.at(GE, v, gv)
+        np.add.at(Gb, v, gb)
+        GE, Gb = (world * GE).astype(np.float32), (world * Gb).astype(np.float32)
+        rows = np.flatnonzero((np.abs(GE).sum(1) > 0) | (Gb != 0))
+        if mode == "sgd":
+            dis.E -= np.float32(1e-3) * GE
+            dis.b -= np.float32(1e-3) * Gb
+        else:
+            dis.opt.step([dis.E, dis.b], [(rows, GE[rows]), (rows, Gb[rows])])
+        eng.d_step(u, v, lab)
+        assert np.allclose(eng.get_embeddings(1), dis.E, rtol=3e-5, atol=2e-6), t
+        assert np.allclose(eng.get_bias(1), dis.b, rtol=3e-5, atol=2e-6), t
+    assert np.array_equal(eng.get_embeddings(1)[n // 4:], Ed[n // 4:])
+    st = eng.comm_stats()
+    assert st["sparse_steps"] == 3 and st["dense_steps"] == 0   # the owner path ran every time (it counts as a sparse step)
+    eng.close()
+
+
 def test_deterministic_small_batch_mode(ga, monkeypatch):
     """GG_DETERMINISTIC=1: the B = 64 steps use the atomic-free single-workgroup gradient kernel --
     two engines give BIT-IDENTICAL tables after many steps with heavy row duplication, and the
@@ -697,7 +743,9 @@ def test_sampled_profiling_and_early_returning_passes(ga, every, monkeypatch):
         assert ca[k] == cb[k], k
     assert cb["walk_launches"] == 6 and ca["walk_launches"] == (2 if every == 3 else 0)
     assert (ca["score_launches"] > 0) == (every == 3) and (ca["score_rows"] > 0) == (every == 3)
-    assert cb["score_rows"] == cb["rows_scored"]  # every launch profiled: the two row counters agree
+    # every launch profiled: the rows of the timed score kernels are all rows but the few the per-walk finisher scores itself
+    # (round 4: walks still going behind the learned number of levels are finished by it instead of rerunning the launch)
+    assert 0.9 * cb["rows_scored"] <= cb["score_rows"] <= cb["rows_scored"]
     for which in (0, 1):
         assert np.array_equal(eng.get_embeddings(which), ref.get_embeddings(which))
     with pytest.raises(ga.GraphGANHipError):
