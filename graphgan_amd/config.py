@@ -55,6 +55,7 @@ engine_device = 0
 engine_tree_device = True    # BFS trees on the GPU (False: threaded host BFS, same trees)
 engine_tree_threads = 0       # host BFS only; 0 = all host cores
 engine_profile_every = 1      # HIP events on every k-th walk launch; 1 = every launch and pass (passes synchronous); 0 = none
-engine_tree_budget_gb = 160.0  # all N BFS trees stay resident (reference :31-46) when they fit this much HBM; otherwise, with update_ratio < 1, trees are built per draw
+engine_tree_budget_gb = 160.0  # all N BFS trees stay resident (reference :31-46) when they fit this much HBM; otherwise the epoch runs over root batches (gg_epoch_*)
+engine_batch_roots = 0        # roots per batch of a root-batched epoch; 0 = what the budget holds (at most 16 384)
 engine_emb_text = True        # write the reference's .emb text after every epoch (graph_gan.py:293-306); ~50 GB per write at N = 10^7, d = 256
 engine_emb_sidecar = False    # also write <emb_filename>.bin: the same fp32 numbers in binary (utils.read_embeddings_bin)

@@ -624,7 +624,13 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
                     const int j0 = 4 * (s - (int)soff[i]);
                     const int cnt = (int)degs[i] - j0;  // >= 1
                     we[it] = e0s[i] + (uint32_t)j0;
-                    w4[it] = *reinterpret_cast<const int4u *>(a.col + we[it]);
+                    if (a.exp & 2) {  // (ablation: computed targets instead of the adjacency loads)
+                        const uint32_t hx = we[it] * 2654435761u;
+                        w4[it].x = (int)(hx % (uint32_t)a.n_node); w4[it].y = (int)((hx >> 3) % (uint32_t)a.n_node);
+                        w4[it].z = (int)((hx >> 5) % (uint32_t)a.n_node); w4[it].w = (int)((hx >> 7) % (uint32_t)a.n_node);
+                    } else {
+                        w4[it] = *reinterpret_cast<const int4u *>(a.col + we[it]);
+                    }
                     cand[it] = cnt >= 4 ? 15u : ((1u << cnt) - 1u);  // valid entries for now
                 }
             }
