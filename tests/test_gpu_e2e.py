@@ -176,13 +176,14 @@ def test_script_entry_point_with_user_config(tmp_path):
 
 def test_update_ratio_below_one_selects_resident_slots(tmp_path):
     """config.update_ratio < 1 (graph_gan.py:189,209): every prepare draws its own subset of roots.  All trees stay
-    resident (the reference's self.trees): the draw only selects slots, so the D-mode mutations (Q3) persist; with
-    engine_tree_budget_gb = 0 the mirror falls back to building the trees of each draw on the GPU."""
+    resident (the reference's self.trees): the draw only selects slots, so the D-mode mutations (Q3) persist; with a tree
+    budget below N trees the mirror runs every prepare over root batches of ITS draw (gg_epoch_*: the mutations then live in
+    the engine's persistent store)."""
     base = str(tmp_path)
     d, n, graph = write_reference_layout(base)
     for budget, resident in ((160.0, True), (0.0, False)):
         cfg = make_cfg(base, n_epochs=1, n_epochs_dis=2, n_epochs_gen=2, dis_interval=1, gen_interval=1, update_ratio=0.05,
-                       engine_optimizer="adam_lazy", engine_profile_every=0, engine_tree_budget_gb=budget)  # no events: passes return early, G walks beside D updates
+                       engine_optimizer="adam_lazy", engine_profile_every=0, engine_tree_budget_gb=budget, engine_batch_roots=100)  # no events: passes return early, G walks beside D updates
         if os.path.exists(cfg.result_filename):
             os.remove(cfg.result_filename)
         from graphgan_amd.graph_gan import GraphGAN
@@ -194,7 +195,11 @@ def test_update_ratio_below_one_selects_resident_slots(tmp_path):
         c = g.engine.counters()
         assert c["d_steps"] > 0 and c["g_steps"] > 0 and 0 < c["walks"] < 4 * 0.2 * n * 25
         nroots = len(g.engine.tree_roots)
-        assert nroots == n if resident else 0.02 * n < nroots < 0.09 * n  # ~5 % of the roots in the last prepare
+        if resident:
+            assert nroots == n and c["bfs_trees"] == n
+        else:  # four prepares (2 D + 2 G), each over its own ~5 % draw in batches of 100 roots; the last batch is resident
+            assert 0 < nroots <= 100 and 4 * 0.02 * n < c["bfs_trees"] < 4 * 0.09 * n
+            assert g.engine.q3_get()[1].any()   # D-mode mutations were kept across the batches
         g.engine.close()
 
 

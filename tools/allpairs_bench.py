@@ -33,7 +33,7 @@ for prec, peak in (("fp32", 157.3), ("bf16", 2500.0)):
         out[prec + ("" if lse else "_max_argmax_only")] = {
             "kernel_ms": best, "call_s_last": wall, "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "bound": "mfma",
             "table_bytes_streamed_per_row_tile": (2 if prec == "bf16" else 4) * n * d,
-            "instruction": "v_mfma_f32_32x32x16_bf16" if prec == "bf16" else "v_mfma_f32_32x32x2_f32"}
+            "instruction": ("v_mfma_f32_16x16x32_bf16 (rows >= 512: all_score_reduce_bf16_x16_kernel) / v_mfma_f32_32x32x16_bf16 (fewer rows)" if prec == "bf16" else "v_mfma_f32_32x32x2_f32")}
         if prec == "fp32" and lse:
             ref_max = res["max"].copy()
         elif prec == "bf16" and lse:
