@@ -88,6 +88,23 @@ class Control:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def all_gather_concat(self, arr):
+        """Concatenation, in rank order, of every rank's 1-D array (lengths may differ)."""
+        arr = np.ascontiguousarray(arr)
+        if self.dist is None:
+            return arr.copy()
+        import torch
+        n = torch.tensor([len(arr)], dtype=torch.int64)
+        ns = [torch.zeros(1, dtype=torch.int64) for _ in range(self.world)]
+        self.dist.all_gather(ns, n)
+        m = max(int(x.item()) for x in ns)
+        pad = np.zeros(max(m, 1), dtype=arr.dtype)
+        pad[: len(arr)] = arr
+        t = torch.from_numpy(pad)
+        out = [torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return np.concatenate([o.numpy()[: int(k.item())] for o, k in zip(out, ns)])
+
     def connect_engine(self, engine):
         """RCCL communicator for ``engine``: rank 0 creates the unique id, everybody joins."""
         if self.world <= 1:
@@ -95,3 +112,24 @@ class Control:
         uid = engine.comm_unique_id() if self.rank == 0 else b""
         uid = self.broadcast_bytes(uid, 128)
         engine.comm_init(uid, self.rank, self.world)
+
+
+def all_score_reduce_sharded(ctl, engine, rows=None, precision="bf16", logsumexp=True):
+    """The all-pairs evaluation of BASELINE.json configs[4] ("8 x MI355X, all-pairs eval as MFMA bf16 GEMM") over the ranks of
+    one node: ``generator.all_score`` (reference generator.py:21) streamed through the fused max / argmax / log-sum-exp
+    consumer (``Engine.all_score_reduce``), ROWS sharded.  Every rank holds a full replica of the table, so the reduction of a
+    row over all N columns is formed on one rank -- no partial (max, argmax, lse) triples to merge -- and the ranks' results
+    are concatenated over the control plane (12 bytes per row).  rows = None: every node.  Returns the same dict as
+    ``Engine.all_score_reduce`` for ALL requested rows, in their order, on every rank; ``kernel_ms`` = the slowest rank's."""
+    n_rows = engine.n_node if rows is None else len(rows)
+    all_rows = np.arange(engine.n_node, dtype=np.int32) if rows is None else np.ascontiguousarray(rows, dtype=np.int32)
+    per = (n_rows + ctl.world - 1) // max(ctl.world, 1)
+    mine = all_rows[ctl.rank * per: min((ctl.rank + 1) * per, n_rows)]
+    if len(mine):
+        res = engine.all_score_reduce(mine, precision=precision, logsumexp=logsumexp)
+    else:
+        res = dict(max=np.zeros(0, np.float32), argmax=np.zeros(0, np.int32), logsumexp=np.zeros(0, np.float32) if logsumexp else None, kernel_ms=0.0)
+    out = dict(max=ctl.all_gather_concat(res["max"]), argmax=ctl.all_gather_concat(res["argmax"]),
+               logsumexp=ctl.all_gather_concat(res["logsumexp"]) if logsumexp else None, kernel_ms=ctl.max(res["kernel_ms"]))
+    assert len(out["max"]) == n_rows
+    return out

@@ -227,3 +227,50 @@ def test_two_rank_trainer_keeps_replicas_identical(tmp_path):
         assert np.array_equal(r["a"], r["b"])                             # identical replicas, identical step counts
     assert np.array_equal(r0["a"], r1["a"]) and r0["a"][-1] > 10 and r0["a"][-2] > 10
     assert r0["wrote"] == 2 * 3 and r1["wrote"] == 0                       # before training + after each of the 2 epochs, rank 0 only
+
+
+class _ScoreEngine(object):
+    """Engine.all_score_reduce on numpy (the stand-in of a rank's GPU: every rank holds the full table)."""
+
+    def __init__(self, E, b):
+        self.E, self.b, self.n_node = E, b, len(b)
+
+    def all_score_reduce(self, rows, precision="bf16", logsumexp=True):
+        S = self.E[np.asarray(rows)] @ self.E.T + self.b[None, :]          # generator.py:21
+        m = S.max(1)
+        return dict(max=m.astype(np.float32), argmax=S.argmax(1).astype(np.int32),
+                    logsumexp=(m + np.log(np.exp(S - m[:, None]).sum(1))).astype(np.float32) if logsumexp else None, kernel_ms=1.0 + len(rows))
+
+
+def _allpairs_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from graphgan_amd import parallel
+    ctl = parallel.Control()
+    rs = np.random.RandomState(4)
+    E, b = rs.randn(301, 16).astype(np.float32), rs.randn(301).astype(np.float32)
+    eng = _ScoreEngine(E, b)
+    full = parallel.all_score_reduce_sharded(ctl, eng)                      # every node, 301 rows over 3 ranks: 101 + 101 + 99
+    some = parallel.all_score_reduce_sharded(ctl, eng, rows=np.array([7, 300], np.int32), logsumexp=False)   # fewer rows than ranks
+    if rank == 0:
+        np.savez(out, max=full["max"], argmax=full["argmax"], lse=full["logsumexp"], ms=full["kernel_ms"], smax=some["max"], sarg=some["argmax"])
+    ctl.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_pairs_consumer_sharded_over_ranks(tmp_path):
+    """BASELINE.json configs[4]: the all-pairs evaluation over the GPUs of a node = rows sharded over the ranks (each holds the
+    full table, so a row's max / argmax / log-sum-exp over all columns needs no merge), results concatenated in rank order:
+    three gloo ranks give exactly the single-rank result, also when there are fewer rows than ranks."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "ap.npz")
+    mp.spawn(_allpairs_worker, args=(3, _free_port(), out), nprocs=3, join=True)
+    got = np.load(out)
+    rs = np.random.RandomState(4)
+    E, b = rs.randn(301, 16).astype(np.float32), rs.randn(301).astype(np.float32)
+    want = _ScoreEngine(E, b).all_score_reduce(np.arange(301))
+    assert np.array_equal(got["max"], want["max"]) and np.array_equal(got["argmax"], want["argmax"]) and np.array_equal(got["lse"], want["logsumexp"])
+    assert got["ms"] == 1.0 + 101                                            # the slowest rank's kernel time
+    w2 = _ScoreEngine(E, b).all_score_reduce(np.array([7, 300]), logsumexp=False)
+    assert np.array_equal(got["smax"], w2["max"]) and np.array_equal(got["sarg"], w2["argmax"])
