@@ -46,6 +46,7 @@ constexpr int BFS_LCAP = 512;            // in-chunk duplicate list
 struct BfsArgs {
     int n_node, n_roots;
     const int64_t *rowptr;
+    const uint32_t *rowptr32;  // the same offsets in 4 bytes (< 2^31 entries): 4 MB for 10^6 nodes stay in an XCD's L2, the 8 MB of rowptr do not
     const int32_t *col;
     const int32_t *roots;    // [n_roots] device (t_root)
     const int64_t *base;     // [n_roots + 1] device (t_base)
@@ -57,8 +58,19 @@ struct BfsArgs {
     uint32_t *gbitmap;       // [grid][bm_words]  (graphs too large for the LDS bitmap)
     uint32_t *gkey;          // [grid][n_node]    all-ones between uses (duplicate-list overflow path)
     int bm_words;
-    int exp;                   // GG_BFS_EXPERIMENT: timing ablations (results are then WRONG): 1 = no cstart stores, 2 = synthetic targets instead of adjacency loads, 4 = no queue stores beyond level 1, 8 = no early exit when the component is complete (results stay right)
-    unsigned long long *prof;  // GG_BFS_PROFILE: [16] shader-clock cycles of wave 0 per phase + event counts (NULL: off)
+    int exp;                   // GG_BFS_EXPERIMENT: timing ablations (results are then WRONG): 1 = no cstart stores, 2 = synthetic targets instead of adjacency loads, 4 = no queue stores beyond level 1, 8 = no early exit when the component is complete, 64 = streaming stores for t_edge, 128 = nothing (the instrumented instance as its own baseline): results stay right with 8 / 64 / 128
+    unsigned long long *prof;  // GG_BFS_PROFILE: [32] shader-clock cycles of wave 0 per phase + event counts (NULL: off)
+    // sparse levels (bfs_order2_kernel with the bitmap in LDS; see "SPARSE LEVEL" there): per-workgroup scratch
+    int sp_k;                  // a level is expanded through its candidate fathers when unseen nodes * sp_k <= level nodes (< 0: never)
+    int sp_min;                // ... and the level has at least this many nodes
+    int sp_buckets;            // rank buckets of a level (passes over the unseen nodes)
+    int sp_cap;                // unseen nodes the scratch holds
+    int32_t *sp_ux;            // [grid][2][sp_cap]   unseen nodes not served yet
+    unsigned long long *sp_ui; // [grid][2][sp_cap]   their first CSR entry | degree << 32
+    int32_t *sp_s;             // [grid][n_node]   queue ranks of the candidate fathers, ascending
+    uint32_t *sp_vis;          // [grid][bm_words] the visited bitmap while the LDS holds a bucket's
+    uint32_t *sp_mark;         // [grid][bm_words] candidate fathers by node id (all-zero between uses)
+    unsigned long long *sp_mask;  // [grid][n_node / 64 + 32] the same by rank: one ballot per 64 ranks of the level
 };
 
 __device__ __forceinline__ int lanes_below(unsigned long long m) {  // popcount of m restricted to the lanes below this one
@@ -432,6 +444,7 @@ constexpr int B2_HASH = 1024;            // in-window duplicates: LDS hash node 
 constexpr int B2_DCAP = 768;             // ... for up to this many duplicates per window (more: the key array in global memory)
 
 typedef int32_t int4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load from a 4-byte aligned address
+typedef uint32_t uint2u __attribute__((ext_vector_type(2), aligned(4)));  // 8-byte load from a 4-byte aligned address
 
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 #pragma unroll
@@ -445,7 +458,255 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 // workgroup barrier that waits for this wavefront's LDS traffic only: global loads / stores in flight stay in flight
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <bool LDS_BM>
+// loads of words this workgroup (or an L2 atomic) wrote earlier in the same launch: served by the L2, never by a stale L1 line
+__device__ __forceinline__ int ldi(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t ldu(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long ldq(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+typedef uint32_t __attribute__((address_space(3))) lds_u32_t;
+typedef int32_t __attribute__((address_space(3))) lds_i32_t;
+
+// SPARSE LEVEL of bfs_order2_kernel (see there): the candidate fathers S of the level [lo, hi) of one root's queue, ascending, into
+// `slist`; returns their number, or -1 if the unseen nodes do not fit the scratch (nothing has changed then).  On return the LDS
+// bitmap `bm` is the visited bitmap again, cstart[lo + 1 .. hi] is zero, and wtot[16] / wtot[17] hold the unseen nodes listed and
+// the bucket passes made (profile).  A function of its own (not inlined): its registers must not compete with the window loop's
+// (inlined, the kernel spilled 84-172 VGPRs, some inside the window loop).  Called by all 1 024 threads of the workgroup.
+// Every loop keeps several independent loads in flight per thread -- a workgroup alone on its CU hides no latency by itself:
+// written as plain one-load-per-iteration loops the search cost 9 M cycles per tree, more than the level popped whole.
+template <bool INSTR>
+__device__ __forceinline__ int sparse_fathers(unsigned long long *sph, lds_u32_t *bm, lds_i32_t *wtot, lds_i32_t *s_live, const uint32_t *__restrict__ rowptr32,
+                                           const int32_t *__restrict__ col, const int32_t *order, int32_t *cstart, int32_t *ux, unsigned long long *ui,
+                                           int32_t *slist, uint32_t *vis, uint32_t *mark, unsigned long long *smask, int n_node, int W, int sp_cap,
+                                           int NBK, int lo, int hi, int Un) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int F = hi - lo;
+    long long tprev = INSTR ? (long long)clock64() : 0;  // phase clocks (GG_BFS_PROFILE): list, cstart zeros, bucket bitmap, scan, restore, rank masks, S list
+#define SP_TICK(k)                                  \
+    if (INSTR) {                                    \
+        const long long tn = (long long)clock64();  \
+        sph[k] += (unsigned long long)(tn - tprev); \
+        tprev = tn;                                 \
+    }
+    const uint32_t lastmask = (n_node & 31) ? (1u << (n_node & 31)) - 1u : 0xffffffffu;
+    // unseen nodes: count (the bitmap is saved on the way), list
+    int zc = 0;
+    for (int i = tid; i < W; i += B2_T) {
+        const uint32_t wd = bm[i];
+        vis[i] = wd;
+        uint32_t z = ~wd;
+        if (i == W - 1) z &= lastmask;
+        zc += (int)__popc(z);
+    }
+    const int zinc = wave_incl_scan(zc, lane);
+    if (lane == 63) wtot[wv] = zinc;
+    lds_barrier();
+    int zpre = 0, nU = 0;
+#pragma unroll
+    for (int i = 0; i < B2_WAVES; ++i) {
+        const int c = wtot[i];
+        if (i < wv) zpre += c;
+        nU += c;
+    }
+    if (nU > sp_cap) return -1;  // (other components' nodes are listed too: they never hit)
+    {
+        int o = zpre + zinc - zc;
+        for (int i = tid; i < W; i += B2_T) {
+            uint32_t z = ~bm[i];
+            if (i == W - 1) z &= lastmask;
+            while (z) {
+                const int b = __ffs((int)z) - 1;
+                z &= z - 1u;
+                ux[o++] = (i << 5) + b;
+            }
+        }
+    }
+    __syncthreads();
+    for (int idx0 = tid; idx0 < nU; idx0 += 4 * B2_T) {  // their adjacency ranges
+        int xs[4];
+        uint2u rp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xs[u] = idx0 + u * B2_T < nU ? ldi(&ux[idx0 + u * B2_T]) : -1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (xs[u] >= 0) rp[u] = *reinterpret_cast<const uint2u *>(rowptr32 + xs[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (xs[u] >= 0) ui[idx0 + u * B2_T] = (unsigned long long)rp[u].x | ((unsigned long long)(rp[u].y - rp[u].x) << 32);
+    }
+    SP_TICK(0)
+    for (int i = lo + 1 + tid; i <= hi; i += B2_T) cstart[i] = 0;
+    if (tid == 0) *s_live = 0;
+    __syncthreads();
+    SP_TICK(1)
+    const int bs = (F + NBK - 1) / NBK;
+    int jdone = 0;
+    int L = nU;  // unseen nodes not served yet: a dense list, rewritten by every pass
+    int32_t *cx = ux, *nx = ux + sp_cap;
+    unsigned long long *ci = ui, *ni = ui + sp_cap;
+    auto probe = [&](int w) -> bool {
+        const uint32_t bit = 1u << (w & 31);
+        if (!(bm[w >> 5] & bit)) return false;
+        (void)__hip_atomic_fetch_or(&mark[w >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return true;
+    };
+    for (int j = 0; j < NBK; ++j) {
+        if (L <= nU - Un) break;  // only other components' nodes are left
+        for (int i = tid; i < W; i += B2_T) bm[i] = 0u;
+        lds_barrier();
+        const int b0 = lo + j * bs, b1 = min(b0 + bs, hi);
+        for (int i0 = b0 + tid; i0 < b1; i0 += 8 * B2_T) {  // the bucket's nodes into the LDS bitmap
+            int vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vv[u] = i0 + u * B2_T < b1 ? ldi(&order[i0 + u * B2_T]) : -1;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (vv[u] >= 0) (void)__hip_atomic_fetch_or(&bm[vv[u] >> 5], 1u << (vv[u] & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        lds_barrier();
+        SP_TICK(2)
+        // Four lanes per list entry, one quad each (the entry's adjacency is one or two cache lines: a wave's load touches ~20
+        // lines; with a lane per entry it touched 64, and the CU's L1 path -- 2-3 cycles per line of a fully divergent load --
+        // was the whole scan); four entries per group and round in flight, the next round's entries under them (eight: registers spill, 3.4 -> 5 M cycles).
+        {
+            const int sub = tid & 3, grp = tid >> 2;
+            constexpr int NG = B2_T / 4, NE = 4;
+            int pxs[NE];
+            unsigned long long pis[NE];
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const int id = grp + e * NG;
+                pxs[e] = id < L ? ldi(&cx[id]) : -1;
+                pis[e] = id < L ? ldq(&ci[id]) : 0ull;
+            }
+            for (int idx = grp; idx < L; idx += NE * NG) {
+                int xs[NE], dg[NE];
+                uint32_t e0[NE];
+                unsigned long long is[NE];
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    xs[e] = pxs[e];
+                    is[e] = pis[e];
+                    e0[e] = (uint32_t)is[e];
+                    dg[e] = xs[e] >= 0 ? (int)(is[e] >> 32) : 0;
+                }
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    const int id = idx + (NE + e) * NG;
+                    pxs[e] = id < L ? ldi(&cx[id]) : -1;
+                    pis[e] = id < L ? ldq(&ci[id]) : 0ull;
+                }
+                int4u w4[NE];
+#pragma unroll
+                for (int e = 0; e < NE; ++e)
+                    if (4 * sub < dg[e]) w4[e] = *reinterpret_cast<const int4u *>(col + e0[e] + (uint32_t)(4 * sub));
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    int hit = 0;
+                    int c = dg[e] - 4 * sub;
+                    if (c > 0) {
+                        hit |= probe(w4[e].x) ? 1 : 0;
+                        if (c > 1) hit |= probe(w4[e].y) ? 1 : 0;
+                        if (c > 2) hit |= probe(w4[e].z) ? 1 : 0;
+                        if (c > 3) hit |= probe(w4[e].w) ? 1 : 0;
+                    }
+                    for (int q = 16 + 4 * sub; q < dg[e]; q += 16) {  // (more than 16 neighbours: this lane's further quads)
+                        const int4u t4 = *reinterpret_cast<const int4u *>(col + e0[e] + (uint32_t)q);
+                        c = dg[e] - q;
+                        hit |= probe(t4.x) ? 1 : 0;
+                        if (c > 1) hit |= probe(t4.y) ? 1 : 0;
+                        if (c > 2) hit |= probe(t4.z) ? 1 : 0;
+                        if (c > 3) hit |= probe(t4.w) ? 1 : 0;
+                    }
+                    hit |= __shfl_xor(hit, 1, 64);  // (the four lanes of a group are active together)
+                    hit |= __shfl_xor(hit, 2, 64);
+                    if (sub == 0 && xs[e] >= 0 && !hit) {  // not served: onto the next pass's list
+                        const int p = __hip_atomic_fetch_add(s_live, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        nx[p] = xs[e];
+                        ni[p] = is[e];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        L = *s_live;
+        { int32_t *const t0 = cx; cx = nx; nx = t0; }
+        { unsigned long long *const t1 = ci; ci = ni; ni = t1; }
+        jdone = j + 1;
+        lds_barrier();  // (everyone has read the count)
+        if (tid == 0) *s_live = 0;
+        SP_TICK(3)
+    }
+    // the marks into LDS (and cleared in global memory): S by rank is 0.75 M bit tests in rank order
+    for (int i0 = tid; i0 < W; i0 += 8 * B2_T) {
+        uint32_t vw[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) vw[u] = i0 + u * B2_T < W ? ldu(&mark[i0 + u * B2_T]) : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u * B2_T < W) {
+                bm[i0 + u * B2_T] = vw[u];
+                if (vw[u]) mark[i0 + u * B2_T] = 0u;
+            }
+    }
+    lds_barrier();
+    SP_TICK(4)
+    // S by rank: the level's ranks up to the last bucket used, a contiguous share per wavefront
+    const long long cend_l = (long long)lo + (long long)jdone * bs;
+    const int cend = cend_l < (long long)hi ? (int)cend_l : hi;
+    const int per = ((cend - lo + 64 * B2_WAVES - 1) / (64 * B2_WAVES)) * 64;
+    const int r0 = lo + wv * per, r1 = min(r0 + per, cend);
+    int scount = 0;
+    for (int base = r0; base < r1; base += 512) {
+        int v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + 64 * u + lane;
+            v[u] = i < r1 ? ldi(&order[i]) : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool bit = v[u] >= 0 && ((bm[v[u] >> 5] >> (v[u] & 31)) & 1u);
+            const unsigned long long m = __ballot(bit);
+            if (base + 64 * u < r1) {
+                if (lane == 0) smask[(base + 64 * u - lo) >> 6] = m;
+                scount += (int)__popcll(m);
+            }
+        }
+    }
+    if (lane == 0) wtot[wv] = scount;
+    __syncthreads();  // the masks have landed; every mark has been read
+    SP_TICK(5)
+    int spre = 0, stot = 0;
+#pragma unroll
+    for (int i = 0; i < B2_WAVES; ++i) {
+        const int c = wtot[i];
+        if (i < wv) spre += c;
+        stot += c;
+    }
+    // the visited bitmap back into LDS
+    for (int i0 = tid; i0 < W; i0 += 8 * B2_T) {
+        uint32_t vw[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) vw[u] = i0 + u * B2_T < W ? ldu(&vis[i0 + u * B2_T]) : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u * B2_T < W) bm[i0 + u * B2_T] = vw[u];
+    }
+    int pos = spre;
+    for (int base = r0; base < r1; base += 64) {
+        const unsigned long long m = ldq(&smask[(base - lo) >> 6]);
+        if ((m >> lane) & 1ull) slist[pos + lanes_below(m)] = base + lane;
+        pos += (int)__popcll(m);
+    }
+    if (tid == 0) { wtot[16] = nU; wtot[17] = jdone; }
+    __syncthreads();
+    SP_TICK(6)
+#undef SP_TICK
+    return stot;
+}
+
+// INSTR: the phase clocks (GG_BFS_PROFILE), event counts and ablation switches (GG_BFS_EXPERIMENT) live in a second instance only.
+template <bool LDS_BM, bool INSTR>
 __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
     extern __shared__ uint32_t lds_bm[];              // [bm_words] when LDS_BM
     __shared__ uint32_t e0s[B2_NB];                   // first CSR entry of each window node (of the segment, for a partial node)
@@ -456,13 +717,15 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
     __shared__ uint32_t winbits[B2_WORDS + 1];        // positions that append a node ([B2_WORDS] stays 0)
     __shared__ int32_t wpre[B2_WORDS + 1];            // exclusive popcount prefix over those words; [B2_WORDS] = total
     __shared__ int32_t wtot[2][B2_WAVES];
-    __shared__ int32_t s_root, s_any, s_Lcount, s_cap, s_max, s_deg;
+    __shared__ int32_t s_root, s_any, s_Lcount, s_cap, s_max, s_deg, s_live;
     __shared__ uint32_t s_e0;
     uint16_t *const emap = reinterpret_cast<uint16_t *>(scratch);
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     uint32_t *const bm = LDS_BM ? lds_bm : a.gbitmap + (size_t)blockIdx.x * a.bm_words;
     uint32_t *const gkey = a.gkey + (size_t)blockIdx.x * a.n_node;
+    // SPARSE LEVEL scratch of this workgroup (LDS_BM only)
+    int32_t *const slist = a.sp_s + (size_t)blockIdx.x * a.n_node;
 
     auto seen = [&](int w) -> bool {
         if (LDS_BM) return (bm[w >> 5] >> (w & 31)) & 1u;
@@ -499,46 +762,111 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
         int head = 0, tail = 1, level_end = 1, depth = 0;
         int fenced = 1;          // queue entries below this index were written before the last full fence
         unsigned long long st_win = 0, st_fence = 0, st_cand = 0, st_slots = 0, st_empty = 0, st_dup = 0, st_key = 0;  // GG_BFS_PROFILE
-        unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // wave 0's clock per phase: setup, scan, claim, duplicates, prefix, append
-        long long tprev = a.prof ? (long long)clock64() : 0;
+        unsigned long long st_sp = 0, st_spu = 0, st_sps = 0, st_spp = 0;  // sparse levels, unseen nodes listed, candidate fathers, passes
+        unsigned long long sph[7] = {0, 0, 0, 0, 0, 0, 0};  // phases of the father search
+        unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // wave 0's clock per phase: setup, scan, claim, duplicates, prefix, append; [8] sparse-level build, [9] its cstart fill
+        long long tprev = INSTR ? (long long)clock64() : 0;
 #define B2_TICK(k)                                  \
-    if (a.prof) {                                   \
+    if (INSTR) {                                    \
         const long long tn = (long long)clock64();  \
         ph[k] += (unsigned long long)(tn - tprev);  \
         tprev = tn;                                 \
     }
         int seg_a = 0;           // > 0: the node at `head` is being scanned in segments, this many entries are done
         int pf_q = -1;           // queue index whose node this thread has prefetched
-        int pf_v = 0, pf_stage = 0;
+        int pf_v = 0, pf_stage = 0, pf_rk = 0;
         uint32_t pf_e0 = 0;
         int pf_deg = 0;
-        while (head < tail) {
-            if (head == level_end) {  // the next level starts: everything up to `tail` belongs to it
-                level_end = tail;
-                ++depth;
+        // SPARSE LEVEL.  Late levels of a small-world graph pop most of the graph to discover a few nodes (1M / 10M bench
+        // graph: 0.5-0.85 M nodes, 10-15 M adjacency entries, for 0.3-200 k unseen nodes).  Only a FATHER -- the first queue
+        // node adjacent to some unseen node -- can append anything, and popping any superset S of the fathers, in queue order,
+        // through the same windows appends the same nodes at the same edges: a node of S that is nobody's first neighbour finds
+        // its unseen neighbours taken.  S is found from the unseen side: the level's ranks are cut into buckets; per bucket the
+        // LDS bitmap holds the bucket's nodes (the visited bitmap waits in global memory), every unseen node not yet served scans
+        // its adjacency and marks the neighbours it has in the bucket -- its father is among the marks of the FIRST bucket it
+        // hits, and it is served.  The marked nodes in rank order are S; nodes outside S have empty child ranges (cstart: the
+        // running maximum over the level).  Cost: the unseen nodes' adjacencies ~2 times + the adjacencies of S, instead of the
+        // whole level's.  `head` indexes S while smode is set.
+        bool smode = false;
+        int s_cnt = 0, s_lo = 0, s_hi = 0;
+        int my_rk = 0;           // queue rank of the window node this thread holds
+        auto fill_level = [&](int lo, int hi) {  // cstart[lo + 1 .. hi]: zeros (nodes outside S, fathers not reached) -> the running maximum
+            __syncthreads();
+            const int per = ((hi - lo + 64 * B2_WAVES - 1) / (64 * B2_WAVES)) * 64;
+            const int r0 = lo + 1 + wv * per, r1 = min(r0 + per, hi + 1);
+            int mx = 0;
+            for (int base = r0; base < r1; base += 64) {
+                const int i = base + lane;
+                if (i < r1) mx = max(mx, ldi(&cstart[i]));
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
+            if (lane == 0) wtot[0][wv] = mx;
+            lds_barrier();
+            int carry = hi;  // the level's children start where the level ends
+#pragma unroll
+            for (int i = 0; i < B2_WAVES; ++i)
+                if (i < wv) carry = max(carry, wtot[0][i]);
+            for (int base = r0; base < r1; base += 64) {
+                const int i = base + lane;
+                int val = i < r1 ? ldi(&cstart[i]) : 0;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int o = __shfl_up(val, off, 64);
+                    if (lane >= off) val = max(val, o);
+                }
+                val = max(val, carry);
+                if (i < r1) cstart[i] = val;
+                carry = __shfl(val, 63, 64);
+            }
+            __syncthreads();
+        };
+        // The window loop proper is the inner loop; the cold steps between runs of windows -- the father search of a sparse
+        // level (a call), the cstart fill behind one, the early exit -- sit in the outer loop, where their registers (and the call's
+        // save area) do not reach into the windows.
+        int why = 0;  // why the window loop stopped: 0 queue empty / error, 1 a sparse level starts, 2 S is through, 3 every node is on the queue
+        for (;;) {
+          why = 0;
+          for (;;) {
+            if (!smode) {
+                if (head >= tail) break;
+                if (head == level_end) {  // the next level starts: everything up to `tail` belongs to it
+                    level_end = tail;
+                    ++depth;
+                    const int F = tail - head, Un = expect - tail;
+                    if (LDS_BM && a.sp_k >= 0 && Un > 0 && F >= a.sp_min && (long long)Un * a.sp_k <= (long long)F) {
+                        why = 1;
+                        break;
+                    }
+                }
+            } else if (head >= s_cnt) {  // S is through: the level is complete
+                why = 2;
+                break;
             }
             // queue entries are read back from global memory (this window's nodes, the next window's prefetch): entries
             // written since the last fence must have landed first
-            if (fenced < tail && head + 2 * B2_NB > fenced) {
+            if (!smode && fenced < tail && head + 2 * B2_NB > fenced) {
                 __syncthreads();
                 fenced = tail;
-                ++st_fence;
+                if (INSTR) ++st_fence;
             }
             int nb = 0;      // complete nodes of this window; 0 = one node, entries [seg_a, seg_a + seg_len)
             int seg_len = 0;
             if (seg_a == 0) {
-                const int navail = min(B2_NB, level_end - head);
+                const int navail = min(B2_NB, (smode ? s_cnt : level_end) - head);
                 uint32_t e0 = 0;
                 int deg = 0;
                 if (tid < navail) {
                     if (pf_q == head + tid) {
                         e0 = pf_e0;
                         deg = pf_deg;
+                        my_rk = pf_rk;
                     } else {
-                        const int v = __hip_atomic_load(&order[head + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const int64_t b = a.rowptr[v];
-                        e0 = (uint32_t)b;
-                        deg = (int)(a.rowptr[v + 1] - b);
+                        my_rk = smode ? ldi(&slist[head + tid]) : head + tid;
+                        const int v = ldi(&order[my_rk]);
+                        const uint2u rp = *reinterpret_cast<const uint2u *>(a.rowptr32 + v);
+                        e0 = rp.x;
+                        deg = (int)(rp.y - rp.x);
                     }
                 }
                 const int q = min((deg + 3) >> 2, B2_SLOTS + 1);  // (a node above the window size ends the window whatever its size)
@@ -579,14 +907,15 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
                     // here, the dependent pair stalled every thread for a memory round trip per window (a third of the kernel).
                     const int q2 = head + nb + tid;
                     pf_q = -1;
-                    if (q2 < fenced) {
-                        pf_v = __hip_atomic_load(&order[q2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (q2 < (smode ? s_cnt : fenced)) {
+                        pf_rk = smode ? ldi(&slist[q2]) : q2;
+                        pf_v = ldi(&order[pf_rk]);
                         pf_q = q2;
                         pf_stage = 1;
                         if (!B2_PF_TWO_STAGE) {
-                            const int64_t b2 = a.rowptr[pf_v];
-                            pf_e0 = (uint32_t)b2;
-                            pf_deg = (int)(a.rowptr[pf_v + 1] - b2);
+                            const uint2u rp2 = *reinterpret_cast<const uint2u *>(a.rowptr32 + pf_v);
+                            pf_e0 = rp2.x;
+                            pf_deg = (int)(rp2.y - rp2.x);
                             pf_stage = 0;
                         }
                     }
@@ -607,8 +936,8 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
             B2_TICK(2)
             const int nbn = nb > 0 ? nb : 1;  // window nodes
             const int T = (int)soff[nbn];
-            ++st_win;
-            st_slots += (unsigned long long)T;
+            if (INSTR) ++st_win;
+            if (INSTR) st_slots += (unsigned long long)T;
 
             // ---------------- SCAN: quads tid, tid + 1024, ...; position of entry k of quad s = 4 s + k (stream order)
             int4u w4[4];
@@ -624,7 +953,7 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
                     const int j0 = 4 * (s - (int)soff[i]);
                     const int cnt = (int)degs[i] - j0;  // >= 1
                     we[it] = e0s[i] + (uint32_t)j0;
-                    if (a.exp & 2) {  // (ablation: computed targets instead of the adjacency loads)
+                    if (INSTR && (a.exp & 2)) {  // (ablation: computed targets instead of the adjacency loads)
                         const uint32_t hx = we[it] * 2654435761u;
                         w4[it].x = (int)(hx % (uint32_t)a.n_node); w4[it].y = (int)((hx >> 3) % (uint32_t)a.n_node);
                         w4[it].z = (int)((hx >> 5) % (uint32_t)a.n_node); w4[it].w = (int)((hx >> 7) % (uint32_t)a.n_node);
@@ -651,23 +980,23 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
             B2_TICK(3)
             lds_barrier();  // every test before any set: a later edge must not hide an earlier one
             if (pf_stage == 1) {  // prefetch, stage 2: the row pointers of the next window's nodes
-                const int64_t b2 = a.rowptr[pf_v];
-                pf_e0 = (uint32_t)b2;
-                pf_deg = (int)(a.rowptr[pf_v + 1] - b2);
+                const uint2u rp2 = *reinterpret_cast<const uint2u *>(a.rowptr32 + pf_v);
+                pf_e0 = rp2.x;
+                pf_deg = (int)(rp2.y - rp2.x);
                 pf_stage = 0;
             }
             B2_TICK(4)
 
             if (!s_any) {
                 // nothing new: every node that ends in this window has its children end at `tail`
-                ++st_empty;
+                if (INSTR) ++st_empty;
                 if (nb > 0) {
-                    if (tid < nb) cstart[head + tid + 1] = tail;
+                    if (tid < nb) cstart[my_rk + 1] = tail;
                     head += nb;
                 } else {
                     seg_a += seg_len;
                     if (seg_a == s_deg) {
-                        if (tid == 0) cstart[head + 1] = tail;
+                        if (tid == 0) cstart[my_rk + 1] = tail;
                         head += 1;
                         seg_a = 0;
                     }
@@ -716,7 +1045,7 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
                             const int k = __ffs((int)c) - 1;
                             c &= c - 1u;
                             int eff = 4 * (tid + it * B2_T) + k;
-                            if (nL > 0 && !(a.exp & 16)) {
+                            if (nL > 0 && !(INSTR && (a.exp & 16))) {
                                 const int w = k == 0 ? w4[it].x : k == 1 ? w4[it].y : k == 2 ? w4[it].z : w4[it].w;
                                 uint32_t h = ((uint32_t)w * 2654435761u) >> 22;
                                 for (;;) {
@@ -731,7 +1060,7 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
                     }
                 } else {
                     // too many duplicates for the list: smallest position per node through the key array (all-ones between uses)
-                    ++st_key;
+                    if (INSTR) ++st_key;
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         uint32_t c = cand[it];
@@ -766,7 +1095,7 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
                         }
                     }
                 }
-                if (nL > 0) ++st_dup;
+                if (INSTR && nL > 0) ++st_dup;
                 lds_barrier();
                 // place of every appending position in stream order = popcount prefix over the mask
                 const int wcnt = tid < B2_WORDS ? (int)__popc(winbits[tid]) : 0;
@@ -784,7 +1113,7 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
                 if (tid == 0) wpre[B2_WORDS] = total;
                 lds_barrier();
                 B2_TICK(6)
-                st_cand += (unsigned long long)total;
+                if (INSTR) st_cand += (unsigned long long)total;
                 // append: every candidate (hardware winner or duplicate) whose position carries the bit
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
@@ -798,7 +1127,8 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
                             const int rank = tail + wpre[p >> 5] + (int)__popc(word & ((1u << (p & 31)) - 1u));
                             if (rank < expect) {
                                 order[rank] = k == 0 ? w4[it].x : k == 1 ? w4[it].y : k == 2 ? w4[it].z : w4[it].w;
-                                tedge[rank] = (int32_t)(we[it] + (uint32_t)k);
+                                if (INSTR && (a.exp & 64)) __builtin_nontemporal_store((int32_t)(we[it] + (uint32_t)k), &tedge[rank]);  // (ablation: streaming stores for the array nobody reads back)
+                                else tedge[rank] = (int32_t)(we[it] + (uint32_t)k);
                             }
                         }
                     }
@@ -807,7 +1137,7 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
                 if (nb > 0) {
                     if (tid < nb) {
                         const int P = 4 * (int)soff[tid + 1];
-                        cstart[head + tid + 1] = tail + wpre[P >> 5] + (int)__popc(winbits[P >> 5] & ((1u << (P & 31)) - 1u));
+                        cstart[my_rk + 1] = tail + wpre[P >> 5] + (int)__popc(winbits[P >> 5] & ((1u << (P & 31)) - 1u));
                     }
                     tail += total;
                     head += nb;
@@ -815,7 +1145,7 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
                     tail += total;
                     seg_a += seg_len;
                     if (seg_a == s_deg) {
-                        if (tid == 0) cstart[head + 1] = tail;
+                        if (tid == 0) cstart[my_rk + 1] = tail;
                         head += 1;
                         seg_a = 0;
                     }
@@ -830,22 +1160,69 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
             B2_TICK(7)
             // Every node of the root's component is on the queue (its size is known from the component sweep): no edge of the
             // nodes still waiting can discover anything -- they are leaves of the tree (empty child ranges at the end of the queue).
-            if (tail == expect && head < tail && !(a.exp & 8)) {
-                for (int i = head + tid; i < expect; i += B2_T) cstart[i + 1] = expect;
-                if (level_end < tail) ++depth;  // the nodes behind level_end are one level deeper than the one being popped
+            if (tail == expect && (smode || head < tail) && !(INSTR && (a.exp & 8))) {
+                why = 3;
                 break;
             }
+          }
+          if (why == 0) break;
+          if (why == 1) {
+              __syncthreads();  // the level's queue entries have landed: the search reads them back
+              fenced = tail;
+              const int got = sparse_fathers<INSTR>(sph, (lds_u32_t *)bm, (lds_i32_t *)&wtot[0][0], (lds_i32_t *)&s_live, a.rowptr32, a.col, order, cstart,
+                                             a.sp_ux + (size_t)blockIdx.x * a.sp_cap * 2, a.sp_ui + (size_t)blockIdx.x * a.sp_cap * 2, slist,
+                                             a.sp_vis + (size_t)blockIdx.x * a.bm_words, a.sp_mark + (size_t)blockIdx.x * a.bm_words,
+                                             a.sp_mask + (size_t)blockIdx.x * ((size_t)a.n_node / 64 + 32), a.n_node, a.bm_words, a.sp_cap, a.sp_buckets,
+                                             head, tail, expect - tail);
+              if (got >= 0) {
+                  smode = true;
+                  s_cnt = got;
+                  s_lo = head;
+                  s_hi = tail;
+                  head = 0;
+                  pf_q = -1;
+                  if (INSTR) {
+                      ++st_sp;
+                      st_spu += (unsigned long long)wtot[1][0];
+                      st_spp += (unsigned long long)wtot[1][1];
+                      st_sps += (unsigned long long)got;
+                  }
+              }  // (else: the level is popped whole -- level_end has moved on, the test above does not fire again)
+              B2_TICK(8)
+              continue;
+          }
+          if (why == 2) {
+              fill_level(s_lo, s_hi);
+              B2_TICK(9)
+              head = s_hi;
+              smode = false;
+              pf_q = -1;
+              continue;
+          }
+          // why == 3.  Every node of the root's component is on the queue (its size is known from the component sweep): no edge of
+          // the nodes still waiting can discover anything -- they are leaves of the tree (empty child ranges at the end of the queue).
+          int first_open = head;  // first queue rank whose children may not be final
+          if (smode) {            // fathers not reached (and the one a segmented scan is inside) end at `expect` like everything behind them
+              fill_level(s_lo, s_hi);
+              first_open = head < s_cnt ? ldi(&slist[head]) : s_hi;
+              smode = false;
+          }
+          for (int i = first_open + tid; i < expect; i += B2_T) cstart[i + 1] = expect;
+          if (level_end < tail) ++depth;  // the nodes behind level_end are one level deeper than the one being popped
+          break;
         }
         __syncthreads();  // (all queue / cstart stores have landed: the child-count sweep below reads cstart)
-        if (a.prof && tid == 0) {
+        if (INSTR && a.prof && tid == 0) {
             atomicAdd(&a.prof[0], st_win); atomicAdd(&a.prof[1], st_fence); atomicAdd(&a.prof[2], st_cand); atomicAdd(&a.prof[3], st_slots);
-            atomicAdd(&a.prof[4], st_empty); atomicAdd(&a.prof[5], st_dup); atomicAdd(&a.prof[6], st_key);
-            for (int k = 0; k < 8; ++k) atomicAdd(&a.prof[8 + k], ph[k]);
+            atomicAdd(&a.prof[4], st_empty); atomicAdd(&a.prof[5], st_dup); atomicAdd(&a.prof[6], st_key); atomicAdd(&a.prof[7], st_sp);
+            for (int k = 0; k < 10; ++k) atomicAdd(&a.prof[8 + k], ph[k]);
+            atomicAdd(&a.prof[18], st_spu); atomicAdd(&a.prof[19], st_sps); atomicAdd(&a.prof[20], st_spp);
+            for (int k = 0; k < 7; ++k) atomicAdd(&a.prof[21 + k], sph[k]);
         }
 #undef B2_TICK
         // ---- per-root results: node count check, depth, longest list (1 + most children)
         int mc = 0;
-        if (tail == expect && !(a.exp & 32))
+        if (tail == expect && !(INSTR && (a.exp & 32)))
             for (int i = tid; i < tail; i += B2_T) mc = max(mc, cstart[i + 1] - cstart[i]);
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) mc = max(mc, __shfl_xor(mc, off, 64));
@@ -881,22 +1258,54 @@ extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t 
     // static LDS of the kernel (eoff, e0s, duplicate list, mask, counters) ~ 21.5 KB; the CU has 160 KB
     const bool v1 = getenv("GG_BFS_V1") != nullptr;  // the chunk kernel of rounds 2-3 (kept for A/B timing and as a second witness in the tests)
     hipFuncAttributes fa;
-    GG_HIP(ctx, hipFuncGetAttributes(&fa, v1 ? (const void *)bfs_order_kernel<true, false> : (const void *)bfs_order2_kernel<true>));
+    GG_HIP(ctx, hipFuncGetAttributes(&fa, v1 ? (const void *)bfs_order_kernel<true, false> : (const void *)bfs_order2_kernel<true, false>));
     const size_t lds_total = 160 * 1024;
     const bool lds_bm = !getenv("GG_BFS_GLOBAL_BITMAP") && fa.sharedSizeBytes + (size_t)bm_words * 4 <= lds_total;
 
     // scratch kept in the context: an epoch over non-resident roots calls this once per root batch
-    DevBuf &gkey = ctx->bfs_key, &gbm = ctx->bfs_bm, &misc = ctx->bfs_misc;
+    DevBuf &gkey = ctx->bfs_key, &gbm = ctx->bfs_bm, &misc = ctx->bfs_misc, &sp = ctx->bfs_sparse;
+    if (!ctx->bfs_rowptr32_valid) {  // 4-byte offsets for the kernels here (nnz < 2^31 was checked above)
+        if (ctx->bfs_rowptr32.reserve(sizeof(uint32_t) * ((size_t)n + 2)) != hipSuccess)
+            return fail(ctx, GG_ENOMEM, "gg_build_trees_device: %zu bytes for the 4-byte row offsets", sizeof(uint32_t) * ((size_t)n + 2));
+        std::vector<uint32_t> r32((size_t)n + 2);
+        for (int i = 0; i <= n; ++i) r32[i] = (uint32_t)ctx->h_rowptr[i];
+        r32[(size_t)n + 1] = r32[n];  // (8-byte loads at the last node read one word further)
+        GG_HIP(ctx, hipMemcpy(ctx->bfs_rowptr32.p, r32.data(), sizeof(uint32_t) * r32.size(), hipMemcpyHostToDevice));
+        ctx->bfs_rowptr32_valid = true;
+    }
     auto cleanup = [&]() {};
     const size_t key_bytes_before = gkey.bytes;
     hipError_t e = gkey.reserve(sizeof(uint32_t) * (size_t)grid * n);
     if (e == hipSuccess && !lds_bm) e = gbm.reserve(sizeof(uint32_t) * (size_t)grid * bm_words);
-    if (e == hipSuccess) e = misc.reserve(sizeof(int32_t) * 8 + sizeof(unsigned long long) * 16);
+    constexpr size_t misc_bytes = sizeof(int32_t) * 8 + sizeof(unsigned long long) * 32;
+    if (e == hipSuccess) e = misc.reserve(misc_bytes);
     if (e != hipSuccess) { cleanup(); return fail(ctx, GG_ENOMEM, "gg_build_trees_device: scratch: %s", hipGetErrorString(e)); }
+    // sparse levels (bfs_order2_kernel, LDS bitmap): GG_BFS_SPARSE=0 switches them off; _K / _MIN / _BUCKETS tune the choice
+    int sp_k = -1, sp_min = 0, sp_buckets = 16, sp_cap = 0;
+    size_t sp_off[6] = {0, 0, 0, 0, 0, 0};
+    if (!v1 && lds_bm && !(getenv("GG_BFS_SPARSE") && atoi(getenv("GG_BFS_SPARSE")) == 0)) {
+        sp_k = getenv("GG_BFS_SPARSE_K") ? std::max(0, atoi(getenv("GG_BFS_SPARSE_K"))) : 3;
+        sp_min = getenv("GG_BFS_SPARSE_MIN") ? std::max(1, atoi(getenv("GG_BFS_SPARSE_MIN"))) : 8192;
+        sp_buckets = getenv("GG_BFS_SPARSE_BUCKETS") ? std::min(1024, std::max(1, atoi(getenv("GG_BFS_SPARSE_BUCKETS")))) : 16;
+        sp_cap = sp_k > 0 ? n / sp_k + 64 : n;  // unseen nodes * k <= level nodes <= n
+        if (sp_cap > n) sp_cap = n;
+        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t sizes[6] = {sizeof(int32_t) * (size_t)grid * sp_cap * 2, sizeof(unsigned long long) * (size_t)grid * sp_cap * 2, sizeof(int32_t) * (size_t)grid * n,
+                                 sizeof(uint32_t) * (size_t)grid * bm_words, sizeof(uint32_t) * (size_t)grid * bm_words,
+                                 sizeof(unsigned long long) * (size_t)grid * ((size_t)n / 64 + 32)};
+        size_t tot = 0;
+        for (int i = 0; i < 6; ++i) { sp_off[i] = tot; tot += up(sizes[i]); }
+        e = sp.reserve(tot);
+        if (e != hipSuccess) {  // (not essential: without the scratch every level is popped whole)
+            (void)hipGetLastError();
+            sp_k = -1;
+        }
+    }
     BfsArgs a{};
     a.n_node = n;
     a.n_roots = n_roots;
     a.rowptr = ctx->g_rowptr;
+    a.rowptr32 = ctx->bfs_rowptr32.as<uint32_t>();
     a.col = ctx->g_col;
     a.roots = ctx->t_root;
     a.base = ctx->t_base;
@@ -911,19 +1320,37 @@ extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t 
     const bool prof = getenv("GG_BFS_PROFILE") != nullptr;
     a.exp = getenv("GG_BFS_EXPERIMENT") ? atoi(getenv("GG_BFS_EXPERIMENT")) : 0;
     a.prof = prof ? (unsigned long long *)(misc.as<int32_t>() + 8) : nullptr;
-    (void)hipMemsetAsync(misc.p, 0, sizeof(int32_t) * 8 + sizeof(unsigned long long) * 16, ctx->stream);
+    a.sp_k = sp_k;
+    a.sp_min = sp_min;
+    a.sp_buckets = sp_buckets;
+    a.sp_cap = sp_cap;
+    if (sp_k >= 0) {
+        char *const b = (char *)sp.p;
+        a.sp_ux = (int32_t *)(b + sp_off[0]);
+        a.sp_ui = (unsigned long long *)(b + sp_off[1]);
+        a.sp_s = (int32_t *)(b + sp_off[2]);
+        a.sp_vis = (uint32_t *)(b + sp_off[3]);
+        a.sp_mark = (uint32_t *)(b + sp_off[4]);
+        a.sp_mask = (unsigned long long *)(b + sp_off[5]);
+        (void)hipMemsetAsync(a.sp_mark, 0, sizeof(uint32_t) * (size_t)grid * bm_words, ctx->stream);  // (the kernel leaves it clean; a launch that failed may not have)
+    }
+    (void)hipMemsetAsync(misc.p, 0, misc_bytes, ctx->stream);
     if (gkey.bytes != key_bytes_before)  // new allocation: all-ones; the kernel restores every word it uses
         (void)hipMemsetAsync(gkey.p, 0xFF, sizeof(uint32_t) * (size_t)grid * n, ctx->stream);
     (void)hipEventRecord(ctx->ev0, ctx->stream);
     if (!v1) {
         const size_t dyn = lds_bm ? (size_t)bm_words * 4 : 0;
+        const bool instr = prof || a.exp != 0;
+        const void *fn = lds_bm ? (instr ? (const void *)bfs_order2_kernel<true, true> : (const void *)bfs_order2_kernel<true, false>)
+                                : (instr ? (const void *)bfs_order2_kernel<false, true> : (const void *)bfs_order2_kernel<false, false>);
         if (lds_bm) {
-            e = hipFuncSetAttribute((const void *)bfs_order2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+            e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
             if (e != hipSuccess) { cleanup(); return fail(ctx, GG_EHIP, "gg_build_trees_device: %zu bytes of LDS: %s", dyn, hipGetErrorString(e)); }
-            hipLaunchKernelGGL((bfs_order2_kernel<true>), dim3(grid), dim3(B2_T), dyn, ctx->stream, a);
-        } else {
-            hipLaunchKernelGGL((bfs_order2_kernel<false>), dim3(grid), dim3(B2_T), 0, ctx->stream, a);
         }
+        if (lds_bm && instr) hipLaunchKernelGGL((bfs_order2_kernel<true, true>), dim3(grid), dim3(B2_T), dyn, ctx->stream, a);
+        else if (lds_bm) hipLaunchKernelGGL((bfs_order2_kernel<true, false>), dim3(grid), dim3(B2_T), dyn, ctx->stream, a);
+        else if (instr) hipLaunchKernelGGL((bfs_order2_kernel<false, true>), dim3(grid), dim3(B2_T), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((bfs_order2_kernel<false, false>), dim3(grid), dim3(B2_T), 0, ctx->stream, a);
     } else if (lds_bm) {
         const size_t dyn = (size_t)bm_words * 4;
         const bool instr = prof || a.exp != 0;
@@ -943,17 +1370,25 @@ extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t 
     if (e == hipSuccess) e = hipMemcpyAsync(stats, a.stats, sizeof(stats), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess && prof && !v1) {
-        unsigned long long pc[16];
-        if (hipMemcpy(pc, a.prof, sizeof(pc), hipMemcpyDeviceToHost) == hipSuccess)
+        unsigned long long pc[32];
+        if (hipMemcpy(pc, a.prof, sizeof(pc), hipMemcpyDeviceToHost) == hipSuccess) {
             fprintf(stderr, "[bfs2 profile] %d roots, grid %d: per root %.0f windows (%.0f without a candidate, %.0f with in-window duplicates, %.0f through the key array), "
                     "%.1f full fences, %.0f nodes appended, %.0f quads scanned\n", n_roots, grid, (double)pc[0] / n_roots, (double)pc[4] / n_roots, (double)pc[5] / n_roots,
                     (double)pc[6] / n_roots, (double)pc[1] / n_roots, (double)pc[2] / n_roots, (double)pc[3] / n_roots);
-        {
-            const char *names[8] = {"setup: node info + scan", "window choice", "quad map", "scan: loads + tests", "scan barrier", "claim", "duplicates + prefix", "append + cstart (empty windows: all behind the scan)"};
+            fprintf(stderr, "[bfs2 profile] sparse levels (k %d, min %d, %d buckets): %.2f per root, %.0f unseen nodes listed, %.1f bucket passes, %.0f candidate fathers per root\n",
+                    sp_k, sp_min, sp_buckets, (double)pc[7] / n_roots, (double)pc[18] / n_roots, (double)pc[20] / n_roots, (double)pc[19] / n_roots);
+            const char *names[10] = {"setup: node info + scan", "window choice", "quad map", "scan: loads + tests", "scan barrier", "claim", "duplicates + prefix",
+                                     "append + cstart (empty windows: all behind the scan)", "sparse level: father search", "sparse level: cstart fill"};
             double tot = 0;
-            for (int k = 0; k < 8; ++k) tot += (double)pc[8 + k];
-            fprintf(stderr, "[bfs2 profile] wave-0 clock per window %.0f:", tot / (double)(pc[0] ? pc[0] : 1));
-            for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.1f%%", names[k], 100.0 * (double)pc[8 + k] / (tot > 0 ? tot : 1));
+            for (int k = 0; k < 10; ++k) tot += (double)pc[8 + k];
+            fprintf(stderr, "[bfs2 profile] wave-0 clock per root %.0f, per window %.0f:", tot / n_roots, tot / (double)(pc[0] ? pc[0] : 1));
+            for (int k = 0; k < 10; ++k) fprintf(stderr, " %s %.1f%%", names[k], 100.0 * (double)pc[8 + k] / (tot > 0 ? tot : 1));
+            fprintf(stderr, "\n");
+            const char *snames[7] = {"unseen list + adjacency ranges", "cstart zeros", "bucket bitmaps", "scans", "marks into LDS", "rank masks", "S list + bitmap restore"};
+            double stot = 0;
+            for (int k = 0; k < 7; ++k) stot += (double)pc[21 + k];
+            fprintf(stderr, "[bfs2 profile] father search, wave-0 clock per root %.0f:", stot / n_roots);
+            for (int k = 0; k < 7; ++k) fprintf(stderr, " %s %.1f%%", snames[k], 100.0 * (double)pc[21 + k] / (stot > 0 ? stot : 1));
             fprintf(stderr, "\n");
         }
     }
@@ -973,10 +1408,10 @@ extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t 
     cleanup();
     if (e != hipSuccess) return fail(ctx, GG_EHIP, "gg_build_trees_device: %s", hipGetErrorString(e));
     if (a.exp) fprintf(stderr, "[bfs experiment %d] kernel %.1f ms for %d roots (results invalid)\n", a.exp, ms, n_roots);
-    GG_CHECK(ctx, stats[2] == 0 || (a.exp & ~8), GG_EINVAL, "gg_build_trees_device: a BFS reached a different number of nodes than the component sweep of the graph");
+    GG_CHECK(ctx, stats[2] == 0 || (a.exp & ~(8 | 64 | 128)), GG_EINVAL, "gg_build_trees_device: a BFS reached a different number of nodes than the component sweep of the graph");
     ctx->tree_max_depth = stats[0];
     ctx->tree_max_list = stats[1];
-    ctx->t_edge_valid = (a.exp & ~8) == 0;
+    ctx->t_edge_valid = (a.exp & ~(8 | 64 | 128)) == 0;
     ctx->ctr.bfs_kernel_ms += ms;
     ctx->ctr.bfs_trees += n_roots;
     return GG_OK;

@@ -451,7 +451,7 @@ int gg_destroy(gg_ctx *ctx) {
                       &ctx->d_ptr, &ctx->g_node1, &ctx->g_node2, &ctx->g_reward, &ctx->g_cnt, &ctx->g_ptr, &ctx->scan_tmp,
                       &ctx->step_u, &ctx->step_v, &ctx->step_x, &ctx->sg_cnt, &ctx->sg_off, &ctx->sg_slot, &ctx->sg_list, &ctx->sg_rows, &ctx->sg_bias, &ctx->sg_tot, &ctx->sg_key, &ctx->touched_ptr, &ctx->x_cnt, &ctx->x_send_ids, &ctx->x_send_rows,
                       &ctx->x_recv_ids, &ctx->x_recv_rows, &ctx->x_nglob, &ctx->x_own, &ctx->st_item, &ctx->st_item2, &ctx->st_cur, &ctx->st_prev, &ctx->st_len,
-                      &ctx->st_alive, &ctx->st_rank, &ctx->bfs_key, &ctx->bfs_bm, &ctx->bfs_misc, &ctx->lv_pfx, &ctx->dc_keys, &ctx->dc_vals, &ctx->dc_words, &ctx->lv_beg, &ctx->lv_k, &ctx->lv_chunks, &ctx->lv_coff, &ctx->lv_scores, &ctx->lv_chunk_owner, &ctx->lv_prefix, &ctx->lv_big, &ctx->lv_fe, &ctx->fin_list,
+                      &ctx->st_alive, &ctx->st_rank, &ctx->bfs_key, &ctx->bfs_bm, &ctx->bfs_misc, &ctx->bfs_sparse, &ctx->bfs_rowptr32, &ctx->lv_pfx, &ctx->dc_keys, &ctx->dc_vals, &ctx->dc_words, &ctx->lv_beg, &ctx->lv_k, &ctx->lv_chunks, &ctx->lv_coff, &ctx->lv_scores, &ctx->lv_chunk_owner, &ctx->lv_prefix, &ctx->lv_big, &ctx->lv_fe, &ctx->fin_list,
                       &ctx->q3_store, &ctx->q3s_off, &ctx->ep_center, &ctx->ep_neighbor, &ctx->ep_label, &ctx->ep_node1, &ctx->ep_node2, &ctx->ep_reward};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : ctx->lv_ev)
@@ -497,6 +497,7 @@ int gg_set_graph_csr(gg_ctx *ctx, const int64_t *rowptr, const int32_t *col) {
     ctx->g_rev = nullptr;
     ctx->t_edge_valid = false;  // edge indices of resident trees named the old graph
     ctx->q3_store_ready = false;  // (the persistent Q3 bits are laid out by the degrees of the graph: epoch.hip)
+    ctx->bfs_rowptr32_valid = false;
     GG_HIP(ctx, hipMalloc((void **)&ctx->g_rowptr, sizeof(int64_t) * (n + 1)));
     GG_HIP(ctx, hipMalloc((void **)&ctx->g_col, sizeof(int32_t) * (std::max<int64_t>(nnz, 1) + 4)));  // (+ 16 B: the BFS reads adjacency in 16-byte quads that may start at the last entry)
     GG_HIP(ctx, hipMemcpy(ctx->g_rowptr, rowptr, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));

@@ -205,7 +205,8 @@ struct gg_ctx {
     bool g_begun = false;
     struct { int32_t n_slots = 0, n_sample = 0; uint64_t seed = 0; uint32_t stream = 0; } g_begun_args;
     gg::DevBuf touched_ptr;
-    gg::DevBuf bfs_key, bfs_bm, bfs_misc;  // scratch of gg_build_trees_device (bfs_gpu.hip)
+    gg::DevBuf bfs_key, bfs_bm, bfs_misc, bfs_sparse, bfs_rowptr32;  // scratch of gg_build_trees_device (bfs_gpu.hip)
+    bool bfs_rowptr32_valid = false;                                 // ... its 4-byte copy of the row offsets matches the graph set
     // epoch over root batches (epoch.hip): persistent Q3 bits of EVERY root -- words [q3s_off[v], q3s_off[v + 1]) for root node v,
     // ceil(deg(v) / 32) of them, bit (rank - 1) for the child of BFS rank `rank` as in t_q3 -- and the rows / pairs the batches
     // of the running epoch have produced so far

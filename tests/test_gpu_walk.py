@@ -231,14 +231,24 @@ def dense_layers_edges(widths=(1, 120, 150, 90), seed=3):
     return edges.astype(np.int32), nxt
 
 
-@pytest.fixture(params=["lds_bitmap", "global_bitmap", "v1_lds_bitmap", "v1_global_bitmap"])
+@pytest.fixture(params=["lds_bitmap", "lds_bitmap_whole_levels", "lds_bitmap_sparse_levels_forced", "lds_bitmap_sparse_levels_forced_3_buckets", "global_bitmap",
+                        "v1_lds_bitmap", "v1_global_bitmap"])
 def bfs_bitmap(request, monkeypatch):
     """Both instances of the BFS kernel: the visited bitmap in LDS (graphs up to ~1.06 M nodes) and in global memory
-    (GG_BFS_GLOBAL_BITMAP=1 forces what larger graphs -- BASELINE.json configs[4], 10^7 nodes -- take by themselves); and both
-    kernels: the scan / claim kernel of round 4 (default) and the chunk kernel of rounds 2-3 (GG_BFS_V1=1)."""
-    for var, on in (("GG_BFS_GLOBAL_BITMAP", "global" in request.param), ("GG_BFS_V1", request.param.startswith("v1"))):
-        if on:
-            monkeypatch.setenv(var, "1")
+    (GG_BFS_GLOBAL_BITMAP=1 forces what larger graphs -- BASELINE.json configs[4], 10^7 nodes -- take by themselves); both
+    kernels: the scan / claim kernel of round 4 (default) and the chunk kernel of rounds 2-3 (GG_BFS_V1=1); and, for the default
+    kernel with the LDS bitmap, its sparse-level path (a level popped through the candidate fathers of the unseen nodes only):
+    as the heuristic takes it (large late levels), never (GG_BFS_SPARSE=0), and FORCED on every level of every tree
+    (GG_BFS_SPARSE_K=0, GG_BFS_SPARSE_MIN=1), with 16 rank buckets and with 3."""
+    env = {"GG_BFS_GLOBAL_BITMAP": "1" if "global" in request.param else None,
+           "GG_BFS_V1": "1" if request.param.startswith("v1") else None,
+           "GG_BFS_SPARSE": "0" if "whole_levels" in request.param else None,
+           "GG_BFS_SPARSE_K": "0" if "forced" in request.param else None,
+           "GG_BFS_SPARSE_MIN": "1" if "forced" in request.param else None,
+           "GG_BFS_SPARSE_BUCKETS": "3" if "3_buckets" in request.param else None}
+    for var, val in env.items():
+        if val is not None:
+            monkeypatch.setenv(var, val)
         else:
             monkeypatch.delenv(var, raising=False)
     return request.param
