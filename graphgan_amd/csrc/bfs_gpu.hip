@@ -440,6 +440,7 @@ constexpr int B2_SLOTS = 4096;           // quads per window
 constexpr int B2_POS = 4 * B2_SLOTS;     // stream positions per window
 constexpr int B2_WORDS = B2_POS / 32;    // words of the position mask (one per thread of the first 8 wavefronts)
 constexpr bool B2_PF_TWO_STAGE = false;  // row pointers of the prefetched nodes issued behind the scan instead of right behind their ids (measured: 48.7 vs 47.2 us per tree)
+constexpr int B2_NARROW = 32;           // a node of up to this many quads writes its own quad -> node entries; the wavefront fills a wider one's together (~100 cycles per such node: with 8, the hub-rich levels 2-3 spent thousands of cycles per window there)
 constexpr int B2_HASH = 1024;            // in-window duplicates: LDS hash node -> smallest duplicate position ...
 constexpr int B2_DCAP = 768;             // ... for up to this many duplicates per window (more: the key array in global memory)
 
@@ -892,10 +893,10 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
                         soff[tid] = (uint16_t)excq;
                         degs[tid] = (uint16_t)deg;
                         if (tid == nb - 1) soff[nb] = (uint16_t)inclq;
-                        if (q <= 8)
+                        if (q <= B2_NARROW)
                             for (int k = 0; k < q; ++k) emap[excq + k] = (uint16_t)tid;
                     }
-                    unsigned long long wide = __ballot(tid < nb && q > 8);  // their quads are filled by the whole wavefront
+                    unsigned long long wide = __ballot(tid < nb && q > B2_NARROW);  // their quads are filled by the whole wavefront
                     while (wide) {
                         const int l = __ffsll((long long)wide) - 1;
                         wide &= wide - 1;
