@@ -439,7 +439,6 @@ constexpr int B2_NB = 1024;              // queue nodes per window
 constexpr int B2_SLOTS = 4096;           // quads per window
 constexpr int B2_POS = 4 * B2_SLOTS;     // stream positions per window
 constexpr int B2_WORDS = B2_POS / 32;    // words of the position mask (one per thread of the first 8 wavefronts)
-constexpr bool B2_PF_TWO_STAGE = false;  // row pointers of the prefetched nodes issued behind the scan instead of right behind their ids (measured: 48.7 vs 47.2 us per tree)
 constexpr int B2_NARROW = 32;           // a node of up to this many quads writes its own quad -> node entries; the wavefront fills a wider one's together (~100 cycles per such node: with 8, the hub-rich levels 2-3 spent thousands of cycles per window there)
 constexpr int B2_HASH = 1024;            // in-window duplicates: LDS hash node -> smallest duplicate position ...
 constexpr int B2_DCAP = 768;             // ... for up to this many duplicates per window (more: the key array in global memory)
@@ -775,7 +774,7 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
     }
         int seg_a = 0;           // > 0: the node at `head` is being scanned in segments, this many entries are done
         int pf_q = -1;           // queue index whose node this thread has prefetched
-        int pf_v = 0, pf_stage = 0, pf_rk = 0;
+        int pf_rk = 0;
         uint32_t pf_e0 = 0;
         int pf_deg = 0;
         // SPARSE LEVEL.  Late levels of a small-world graph pop most of the graph to discover a few nodes (1M / 10M bench
@@ -903,22 +902,20 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
                         const int qq = __shfl(q, l, 64), ss = __shfl(excq, l, 64);
                         for (int k = lane; k < qq; k += 64) emap[ss + k] = (uint16_t)((wv << 6) + l);
                     }
-                    // prefetch the next window's nodes, stage 1: their ids (queue entries below `fenced` have landed).  Stage 2 --
-                    // the row pointers, which need the id -- is issued behind the scan, when the id has long arrived: issued
-                    // here, the dependent pair stalled every thread for a memory round trip per window (a third of the kernel).
+                    // prefetch the next window's nodes (queue entries below `fenced` have landed): id -> row offsets -> degree.  The
+                    // compiler waits behind every link (s_waitcnt vmcnt(0) in the disassembly): ~2 memory round trips of every window.
+                    // Measured and not kept (r4_bfs_notes.txt): the row offsets issued behind the scan (48.7 vs 47.2 us per tree), the
+                    // row info of a whole level gathered at its start (39.9 vs 39.8), the chain stepped at the window's barriers (40.4
+                    // vs 37.9: the waits then cover the append's stores) -- hand-placed waits are what is left to try.
                     const int q2 = head + nb + tid;
                     pf_q = -1;
                     if (q2 < (smode ? s_cnt : fenced)) {
                         pf_rk = smode ? ldi(&slist[q2]) : q2;
-                        pf_v = ldi(&order[pf_rk]);
+                        const int pf_v = ldi(&order[pf_rk]);
+                        const uint2u rp2 = *reinterpret_cast<const uint2u *>(a.rowptr32 + pf_v);
+                        pf_e0 = rp2.x;
+                        pf_deg = (int)(rp2.y - rp2.x);
                         pf_q = q2;
-                        pf_stage = 1;
-                        if (!B2_PF_TWO_STAGE) {
-                            const uint2u rp2 = *reinterpret_cast<const uint2u *>(a.rowptr32 + pf_v);
-                            pf_e0 = rp2.x;
-                            pf_deg = (int)(rp2.y - rp2.x);
-                            pf_stage = 0;
-                        }
                     }
                 }
             }
@@ -980,12 +977,6 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
             if (__ballot(anyc != 0u) && lane == 0) s_any = 1;
             B2_TICK(3)
             lds_barrier();  // every test before any set: a later edge must not hide an earlier one
-            if (pf_stage == 1) {  // prefetch, stage 2: the row pointers of the next window's nodes
-                const uint2u rp2 = *reinterpret_cast<const uint2u *>(a.rowptr32 + pf_v);
-                pf_e0 = rp2.x;
-                pf_deg = (int)(rp2.y - rp2.x);
-                pf_stage = 0;
-            }
             B2_TICK(4)
 
             if (!s_any) {
