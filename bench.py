@@ -190,7 +190,10 @@ def comm_model(n, ld, d_rows_touched, g_rows_touched, d_pairs, g_pairs):
         packs = sum((P - 1) * min(n, 2 * pairs) * row_b for pairs in (d_pairs, g_pairs))
         owner = sum(f * t * row_b + f * min(n, P * t) * row_b for t in (d_rows_touched, g_rows_touched))
         out["P=%d" % P] = {"dense_rs_ag": dense, "row_packs_allgather": packs, "owner_partitioned_sparse": owner,
-                           "picked_today": "dense_rs_ag" if P * min(n, 2 * max(d_pairs, g_pairs)) >= 1.5 * n else "row_packs_allgather"}
+                           # (steps.hip::exchange_sparse: packs while world x capacity < 1.5 N rows; above that the owner-partitioned
+                           # exchange when the bound is >= GG_COMM_OWNER_MIN rows and ncclSend / ncclRecv resolve, else dense)
+                           "picked_today": ("row_packs_allgather" if P * min(n, 2 * max(d_pairs, g_pairs)) < 1.5 * n else
+                                            "owner_partitioned_sparse (dense_rs_ag if ncclSend / ncclRecv are missing or GG_COMM_OWNER=0)")}
     return out
 
 
