@@ -229,6 +229,82 @@ def test_two_rank_trainer_keeps_replicas_identical(tmp_path):
     assert r0["wrote"] == 2 * 3 and r1["wrote"] == 0                       # before training + after each of the 2 epochs, rank 0 only
 
 
+class _BatchedReplicaEngine(_ReplicaEngine):
+    """The same stand-in when the trees cannot be resident (every estimate exceeds the budget): the trainer runs its prepares
+    over root batches -- epoch_add WITHOUT a collective (the ranks' batch counts differ), epoch_commit WITH one (the max of the
+    ranks' row counts, as gg_epoch_commit does): a rank that commits once more or once less than the other hangs the test."""
+
+    def tree_bytes_estimate(self, n_roots): return 1e15 * max(1, n_roots)
+
+    def epoch_begin(self, reset_d=True, reset_g=True):
+        if not hasattr(self, "adds"):
+            self.adds, self.commits, self.ep_rows = 0, 0, [0, 0]
+        if reset_d: self.ep_rows[1] = 0
+        if reset_g: self.ep_rows[0] = 0
+
+    def epoch_add(self, roots, do_d, do_g, n_sample, seed, stream_d, stream_g):
+        assert len(roots) > 0
+        self.adds += 1
+        if do_d: self.ep_rows[1] += int(2 * self.deg[np.asarray(roots)].sum())
+        if do_g: self.ep_rows[0] += 37 * len(roots) + 5 * self.rank
+        return self.ep_rows[1], self.ep_rows[0]
+
+    def epoch_commit(self, which_d):
+        import torch
+        which = 1 if which_d else 0
+        t = torch.tensor([float(self.ep_rows[which])], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)   # (the engine's exchange_count_max: once per commit, not per batch)
+        self.commits += 1
+        self.rows[which] = self.ep_rows[which]
+        return self.rows[which]
+
+
+def _batched_trainer_worker(rank, world, port, base, out, update_ratio):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch
+    import torch.distributed as dist
+    from graphgan_amd import engine as eng_mod, graph_gan
+    from tests.test_gpu_e2e import make_cfg
+    eng_mod.Engine = _BatchedReplicaEngine
+    cfg = make_cfg(base, n_epochs=2, n_epochs_dis=2, n_epochs_gen=2, dis_interval=1, gen_interval=1, engine_seed=3, update_ratio=update_ratio,
+                   batch_size_dis=4096, batch_size_gen=4096, engine_batch_roots=900)
+    g = graph_gan.GraphGAN(cfg)
+    assert not g._all_resident and g._batch_roots == 900
+    g.train()
+    e = g.engine
+    state = torch.from_numpy(np.concatenate([e.model[0], e.model[1], np.array(e.steps + [e.commits], dtype=np.float64)]))
+    both = [torch.zeros_like(state) for _ in range(world)]
+    dist.all_gather(both, state)
+    np.savez(out % rank, a=both[0].numpy(), b=both[1].numpy(), adds=e.adds, commits=e.commits, n_roots=len(g.root_nodes))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("update_ratio", [1.0, 0.3])
+def test_two_rank_trainer_over_root_batches(tmp_path, update_ratio):
+    """The root-batched epoch (trees not resident: gg_epoch_*) on two ranks: the ranks add different numbers of root batches
+    (their shares and draws differ) without any collective in between, commit equally often, issue the same number of steps in
+    every pass, and end with identical replicas (graph_gan.py::_prepare_root_batches; reference schedule :144-176)."""
+    import torch.multiprocessing as mp
+    from tests.test_gpu_e2e import write_reference_layout
+    base = str(tmp_path)
+    write_reference_layout(base)
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_batched_trainer_worker, args=(2, _free_port(), base, out, update_ratio), nprocs=2, join=True)
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    for r in (r0, r1):
+        assert np.array_equal(r["a"], r["b"])                 # identical replicas, step counts and commit counts
+    assert np.array_equal(r0["a"], r1["a"]) and r0["a"][-2] > 0 and r0["a"][-3] > 0
+    assert r0["commits"] == r1["commits"] and r0["commits"] >= 4
+    if update_ratio >= 1:
+        # every prepare adds ceil(own roots / 900) batches; with update_ratio >= 1 the last D prepare of an outer epoch also samples
+        # the first G epoch's pairs (one BFS per root for both), so an outer epoch has 2 D prepares + 1 G-only prepare
+        for r in (r0, r1):
+            assert r["adds"] == 2 * 3 * -(-int(r["n_roots"]) // 900)
+    else:
+        assert r0["adds"] > 0 and r1["adds"] > 0
+
+
 class _ScoreEngine(object):
     """Engine.all_score_reduce on numpy (the stand-in of a rank's GPU: every rank holds the full table)."""
 
