@@ -254,7 +254,7 @@ def bfs_bitmap(request, monkeypatch):
     return request.param
 
 
-@pytest.mark.parametrize("case", ["small0", "small3", "star", "big_star", "ca_grqc", "powerlaw", "dense_layers"])
+@pytest.mark.parametrize("case", ["small0", "small3", "star", "big_star", "ca_grqc", "powerlaw", "dense_layers", "grid", "two_components"])
 def test_gpu_bfs_builds_the_reference_trees(ga, case, bfs_bitmap):
     """gg_build_trees_device == the host builder == reference construct_trees (pop order, child order,
     self-loops, isolated nodes, several components), offsets / lists / depth / longest list."""
@@ -276,6 +276,27 @@ def test_gpu_bfs_builds_the_reference_trees(ga, case, bfs_bitmap):
         d, n, graph = load_ca_grqc()
         rowptr, col = ga.graph_to_csr(n, graph)
         roots = np.arange(n, dtype=np.int32)
+    elif case == "grid":
+        # 120 x 100 lattice, edges shuffled: 218 levels of ~100 nodes -- long queues of tiny levels (forced sparse levels: 218 father
+        # searches per tree, most unseen nodes several levels away from the level being popped: they stay on the list through every pass)
+        W_, H_ = 120, 100
+        idx = np.arange(W_ * H_).reshape(H_, W_)
+        edges = np.concatenate([np.stack([idx[:, :-1].ravel(), idx[:, 1:].ravel()], 1), np.stack([idx[:-1].ravel(), idx[1:].ravel()], 1)])
+        edges = edges[np.random.RandomState(4).permutation(len(edges))].astype(np.int32)
+        n = W_ * H_
+        rowptr, col = ga.edges_to_csr(n, edges)
+        roots = np.array([0, W_ - 1, n // 2 + 17, n - 1, 4242], dtype=np.int32)
+    elif case == "two_components":
+        # two power-law components of 30 000 and 20 000 nodes with interleaved ids + 500 isolated nodes: the unseen-node list of a sparse
+        # level holds the OTHER component's nodes as well (they never hit; the search ends when only they are left), and when they
+        # outnumber the scratch the level falls back to being popped whole
+        na, nb_, iso = 30_000, 20_000, 500
+        ea, eb = ga.synth_powerlaw(na, 10, 1, 2), ga.synth_powerlaw(nb_, 8, 3, 4)
+        n = na + nb_ + iso
+        perm = np.random.RandomState(9).permutation(n).astype(np.int32)
+        edges = np.concatenate([perm[ea], perm[na + eb]]).astype(np.int32)
+        rowptr, col = ga.edges_to_csr(n, edges)
+        roots = np.concatenate([perm[:40], perm[na:na + 40], perm[na + nb_:na + nb_ + 3]]).astype(np.int32)
     else:
         n = 50_000
         rowptr, col = ga.edges_to_csr(n, ga.synth_powerlaw(n, 10, 1, 2))
