@@ -941,25 +941,35 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
             int4u w4[4];
             uint32_t we[4];     // CSR index of the quad's first entry
             uint32_t cand[4];   // entries whose target is unseen
+            // Straight-line on purpose: quad -> node -> CSR index for all four quads, then the four loads back to back, UNCONDITIONALLY
+            // (a thread without a quad re-reads entry 0).  With the load inside `if (s < T)` the compiler merged the loaded registers
+            // with the not-loaded case behind every branch -- a copy, hence an s_waitcnt vmcnt(0) behind EACH load: a thread's four
+            // loads were four memory round trips per window instead of one (rounds 3-4; found in the disassembly).
+            bool okq[4];
+            uint32_t cnt4[4];
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int s = tid + it * B2_T;
-                cand[it] = 0u;
-                we[it] = 0xffffffffu;  // (no quad)
-                if (s < T) {
-                    const int i = (int)emap[s];
-                    const int j0 = 4 * (s - (int)soff[i]);
-                    const int cnt = (int)degs[i] - j0;  // >= 1
-                    we[it] = e0s[i] + (uint32_t)j0;
-                    if (INSTR && (a.exp & 2)) {  // (ablation: computed targets instead of the adjacency loads)
-                        const uint32_t hx = we[it] * 2654435761u;
-                        w4[it].x = (int)(hx % (uint32_t)a.n_node); w4[it].y = (int)((hx >> 3) % (uint32_t)a.n_node);
-                        w4[it].z = (int)((hx >> 5) % (uint32_t)a.n_node); w4[it].w = (int)((hx >> 7) % (uint32_t)a.n_node);
-                    } else {
-                        w4[it] = *reinterpret_cast<const int4u *>(a.col + we[it]);
-                    }
-                    cand[it] = cnt >= 4 ? 15u : ((1u << cnt) - 1u);  // valid entries for now
+                okq[it] = s < T;
+                const int i = (int)emap[okq[it] ? s : 0];
+                const int j0 = okq[it] ? 4 * (s - (int)soff[i]) : 0;
+                cnt4[it] = (uint32_t)((int)degs[i] - j0);  // >= 1 for a real quad
+                we[it] = okq[it] ? e0s[i] + (uint32_t)j0 : 0u;
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                if (INSTR && (a.exp & 2)) {  // (ablation: computed targets instead of the adjacency loads)
+                    const uint32_t hx = we[it] * 2654435761u;
+                    w4[it].x = (int)(hx % (uint32_t)a.n_node); w4[it].y = (int)((hx >> 3) % (uint32_t)a.n_node);
+                    w4[it].z = (int)((hx >> 5) % (uint32_t)a.n_node); w4[it].w = (int)((hx >> 7) % (uint32_t)a.n_node);
+                } else {
+                    w4[it] = *reinterpret_cast<const int4u *>(a.col + we[it]);
                 }
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                cand[it] = !okq[it] ? 0u : cnt4[it] >= 4u ? 15u : ((1u << cnt4[it]) - 1u);  // valid entries for now
+                if (!okq[it]) we[it] = 0xffffffffu;  // (no quad)
             }
             uint32_t anyc = 0;
 #pragma unroll
