@@ -67,7 +67,7 @@ struct BfsArgs {
     int sp_cap;                // unseen nodes the scratch holds
     int32_t *sp_ux;            // [grid][2][sp_cap]   unseen nodes not served yet
     unsigned long long *sp_ui; // [grid][2][sp_cap]   their first CSR entry | degree << 32
-    int32_t *sp_s;             // [grid][n_node]   queue ranks of the candidate fathers, ascending
+    unsigned long long *sp_s;  // [grid][n_node]   the candidate fathers, ascending: queue rank | node id << 32
     uint32_t *sp_vis;          // [grid][bm_words] the visited bitmap while the LDS holds a bucket's
     uint32_t *sp_mark;         // [grid][bm_words] candidate fathers by node id (all-zero between uses)
     unsigned long long *sp_mask;  // [grid][n_node / 64 + 32] the same by rank: one ballot per 64 ranks of the level
@@ -476,7 +476,7 @@ typedef int32_t __attribute__((address_space(3))) lds_i32_t;
 template <bool INSTR>
 __device__ __forceinline__ int sparse_fathers(unsigned long long *sph, lds_u32_t *bm, lds_i32_t *wtot, lds_i32_t *s_live, const uint32_t *__restrict__ rowptr32,
                                            const int32_t *__restrict__ col, const int32_t *order, int32_t *cstart, int32_t *ux, unsigned long long *ui,
-                                           int32_t *slist, uint32_t *vis, uint32_t *mark, unsigned long long *smask, int n_node, int W, int sp_cap,
+                                           unsigned long long *slist, uint32_t *vis, uint32_t *mark, unsigned long long *smask, int n_node, int W, int sp_cap,
                                            int NBK, int lo, int hi, int Un) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int F = hi - lo;
@@ -695,10 +695,21 @@ __device__ __forceinline__ int sparse_fathers(unsigned long long *sph, lds_u32_t
     int pos = spre;
     for (int base = r0; base < r1; base += 64) {
         const unsigned long long m = ldq(&smask[(base - lo) >> 6]);
-        if ((m >> lane) & 1ull) slist[pos + lanes_below(m)] = base + lane;
+        if ((m >> lane) & 1ull) slist[pos + lanes_below(m)] = (unsigned long long)(base + lane);
         pos += (int)__popcll(m);
     }
     if (tid == 0) { wtot[16] = nU; wtot[17] = jdone; }
+    __syncthreads();
+    for (int p0 = tid; p0 < stot; p0 += 8 * B2_T) {  // ... and their node ids beside the ranks (what the windows' prefetch starts from)
+        int rk[8], vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rk[u] = p0 + u * B2_T < stot ? (int)ldq(&slist[p0 + u * B2_T]) : -1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) vv[u] = rk[u] >= 0 ? ldi(&order[rk[u]]) : -1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (rk[u] >= 0) slist[p0 + u * B2_T] = (unsigned long long)(uint32_t)rk[u] | ((unsigned long long)(uint32_t)vv[u] << 32);
+    }
     __syncthreads();
     SP_TICK(6)
 #undef SP_TICK
@@ -725,7 +736,7 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
     uint32_t *const bm = LDS_BM ? lds_bm : a.gbitmap + (size_t)blockIdx.x * a.bm_words;
     uint32_t *const gkey = a.gkey + (size_t)blockIdx.x * a.n_node;
     // SPARSE LEVEL scratch of this workgroup (LDS_BM only)
-    int32_t *const slist = a.sp_s + (size_t)blockIdx.x * a.n_node;
+    unsigned long long *const slist = a.sp_s + (size_t)blockIdx.x * a.n_node;
 
     auto seen = [&](int w) -> bool {
         if (LDS_BM) return (bm[w >> 5] >> (w & 31)) & 1u;
@@ -774,7 +785,17 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
     }
         int seg_a = 0;           // > 0: the node at `head` is being scanned in segments, this many entries are done
         int pf_q = -1;           // queue index whose node this thread has prefetched
-        int pf_rk = 0;
+        // THE PREFETCH of the next window's nodes is a chain node id -> row offsets -> degree (a sparse level's list carries the id
+        // beside the rank).  The compiler waits for a load where its value is first USED: requested and used in one place (rounds
+        // 2-4) the chain cost every window two memory round trips, ~5 k of its ~37 k cycles.  So each link is requested at one point
+        // of the window and used at a later one, where it has long arrived: the id behind the window choice, the row offsets behind
+        // the scan barrier, the degree in front of the append (claim and prefix touch LDS only; the append's stores come later).
+        // This only works with the explicit vmcnt(0) behind the scan barrier: without it the compiler's wait insertion carries
+        // "maybe still in flight" marks of the scan's loads into the loops of the claim and waits there for EVERYTHING in flight.
+        // pf_stage: 2 = the id is requested, 3 = the row offsets, 0 = pf_e0 / pf_deg hold them.
+        int pf_v = 0, pf_stage = 0;
+        unsigned long long pf_sl = 0ull;
+        uint2u pf_rp = {0u, 0u};
         uint32_t pf_e0 = 0;
         int pf_deg = 0;
         // SPARSE LEVEL.  Late levels of a small-world graph pop most of the graph to discover a few nodes (1M / 10M bench
@@ -858,12 +879,22 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
                 int deg = 0;
                 if (tid < navail) {
                     if (pf_q == head + tid) {
+                        if (pf_stage == 2) {  // (only behind a mode switch)
+                            pf_rp = *reinterpret_cast<const uint2u *>(a.rowptr32 + (smode ? (int)(pf_sl >> 32) : pf_v));
+                            pf_stage = 3;
+                        }
+                        if (pf_stage == 3) {  // (a window without a candidate ends before the chain does)
+                            pf_e0 = pf_rp.x;
+                            pf_deg = (int)(pf_rp.y - pf_rp.x);
+                            pf_stage = 0;
+                        }
                         e0 = pf_e0;
                         deg = pf_deg;
-                        my_rk = pf_rk;
+                        my_rk = smode ? (int)(uint32_t)pf_sl : head + tid;
                     } else {
-                        my_rk = smode ? ldi(&slist[head + tid]) : head + tid;
-                        const int v = ldi(&order[my_rk]);
+                        const unsigned long long sl = smode ? ldq(&slist[head + tid]) : 0ull;
+                        my_rk = smode ? (int)(uint32_t)sl : head + tid;
+                        const int v = smode ? (int)(sl >> 32) : ldi(&order[my_rk]);
                         const uint2u rp = *reinterpret_cast<const uint2u *>(a.rowptr32 + v);
                         e0 = rp.x;
                         deg = (int)(rp.y - rp.x);
@@ -902,20 +933,15 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
                         const int qq = __shfl(q, l, 64), ss = __shfl(excq, l, 64);
                         for (int k = lane; k < qq; k += 64) emap[ss + k] = (uint16_t)((wv << 6) + l);
                     }
-                    // prefetch the next window's nodes (queue entries below `fenced` have landed): id -> row offsets -> degree.  The
-                    // compiler waits behind every link (s_waitcnt vmcnt(0) in the disassembly): ~2 memory round trips of every window.
-                    // Measured and not kept (r4_bfs_notes.txt): the row offsets issued behind the scan (48.7 vs 47.2 us per tree), the
-                    // row info of a whole level gathered at its start (39.9 vs 39.8), the chain stepped at the window's barriers (40.4
-                    // vs 37.9: the waits then cover the append's stores) -- hand-placed waits are what is left to try.
+                    // the next window's nodes: the first link of the prefetch chain (queue entries below `fenced` have landed)
                     const int q2 = head + nb + tid;
                     pf_q = -1;
+                    pf_stage = 0;
                     if (q2 < (smode ? s_cnt : fenced)) {
-                        pf_rk = smode ? ldi(&slist[q2]) : q2;
-                        const int pf_v = ldi(&order[pf_rk]);
-                        const uint2u rp2 = *reinterpret_cast<const uint2u *>(a.rowptr32 + pf_v);
-                        pf_e0 = rp2.x;
-                        pf_deg = (int)(rp2.y - rp2.x);
+                        if (smode) pf_sl = ldq(&slist[q2]);
+                        else pf_v = ldi(&order[q2]);
                         pf_q = q2;
+                        pf_stage = 2;
                     }
                 }
             }
@@ -987,6 +1013,11 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
             if (__ballot(anyc != 0u) && lane == 0) s_any = 1;
             B2_TICK(3)
             lds_barrier();  // every test before any set: a later edge must not hide an earlier one
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), stated where the compiler sees it (free: the scan has just used its loads): see "THE PREFETCH"
+            if (pf_stage == 2) {  // second link: the row offsets (the id arrived under the scan)
+                pf_rp = *reinterpret_cast<const uint2u *>(a.rowptr32 + (smode ? (int)(pf_sl >> 32) : pf_v));
+                pf_stage = 3;
+            }
             B2_TICK(4)
 
             if (!s_any) {
@@ -1114,6 +1145,11 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
                 if (tid < B2_WORDS) wpre[tid] = wpr + winc - wcnt;
                 if (tid == 0) wpre[B2_WORDS] = total;
                 lds_barrier();
+                if (pf_stage == 3) {  // third link: the degree (the offsets arrived under claim and prefix; the append's stores are not waited for)
+                    pf_e0 = pf_rp.x;
+                    pf_deg = (int)(pf_rp.y - pf_rp.x);
+                    pf_stage = 0;
+                }
                 B2_TICK(6)
                 if (INSTR) st_cand += (unsigned long long)total;
                 // append: every candidate (hardware winner or duplicate) whose position carries the bit
@@ -1206,7 +1242,7 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
           int first_open = head;  // first queue rank whose children may not be final
           if (smode) {            // fathers not reached (and the one a segmented scan is inside) end at `expect` like everything behind them
               fill_level(s_lo, s_hi);
-              first_open = head < s_cnt ? ldi(&slist[head]) : s_hi;
+              first_open = head < s_cnt ? (int)ldq(&slist[head]) : s_hi;
               smode = false;
           }
           for (int i = first_open + tid; i < expect; i += B2_T) cstart[i + 1] = expect;
@@ -1292,7 +1328,7 @@ extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t 
         sp_cap = sp_k > 0 ? n / sp_k + 64 : n;  // unseen nodes * k <= level nodes <= n
         if (sp_cap > n) sp_cap = n;
         auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-        const size_t sizes[6] = {sizeof(int32_t) * (size_t)grid * sp_cap * 2, sizeof(unsigned long long) * (size_t)grid * sp_cap * 2, sizeof(int32_t) * (size_t)grid * n,
+        const size_t sizes[6] = {sizeof(int32_t) * (size_t)grid * sp_cap * 2, sizeof(unsigned long long) * (size_t)grid * sp_cap * 2, sizeof(unsigned long long) * (size_t)grid * n,
                                  sizeof(uint32_t) * (size_t)grid * bm_words, sizeof(uint32_t) * (size_t)grid * bm_words,
                                  sizeof(unsigned long long) * (size_t)grid * ((size_t)n / 64 + 32)};
         size_t tot = 0;
@@ -1330,7 +1366,7 @@ extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t 
         char *const b = (char *)sp.p;
         a.sp_ux = (int32_t *)(b + sp_off[0]);
         a.sp_ui = (unsigned long long *)(b + sp_off[1]);
-        a.sp_s = (int32_t *)(b + sp_off[2]);
+        a.sp_s = (unsigned long long *)(b + sp_off[2]);
         a.sp_vis = (uint32_t *)(b + sp_off[3]);
         a.sp_mark = (uint32_t *)(b + sp_off[4]);
         a.sp_mask = (unsigned long long *)(b + sp_off[5]);
