@@ -446,12 +446,16 @@ constexpr int B2_DCAP = 768;             // ... for up to this many duplicates p
 typedef int32_t int4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load from a 4-byte aligned address
 typedef uint32_t uint2u __attribute__((ext_vector_type(2), aligned(4)));  // 8-byte load from a 4-byte aligned address
 
-__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(v, off, 64);
-        if (lane >= off) v += o;
-    }
+// inclusive prefix sum over the wavefront with data-parallel-primitive moves (no LDS round trips: six dependent ds_bpermute made a
+// scan ~700 cycles, and a window has two): shifts by 1, 2, 4, 8 inside the rows of 16 lanes, then lane 15 of row 0 / 2 broadcast into
+// row 1 / 3 and lane 31 into rows 2-3 (the sequence of LLVM's own wave64 scan for this ISA family)
+__device__ __forceinline__ int wave_incl_scan(int v, int /*lane*/) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
     return v;
 }
 
