@@ -621,8 +621,8 @@ __device__ __forceinline__ int sparse_fathers(unsigned long long *sph, lds_u32_t
                         if (c > 2) hit |= probe(t4.z) ? 1 : 0;
                         if (c > 3) hit |= probe(t4.w) ? 1 : 0;
                     }
-                    hit |= __shfl_xor(hit, 1, 64);  // (the four lanes of a group are active together)
-                    hit |= __shfl_xor(hit, 2, 64);
+                    hit |= __builtin_amdgcn_mov_dpp(hit, 0xB1, 0xf, 0xf, true);  // quad_perm:[1,0,3,2] (the four lanes of a group are active together)
+                    hit |= __builtin_amdgcn_mov_dpp(hit, 0x4E, 0xf, 0xf, true);  // quad_perm:[2,3,0,1]
                     if (sub == 0 && xs[e] >= 0 && !hit) {  // not served: onto the next pass's list
                         const int p = __hip_atomic_fetch_add(s_live, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         nx[p] = xs[e];
@@ -816,13 +816,19 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
         int s_cnt = 0, s_lo = 0, s_hi = 0;
         int my_rk = 0;           // queue rank of the window node this thread holds
         auto fill_level = [&](int lo, int hi) {  // cstart[lo + 1 .. hi]: zeros (nodes outside S, fathers not reached) -> the running maximum
+            // (a contiguous share per wavefront, eight groups of 64 entries requested together: one group per iteration was a memory
+            // round trip + six LDS permutes per 64 entries, ~3 M cycles for a level of 0.85 M nodes -- and invisible in the phase
+            // clocks when the early exit calls it)
             __syncthreads();
             const int per = ((hi - lo + 64 * B2_WAVES - 1) / (64 * B2_WAVES)) * 64;
             const int r0 = lo + 1 + wv * per, r1 = min(r0 + per, hi + 1);
             int mx = 0;
-            for (int base = r0; base < r1; base += 64) {
-                const int i = base + lane;
-                if (i < r1) mx = max(mx, ldi(&cstart[i]));
+            for (int base = r0; base < r1; base += 512) {
+                int vals[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) vals[u] = base + 64 * u + lane < r1 ? ldi(&cstart[base + 64 * u + lane]) : 0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) mx = max(mx, vals[u]);
             }
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
@@ -832,17 +838,23 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
 #pragma unroll
             for (int i = 0; i < B2_WAVES; ++i)
                 if (i < wv) carry = max(carry, wtot[0][i]);
-            for (int base = r0; base < r1; base += 64) {
-                const int i = base + lane;
-                int val = i < r1 ? ldi(&cstart[i]) : 0;
+            for (int base = r0; base < r1; base += 512) {
+                int vals[8];
 #pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int o = __shfl_up(val, off, 64);
-                    if (lane >= off) val = max(val, o);
+                for (int u = 0; u < 8; ++u) vals[u] = base + 64 * u + lane < r1 ? ldi(&cstart[base + 64 * u + lane]) : 0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    int val = vals[u];  // inclusive running maximum over the wavefront (values >= 0: 0 is the identity), then the carry
+                    val = max(val, __builtin_amdgcn_update_dpp(0, val, 0x111, 0xf, 0xf, false));
+                    val = max(val, __builtin_amdgcn_update_dpp(0, val, 0x112, 0xf, 0xf, false));
+                    val = max(val, __builtin_amdgcn_update_dpp(0, val, 0x114, 0xf, 0xf, false));
+                    val = max(val, __builtin_amdgcn_update_dpp(0, val, 0x118, 0xf, 0xf, false));
+                    val = max(val, __builtin_amdgcn_update_dpp(0, val, 0x142, 0xa, 0xf, false));
+                    val = max(val, __builtin_amdgcn_update_dpp(0, val, 0x143, 0xc, 0xf, false));
+                    val = max(val, carry);
+                    if (base + 64 * u + lane < r1) cstart[base + 64 * u + lane] = val;
+                    carry = __builtin_amdgcn_readlane(val, 63);
                 }
-                val = max(val, carry);
-                if (i < r1) cstart[i] = val;
-                carry = __shfl(val, 63, 64);
             }
             __syncthreads();
         };
@@ -934,7 +946,7 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
                     while (wide) {
                         const int l = __ffsll((long long)wide) - 1;
                         wide &= wide - 1;
-                        const int qq = __shfl(q, l, 64), ss = __shfl(excq, l, 64);
+                        const int qq = __builtin_amdgcn_readlane(q, l), ss = __builtin_amdgcn_readlane(excq, l);
                         for (int k = lane; k < qq; k += 64) emap[ss + k] = (uint16_t)((wv << 6) + l);
                     }
                     // the next window's nodes: the first link of the prefetch chain (queue entries below `fenced` have landed)
