@@ -697,10 +697,15 @@ __device__ __forceinline__ int sparse_fathers(unsigned long long *sph, lds_u32_t
             if (i0 + u * B2_T < W) bm[i0 + u * B2_T] = vw[u];
     }
     int pos = spre;
-    for (int base = r0; base < r1; base += 64) {
-        const unsigned long long m = ldq(&smask[(base - lo) >> 6]);
-        if ((m >> lane) & 1ull) slist[pos + lanes_below(m)] = (unsigned long long)(base + lane);
-        pos += (int)__popcll(m);
+    for (int base = r0; base < r1; base += 512) {  // (eight masks requested together)
+        unsigned long long ms[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ms[u] = base + 64 * u < r1 ? ldq(&smask[(base + 64 * u - lo) >> 6]) : 0ull;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if ((ms[u] >> lane) & 1ull) slist[pos + lanes_below(ms[u])] = (unsigned long long)(base + 64 * u + lane);
+            pos += (int)__popcll(ms[u]);
+        }
     }
     if (tid == 0) { wtot[16] = nU; wtot[17] = jdone; }
     __syncthreads();
