@@ -831,10 +831,13 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const
                     acc = __builtin_fmaf(gc[cc].z, y[u][cc].z, acc);
                     acc = __builtin_fmaf(gc[cc].w, y[u][cc].w, acc);
                 }
-                acc = acc + __shfl_xor(acc, 8, 64);
-                acc = acc + __shfl_xor(acc, 4, 64);
-                acc = acc + __shfl_xor(acc, 2, 64);
-                acc = acc + __shfl_xor(acc, 1, 64);
+                // the xor butterfly over the 16 lanes (spec S1) as four rotate-and-add DPP instructions instead of four LDS permutes:
+                // bit-identical -- behind the step of width w every lane's value has period w inside its row of 16, so the partner
+                // a rotation by w reaches holds the same value as lane ^ w, and fp32 addition is commutative
+                acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x128, 0xf, 0xf, false));  // row_ror:8
+                acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x124, 0xf, 0xf, false));  // row_ror:4
+                acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x122, 0xf, 0xf, false));  // row_ror:2
+                acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x121, 0xf, 0xf, false));  // row_ror:1
                 if (t == j0 + u) mysc = acc + mybias;  // lane j keeps the score of candidate j
             }
         }
