@@ -240,7 +240,7 @@ struct gg_ctx {
     int64_t step_bound = 0;            // pairs any rank can contribute to the step being enqueued -> capacity of its row packs
     int64_t comm_steps_sparse = 0, comm_steps_dense = 0, comm_bytes_sent = 0;  // gg_comm_stats
     int32_t rank = 0, world = 1;
-    bool deterministic = false;  // GG_DETERMINISTIC=1: atomic-free gradient kernel for batches <= 256 pairs
+    bool deterministic = true;   // atomic-free single-workgroup gradient kernel for batches <= 256 pairs (the reference's batch 64); GG_DETERMINISTIC=0: atomics
     float dense_exchange_ratio = 1.5f;  // sparse exchange only while (rows touched over all ranks) < ratio * n_node (GG_COMM_DENSE_RATIO)
     int32_t fake_world = 0;  // GG_COMM_FAKE_WORLD=k: exercise the k-rank exchange code on one GPU (every rank = this one)
     gg::DevBuf x_cnt, x_send_ids, x_send_rows, x_recv_ids, x_recv_rows;  // sparse gradient exchange

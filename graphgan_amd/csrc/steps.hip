@@ -291,30 +291,48 @@ __global__ __launch_bounds__(256) void pair_grad16_kernel(const StepArgs a) {
     }
 }
 
-// Deterministic variant for the reference's small batches (n <= DET_MAX_PAIRS; GG_DETERMINISTIC=1):
-// ONE workgroup, no atomics.  Pair coefficients go to LDS; every distinct row of the batch is
-// owned by the first slot that names it (slots = [u_0..u_{n-1}, v_0..v_{n-1}]) and its owner sums
-// the row's contributions in slot order, so two runs give bit-identical tables (the atomic kernel's
-// fp32 sums depend on scheduling).  Used to diff against the atomic mode and for reproducible runs.
+// The reference's small batches (n <= DET_MAX_PAIRS, i.e. every step of the default schedule: batch 64,
+// graph_gan.py:149-157,168-176) -- ONE workgroup of 64 sixteen-lane groups, NO atomics, rows resident in LDS:
+//   phase 1  group p loads the two rows of pair p ONCE (global -> registers -> LDS), takes the dot product, the pair's
+//            coefficient dL/ds (discriminator.py:21-30 / generator.py:22-29) goes to LDS;
+//   phase 2  every distinct table row of the batch is owned by the first slot that names it (slots = [u_0..u_{n-1},
+//            v_0..v_{n-1}]); its owner sums the row's contributions in ascending slot order out of LDS and STORES the
+//            gradient row.
+// Two runs of one build therefore give bit-identical tables (the fp32 atomics of pair_grad_kernel add in scheduling
+// order), which is what lets the end-to-end tests compare whole schedules per seed, and the one dependent round of
+// global loads makes it no slower than the atomic kernel.  Default for these batches; GG_DETERMINISTIC=0 selects the
+// atomic kernel.  When 2 n rows do not fit the LDS (n > 64 with wide rows) the partner rows are re-read from the table.
 constexpr int DET_MAX_PAIRS = 256;
+constexpr int DET_THREADS = 1024;
+constexpr int DET_GROUPS = DET_THREADS / 16;
+constexpr size_t DET_LDS_ROW_BYTES = 144 * 1024;  // of the CU's 160 KB
 
-template <int NF>
-__global__ __launch_bounds__(256) void pair_grad_det_kernel(const StepArgs a) {
+__device__ __forceinline__ unsigned group16_ballot(bool pred) {  // the 16 predicate bits of this lane's row of 16 lanes
+    const uint64_t m = __ballot(pred);
+    return (unsigned)(m >> (threadIdx.x & 48)) & 0xffffu;
+}
+
+template <int NF, bool ROWS_IN_LDS>
+__global__ __launch_bounds__(DET_THREADS) void pair_grad_det_kernel(const StepArgs a) {
+    extern __shared__ float det_rows[];  // [2 n][ld] when ROWS_IN_LDS
     __shared__ int32_t ids[2 * DET_MAX_PAIRS];
     __shared__ float coef[DET_MAX_PAIRS], coefb[DET_MAX_PAIRS];
-    __shared__ uint8_t leader[2 * DET_MAX_PAIRS];
     const int t = threadIdx.x & 15, g = threadIdx.x >> 4;
-    const int n = a.n, nchunk = a.ld >> 2;
+    const int n = a.n, ld = a.ld, nchunk = ld >> 2;
     const float inv_n = a.n_glob ? 1.0f / (float)(*a.n_glob) : a.inv_n;
-    for (int s = threadIdx.x; s < 2 * n; s += 256) ids[s] = s < n ? a.u[s] : a.v[s - n];
+    for (int s = threadIdx.x; s < 2 * n; s += DET_THREADS) ids[s] = s < n ? a.u[s] : a.v[s - n];
     __syncthreads();
-    for (int p = g; p < n; p += 16) {
+    for (int p = g; p < n; p += DET_GROUPS) {
         const int iu = ids[p], iv = ids[n + p];
-        const float4 *ru = (const float4 *)(a.E + (int64_t)iu * a.ld);
-        const float4 *rv = (const float4 *)(a.E + (int64_t)iv * a.ld);
+        const float4 *ru = (const float4 *)(a.E + (int64_t)iu * ld);
+        const float4 *rv = (const float4 *)(a.E + (int64_t)iv * ld);
         float acc = 0.f;
         for (int c = t; c < nchunk; c += 16) {
             const float4 x = ru[c], y = rv[c];
+            if (ROWS_IN_LDS) {
+                ((float4 *)(det_rows + (size_t)p * ld))[c] = x;
+                ((float4 *)(det_rows + (size_t)(n + p) * ld))[c] = y;
+            }
             acc = __builtin_fmaf(x.x, y.x, acc);
             acc = __builtin_fmaf(x.y, y.y, acc);
             acc = __builtin_fmaf(x.z, y.z, acc);
@@ -339,44 +357,64 @@ __global__ __launch_bounds__(256) void pair_grad_det_kernel(const StepArgs a) {
             coefb[p] = a.is_d ? ds + a.lambda * bv : ds;
         }
     }
-    for (int s = threadIdx.x; s < 2 * n; s += 256) {
-        bool first = true;
-        const int r = ids[s];
-        for (int s2 = 0; s2 < s; ++s2) first &= ids[s2] != r;
-        leader[s] = first;
-    }
     __syncthreads();
-    for (int s = g; s < 2 * n; s += 16) {
-        if (!leader[s]) continue;
+    for (int s = g; s < 2 * n; s += DET_GROUPS) {  // (uniform per group: the ballots below see whole rows of 16 lanes)
         const int r = ids[s];
-        const float *own = a.E + (int64_t)r * a.ld;
-        float acc[NF], accb = 0.f;
-#pragma unroll
-        for (int i = 0; i < NF; ++i) acc[i] = 0.f;
-        for (int s2 = s; s2 < 2 * n; ++s2) {
-            if (ids[s2] != r) continue;
-            const int p = s2 < n ? s2 : s2 - n;
-            const int partner = s2 < n ? ids[n + p] : ids[p];
-            const float *prow = a.E + (int64_t)partner * a.ld;
-            const float c = coef[p];
-#pragma unroll
-            for (int i = 0; i < NF; ++i) {
-                const int f = t + 16 * i;
-                if (f < a.ld) acc[i] += c * prow[f] + a.lambda * own[f];
-            }
-            if (s2 >= n) accb += coefb[p];
-        }
-        float *gr = a.gE + (int64_t)r * a.ld;
+        unsigned earlier = 0;
+        for (int base = 0; base < s; base += 16) earlier |= group16_ballot(base + t < s && ids[base + t] == r);
+        if (earlier) continue;  // not the first slot of this row
+        float own[NF], acc[NF], accb = 0.f;
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
             const int f = t + 16 * i;
-            if (f < a.ld) gr[f] = acc[i];
+            own[i] = f < ld ? (ROWS_IN_LDS ? det_rows[(size_t)s * ld + f] : a.E[(int64_t)r * ld + f]) : 0.f;
+            acc[i] = 0.f;
+        }
+        for (int base = s & ~15; base < 2 * n; base += 16) {
+            unsigned m = group16_ballot(base + t >= s && base + t < 2 * n && ids[base + t] == r);
+            while (m) {  // ascending slot order
+                const int s2 = base + __builtin_ctz(m);
+                m &= m - 1;
+                const int p = s2 < n ? s2 : s2 - n;
+                const int ps = s2 < n ? n + p : p;  // the partner's slot
+                const float c = coef[p];
+                const float *prow = ROWS_IN_LDS ? det_rows + (size_t)ps * ld : a.E + (int64_t)ids[ps] * ld;
+#pragma unroll
+                for (int i = 0; i < NF; ++i) {
+                    const int f = t + 16 * i;
+                    if (f < ld) acc[i] += c * prow[f] + a.lambda * own[i];
+                }
+                if (s2 >= n) accb += coefb[p];
+            }
+        }
+        float *gr = a.gE + (int64_t)r * ld;
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int f = t + 16 * i;
+            if (f < ld) gr[f] = acc[i];
         }
         if (t == 0) {
             a.gb[r] = accb;
             if (a.track) a.touched[r] = 1;
         }
     }
+}
+
+template <int NF>
+static hipError_t launch_pair_grad_det(gg_ctx *ctx, const StepArgs &s) {
+    const size_t row_bytes = (size_t)2 * s.n * s.ld * sizeof(float);
+    if (row_bytes <= DET_LDS_ROW_BYTES) {
+        static bool raised = false;  // (one context per process drives one device; the attribute belongs to the function)
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute((const void *)pair_grad_det_kernel<NF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DET_LDS_ROW_BYTES);
+            if (e != hipSuccess) return e;
+            raised = true;
+        }
+        hipLaunchKernelGGL((pair_grad_det_kernel<NF, true>), dim3(1), dim3(DET_THREADS), row_bytes, ctx->stream, s);
+    } else {
+        hipLaunchKernelGGL((pair_grad_det_kernel<NF, false>), dim3(1), dim3(DET_THREADS), 0, ctx->stream, s);
+    }
+    return hipSuccess;
 }
 
 // G pass over whole walks (fast mode: one fused batch = every prepared pair, graph_gan.py:168-176 with
@@ -1070,10 +1108,12 @@ int run_step(gg_ctx *ctx, int which, const int32_t *d_u, const int32_t *d_v, con
     s.ppg = n >= 16384 ? PAIRS_PER_GROUP : (n >= 2048 ? 4 : 1);
     if (ctx->deterministic && n <= DET_MAX_PAIRS) {
         const int nfd = (ctx->ld + 15) / 16;
-        if (nfd <= 4) hipLaunchKernelGGL(pair_grad_det_kernel<4>, dim3(1), dim3(256), 0, ctx->stream, s);
-        else if (nfd <= 8) hipLaunchKernelGGL(pair_grad_det_kernel<8>, dim3(1), dim3(256), 0, ctx->stream, s);
-        else if (nfd <= 16) hipLaunchKernelGGL(pair_grad_det_kernel<16>, dim3(1), dim3(256), 0, ctx->stream, s);
-        else hipLaunchKernelGGL(pair_grad_det_kernel<32>, dim3(1), dim3(256), 0, ctx->stream, s);
+        hipError_t e;
+        if (nfd <= 4) e = launch_pair_grad_det<4>(ctx, s);
+        else if (nfd <= 8) e = launch_pair_grad_det<8>(ctx, s);
+        else if (nfd <= 16) e = launch_pair_grad_det<16>(ctx, s);
+        else e = launch_pair_grad_det<32>(ctx, s);
+        GG_HIP(ctx, e);
         return apply_optimizer(ctx, which, n);
     }
     const int groups = cdiv(n, s.ppg);
@@ -1620,7 +1660,7 @@ static int run_pass(gg_ctx *ctx, int which, const int64_t *starts, int64_t n_bat
     // per-kernel timing (gradient kernel | exchange + optimizer kernel) of every profile_every-th fused pass; the events
     // are read at the next host synchronisation (harvest_timings), the pass itself does not wait for them
     ctx->tm_cur = -1;
-    if (whole && ctx->profile_every > 0 && (ctx->pass_call_index[which]++ % ctx->profile_every) == 0 && !ctx->deterministic) {
+    if (whole && ctx->profile_every > 0 && (ctx->pass_call_index[which]++ % ctx->profile_every) == 0 && !(ctx->deterministic && rows <= DET_MAX_PAIRS)) {
         ctx->tm_cur = timing_slot(ctx);
         if (ctx->tm_cur >= 0) GG_HIP(ctx, hipEventRecord(ctx->tm_ev[ctx->tm_cur][0], ctx->stream));
     }

@@ -107,18 +107,40 @@ struct WalkArgs {
     int32_t exp;             // GG_WALK_EXPERIMENT: timing ablations (results are then WRONG): 1 / 2 = the weights kernel skips its big / small tasks, 64 / 32 = runs them twice (results stay right), 8 = per-level row counts
 };
 
-__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint64_t o = __shfl_up(v, off, 64);
-        if (lane >= off) v += o;
-    }
+// ---- cross-lane moves without an LDS round trip (DPP): shifts / rotations inside a row of 16 lanes, row broadcasts across rows.
+// (UNVALIDATED ON HARDWARE in this branch: compiled and checked against a CPU model of the DPP controls only.)
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint64_t dpp_u64(uint64_t v) {  // both halves moved by the same control; lanes without a source get 0
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+    return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+__device__ __forceinline__ uint64_t group16_incl_scan_u64_dpp(uint64_t v) {  // inclusive prefix sum inside every row of 16 lanes
+    v += dpp_u64<0x111>(v);  // row_shr:1
+    v += dpp_u64<0x112>(v);  // row_shr:2
+    v += dpp_u64<0x114>(v);  // row_shr:4
+    v += dpp_u64<0x118>(v);  // row_shr:8
     return v;
 }
-
+__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, int /*lane*/) {
+    v = group16_incl_scan_u64_dpp(v);
+    v += dpp_u64<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_u64<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false)); }
+__device__ __forceinline__ float group16_max_f32(float v) {  // maximum over every row of 16 lanes, in all its lanes (rotations: every lane has a source)
+    v = fmaxf(v, dpp_f32<0x128>(v));  // row_ror:8
+    v = fmaxf(v, dpp_f32<0x124>(v));
+    v = fmaxf(v, dpp_f32<0x122>(v));
+    v = fmaxf(v, dpp_f32<0x121>(v));
+    return v;
+}
 __device__ __forceinline__ float wave_max_f32(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    v = group16_max_f32(v);
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
     return v;
 }
 
@@ -756,14 +778,7 @@ __global__ void level_expand_kernel(const WalkArgs a) {
     for (int i = 0; i < n; ++i) write_chunk_desc(a.lv_chunk_desc, c0 + i, cur, k, hf, father, beg, i, pfx);
 }
 
-__device__ __forceinline__ uint64_t group16_incl_scan_u64(uint64_t v, int t) {
-#pragma unroll
-    for (int off = 1; off < 16; off <<= 1) {
-        const uint64_t o = __shfl_up(v, off, 16);
-        if (t >= off) v += o;
-    }
-    return v;
-}
+__device__ __forceinline__ uint64_t group16_incl_scan_u64(uint64_t v, int /*t*/) { return group16_incl_scan_u64_dpp(v); }
 
 // One 16-lane group per 16-candidate chunk (grid-stride): four independent chunks in flight per
 // wavefront, so the short dependent chain (descriptor -> ids + current row -> neighbour rows) of
@@ -845,8 +860,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void level_score_kernel(const
             // the whole distribution sits in this group's lanes: max, exact fixed-point weights and their
             // inclusive prefix sums (spec S2, S3) right here -- no score round trip, no second kernel
             float mx = (t < nblock) ? mysc : -INFINITY;
-#pragma unroll
-            for (int off2 = 8; off2 >= 1; off2 >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off2, 16));
+            mx = group16_max_f32(mx);
             const uint64_t wgt = (t < nblock) ? weight_fix40(exp_spec(mysc - mx)) : 0ull;
             const uint64_t C = group16_incl_scan_u64(wgt, t);
             const int64_t pfx = ((int64_t)d2.z << 32) | (unsigned)d2.y;
@@ -927,8 +941,7 @@ __device__ __forceinline__ void weights_small_tasks(const WalkArgs &a, const int
         float mx = v[u][0];
 #pragma unroll
         for (int i = 1; i < PER_LANE; ++i) mx = fmaxf(mx, v[u][i]);
-#pragma unroll
-        for (int off = 8; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 16));
+        mx = group16_max_f32(mx);
         uint64_t carry = 0;
 #pragma unroll
         for (int i = 0; i < PER_LANE; ++i) {
@@ -937,7 +950,7 @@ __device__ __forceinline__ void weights_small_tasks(const WalkArgs &a, const int
                 const uint64_t wgt = (jj < k) ? weight_fix40(exp_spec(v[u][i] - mx)) : 0ull;
                 const uint64_t C = carry + group16_incl_scan_u64(wgt, t);
                 if (jj < k) pf[u][jj] = C;
-                if (PER_LANE > 1) carry = __shfl(C, 15, 16);
+                if (PER_LANE > 1) carry = dpp_u64<0x15F>(C);  // row_newbcast:15: the row's last lane to all its lanes
             }
         }
     }
