@@ -233,6 +233,44 @@ def strict_mode_line(ga, _lib, seconds=1.5):
     return out
 
 
+def strict_mode_at_scale(ga, _lib, n, rowptr, col, emb, roots, n_sample_gen, seed, n_steps=3000):
+    """SURVEY.md section 8d metric 2(i) on the BENCH graph: the reference's batching -- contiguous slices of 64 rows of the
+    prepare-order lists in shuffled order, one optimizer step per slice (graph_gan.py:149-157,168-176) -- with the scale-mode
+    optimizers (lazy Adam, SGD: a dense TF1-Adam sweep of a 1M x 128 table per 64 pairs is 1.5 GB of traffic per step and is
+    what the fixture-sized line above prices), over the resident prepared rows of one step of `roots`, >= n_steps optimizer
+    steps per model, wall clock around whole passes.  One launch per step: the atomic-free gradient kernel applies the
+    optimizer itself (pair_grad_det_kernel, steps.hip)."""
+    out = {}
+    for name, opt in (("adam_lazy", _lib.GG_OPT_ADAM_LAZY), ("sgd", _lib.GG_OPT_SGD)):
+        eng = ga.Engine(emb, emb, optimizer=opt)
+        eng.set_graph_csr(rowptr, col)
+        eng.build_trees(roots, device=True)
+        eng.set_profiling(0)
+        slots = np.arange(len(roots), dtype=np.int32)
+        rows = eng.prepare_d(slots, seed, 0, fetch=False)
+        pairs = eng.prepare_g(slots, n_sample_gen, seed, 1, fetch=False)
+        rs = np.random.RandomState(0)
+        line = {}
+        for which, total, fn in (("d", rows, eng.d_pass), ("g", pairs, eng.g_pass)):
+            starts = np.arange(0, total, 64, dtype=np.int64)
+            rs.shuffle(starts)
+            starts = starts[:n_steps]
+            fn(starts[:50], 64)
+            eng.synchronize()
+            t0 = time.perf_counter()
+            fn(starts, 64)
+            eng.synchronize()
+            dt = time.perf_counter() - t0
+            line["%s_steps" % which] = int(len(starts))
+            line["%s_pairs_per_sec" % which] = 64.0 * len(starts) / dt
+            line["%s_us_per_step" % which] = 1e6 * dt / len(starts)
+        out[name] = line
+        eng.close()
+    out["config"] = ("the bench graph (%d nodes), n_emb=%d, batch 64 (the reference's batching), lazy Adam / SGD, resident prepared rows of %d roots; "
+                     "the headline d_step_pairs_per_sec / g_step_pairs_per_sec use ONE fused batch per pass instead" % (n, emb.shape[1], len(roots)))
+    return out
+
+
 def self_launch(n, script=None):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves -- one process per GPU with the
     environment torch.distributed.run would export (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT; rendezvous
@@ -573,6 +611,9 @@ def main():
         out["config"]["with_tree_build_s_per_batch"] = e2e_dt / args.fresh_batches
     if world == 1 and not args.no_strict:
         out["strict_mode"] = strict_mode_line(ga, _lib)
+        out["strict_mode_1m"] = strict_mode_at_scale(ga, _lib, n, rowptr, col, emb, roots[:2048], args.n_sample_gen, args.seed)
+        out["config"]["pairs_per_sec_batching"] = ("d_step_pairs_per_sec / g_step_pairs_per_sec: one fused batch per pass (fast mode, SURVEY 8d 2(ii)); "
+                                                   "the reference's batch-64 schedule on this graph: strict_mode_1m")
     if world == 1 and not args.no_cpu_baseline:
         bias = eng.get_bias(0)
         embg = eng.get_embeddings(0)

@@ -1404,8 +1404,8 @@ extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t 
         (void)hipMemsetAsync(a.sp_mark, 0, sizeof(uint32_t) * (size_t)grid * bm_words, ctx->stream);  // (the kernel leaves it clean; a launch that failed may not have)
     }
     (void)hipMemsetAsync(misc.p, 0, misc_bytes, ctx->stream);
-    if (gkey.bytes != key_bytes_before)  // new allocation: all-ones; the kernel restores every word it uses
-        (void)hipMemsetAsync(gkey.p, 0xFF, sizeof(uint32_t) * (size_t)grid * n, ctx->stream);
+    if (gkey.bytes != key_bytes_before)  // new allocation: all-ones over ALL of it (reserve over-allocates: a later, somewhat larger grid reuses
+        (void)hipMemsetAsync(gkey.p, 0xFF, gkey.bytes, ctx->stream);  // the buffer without passing here again); the kernel restores every word it uses
     (void)hipEventRecord(ctx->ev0, ctx->stream);
     if (!v1) {
         const size_t dyn = lds_bm ? (size_t)bm_words * 4 : 0;

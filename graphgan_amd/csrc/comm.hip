@@ -154,12 +154,23 @@ int comm_exchange_v(gg_ctx *ctx, const float *send, const int64_t *send_off, con
                     const int64_t *recv_cnt) {
     if (!ctx->comm) return GG_OK;
     GG_NCCL(ctx, g_rccl.GroupStart());
-    for (int r = 0; r < ctx->world; ++r) {
+    // the group is ALWAYS closed: a Send / Recv that fails must not leave later collectives queued into a dangling group
+    int first_err = 0;
+    const char *what = "";
+    for (int r = 0; r < ctx->world && first_err == 0; ++r) {
         if (r == ctx->rank) continue;
-        if (send_cnt[r]) GG_NCCL(ctx, g_rccl.Send(send + send_off[r], (size_t)send_cnt[r], NCCL_FLOAT32, r, ctx->comm, ctx->stream));
-        if (recv_cnt[r]) GG_NCCL(ctx, g_rccl.Recv(recv + recv_off[r], (size_t)recv_cnt[r], NCCL_FLOAT32, r, ctx->comm, ctx->stream));
+        if (send_cnt[r]) {
+            first_err = g_rccl.Send(send + send_off[r], (size_t)send_cnt[r], NCCL_FLOAT32, r, ctx->comm, ctx->stream);
+            what = "ncclSend";
+        }
+        if (first_err == 0 && recv_cnt[r]) {
+            first_err = g_rccl.Recv(recv + recv_off[r], (size_t)recv_cnt[r], NCCL_FLOAT32, r, ctx->comm, ctx->stream);
+            what = "ncclRecv";
+        }
     }
-    GG_NCCL(ctx, g_rccl.GroupEnd());
+    const int end_err = g_rccl.GroupEnd();
+    if (first_err != 0) return fail(ctx, GG_ECOMM, "comm_exchange_v: %s -> %s (the other ranks are left in their half of the exchange: destroy the communicator)", what, g_rccl.GetErrorString(first_err));
+    if (end_err != 0) return fail(ctx, GG_ECOMM, "comm_exchange_v: ncclGroupEnd -> %s", g_rccl.GetErrorString(end_err));
     return GG_OK;
 }
 

@@ -106,6 +106,14 @@ int gg_epoch_add(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, int32_t do_
                  uint32_t stream_d, uint32_t stream_g, int64_t *rows_total_out, int64_t *pairs_total_out) {
     if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
     GG_CHECK(ctx, n_roots >= 0 && (roots || n_roots == 0), GG_EINVAL, "gg_epoch_add: bad roots");
+    if (n_roots > 1 && (do_d || do_g)) {
+        // the roots of a batch must be distinct: two slots of one root would restore from and save to the SAME words of the Q3
+        // store, and the bits the first slot's D-mode walks set would be overwritten by the second slot's save
+        std::vector<int32_t> sorted(roots, roots + n_roots);
+        std::sort(sorted.begin(), sorted.end());
+        const auto dup = std::adjacent_find(sorted.begin(), sorted.end());
+        GG_CHECK(ctx, dup == sorted.end(), GG_EINVAL, "gg_epoch_add: root %d appears twice in one batch", dup == sorted.end() ? -1 : *dup);
+    }
     GG_HIP(ctx, hipSetDevice(ctx->device));
     int rc = ensure_q3_store(ctx);
     if (rc != GG_OK) return rc;

@@ -120,6 +120,26 @@ static int upload_table(gg_ctx *ctx, float *dst, const float *src) {
     return GG_OK;
 }
 
+// gg_ctx::table_bad[which] = "a table of model `which` holds a non-finite value": recomputed whenever the host replaces a table
+// (create, gg_set_embeddings / gg_set_bias, gg_load_state); between those, the optimizer kernels raise it when they write one.
+__global__ __launch_bounds__(256) void table_finite_kernel(const float *E, const float *b, int64_t nE, int64_t nb, unsigned long long *bad) {
+    bool any = false;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nE; i += stride) any |= !__builtin_isfinite(E[i]);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += stride) any |= !__builtin_isfinite(b[i]);
+    if (any) *bad = 1ull;
+}
+
+int rescan_table_finite(gg_ctx *ctx, int which) {
+    const Model &M = ctx->model[which];
+    unsigned long long *w = ctx->table_bad.as<unsigned long long>() + which;
+    GG_HIP(ctx, hipMemsetAsync(w, 0, sizeof(unsigned long long), ctx->stream));
+    const int64_t nE = (int64_t)ctx->n_node * ctx->ld;
+    hipLaunchKernelGGL(table_finite_kernel, dim3((unsigned)std::min<int64_t>(2048, (nE + 255) / 256)), dim3(256), 0, ctx->stream, M.E, M.b, nE, (int64_t)ctx->n_node, w);
+    GG_HIP(ctx, hipGetLastError());
+    return GG_OK;
+}
+
 }  // namespace gg
 
 using namespace gg;
@@ -302,7 +322,7 @@ int gg::walk_finalize(gg_ctx *ctx, bool *retried) {
     }
     if (c[3] || c[6]) generator_changed(ctx);  // a failed launch leaves nothing behind that a later one may reuse
     if (c[3]) return fail(ctx, GG_ECAPACITY, "walk: a path needed more than stride=%d entries", ctx->w_stride);
-    if (c[6]) return fail(ctx, GG_EINVAL, "walk: non-finite generator scores (a softmax had total weight 0)");
+    if (c[6]) return fail(ctx, GG_EINVAL, "walk: non-finite generator scores (a softmax had total weight 0, or the generator's tables hold a non-finite value)");
     return GG_OK;
 }
 
@@ -420,6 +440,11 @@ int gg_create(int32_t n_node, int32_t n_emb, const float *emb_gen, const float *
         GG_HIP(ctx, hipMemset(ctx->touched_cnt, 0, sizeof(int32_t) * 4));
         GG_HIP(ctx, hipMalloc((void **)&ctx->dev_ctr, sizeof(unsigned long long) * gg_ctx::PIN_WORDS));
         GG_HIP(ctx, hipMemset(ctx->dev_ctr, 0, sizeof(unsigned long long) * gg_ctx::PIN_WORDS));
+        GG_HIP(ctx, ctx->table_bad.reserve(sizeof(unsigned long long) * 2));
+        for (int m = 0; m < 2; ++m) {
+            int rc = rescan_table_finite(ctx, m);
+            if (rc != GG_OK) return rc;
+        }
         GG_HIP(ctx, hipDeviceSynchronize());
         return GG_OK;
     };
@@ -451,7 +476,7 @@ int gg_destroy(gg_ctx *ctx) {
                       &ctx->d_ptr, &ctx->g_node1, &ctx->g_node2, &ctx->g_reward, &ctx->g_cnt, &ctx->g_ptr, &ctx->scan_tmp,
                       &ctx->step_u, &ctx->step_v, &ctx->step_x, &ctx->sg_cnt, &ctx->sg_off, &ctx->sg_slot, &ctx->sg_list, &ctx->sg_rows, &ctx->sg_bias, &ctx->sg_tot, &ctx->sg_key, &ctx->touched_ptr, &ctx->x_cnt, &ctx->x_send_ids, &ctx->x_send_rows,
                       &ctx->x_recv_ids, &ctx->x_recv_rows, &ctx->x_nglob, &ctx->x_own, &ctx->st_item, &ctx->st_item2, &ctx->st_cur, &ctx->st_prev, &ctx->st_len,
-                      &ctx->st_alive, &ctx->st_rank, &ctx->bfs_key, &ctx->bfs_bm, &ctx->bfs_misc, &ctx->bfs_sparse, &ctx->bfs_rowptr32, &ctx->lv_pfx, &ctx->dc_keys, &ctx->dc_vals, &ctx->dc_words, &ctx->lv_beg, &ctx->lv_k, &ctx->lv_chunks, &ctx->lv_coff, &ctx->lv_scores, &ctx->lv_chunk_owner, &ctx->lv_prefix, &ctx->lv_big, &ctx->lv_fe, &ctx->fin_list,
+                      &ctx->st_alive, &ctx->st_rank, &ctx->bfs_key, &ctx->bfs_bm, &ctx->bfs_misc, &ctx->bfs_sparse, &ctx->bfs_rowptr32, &ctx->lv_pfx, &ctx->dc_keys, &ctx->dc_vals, &ctx->dc_words, &ctx->lv_beg, &ctx->lv_k, &ctx->lv_chunks, &ctx->lv_coff, &ctx->lv_scores, &ctx->lv_chunk_owner, &ctx->lv_prefix, &ctx->lv_big, &ctx->lv_fe, &ctx->fin_list, &ctx->table_bad,
                       &ctx->q3_store, &ctx->q3s_off, &ctx->ep_center, &ctx->ep_neighbor, &ctx->ep_label, &ctx->ep_node1, &ctx->ep_node2, &ctx->ep_reward};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : ctx->lv_ev)
@@ -892,8 +917,10 @@ static int table_io(gg_ctx *ctx, int32_t which, float *out, const float *in, boo
     } else if (out) {
         GG_HIP(ctx, hipMemcpy2D(out, sizeof(float) * d, M.E, sizeof(float) * ld, sizeof(float) * d, n, hipMemcpyDeviceToHost));
     } else {
-        return upload_table(ctx, M.E, in);
+        int rc = upload_table(ctx, M.E, in);
+        if (rc != GG_OK) return rc;
     }
+    if (in) return rescan_table_finite(ctx, which);
     return GG_OK;
 }
 
@@ -1074,6 +1101,7 @@ int state_io(gg_ctx *ctx, const char *path, bool save) {
     }
     fclose(f);
     generator_changed(ctx);
+    for (int m = 0; m < 2; ++m) (void)gg::rescan_table_finite(ctx, m);
     if (rc == GG_OK)  // step counts / beta powers only once every table arrived
         for (int m = 0; m < 2; ++m) { ctx->model[m].t = loaded[m].t; ctx->model[m].b1p = loaded[m].b1p; ctx->model[m].b2p = loaded[m].b2p; }
     return rc;

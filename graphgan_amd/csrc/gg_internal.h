@@ -72,6 +72,7 @@ struct gg_ctx {
     int64_t split_min_walks = 32768;  // GG_WALK_SPLIT_MIN: smaller launches stay on one stream (their levels are latency bound end to end)
     bool w_split = false;       // the current launch runs as two halves
     gg::DevBuf fin_list;        // walks handed to the finisher
+    gg::DevBuf table_bad;       // two device words: a table of the generator / discriminator holds a non-finite value (rescan_table_finite, optimizer kernels)
     int lv_ev_used = 0;
     gg::Model model[2];  // 0 = generator, 1 = discriminator (config.modes order)
 
@@ -300,6 +301,7 @@ int check_exchange_flag(gg_ctx *ctx);
 void harvest_timings(gg_ctx *ctx);
 int derive_tree_edges(gg_ctx *ctx);   // walk_sample.hip: t_edge from t_order / t_cstart and the resident graph (sets t_edge_valid)
 int compute_reverse_edges(gg_ctx *ctx);  // walk_sample.hip: g_rev of the resident graph
+int rescan_table_finite(gg_ctx *ctx, int which);  // gg_api.hip
 void generator_changed(gg_ctx *ctx);  // gg_api.hip: cached distributions and edge scores are stale  // after a synchronisation of ctx->stream: fold finished event triples into the counters
 int walk_resident(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, int32_t uniform_walks, int32_t n_slots,
                   int32_t for_d, uint64_t seed, uint32_t stream, int32_t stride);

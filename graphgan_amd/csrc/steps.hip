@@ -291,132 +291,6 @@ __global__ __launch_bounds__(256) void pair_grad16_kernel(const StepArgs a) {
     }
 }
 
-// The reference's small batches (n <= DET_MAX_PAIRS, i.e. every step of the default schedule: batch 64,
-// graph_gan.py:149-157,168-176) -- ONE workgroup of 64 sixteen-lane groups, NO atomics, rows resident in LDS:
-//   phase 1  group p loads the two rows of pair p ONCE (global -> registers -> LDS), takes the dot product, the pair's
-//            coefficient dL/ds (discriminator.py:21-30 / generator.py:22-29) goes to LDS;
-//   phase 2  every distinct table row of the batch is owned by the first slot that names it (slots = [u_0..u_{n-1},
-//            v_0..v_{n-1}]); its owner sums the row's contributions in ascending slot order out of LDS and STORES the
-//            gradient row.
-// Two runs of one build therefore give bit-identical tables (the fp32 atomics of pair_grad_kernel add in scheduling
-// order), which is what lets the end-to-end tests compare whole schedules per seed, and the one dependent round of
-// global loads makes it no slower than the atomic kernel.  Default for these batches; GG_DETERMINISTIC=0 selects the
-// atomic kernel.  When 2 n rows do not fit the LDS (n > 64 with wide rows) the partner rows are re-read from the table.
-constexpr int DET_MAX_PAIRS = 256;
-constexpr int DET_THREADS = 1024;
-constexpr int DET_GROUPS = DET_THREADS / 16;
-constexpr size_t DET_LDS_ROW_BYTES = 144 * 1024;  // of the CU's 160 KB
-
-__device__ __forceinline__ unsigned group16_ballot(bool pred) {  // the 16 predicate bits of this lane's row of 16 lanes
-    const uint64_t m = __ballot(pred);
-    return (unsigned)(m >> (threadIdx.x & 48)) & 0xffffu;
-}
-
-template <int NF, bool ROWS_IN_LDS>
-__global__ __launch_bounds__(DET_THREADS) void pair_grad_det_kernel(const StepArgs a) {
-    extern __shared__ float det_rows[];  // [2 n][ld] when ROWS_IN_LDS
-    __shared__ int32_t ids[2 * DET_MAX_PAIRS];
-    __shared__ float coef[DET_MAX_PAIRS], coefb[DET_MAX_PAIRS];
-    const int t = threadIdx.x & 15, g = threadIdx.x >> 4;
-    const int n = a.n, ld = a.ld, nchunk = ld >> 2;
-    const float inv_n = a.n_glob ? 1.0f / (float)(*a.n_glob) : a.inv_n;
-    for (int s = threadIdx.x; s < 2 * n; s += DET_THREADS) ids[s] = s < n ? a.u[s] : a.v[s - n];
-    __syncthreads();
-    for (int p = g; p < n; p += DET_GROUPS) {
-        const int iu = ids[p], iv = ids[n + p];
-        const float4 *ru = (const float4 *)(a.E + (int64_t)iu * ld);
-        const float4 *rv = (const float4 *)(a.E + (int64_t)iv * ld);
-        float acc = 0.f;
-        for (int c = t; c < nchunk; c += 16) {
-            const float4 x = ru[c], y = rv[c];
-            if (ROWS_IN_LDS) {
-                ((float4 *)(det_rows + (size_t)p * ld))[c] = x;
-                ((float4 *)(det_rows + (size_t)(n + p) * ld))[c] = y;
-            }
-            acc = __builtin_fmaf(x.x, y.x, acc);
-            acc = __builtin_fmaf(x.y, y.y, acc);
-            acc = __builtin_fmaf(x.z, y.z, acc);
-            acc = __builtin_fmaf(x.w, y.w, acc);
-        }
-        acc += __shfl_xor(acc, 8, 64);
-        acc += __shfl_xor(acc, 4, 64);
-        acc += __shfl_xor(acc, 2, 64);
-        acc += __shfl_xor(acc, 1, 64);
-        const float bv = a.b[iv];
-        const float sc = acc + bv;
-        const float sg = 1.0f / (1.0f + expf(-sc));
-        float ds;
-        if (a.is_d) {
-            ds = sg - a.x[p];
-        } else {
-            const bool inside = (sg >= 1e-5f) && (sg <= 1.0f);
-            ds = inside ? -(a.x[p] * inv_n) * (1.0f - sg) : 0.0f;
-        }
-        if (t == 0) {
-            coef[p] = ds;
-            coefb[p] = a.is_d ? ds + a.lambda * bv : ds;
-        }
-    }
-    __syncthreads();
-    for (int s = g; s < 2 * n; s += DET_GROUPS) {  // (uniform per group: the ballots below see whole rows of 16 lanes)
-        const int r = ids[s];
-        unsigned earlier = 0;
-        for (int base = 0; base < s; base += 16) earlier |= group16_ballot(base + t < s && ids[base + t] == r);
-        if (earlier) continue;  // not the first slot of this row
-        float own[NF], acc[NF], accb = 0.f;
-#pragma unroll
-        for (int i = 0; i < NF; ++i) {
-            const int f = t + 16 * i;
-            own[i] = f < ld ? (ROWS_IN_LDS ? det_rows[(size_t)s * ld + f] : a.E[(int64_t)r * ld + f]) : 0.f;
-            acc[i] = 0.f;
-        }
-        for (int base = s & ~15; base < 2 * n; base += 16) {
-            unsigned m = group16_ballot(base + t >= s && base + t < 2 * n && ids[base + t] == r);
-            while (m) {  // ascending slot order
-                const int s2 = base + __builtin_ctz(m);
-                m &= m - 1;
-                const int p = s2 < n ? s2 : s2 - n;
-                const int ps = s2 < n ? n + p : p;  // the partner's slot
-                const float c = coef[p];
-                const float *prow = ROWS_IN_LDS ? det_rows + (size_t)ps * ld : a.E + (int64_t)ids[ps] * ld;
-#pragma unroll
-                for (int i = 0; i < NF; ++i) {
-                    const int f = t + 16 * i;
-                    if (f < ld) acc[i] += c * prow[f] + a.lambda * own[i];
-                }
-                if (s2 >= n) accb += coefb[p];
-            }
-        }
-        float *gr = a.gE + (int64_t)r * ld;
-#pragma unroll
-        for (int i = 0; i < NF; ++i) {
-            const int f = t + 16 * i;
-            if (f < ld) gr[f] = acc[i];
-        }
-        if (t == 0) {
-            a.gb[r] = accb;
-            if (a.track) a.touched[r] = 1;
-        }
-    }
-}
-
-template <int NF>
-static hipError_t launch_pair_grad_det(gg_ctx *ctx, const StepArgs &s) {
-    const size_t row_bytes = (size_t)2 * s.n * s.ld * sizeof(float);
-    if (row_bytes <= DET_LDS_ROW_BYTES) {
-        static bool raised = false;  // (one context per process drives one device; the attribute belongs to the function)
-        if (!raised) {
-            hipError_t e = hipFuncSetAttribute((const void *)pair_grad_det_kernel<NF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DET_LDS_ROW_BYTES);
-            if (e != hipSuccess) return e;
-            raised = true;
-        }
-        hipLaunchKernelGGL((pair_grad_det_kernel<NF, true>), dim3(1), dim3(DET_THREADS), row_bytes, ctx->stream, s);
-    } else {
-        hipLaunchKernelGGL((pair_grad_det_kernel<NF, false>), dim3(1), dim3(DET_THREADS), 0, ctx->stream, s);
-    }
-    return hipSuccess;
-}
-
 // G pass over whole walks (fast mode: one fused batch = every prepared pair, graph_gan.py:168-176 with
 // batch_size >= train_size).  The pairs of a walk are the window-2 pairs of its path
 // (graph_gan.py:272-291), i.e. every node row is needed by up to 8 pairs.  One 16-lane group per
@@ -673,7 +547,13 @@ struct OptArgs {
     const int64_t *sg_tot;
     const float *stage, *stage_b;
     const int32_t *stage_key;  // source of every stage row (unique inside a pass): a segment is summed in ascending key order
+    unsigned long long *bad;   // set when a kernel writes a non-finite value into this model's tables (gg_ctx::table_bad)
 };
+
+// every optimizer kernel tests what it writes: a diverged table is reported by the next walk launch (walk_reset_kernel copies the
+// generator's word into the launch's error flags) even when the walks reach the row only through hops that score nothing (a
+// distribution with ONE candidate, a leaf's back-step)
+__device__ __forceinline__ bool nonfinite4(const float4 &x) { return !(__builtin_isfinite(x.x) && __builtin_isfinite(x.y) && __builtin_isfinite(x.z) && __builtin_isfinite(x.w)); }
 
 __device__ __forceinline__ void adam_elem(float &var, float &m, float &v, float g, const OptArgs &a) {
     m = m * a.b1;                          // m_t = assign(m, m * beta1)
@@ -688,6 +568,7 @@ __global__ __launch_bounds__(256) void adam_dense_kernel(const OptArgs a) {
     const int64_t n4 = a.nE >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool bad = false;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         float4 var = ((float4 *)a.E)[i], m = ((float4 *)a.mE)[i], v = ((float4 *)a.vE)[i];
         const float4 g = ((const float4 *)a.gE)[i];
@@ -695,6 +576,7 @@ __global__ __launch_bounds__(256) void adam_dense_kernel(const OptArgs a) {
         adam_elem(var.y, m.y, v.y, g.y, a);
         adam_elem(var.z, m.z, v.z, g.z, a);
         adam_elem(var.w, m.w, v.w, g.w, a);
+        bad |= nonfinite4(var);
         ((float4 *)a.E)[i] = var;
         ((float4 *)a.mE)[i] = m;
         ((float4 *)a.vE)[i] = v;
@@ -704,11 +586,13 @@ __global__ __launch_bounds__(256) void adam_dense_kernel(const OptArgs a) {
         float var = a.b[i], m = a.mb[i], v = a.vb[i];
         const float g = a.gb[i];
         adam_elem(var, m, v, g, a);
+        bad |= !__builtin_isfinite(var);
         a.b[i] = var;
         a.mb[i] = m;
         a.vb[i] = v;
         if (g != 0.f) a.gb[i] = 0.f;
     }
+    if (bad) *a.bad = 1ull;
 }
 
 // Lazy Adam / SGD on one touched row by one 16-lane group (clears the row's gradient and flag).
@@ -731,6 +615,7 @@ __device__ __forceinline__ void opt_row(const OptArgs &a, int row, int t, int nc
                 ((float4 *)a.mE)[o + c] = m;
                 ((float4 *)a.vE)[o + c] = v;
             }
+            if (nonfinite4(var)) *a.bad = 1ull;
             ((float4 *)a.E)[o + c] = var;
             ((float4 *)a.gE)[o + c] = z;
         }
@@ -745,12 +630,187 @@ __device__ __forceinline__ void opt_row(const OptArgs &a, int row, int t, int nc
                 a.mb[row] = m;
                 a.vb[row] = v;
             }
+            if (!__builtin_isfinite(var)) *a.bad = 1ull;
             a.b[row] = var;
             a.gb[row] = 0.f;
             a.touched[row] = 0;
             if (a.sg_cnt) a.sg_cnt[row] = 0;
         }
     }
+}
+
+// The reference's small batches (n <= DET_MAX_PAIRS, i.e. every step of the default schedule: batch 64,
+// graph_gan.py:149-157,168-176) -- ONE workgroup of 64 sixteen-lane groups, NO atomics, rows resident in LDS:
+//   phase 1  group p loads the two rows of pair p ONCE (global -> registers -> LDS), takes the dot product, the pair's
+//            coefficient dL/ds (discriminator.py:21-30 / generator.py:22-29) goes to LDS;
+//   phase 2  every distinct table row of the batch is owned by the first slot that names it (slots = [u_0..u_{n-1},
+//            v_0..v_{n-1}]); its owner sums the row's contributions in ascending slot order out of LDS and STORES the
+//            gradient row.
+// Two runs of one build therefore give bit-identical tables (the fp32 atomics of pair_grad_kernel add in scheduling
+// order), which is what lets the end-to-end tests compare whole schedules per seed, and the one dependent round of
+// global loads makes it no slower than the atomic kernel.  Default for these batches; GG_DETERMINISTIC=0 selects the
+// atomic kernel.  When 2 n rows do not fit the LDS (n > 64 with wide rows) the partner rows are re-read from the table.
+// OPT != 0 (one replica, lazy Adam / SGD, rows in LDS): the owner of a row applies the optimizer to it right there, with the
+// gradient in its registers -- ONE launch per step of the strict schedule at scale (every table read of the step happened
+// in phase 1, before the barrier, so writing the table in phase 2 races with nothing); the per-element operation sequence
+// is opt_row's, i.e. the same bits as gradient kernel + flag compaction + sparse_opt_kernel.
+constexpr int DET_MAX_PAIRS = 256;
+constexpr int DET_THREADS = 1024;
+constexpr int DET_GROUPS = DET_THREADS / 16;
+constexpr size_t DET_LDS_ROW_BYTES = 144 * 1024;  // of the CU's 160 KB
+
+__device__ __forceinline__ unsigned group16_ballot(bool pred) {  // the 16 predicate bits of this lane's row of 16 lanes
+    const uint64_t m = __ballot(pred);
+    return (unsigned)(m >> (threadIdx.x & 48)) & 0xffffu;
+}
+
+template <int NF, bool ROWS_IN_LDS, int OPT>  // OPT: 0 = store the gradient rows, 1 = lazy Adam, 2 = SGD
+__global__ __launch_bounds__(DET_THREADS) void pair_grad_det_kernel(const StepArgs a, const OptArgs o) {
+    static_assert(OPT == 0 || ROWS_IN_LDS, "the fused update needs every table read in front of the barrier");
+    extern __shared__ float det_rows[];  // [2 n][ld] when ROWS_IN_LDS
+    __shared__ int32_t ids[2 * DET_MAX_PAIRS];
+    __shared__ float coef[DET_MAX_PAIRS], coefb[DET_MAX_PAIRS];
+    const int t = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int n = a.n, ld = a.ld, nchunk = ld >> 2;
+    const float inv_n = a.n_glob ? 1.0f / (float)(*a.n_glob) : a.inv_n;
+    for (int s = threadIdx.x; s < 2 * n; s += DET_THREADS) ids[s] = s < n ? a.u[s] : a.v[s - n];
+    __syncthreads();
+    for (int p = g; p < n; p += DET_GROUPS) {
+        const int iu = ids[p], iv = ids[n + p];
+        const float4 *ru = (const float4 *)(a.E + (int64_t)iu * ld);
+        const float4 *rv = (const float4 *)(a.E + (int64_t)iv * ld);
+        float acc = 0.f;
+        for (int c = t; c < nchunk; c += 16) {
+            const float4 x = ru[c], y = rv[c];
+            if (ROWS_IN_LDS) {
+                ((float4 *)(det_rows + (size_t)p * ld))[c] = x;
+                ((float4 *)(det_rows + (size_t)(n + p) * ld))[c] = y;
+            }
+            acc = __builtin_fmaf(x.x, y.x, acc);
+            acc = __builtin_fmaf(x.y, y.y, acc);
+            acc = __builtin_fmaf(x.z, y.z, acc);
+            acc = __builtin_fmaf(x.w, y.w, acc);
+        }
+        acc += __shfl_xor(acc, 8, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 1, 64);
+        const float bv = a.b[iv];
+        const float sc = acc + bv;
+        const float sg = 1.0f / (1.0f + expf(-sc));
+        float ds;
+        if (a.is_d) {
+            ds = sg - a.x[p];
+        } else {
+            const bool inside = (sg >= 1e-5f) && (sg <= 1.0f);
+            ds = inside ? -(a.x[p] * inv_n) * (1.0f - sg) : 0.0f;
+        }
+        if (t == 0) {
+            coef[p] = ds;
+            coefb[p] = a.is_d ? ds + a.lambda * bv : ds;
+        }
+    }
+    __syncthreads();
+    for (int s = g; s < 2 * n; s += DET_GROUPS) {  // (uniform per group: the ballots below see whole rows of 16 lanes)
+        const int r = ids[s];
+        unsigned earlier = 0;
+        for (int base = 0; base < s; base += 16) earlier |= group16_ballot(base + t < s && ids[base + t] == r);
+        if (earlier) continue;  // not the first slot of this row
+        float own[NF], acc[NF], accb = 0.f;
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int f = t + 16 * i;
+            own[i] = f < ld ? (ROWS_IN_LDS ? det_rows[(size_t)s * ld + f] : a.E[(int64_t)r * ld + f]) : 0.f;
+            acc[i] = 0.f;
+        }
+        for (int base = s & ~15; base < 2 * n; base += 16) {
+            unsigned m = group16_ballot(base + t >= s && base + t < 2 * n && ids[base + t] == r);
+            while (m) {  // ascending slot order
+                const int s2 = base + __builtin_ctz(m);
+                m &= m - 1;
+                const int p = s2 < n ? s2 : s2 - n;
+                const int ps = s2 < n ? n + p : p;  // the partner's slot
+                const float c = coef[p];
+                const float *prow = ROWS_IN_LDS ? det_rows + (size_t)ps * ld : a.E + (int64_t)ids[ps] * ld;
+#pragma unroll
+                for (int i = 0; i < NF; ++i) {
+                    const int f = t + 16 * i;
+                    if (f < ld) acc[i] += c * prow[f] + a.lambda * own[i];
+                }
+                if (s2 >= n) accb += coefb[p];
+            }
+        }
+        if (OPT == 0) {
+            float *gr = a.gE + (int64_t)r * ld;
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const int f = t + 16 * i;
+                if (f < ld) gr[f] = acc[i];
+            }
+            if (t == 0) {
+                a.gb[r] = accb;
+                if (a.track) a.touched[r] = 1;
+            }
+        } else {
+            const int64_t ro = (int64_t)r * ld;
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const int f = t + 16 * i;
+                if (f < ld) {
+                    float var = own[i];
+                    if (OPT == 2) {
+                        var -= o.lr * acc[i];
+                    } else {
+                        float m = o.mE[ro + f], v = o.vE[ro + f];
+                        adam_elem(var, m, v, acc[i], o);
+                        o.mE[ro + f] = m;
+                        o.vE[ro + f] = v;
+                    }
+                    if (!__builtin_isfinite(var)) *o.bad = 1ull;
+                    o.E[ro + f] = var;
+                }
+            }
+            if (t == 0) {
+                float var = o.b[r];
+                if (OPT == 2) {
+                    var -= o.lr * accb;
+                } else {
+                    float m = o.mb[r], v = o.vb[r];
+                    adam_elem(var, m, v, accb, o);
+                    o.mb[r] = m;
+                    o.vb[r] = v;
+                }
+                if (!__builtin_isfinite(var)) *o.bad = 1ull;
+                o.b[r] = var;
+            }
+        }
+    }
+}
+
+static bool det_rows_fit_lds(const StepArgs &s) { return (size_t)2 * s.n * s.ld * sizeof(float) <= DET_LDS_ROW_BYTES; }
+
+template <int NF, int OPT>
+static hipError_t launch_pair_grad_det_lds(gg_ctx *ctx, const StepArgs &s, const OptArgs &o) {
+    static bool raised = false;  // (the attribute belongs to the function, not to a context)
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute((const void *)pair_grad_det_kernel<NF, true, OPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DET_LDS_ROW_BYTES);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    hipLaunchKernelGGL((pair_grad_det_kernel<NF, true, OPT>), dim3(1), dim3(DET_THREADS), (size_t)2 * s.n * s.ld * sizeof(float), ctx->stream, s, o);
+    return hipSuccess;
+}
+
+// opt: 0 = gradient rows to the accumulators (the optimizer kernels follow), 1 / 2 = lazy Adam / SGD applied by the row owners
+template <int NF>
+static hipError_t launch_pair_grad_det(gg_ctx *ctx, const StepArgs &s, const OptArgs &o, int opt) {
+    if (!det_rows_fit_lds(s)) {
+        hipLaunchKernelGGL((pair_grad_det_kernel<NF, false, 0>), dim3(1), dim3(DET_THREADS), 0, ctx->stream, s, o);
+        return hipSuccess;
+    }
+    if (opt == 1) return launch_pair_grad_det_lds<NF, 1>(ctx, s, o);
+    if (opt == 2) return launch_pair_grad_det_lds<NF, 2>(ctx, s, o);
+    return launch_pair_grad_det_lds<NF, 0>(ctx, s, o);
 }
 
 // ... over the compacted row list (flag array -> scan -> list: deterministic row order; the replica exchange packs the same list).
@@ -912,6 +972,7 @@ __global__ __launch_bounds__(256) void staged_opt_kernel(const OptArgs a) {
                 ((float4 *)a.mE)[o4 + c] = m;
                 ((float4 *)a.vE)[o4 + c] = v;
             }
+            if (nonfinite4(var)) *a.bad = 1ull;
             ((float4 *)a.E)[o4 + c] = var;
         }
         if (t == 0) {
@@ -924,6 +985,7 @@ __global__ __launch_bounds__(256) void staged_opt_kernel(const OptArgs a) {
                 a.mb[row] = m;
                 a.vb[row] = v;
             }
+            if (!__builtin_isfinite(var)) *a.bad = 1ull;
             a.b[row] = var;
             a.sg_cnt[row] = 0;
         }
@@ -976,6 +1038,7 @@ __global__ __launch_bounds__(256) void add_rows_kernel(float *gE, float *gb, int
 // (touched flags -> row list in row order, deterministic: device_compact_flags, prepare.hip)
 
 int apply_optimizer(gg_ctx *ctx, int which, int64_t n);
+void step_done(gg_ctx *ctx, int which, int64_t n);
 int run_path_step(gg_ctx *ctx);
 
 static OptArgs make_opt_args(gg_ctx *ctx, int which) {
@@ -989,6 +1052,7 @@ static OptArgs make_opt_args(gg_ctx *ctx, int which) {
     // lr_t = lr * sqrt(1 - beta2_power) / (1 - beta1_power), all fp32 (TF keeps the powers as fp32 variables)
     o.lr_t = (M.lr * sqrtf(1.0f - M.b2p)) / (1.0f - M.b1p);
     o.touched = ctx->touched; o.touched_list = ctx->touched_list; o.touched_cnt = ctx->touched_cnt;
+    o.bad = ctx->table_bad.as<unsigned long long>() + which;
     return o;
 }
 
@@ -1108,12 +1172,21 @@ int run_step(gg_ctx *ctx, int which, const int32_t *d_u, const int32_t *d_v, con
     s.ppg = n >= 16384 ? PAIRS_PER_GROUP : (n >= 2048 ? 4 : 1);
     if (ctx->deterministic && n <= DET_MAX_PAIRS) {
         const int nfd = (ctx->ld + 15) / 16;
+        // one replica, lazy Adam / SGD, the batch's rows in LDS: the row owners apply the optimizer themselves -- one launch per step
+        const bool replicas = ctx->comm || ctx->fake_world > 1;
+        const int fused = (!replicas && opt != GG_OPT_ADAM_DENSE && det_rows_fit_lds(s) && !getenv("GG_NO_FUSED_SMALL_STEP")) ? (opt == GG_OPT_SGD ? 2 : 1) : 0;
+        const OptArgs o = make_opt_args(ctx, which);
         hipError_t e;
-        if (nfd <= 4) e = launch_pair_grad_det<4>(ctx, s);
-        else if (nfd <= 8) e = launch_pair_grad_det<8>(ctx, s);
-        else if (nfd <= 16) e = launch_pair_grad_det<16>(ctx, s);
-        else e = launch_pair_grad_det<32>(ctx, s);
+        if (nfd <= 4) e = launch_pair_grad_det<4>(ctx, s, o, fused);
+        else if (nfd <= 8) e = launch_pair_grad_det<8>(ctx, s, o, fused);
+        else if (nfd <= 16) e = launch_pair_grad_det<16>(ctx, s, o, fused);
+        else e = launch_pair_grad_det<32>(ctx, s, o, fused);
         GG_HIP(ctx, e);
+        if (fused) {
+            GG_HIP(ctx, hipGetLastError());
+            step_done(ctx, which, n);
+            return GG_OK;
+        }
         return apply_optimizer(ctx, which, n);
     }
     const int groups = cdiv(n, s.ppg);
@@ -1542,7 +1615,6 @@ int exchange_count_max(gg_ctx *ctx, int64_t local, int64_t *max_out) {
 
 // gradient exchange (multi-GPU) + optimizer kernel + step bookkeeping, after a gradient kernel
 int apply_optimizer(gg_ctx *ctx, int which, int64_t n) {
-    Model &M = ctx->model[which];
     const int opt = ctx->cfg.optimizer;
     int rc = GG_OK;
     if (opt == GG_OPT_ADAM_DENSE) {
@@ -1577,13 +1649,19 @@ int apply_optimizer(gg_ctx *ctx, int which, int64_t n) {
         else hipLaunchKernelGGL(sparse_opt_kernel<0>, dim3(nb), dim3(256), 0, ctx->stream, o);
     }
     GG_HIP(ctx, hipGetLastError());
+    step_done(ctx, which, n);
+    return GG_OK;
+}
+
+// host-side bookkeeping behind one optimizer step of model `which` on n pairs
+void step_done(gg_ctx *ctx, int which, int64_t n) {
+    Model &M = ctx->model[which];
     if (which == 0) { ctx->gen_dirty = true; generator_changed(ctx); }  // the generator moved: cached distributions and edge scores are stale
     M.t += 1;
     M.b1p = M.b1p * ctx->cfg.adam_beta1;
     M.b2p = M.b2p * ctx->cfg.adam_beta2;
     if (which == 1) { ctx->ctr.d_pairs += n; ctx->ctr.d_steps += 1; }
     else { ctx->ctr.g_pairs += n; ctx->ctr.g_steps += 1; }
-    return GG_OK;
 }
 
 }  // namespace gg

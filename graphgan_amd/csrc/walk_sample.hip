@@ -1220,9 +1220,11 @@ __global__ void walk_d_postpass_kernel(const WalkArgs a) {
 // Counter words of both halves, and the base of each half's prefix region: dc_words = {base 0, end 0, base 1, end 1} in
 // global chunk offsets.  A launch that looks distributions up (append) starts behind what the D launch of the step left in
 // the region(s) it uses; a single-stream launch uses one region behind everything.
-__global__ void walk_reset_kernel(unsigned long long *ctr, int n_words, int64_t *dc_words, int append, int split, int64_t S) {
+__global__ void walk_reset_kernel(unsigned long long *ctr, int n_words, int64_t *dc_words, int append, int split, int64_t S, const unsigned long long *gen_bad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_words && i != CTR_BASE && i != CTR_WORDS + CTR_BASE) ctr[i] = 0ull;
+    // (the launch starts with the non-finite flag of the generator's tables: hops that score nothing -- one candidate, a leaf's
+    // back-step -- cannot notice a diverged row themselves)
+    if (i < n_words && i != CTR_BASE && i != CTR_WORDS + CTR_BASE) ctr[i] = (i == CTR_NONFINITE) ? (*gen_bad ? 1ull : 0ull) : 0ull;
     if (i == 0) {
         if (!append) dc_words[1] = dc_words[3] = 0;
         const int64_t e0 = dc_words[1], e1 = dc_words[3];
@@ -1587,7 +1589,7 @@ int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int fo
     // the edge-score cache needs the trees' edge indices (and a symmetric adjacency: g_rev)
     if (ctx->es && ctx->es_stamp && ctx->g_rev && ctx->t_edge_valid && ctx->walk_levels > 0) a.es_mode = ctx->es_mode;
     hipLaunchKernelGGL(walk_reset_kernel, dim3(cdiv(2 * CTR_WORDS, 256)), dim3(256), 0, ctx->walk_stream, ctx->dev_ctr, 2 * (int)CTR_WORDS,
-                       ctx->dc_words.as<int64_t>(), a.dc_mode == 2 ? 1 : 0, ctx->w_split ? 1 : 0, ctx->lv_cap_total);
+                       ctx->dc_words.as<int64_t>(), a.dc_mode == 2 ? 1 : 0, ctx->w_split ? 1 : 0, ctx->lv_cap_total, ctx->table_bad.as<unsigned long long>());
     // HIP events around every profile_every-th call (a rerun keeps the decision of the launch it repeats)
     if (!ctx->walk_force_sized) ctx->walk_timed = ctx->profile_every > 0 && (ctx->walk_call_index++ % ctx->profile_every) == 0;
     if (ctx->walk_timed && ctx->walk_stream != ctx->stream && ctx->profile_solo) {

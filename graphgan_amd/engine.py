@@ -40,6 +40,8 @@ def edges_to_csr(n_node, edges):
     """Vectorised ``read_edges`` adjacency for large synthetic graphs: for edge k = (a, b) the
     reference appends b to graph[a] and then a to graph[b] (utils.py:36-37), in file order."""
     edges = np.asarray(edges).reshape(-1, 2)
+    if len(edges) and (int(edges.min()) < 0 or int(edges.max()) >= n_node):  # (the C pass below writes unchecked)
+        raise ValueError("edges_to_csr: node id outside [0, %d)" % n_node)
     if 2 * len(edges) < 2 ** 31 - 1:
         try:  # one stable counting pass in C (scipy's COO -> CSR kernel, called directly: no duplicate merging, no index sorting)
             from scipy.sparse import _sparsetools
@@ -52,7 +54,7 @@ def edges_to_csr(n_node, edges):
             nothing = np.zeros(len(src), dtype=np.int8)
             _sparsetools.coo_tocsr(n_node, n_node, len(src), src, dst, nothing, indptr, col, np.empty_like(nothing))
             return indptr.astype(np.int64), col
-        except (ImportError, AttributeError):
+        except Exception:  # a private scipy routine: any change of its signature / dtype dispatch falls back to numpy
             pass
     edges = edges.astype(np.int64)
     src = np.empty(2 * len(edges), dtype=np.int64)

@@ -203,22 +203,24 @@ def test_update_ratio_below_one_selects_resident_slots(tmp_path):
         g.engine.close()
 
 
-@pytest.mark.parametrize("seed", [4, 11])
-def test_full_schedule_epochs_match_committed_oracle_runs(tmp_path, seed):
-    """TWO outer epochs of the reference's DEFAULT schedule (30 + 30 inner passes, batch 64, dense TF1-Adam,
-    ~330 k optimizer steps each) against the CPU oracle's results for the same seed (tests/golden/
-    oracle_epochs_multiseed.json, ~7 CPU-minutes per epoch; 15 seeds are compared in DESIGN.md section 8).
-    Epoch 0: the discriminator's accuracy has matched the oracle to the digit in every run so far -- the gate allows
-    two of the 2 898 test edges (fp32 atomic order) -- and the north star's 0.5 % for the generator.  Epoch 1: the
-    two trajectories are then different samples of the same chaotic process (one flipped walk changes everything
-    after it; the generator has fallen to chance on BOTH sides); the gate is the per-seed spread observed over 15
-    seeds with margin -- discriminator 1.0 % (largest seen 0.55 %), generator 3.0 % (largest seen 2.3 %)."""
+# ---- float parity over whole schedules (north star: +-0.5 % absolute) -------------------------------
+# The strict schedule (batch 64, dense TF1 Adam) runs without a single float atomic (pair_grad_det_kernel, steps.hip), so one
+# build gives the SAME BITS for a seed every time: these gates compare fixed numbers, not samples of a scheduling-dependent
+# process.  What stays chaotic is the training process itself: the oracle's own <= 1-ulp variant (sigmoid evaluated in fp64,
+# tests/golden/oracle_epochs_multiseed.json "epochs_sigmoid64") moves a seed's accuracy by up to 1.0 % once the generator has
+# fallen to chance (default schedule, after the second outer epoch) and on the generator's falling edge (short schedule, after
+# the third), because one flipped walk changes every batch behind it.  There, +-0.5 % is asserted for the MEAN over the seeds --
+# the quantity a last-bit difference cannot move -- and per seed everywhere else.  No gate in this file is wider than 0.005.
+GATE = 0.005
+SHORT_SEEDS = list(range(8))
+FULL_SEEDS = list(range(8))
+
+
+def _train_schedule(base, seed, **over):
     import json
     from tests.helpers import ca_grqc_init_embeddings
-    want = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_epochs_multiseed.json")))["epochs"][str(seed)]
-    base = str(tmp_path)
     d, n, graph = write_reference_layout(base)
-    cfg = make_cfg(base, n_epochs=2, engine_seed=seed)
+    cfg = make_cfg(base, engine_seed=seed, **over)
     from graphgan_amd.graph_gan import GraphGAN
     g = GraphGAN(cfg)
     init = ca_grqc_init_embeddings(d, n, seed=0).astype(np.float32)
@@ -227,54 +229,104 @@ def test_full_schedule_epochs_match_committed_oracle_runs(tmp_path, seed):
     g.train()
     lines = open(cfg.result_filename).read().split()
     acc = [[float(lines[2 * i][4:]), float(lines[2 * i + 1][4:])] for i in range(len(lines) // 2)]
+    c = g.engine.counters()
+    tables = [g.engine.get_embeddings(0), g.engine.get_embeddings(1)]
+    g.engine.close()
+    return acc, c, tables
+
+
+@pytest.fixture(scope="module")
+def short_runs(tmp_path_factory):
+    """the reference's schedule with 2 + 2 inner passes per outer epoch (batch 64, dense TF1 Adam, all 5 242 roots, ~15 600
+    optimizer steps per epoch), three outer epochs, every seed of tests/golden/oracle_epochs_short.json"""
+    out = {}
+    for seed in SHORT_SEEDS:
+        out[seed] = _train_schedule(str(tmp_path_factory.mktemp("short%d" % seed)), seed, n_epochs=3, n_epochs_dis=2, n_epochs_gen=2,
+                                    dis_interval=2, gen_interval=2)
+    print("short schedule, engine [gen, dis] per seed:", {k: v[0] for k, v in out.items()})
+    return out
+
+
+@pytest.fixture(scope="module")
+def full_runs(tmp_path_factory):
+    """TWO outer epochs of the reference's DEFAULT schedule (30 + 30 inner passes, batch 64, dense TF1 Adam, ~330 k optimizer
+    steps each), seeds of tests/golden/oracle_epochs_multiseed.json (~7 CPU-minutes per epoch on the oracle side)"""
+    out = {}
+    for seed in FULL_SEEDS:
+        out[seed] = _train_schedule(str(tmp_path_factory.mktemp("full%d" % seed)), seed, n_epochs=2)
+    print("default schedule, engine [gen, dis] per seed:", {k: v[0] for k, v in out.items()})
+    return out
+
+
+def _golden(name):
+    import json
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", name)))["epochs"]
+
+
+@pytest.mark.parametrize("seed", SHORT_SEEDS)
+def test_short_schedule_epochs_match_the_oracle_per_seed(short_runs, seed):
+    """The INFORMATIVE float-parity workload: the short schedule moves the generator UP, 0.760 -> 0.873 -> 0.876, and keeps the
+    discriminator near 0.78 -- far from the start and far from chance, with a seed-to-seed spread of 0.1-0.2 % on the oracle side.
+    Gate: +-0.5 % PER SEED for both models after outer epochs 0 and 1, and for the discriminator after epoch 2 (where the
+    generator turns and falls: see the seed-mean test)."""
+    want = _golden("oracle_epochs_short.json")[str(seed)]
+    acc = short_runs[seed][0]
+    print("seed %d engine %s oracle %s" % (seed, acc, want[:4]))
+    assert len(acc) == 4 and acc[0] == want[0]
+    for ep in (1, 2):
+        assert abs(acc[ep][0] - want[ep][0]) <= GATE and abs(acc[ep][1] - want[ep][1]) <= GATE, (ep, acc[ep], want[ep])
+        assert acc[ep][0] > 0.85 and 0.75 < acc[ep][1] < 0.82       # informative: nowhere near chance
+    assert abs(acc[3][1] - want[3][1]) <= GATE, (acc[3], want[3])
+    c = short_runs[seed][1]
+    assert c["d_steps"] > 3 * 2 * 125 and c["g_steps"] > 3 * 2 * 7000
+
+
+def test_short_schedule_seed_means_match_the_oracle(short_runs):
+    """After the third outer epoch the generator is on its falling edge (0.876 -> 0.63-0.65 within the epoch; the oracle's seeds
+    span 2 % there): the +-0.5 % bar is asserted for the mean over the 8 seeds, for every epoch and both models."""
+    want = _golden("oracle_epochs_short.json")
+    E = np.array([short_runs[s][0] for s in SHORT_SEEDS])
+    O = np.array([want[str(s)][:4] for s in SHORT_SEEDS])
+    diff = (E - O).mean(0)
+    print("short schedule: seed-mean engine - oracle per epoch [gen, dis] =", diff.tolist(), "max per-seed |diff| =", np.abs(E - O).max(0).tolist())
+    assert np.abs(diff).max() <= GATE
+    assert 0.55 < E[:, 3, 0].mean() < 0.75   # it HAS fallen, and not to chance -- on both sides
+    assert 0.55 < O[:, 3, 0].mean() < 0.75
+
+
+@pytest.mark.parametrize("seed", FULL_SEEDS)
+def test_full_schedule_first_epoch_matches_the_oracle_per_seed(full_runs, seed):
+    """Default schedule, after the first outer epoch (~330 k optimizer steps): +-0.5 % per seed for both models."""
+    want = _golden("oracle_epochs_multiseed.json")[str(seed)]
+    acc, c, _ = full_runs[seed]
     print("seed %d engine %s oracle %s" % (seed, acc, want[:3]))
     assert len(acc) == 3
     assert acc[0] == want[0]  # before training: the shipped embeddings under the shipped evaluator
-    assert abs(acc[1][1] - want[1][1]) <= 2.0 / 2898 + 1e-12
-    assert abs(acc[1][0] - want[1][0]) <= 0.005
-    assert abs(acc[2][1] - want[2][1]) <= 0.010
-    assert abs(acc[2][0] - want[2][0]) <= 0.030
-    c = g.engine.counters()
+    assert abs(acc[1][0] - want[1][0]) <= GATE and abs(acc[1][1] - want[1][1]) <= GATE, (acc[1], want[1])
     assert c["d_steps"] > 6000 and c["g_steps"] > 400000
-    g.engine.close()
 
 
-@pytest.mark.parametrize("seed", [2, 5])
-def test_short_schedule_epochs_match_the_oracle_per_seed(tmp_path, seed):
-    """The INFORMATIVE float-parity workload (round 4): the reference's schedule with 2 + 2 inner passes per outer epoch
-    (batch 64, dense TF1 Adam, all 5 242 roots, ~15 600 optimizer steps per epoch).  Unlike the default 30 + 30 schedule --
-    which drives the shipped embeddings to chance on both sides, so that later epochs compare coin flips -- this one moves the
-    generator UP, 0.760 -> 0.873 -> 0.876, and keeps the discriminator near 0.78: far from the start and far from chance, with
-    a seed-to-seed spread of 0.1-0.2 % on the oracle side (tests/golden/oracle_epochs_short.json, 8 seeds).  Gate: the north
-    star's +-0.5 % PER SEED for both models after outer epochs 0 and 1; after epoch 2 -- where the generator turns and falls
-    (0.65 +- 0.6 % over the seeds) -- +-0.5 % for the discriminator and +-2 % for the generator."""
-    import json
-    from tests.helpers import ca_grqc_init_embeddings
-    want = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_epochs_short.json")))["epochs"][str(seed)]
-    base = str(tmp_path)
-    d, n, graph = write_reference_layout(base)
-    cfg = make_cfg(base, n_epochs=3, n_epochs_dis=2, n_epochs_gen=2, dis_interval=2, gen_interval=2, engine_seed=seed)
-    from graphgan_amd.graph_gan import GraphGAN
-    g = GraphGAN(cfg)
-    init = ca_grqc_init_embeddings(d, n, seed=0).astype(np.float32)
-    g.engine.set_embeddings(0, init)
-    g.engine.set_embeddings(1, init)
-    g.train()
-    lines = open(cfg.result_filename).read().split()
-    acc = [[float(lines[2 * i][4:]), float(lines[2 * i + 1][4:])] for i in range(len(lines) // 2)]
-    print("seed %d engine %s oracle %s" % (seed, acc, want[:4]))
-    assert len(acc) == 4 and acc[0] == want[0]
-    # epochs 1 and 2: within 1.5 % of the oracle run of the same seed.  (The engine's float sums are atomics: their order, and with it
-    # the trajectory, changes from run to run on one build -- over ~12 runs of this test per seed the generator after epoch 2 was within
-    # 0.1 % of the oracle in all but one, 0.55 % off in that one; the north star's 0.5 % holds for the seed MEAN, tests/compare_epochs.py.)
-    for ep in (1, 2):
-        assert abs(acc[ep][0] - want[ep][0]) <= 0.015 and abs(acc[ep][1] - want[ep][1]) <= 0.015, (ep, acc[ep], want[ep])
-        assert acc[ep][0] > 0.85 and 0.75 < acc[ep][1] < 0.82       # informative: nowhere near chance
-    # epoch 3: the generator is on its falling edge there (0.876 -> 0.63-0.65 in one epoch), where the order of the float atomics moves
-    # it from run to run on ONE build and seed (0.654 and 0.634 seen for seed 5; gates of 2 % and of 5 % both failed once in a handful of
-    # full-suite runs): only THAT it has fallen, and not to chance, is asserted; the discriminator, which barely moves, within 1 %
-    assert abs(acc[3][1] - want[3][1]) <= 0.01 and 0.52 < acc[3][0] < 0.80 and 0.52 < want[3][0] < 0.80, (acc[3], want[3])
-    g.engine.close()
+def test_full_schedule_seed_means_match_the_oracle(full_runs):
+    """Default schedule, after the second outer epoch: the generator has fallen to chance on BOTH sides (0.50-0.53) and the
+    trajectories are different samples of one chaotic process -- the oracle's own fp64-sigmoid variant differs from the oracle by
+    up to 1.0 % (generator) / 0.9 % (discriminator) per seed there.  Gate: +-0.5 % on the mean over the seeds, every epoch, both
+    models; and every engine value inside the band the oracle's 15 seeds span, widened by the same 0.5 %."""
+    gold = _golden("oracle_epochs_multiseed.json")
+    E = np.array([full_runs[s][0] for s in FULL_SEEDS])
+    O = np.array([gold[str(s)][:3] for s in FULL_SEEDS])
+    diff = (E - O).mean(0)
+    print("default schedule: seed-mean engine - oracle per epoch [gen, dis] =", diff.tolist(), "max per-seed |diff| =", np.abs(E - O).max(0).tolist())
+    assert np.abs(diff).max() <= GATE
+    allo = np.array([v[:3] for v in gold.values()])
+    assert (E >= allo.min(0) - GATE).all() and (E <= allo.max(0) + GATE).all()
+
+
+def test_schedules_are_bit_reproducible(short_runs, tmp_path):
+    """A second training run of one seed -- new process state, new engine, same build -- ends on the SAME accuracies and the same
+    bits in both tables: nothing on the strict path depends on the order in which the hardware retires work."""
+    acc, _, tables = _train_schedule(str(tmp_path), 3, n_epochs=3, n_epochs_dis=2, n_epochs_gen=2, dis_interval=2, gen_interval=2)
+    assert acc == short_runs[3][0]
+    assert np.array_equal(tables[0], short_runs[3][2][0]) and np.array_equal(tables[1], short_runs[3][2][1])
 
 
 def test_tree_cache_file_replaces_the_pickle(tmp_path):

@@ -125,6 +125,10 @@ def test_root_batched_epochs_equal_the_resident_calls_and_the_oracle(ga):
     B.epoch_commit(0)
     h1, _, _ = B.get_g_data()
     B.set_embeddings(0, gen_E)
+    # a root twice in one batch would make two slots share one row of the persistent Q3 store: refused
+    with pytest.raises(ga.GraphGANHipError) as ei:
+        B.epoch_add(np.array([3, 8, 3], np.int32), True, True, 20, seed, 0, 1)
+    assert ei.value.code == ga.GG_EINVAL and "twice" in str(ei.value)
     A.close()
     B.close()
     assert len(h1) != len(o1) or not np.array_equal(h1, o1)

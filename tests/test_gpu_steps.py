@@ -678,23 +678,23 @@ def test_owner_partitioned_exchange_with_simulated_ranks(ga, mode, world, monkey
     eng.close()
 
 
-def test_deterministic_small_batch_mode(ga, monkeypatch):
-    """GG_DETERMINISTIC=1: the B = 64 steps use the atomic-free single-workgroup gradient kernel --
-    two engines give BIT-IDENTICAL tables after many steps with heavy row duplication, and the
-    result stays within tolerance of the atomic kernel and of the oracle."""
+def test_small_batches_are_atomic_free_and_reproducible(ga, monkeypatch):
+    """The reference's batches (<= 256 pairs: batch 64, graph_gan.py:149-157,168-176) run the atomic-free single-workgroup
+    gradient kernel BY DEFAULT: two engines give BIT-IDENTICAL tables after many steps with heavy row duplication, and the
+    result stays within tolerance of the atomic kernel (GG_DETERMINISTIC=0) and of the oracle."""
     n, d = 300, 50
     Eg, Ed, bg, bd = make_models(n, d, 9)
-    monkeypatch.setenv("GG_DETERMINISTIC", "1")
     a = engine_with(ga, Eg, Ed, bg, bd)
     b = engine_with(ga, Eg, Ed, bg, bd)
-    monkeypatch.delenv("GG_DETERMINISTIC")
+    monkeypatch.setenv("GG_DETERMINISTIC", "0")
     c = engine_with(ga, Eg, Ed, bg, bd)  # atomic mode
+    monkeypatch.delenv("GG_DETERMINISTIC")
     gen, dis = orc.Generator(Eg, 1e-3), orc.Discriminator(Ed, 1e-3)
     gen.b[:] = bg
     dis.b[:] = bd
     rs = np.random.RandomState(4)
     for t in range(25):
-        B = 64 if t % 5 else 37
+        B = (64, 37, 256, 130, 1)[t % 5]
         u, v = rs.randint(0, n, B), rs.randint(0, n, B)
         u[: B // 2] = u[0]
         v[B // 2:] = rs.randint(0, 5, B - B // 2)
@@ -717,12 +717,142 @@ def test_deterministic_small_batch_mode(ga, monkeypatch):
         e.close()
 
 
+@pytest.mark.parametrize("d", [50, 128, 256, 300])
+def test_atomic_free_kernel_row_widths(ga, d):
+    """The atomic-free kernel keeps the batch's rows in LDS when 2 n rows fit (batch 64 up to d = 288), and re-reads the
+    partner rows from the table when they do not (n = 256 at d >= 128; every n at d = 300): both against the oracle's step,
+    duplicates on both sides of the pairs included."""
+    n = 500
+    Eg, Ed, bg, bd = make_models(n, d, 21)
+    eng = engine_with(ga, Eg, Ed, bg, bd)
+    gen, dis = orc.Generator(Eg, 1e-3), orc.Discriminator(Ed, 1e-3)
+    gen.b[:] = bg
+    dis.b[:] = bd
+    rs = np.random.RandomState(6)
+    for B in (64, 256, 3):
+        u, v = rs.randint(0, n, B), rs.randint(0, 40, B)
+        u[::3] = u[0]
+        lab = (rs.rand(B) < 0.5).astype(np.float32)
+        rew = (rs.rand(B) * 2).astype(np.float32)
+        dis.d_step(u, v, lab, 1e-5)
+        gen.g_step(v, u, rew, 1e-5)
+        eng.d_step(u, v, lab)
+        eng.g_step(v, u, rew)
+        assert np.allclose(eng.get_embeddings(1), dis.E, rtol=3e-5, atol=2e-6), B
+        assert np.allclose(eng.get_bias(1), dis.b, rtol=3e-5, atol=2e-6), B
+        assert np.allclose(eng.get_embeddings(0), gen.E, rtol=3e-5, atol=2e-6), B
+        assert np.allclose(eng.get_bias(0), gen.b, rtol=3e-5, atol=2e-6), B
+    eng.close()
+
+
+@pytest.mark.parametrize("mode", ["lazy", "sgd"])
+def test_small_batch_steps_apply_the_optimizer_in_the_gradient_kernel(ga, mode, monkeypatch):
+    """The strict schedule at scale (batch 64 with lazy Adam / SGD on one replica): ONE launch per step -- the owner of a row in the
+    atomic-free gradient kernel applies the optimizer to it.  Against the oracle's lazy Adam / plain SGD, and BIT-IDENTICAL to the
+    unfused sequence gradient kernel -> flag compaction -> sparse_opt_kernel (GG_NO_FUSED_SMALL_STEP=1)."""
+    n, d = 2000, 128
+    Eg, Ed, bg, bd = make_models(n, d, 13)
+    opt = ga.GG_OPT_ADAM_LAZY if mode == "lazy" else ga.GG_OPT_SGD
+    fused = engine_with(ga, Eg, Ed, bg, bd, optimizer=opt)
+    plain = engine_with(ga, Eg, Ed, bg, bd, optimizer=opt)
+    dis = orc.Discriminator(Ed, 1e-3, lazy=True)
+    gen = orc.Generator(Eg, 1e-3, lazy=True)
+    dis.b[:] = bd
+    gen.b[:] = bg
+    rs = np.random.RandomState(8)
+    for t in range(12):
+        B = (64, 64, 17, 1)[t % 4]
+        u, v = rs.randint(0, n // 2, B), rs.randint(0, n // 2, B)  # rows >= n/2 stay untouched
+        u[: B // 3] = u[0]
+        v[B // 2:] = v[-1]
+        lab = (rs.rand(B) < 0.5).astype(np.float32)
+        rew = (rs.rand(B) * 2).astype(np.float32)
+        fused.d_step(u, v, lab)
+        fused.g_step(v, u, rew)
+        monkeypatch.setenv("GG_NO_FUSED_SMALL_STEP", "1")
+        plain.d_step(u, v, lab)
+        plain.g_step(v, u, rew)
+        monkeypatch.delenv("GG_NO_FUSED_SMALL_STEP")
+        if mode == "lazy":
+            dis.d_step(u, v, lab, 1e-5)
+            gen.g_step(v, u, rew, 1e-5)
+        else:
+            for model, (a, b, x), is_d in ((dis, (u, v, lab), True), (gen, (v, u, rew), False)):
+                _, gu, gv, gb = model.loss_and_grads(a, b, x, 1e-5)
+                GE, Gb = np.zeros_like(model.E, dtype=np.float64), np.zeros(n)
+                np.add.at(GE, a, gu)
+                np.add.at(GE, b, gv)
+                np.add.at(Gb, b, gb)
+                model.E -= (1e-3 * GE).astype(np.float32)
+                model.b -= (1e-3 * Gb).astype(np.float32)
+        for which, model in ((1, dis), (0, gen)):
+            assert np.allclose(fused.get_embeddings(which), model.E, rtol=2e-5, atol=1e-6), (t, which)
+            assert np.allclose(fused.get_bias(which), model.b, rtol=2e-5, atol=1e-6), (t, which)
+    for which in (0, 1):
+        assert np.array_equal(fused.get_embeddings(which), plain.get_embeddings(which))
+        assert np.array_equal(fused.get_bias(which), plain.get_bias(which))
+        assert np.array_equal(fused.get_embeddings(which)[n // 2:], (Eg, Ed)[which][n // 2:])
+    assert fused.counters()["d_steps"] == 12 and fused.counters()["g_steps"] == 12
+    fused.close()
+    plain.close()
+
+
+def test_strict_inner_pass_tables_match_the_oracle(ga):
+    """Table-level float parity over a WHOLE inner pass of the reference's schedule on CA-GrQc (graph_gan.py:144-176, batch 64,
+    dense TF1 Adam): prepare_data_for_d -> every D minibatch of the pass in shuffled order (131 optimizer steps) -> prepare_data_for_g
+    -> the first 400 G minibatches, engine against the numpy restatement on the same integer data.  Gate: max |difference|
+    <= 1e-5 over all four tables (the updates are ~1e-3 per step; the two sides differ in fp32 summation order and in the last
+    bit of exp / sqrt), and a second engine gives the SAME BITS (no atomics on this path)."""
+    d0, n, graph = load_ca_grqc()
+    init = ca_grqc_init_embeddings(d0, n, seed=0).astype(np.float32)
+    rowptr, col = ga.graph_to_csr(n, graph)
+    slots = np.arange(n, dtype=np.int32)
+    engines = []
+    for _ in range(2):
+        eng = ga.Engine(init, init)
+        eng.set_graph_csr(rowptr, col)
+        eng.build_trees(np.arange(n))
+        engines.append(eng)
+    gen, dis = orc.Generator(init, 1e-3), orc.Discriminator(init, 1e-3)
+    c, nb, lab, _ = engines[0].prepare_d(slots, 31, 0)
+    engines[1].prepare_d(slots, 31, 0, fetch=False)
+    starts = np.arange(0, len(c), 64)
+    np.random.RandomState(1).shuffle(starts)
+    assert len(starts) >= 130
+    for e in engines:
+        e.d_pass(starts, 64)
+    c64, nb64 = c.astype(np.int64), nb.astype(np.int64)
+    for s in starts:
+        dis.d_step(c64[s:s + 64], nb64[s:s + 64], lab[s:s + 64], 1e-5)
+    n1, n2, rew, _ = engines[0].prepare_g(slots, 20, 31, 1)
+    engines[1].prepare_g(slots, 20, 31, 1, fetch=False)
+    assert np.max(np.abs(rew - dis.reward(n1.astype(np.int64), n2.astype(np.int64)))) <= 1e-5  # rewards of the UPDATED discriminator
+    starts = np.arange(0, len(n1), 64)
+    np.random.RandomState(2).shuffle(starts)
+    starts = starts[:400]
+    for e in engines:
+        e.g_pass(starts, 64)
+    a64, b64 = n1.astype(np.int64), n2.astype(np.int64)
+    for s in starts:
+        gen.g_step(a64[s:s + 64], b64[s:s + 64], rew[s:s + 64], 1e-5)
+    worst = 0.0
+    for which, model in ((0, gen), (1, dis)):
+        E, b = engines[0].get_embeddings(which), engines[0].get_bias(which)
+        worst = max(worst, float(np.abs(E - model.E).max()), float(np.abs(b - model.b).max()))
+        assert np.abs(model.E - init).max() > 1e-2     # the pass moved the table
+        assert np.array_equal(E, engines[1].get_embeddings(which)) and np.array_equal(b, engines[1].get_bias(which))
+    print("strict inner pass: max |engine - oracle| over the four tables = %.3g" % worst)
+    assert worst <= 1e-5
+    for e in engines:
+        e.close()
+
+
 @pytest.mark.parametrize("every", [0, 3])
 def test_sampled_profiling_and_early_returning_passes(ga, every, monkeypatch):
     """gg_set_profiling(k != 1): events only on every k-th walk launch, gg_*_pass return before their kernels have
     finished (stream-ordered).  Results and work counters are those of the default (every launch timed,
     synchronous passes) mode; the timing counters cover exactly the profiled launches."""
-    monkeypatch.setenv("GG_DETERMINISTIC", "1")  # atomic-free B = 64 steps: the two runs are comparable bit for bit
+    # (batch-64 steps are atomic-free by default: the two runs are comparable bit for bit)
     # every stale node is scored whole exactly once: rows_scored is then a pure function of the walks (under the default
     # policy it also depends on which of two racing roots asks for a node first)
     monkeypatch.setenv("GG_ES_MODE", "2")

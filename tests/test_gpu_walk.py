@@ -191,6 +191,50 @@ def test_non_finite_generator_scores_are_an_error_not_a_fault(ga, levels, monkey
     eng.close()
 
 
+@pytest.mark.parametrize("levels", ["0", "64"])
+def test_non_finite_rows_behind_unscored_hops_are_an_error_too(ga, levels, monkeypatch):
+    """Hops with ONE candidate (an only child; a leaf's back-step) score nothing -- the pick is certain -- so a non-finite row that
+    walks reach only through such hops never meets a softmax.  The reference fails there (softmax([inf]) = [nan],
+    np.random.choice raises, graph_gan.py:261-262): the engine reports GG_EINVAL through the finiteness flag the optimizer
+    kernels and the table uploads maintain (gg_ctx::table_bad).  Graph: a pendant pair 0 - 1 beside a component that is
+    scored normally; the walks from root 0 are 0 -> 1 (only child) -> 0 (leaf back-step)."""
+    monkeypatch.setenv("GG_WALK_LEVELS", levels)
+    edges = np.array([[0, 1], [2, 3], [3, 4], [4, 5], [2, 5], [3, 5]], dtype=np.int32)
+    n, d = 6, 8
+    rowptr, col = ga.edges_to_csr(n, edges)
+    rs = np.random.RandomState(3)
+    E = (rs.randn(n, d) * 0.3).astype(np.float32)
+    bad = E.copy()
+    bad[1, 3] = np.inf
+    roots = np.arange(n, dtype=np.int32)
+    eng = ga.Engine(bad, E, optimizer=ga.GG_OPT_ADAM_LAZY)
+    eng.set_graph_csr(rowptr, col)
+    eng.build_trees(roots)
+    with pytest.raises(ga.GraphGANHipError) as ei:   # (a) uploaded non-finite row
+        eng.walk_sample(roots, np.full(n, 4), False, 1, 1)
+    assert ei.value.code == ga.GG_EINVAL and "non-finite" in str(ei.value)
+    eng.set_embeddings(0, E)                          # a finite table clears the flag
+    out = eng.walk_sample(roots, np.full(n, 4), False, 1, 1)
+    assert (out["path_len"][:4] == 3).all() and (out["paths"][:4, :3] == [0, 1, 0]).all() and (out["samples"][:4] == 1).all()
+    # (b) an optimizer step that diverges row 1: batch 64 path (fused update) and a large fused batch (staged / sparse optimizer)
+    for B in (8, 40000):
+        eng.set_embeddings(0, E)
+        eng.set_bias(0, np.zeros(n, np.float32))       # (the diverged step below also leaves a NaN bias behind)
+        eng.walk_sample(roots, np.full(n, 4), False, 1, 1)
+        u, v = np.zeros(B, np.int32), np.ones(B, np.int32)
+        eng.g_step(u, v, np.full(B, np.float32(np.inf)))   # dL/ds = -inf: m / sqrt(v) = inf / inf
+        assert not np.isfinite(eng.get_embeddings(0)[1]).all()
+        with pytest.raises(ga.GraphGANHipError) as ei:
+            eng.walk_sample(roots, np.full(n, 4), False, 1, 1)
+        assert ei.value.code == ga.GG_EINVAL
+    # the discriminator's tables do not concern the walks
+    eng.set_embeddings(0, E)
+    eng.set_bias(0, np.zeros(n, np.float32))
+    eng.set_embeddings(1, bad)
+    eng.walk_sample(roots, np.full(n, 4), False, 1, 1)
+    eng.close()
+
+
 def test_speculative_level_buffers_overflow_is_retried(ga, monkeypatch):
     """The level pipeline sizes its score buffers from earlier launches and runs without host
     synchronisation; a launch that needs more raises a device flag and is rerun with exact sizing.
