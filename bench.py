@@ -166,34 +166,62 @@ def exchange_label(comm):
     """What the replicas' gradient exchanges of this run actually were (gg_comm_stats), not what was planned."""
     if not comm:
         return "none (counters unavailable)"
-    sp, de = comm.get("sparse_steps", 0), comm.get("dense_steps", 0)
+    pk, ow, de = comm.get("pack_steps", 0), comm.get("owner_steps", 0), comm.get("dense_steps", 0)
     kinds = []
-    if sp:
-        kinds.append("%d x all-gather of fixed-capacity row packs" % sp)
+    if pk:
+        kinds.append("%d x all-gather of fixed-capacity row packs" % pk)
+    if ow:
+        kinds.append("%d x owner-partitioned send / recv + all-gather of the reduced rows (%s rows)" % (ow, "bf16" if comm.get("bf16_rows") else "fp32"))
     if de:
         kinds.append("%d x dense reduce-scatter + all-gather of the accumulators" % de)
     return ", ".join(kinds) if kinds else "no exchange ran"
 
 
-def comm_model(n, ld, d_rows_touched, g_rows_touched, d_pairs, g_pairs):
+XGMI_LINK_GBS = 153.0   # per direction and link; 7 links per GPU, point to point (the task brief's figure: the guides give none)
+XGMI_EFFICIENCY = 0.8   # assumed payload fraction of the link rate for RCCL send / recv of >= 1 MB segments (NOT measured)
+HOST_ROUND_TRIP_MS = 0.03  # the owner exchange's two small host synchronisations (count matrix, largest owner), each
+
+
+def comm_model(n, ld, d_rows_touched, g_rows_touched, d_pairs, g_pairs, step_ms=None, d_pass_ms=None, g_walk_ms=None):
     """Bytes ONE rank sends per step (D exchange + G exchange) at P = 2 / 4 / 8 under each strategy, from this run's real
     per-rank counts (touched rows of the two passes, pairs of the two passes).  Weak scaling: every rank brings the same
     counts.  dense = reduce-scatter + all-gather of the [N, ld + 1] accumulators (+ the int32 row flags);
     packs = all-gather of fixed-capacity row packs, capacity min(N, 2 * pairs) rows of (ld + 2) words, sent to P - 1 peers;
     owner = owner-partitioned sparse reduce: each touched row goes to its owner (row mod P), the owner's reduced rows -- the
-    union over ranks, bounded by min(N, P * touched) -- go to the P - 1 peers.  No N > 1 run exists: this is a model."""
+    union over ranks, bounded by min(N, P * touched) -- go to the P - 1 peers; owner_bf16 = the same with bf16 rows
+    (GG_COMM_BF16=1).  TIME (round 5): every transfer of the owner exchange is a personalised all-to-all / all-gather in which
+    each pair of ranks uses its own xGMI link, so a rank's bytes move over P - 1 links at once: ms = bytes / ((P - 1) x link
+    rate x efficiency) + two host round trips.  EXPOSED time per step: the D exchange runs on the main stream beside the G-mode
+    walks of the side stream (gg_prepare_g_begin), so only what (D pass + D exchange) exceeds those walks by is exposed; the G
+    exchange sits between the generator's gradient and optimizer kernels with nothing to hide behind (the next D-mode walks
+    need the updated generator).  Estimated weak-scaling efficiency = step / (step + exposed).  No N > 1 run exists: a MODEL."""
     row_b = 4.0 * (ld + 2)
+    row_h = 2.0 * (ld + 2) + 4.0
     out = {}
     for P in (2, 4, 8):
         f = (P - 1.0) / P
         dense = 2 * (2.0 * f * 4.0 * n * (ld + 1) + 2.0 * f * 4.0 * n)
         packs = sum((P - 1) * min(n, 2 * pairs) * row_b for pairs in (d_pairs, g_pairs))
-        owner = sum(f * t * row_b + f * min(n, P * t) * row_b for t in (d_rows_touched, g_rows_touched))
-        out["P=%d" % P] = {"dense_rs_ag": dense, "row_packs_allgather": packs, "owner_partitioned_sparse": owner,
-                           # (steps.hip::exchange_sparse: packs while world x capacity < 1.5 N rows; above that the owner-partitioned
-                           # exchange when the bound is >= GG_COMM_OWNER_MIN rows and ncclSend / ncclRecv resolve, else dense)
-                           "picked_today": ("row_packs_allgather" if P * min(n, 2 * max(d_pairs, g_pairs)) < 1.5 * n else
-                                            "owner_partitioned_sparse (dense_rs_ag if ncclSend / ncclRecv are missing or GG_COMM_OWNER=0)")}
+        own = {"fp32": [f * t * row_b + f * min(n, P * t) * row_b for t in (d_rows_touched, g_rows_touched)],
+               "bf16": [f * t * row_h + f * min(n, P * t) * row_h for t in (d_rows_touched, g_rows_touched)]}
+        entry = {"dense_rs_ag": dense, "row_packs_allgather": packs, "owner_partitioned_sparse": sum(own["fp32"]),
+                 "owner_partitioned_sparse_bf16": sum(own["bf16"]),
+                 # (steps.hip::exchange_sparse: packs while world x capacity < 1.5 N rows; above that the owner-partitioned
+                 # exchange when the bound is >= GG_COMM_OWNER_MIN rows and ncclSend / ncclRecv resolve, else dense)
+                 "picked_today": ("row_packs_allgather" if P * min(n, 2 * max(d_pairs, g_pairs)) < 1.5 * n else
+                                  "owner_partitioned_sparse (dense_rs_ag if ncclSend / ncclRecv are missing or GG_COMM_OWNER=0)")}
+        rate = (P - 1) * XGMI_LINK_GBS * 1e9 * XGMI_EFFICIENCY  # bytes / s leaving one rank over the links the exchange uses
+        for kind, (bd, bg) in own.items():
+            d_ms, g_ms = 1e3 * bd / rate + 2 * HOST_ROUND_TRIP_MS, 1e3 * bg / rate + 2 * HOST_ROUND_TRIP_MS
+            t = {"d_exchange_ms": d_ms, "g_exchange_ms": g_ms}
+            if step_ms and d_pass_ms is not None and g_walk_ms is not None:
+                exposed = max(0.0, d_pass_ms + d_ms - g_walk_ms) + g_ms
+                t.update(exposed_ms_per_step=exposed, weak_scaling_efficiency_estimate=step_ms / (step_ms + exposed))
+            entry["modelled_time_owner_%s" % kind] = t
+        entry["modelled_time_dense_ms"] = 1e3 * dense / rate
+        out["P=%d" % P] = entry
+    out["assumptions"] = {"xgmi_link_GBs": XGMI_LINK_GBS, "links_used": "P - 1 (one per peer)", "link_efficiency": XGMI_EFFICIENCY,
+                          "host_round_trip_ms": HOST_ROUND_TRIP_MS, "step_ms": step_ms, "d_pass_ms": d_pass_ms, "g_walk_ms": g_walk_ms}
     return out
 
 
@@ -591,10 +619,13 @@ def main():
     if cont:
         out["batch_of_rounds_1_2"] = cont
     if c["d_passes_timed"] and c["g_passes_timed"]:
+        d_pass_ms = (c["d_grad_ms"] + c["d_opt_ms"]) / c["d_passes_timed"]
         out["comm_model"] = dict(comm_model(n, eng.n_emb + (-eng.n_emb) % 4, c["d_rows_timed"] / c["d_passes_timed"], c["g_rows_timed"] / c["g_passes_timed"],
-                                            c["d_pairs"] / args.steps, c["g_pairs"] / args.steps),
-                                 what="bytes one rank would send per step for its two gradient exchanges, from this run's per-rank touched rows / pairs; "
-                                      "unit B; NOT measured (no multi-GPU box)")
+                                            c["d_pairs"] / args.steps, c["g_pairs"] / args.steps, step_ms=1e3 * dt / args.steps, d_pass_ms=d_pass_ms,
+                                            g_walk_ms=walk_ms / launches if launches else None),
+                                 what="bytes one rank would send per step for its two gradient exchanges, from this run's per-rank touched rows / pairs "
+                                      "(unit B), the time they would take on xGMI and the weak-scaling efficiency that follows; a MODEL, NOT measured "
+                                      "(no multi-GPU box has run this code)")
     if comm:
         out["comm"] = dict(comm, what="rank 0's gradient exchanges up to the end of the timed region (RCCL over xGMI): optimizer steps that exchanged "
                                       "fixed-capacity row packs (sparse) / reduce-scatter + all-gather of the accumulators (dense), bytes sent")

@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgraphgan_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "graphgan_hip.h")
-ABI_VERSION = 5  # == GG_ABI_VERSION of include/graphgan_hip.h (tests/test_host_cpu.py keeps header, binding and library in step)
+ABI_VERSION = 6  # == GG_ABI_VERSION of include/graphgan_hip.h (tests/test_host_cpu.py keeps header, binding and library in step)
 
 
 def header_abi_version(path=HEADER_PATH):
@@ -126,6 +126,7 @@ SIGNATURES = {
     "gg_comm_init": (ctypes.c_int, [_P, _P, _i32, _i32]),
     "gg_comm_barrier": (ctypes.c_int, [_P]),
     "gg_comm_stats": (ctypes.c_int, [_P, _P]),
+    "gg_comm_stats_ex": (ctypes.c_int, [_P, _P]),
     "gg_synth_powerlaw": (_i64, [_i32, _i32, _u64, _u64, _P, _i64]),
     "gg_host_read_edges": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(GGGraph)]),
     "gg_host_free_graph": (None, [ctypes.POINTER(GGGraph)]),

@@ -245,6 +245,18 @@ int gg_comm_barrier(gg_ctx *ctx) {
 }  // extern "C"
 
 // gg_comm_stats: see include/graphgan_hip.h.
+extern "C" int gg_comm_stats_ex(gg_ctx *ctx, int64_t *out8) {
+    if (!ctx || !out8) return fail(ctx, GG_EINVAL, "gg_comm_stats_ex: NULL argument");
+    out8[0] = ctx->comm_steps_sparse - ctx->comm_steps_owner;
+    out8[1] = ctx->comm_steps_owner;
+    out8[2] = ctx->comm_steps_dense;
+    out8[3] = ctx->comm_bytes_sent;
+    out8[4] = ctx->world;
+    out8[5] = ctx->comm_bf16 ? 1 : 0;
+    out8[6] = out8[7] = 0;
+    return GG_OK;
+}
+
 extern "C" int gg_comm_stats(gg_ctx *ctx, int64_t *out4) {
     if (!ctx || !out4) return fail(ctx, GG_EINVAL, "gg_comm_stats: NULL argument");
     out4[0] = ctx->comm_steps_sparse;

@@ -156,6 +156,10 @@ static int launch_and_join(gg_ctx *ctx, int32_t n_slots, int64_t total, int32_t 
     if (side) {
         GG_HIP(ctx, hipEventRecord(ctx->ev_walk_done, ctx->walk_stream));
         if (join) GG_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_walk_done, 0));  // (gg_prepare_g_begin: joined by the adopting gg_prepare_g)
+        if (!for_d) {  // behind the walks on their stream: the staging index of the generator pass that will consume them
+            rc = enqueue_path_slots(ctx);
+            if (rc != GG_OK) return rc;
+        }
     }
     return GG_OK;
 }
@@ -235,6 +239,10 @@ int gg::walk_launch_async(gg_ctx *ctx, const int32_t *slots, const int32_t *n_wa
     ctx->w_uniform = (!n_walks && uniform_walks >= 0) ? uniform_walks : -1;
     ctx->w_args = {for_d, seed, stream};
     ctx->g_paths_valid = false;
+    if (ctx->g_slots_ready) {  // an index being built for the walks this launch overwrites: let its kernels finish reading them
+        GG_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_slots_done, 0));
+        ctx->g_slots_ready = false;
+    }
     if (n_slots == 0) {
         ctx->walk_stream = ctx->stream;
         return GG_OK;
@@ -368,6 +376,7 @@ int gg_create(int32_t n_node, int32_t n_emb, const float *emb_gen, const float *
     if (const char *pe = getenv("GG_PROFILE_EVERY")) ctx->profile_every = std::max(0, atoi(pe));
     if (const char *fw = getenv("GG_COMM_FAKE_WORLD")) ctx->fake_world = atoi(fw);
     if (const char *ow = getenv("GG_COMM_OWNER")) ctx->owner_exchange = atoi(ow);
+    if (const char *bf = getenv("GG_COMM_BF16")) ctx->comm_bf16 = atoi(bf) != 0;
     if (const char *om = getenv("GG_COMM_OWNER_MIN")) ctx->owner_min_bound = atoll(om);
     if (const char *dt = getenv("GG_DETERMINISTIC")) ctx->deterministic = atoi(dt) != 0;
     if (const char *nc = getenv("GG_NO_DIST_CACHE")) ctx->dc_enabled = atoi(nc) == 0;
@@ -476,7 +485,7 @@ int gg_destroy(gg_ctx *ctx) {
                       &ctx->d_ptr, &ctx->g_node1, &ctx->g_node2, &ctx->g_reward, &ctx->g_cnt, &ctx->g_ptr, &ctx->scan_tmp,
                       &ctx->step_u, &ctx->step_v, &ctx->step_x, &ctx->sg_cnt, &ctx->sg_off, &ctx->sg_slot, &ctx->sg_list, &ctx->sg_rows, &ctx->sg_bias, &ctx->sg_tot, &ctx->sg_key, &ctx->touched_ptr, &ctx->x_cnt, &ctx->x_send_ids, &ctx->x_send_rows,
                       &ctx->x_recv_ids, &ctx->x_recv_rows, &ctx->x_nglob, &ctx->x_own, &ctx->st_item, &ctx->st_item2, &ctx->st_cur, &ctx->st_prev, &ctx->st_len,
-                      &ctx->st_alive, &ctx->st_rank, &ctx->bfs_key, &ctx->bfs_bm, &ctx->bfs_misc, &ctx->bfs_sparse, &ctx->bfs_rowptr32, &ctx->lv_pfx, &ctx->dc_keys, &ctx->dc_vals, &ctx->dc_words, &ctx->lv_beg, &ctx->lv_k, &ctx->lv_chunks, &ctx->lv_coff, &ctx->lv_scores, &ctx->lv_chunk_owner, &ctx->lv_prefix, &ctx->lv_big, &ctx->lv_fe, &ctx->fin_list, &ctx->table_bad,
+                      &ctx->st_alive, &ctx->st_rank, &ctx->bfs_key, &ctx->bfs_bm, &ctx->bfs_misc, &ctx->bfs_sparse, &ctx->bfs_rowptr32, &ctx->lv_pfx, &ctx->dc_keys, &ctx->dc_vals, &ctx->dc_words, &ctx->lv_beg, &ctx->lv_k, &ctx->lv_chunks, &ctx->lv_coff, &ctx->lv_scores, &ctx->lv_chunk_owner, &ctx->lv_prefix, &ctx->lv_big, &ctx->lv_fe, &ctx->fin_list, &ctx->table_bad, &ctx->sgp_cnt, &ctx->sgp_off, &ctx->sgp_slot, &ctx->sgp_list, &ctx->sgp_tot, &ctx->sgp_key, &ctx->sgp_scan,
                       &ctx->q3_store, &ctx->q3s_off, &ctx->ep_center, &ctx->ep_neighbor, &ctx->ep_label, &ctx->ep_node1, &ctx->ep_node2, &ctx->ep_reward};
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : ctx->lv_ev)
@@ -485,7 +494,7 @@ int gg_destroy(gg_ctx *ctx) {
         for (hipEvent_t e : tr)
             if (e) (void)hipEventDestroy(e);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
-    for (hipEvent_t e : {ctx->ev_walk_done, ctx->ev_gen_pass, ctx->ev_main_mark, ctx->ev_fork, ctx->ev_join, ctx->ev_score[0], ctx->ev_score[1]})
+    for (hipEvent_t e : {ctx->ev_walk_done, ctx->ev_slots_done, ctx->ev_gen_pass, ctx->ev_main_mark, ctx->ev_fork, ctx->ev_join, ctx->ev_score[0], ctx->ev_score[1]})
         if (e) (void)hipEventDestroy(e);
     if (ctx->stream3) {
         (void)hipStreamSynchronize(ctx->stream3);

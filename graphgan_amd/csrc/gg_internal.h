@@ -225,6 +225,17 @@ struct gg_ctx {
     gg::DevBuf sg_cnt, sg_off, sg_slot, sg_list, sg_rows, sg_bias, sg_tot, sg_key;  // sg_key: source of each stage row (sum order)
     bool g_pairs_filled = false;       // g_node1 / g_node2 hold the pairs of the resident G walks (prepare.hip, ensure_g_pairs)
     bool sg_cnt_dirty = false;         // a staged pass counted rows and has not (yet) applied them
+    // The generator pass's staging INDEX (per-row counts, segment offsets, slots, small-row list, keys) depends on the G-mode walks
+    // only, so it is built on the side stream right behind them (enqueue_path_slots, steps.hip) -- beside the reward kernels
+    // of the main stream -- in buffers of its own (the discriminator pass uses sg_* at the same time); ev_slots_done orders the
+    // gradient kernel behind it.
+    gg::DevBuf sgp_cnt, sgp_off, sgp_slot, sgp_list, sgp_tot, sgp_key, sgp_scan;
+    hipEvent_t ev_slots_done = nullptr;
+    bool g_slots_ready = false;        // the index of the resident G-mode walks is enqueued / done
+    bool sgp_cnt_clean = false;        // sgp_cnt is all zero
+    int64_t g_slots_walks = 0;
+    int32_t g_slots_stride = 0;
+    int32_t *sg_cnt_active = nullptr;  // the count array of the staged pass that is applying its hub rows (sg_active)
     bool sg_active = false;            // a staged G pass is applying its hub rows (apply_optimizer resets their counts)
     int sg_threshold = 64;             // GG_STAGE_T: rows with more staged gradients than this keep the atomic path; 0 = everything atomic
 
@@ -248,6 +259,7 @@ struct gg_ctx {
     gg::DevBuf x_nglob;  // pairs of all ranks in the generator step in flight (device word)
     gg::DevBuf x_own;    // owner-partitioned exchange: per-owner counts / fill cursors / the gathered count matrix (int64 words)
     int32_t owner_exchange = 1;       // GG_COMM_OWNER=0 switches the owner-partitioned sparse exchange off
+    bool comm_bf16 = false;           // GG_COMM_BF16=1: the owner-partitioned exchange moves bf16 rows (fp32 sums at the owner; the reduced rows are rounded once more)
     int64_t owner_min_bound = 4096;   // GG_COMM_OWNER_MIN: steps of fewer pairs never try it (its two host round trips outweigh a minibatch)
     int64_t comm_steps_owner = 0;     // optimizer steps that took it (gg_comm_stats counts them with the sparse steps)
 
@@ -277,7 +289,8 @@ int fail(gg_ctx *ctx, int code, const char *fmt, ...);
 int device_exclusive_scan(gg_ctx *ctx, const int32_t *cnt, int64_t *ptr, int64_t n);
 int ensure_g_pairs(gg_ctx *ctx);  // prepare.hip: (node_1, node_2) of the resident G walks, written on first use
 int device_compact_flags(gg_ctx *ctx, const int32_t *flag, int64_t n, int32_t *list, int64_t *total_out);  // prepare.hip
-int device_segment_rows(gg_ctx *ctx, const int32_t *cnt, int64_t n, int T, int32_t *off, int4 *list, int64_t *totals);  // prepare.hip
+int device_segment_rows(gg_ctx *ctx, const int32_t *cnt, int64_t n, int T, int32_t *off, int4 *list, int64_t *totals, hipStream_t stream = nullptr,
+                        DevBuf *scratch = nullptr);  // prepare.hip (defaults: the main stream and its scan scratch)
 
 // trees (gg_api.hip / tree_builder.cpp)
 int alloc_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int64_t *node_counts, const int64_t *root_children);
@@ -302,6 +315,7 @@ void harvest_timings(gg_ctx *ctx);
 int derive_tree_edges(gg_ctx *ctx);   // walk_sample.hip: t_edge from t_order / t_cstart and the resident graph (sets t_edge_valid)
 int compute_reverse_edges(gg_ctx *ctx);  // walk_sample.hip: g_rev of the resident graph
 int rescan_table_finite(gg_ctx *ctx, int which);  // gg_api.hip
+int enqueue_path_slots(gg_ctx *ctx);  // steps.hip: staging index of the G-mode walks just enqueued, on the side stream
 void generator_changed(gg_ctx *ctx);  // gg_api.hip: cached distributions and edge scores are stale  // after a synchronisation of ctx->stream: fold finished event triples into the counters
 int walk_resident(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, int32_t uniform_walks, int32_t n_slots,
                   int32_t for_d, uint64_t seed, uint32_t stream, int32_t stride);

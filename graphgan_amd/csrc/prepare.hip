@@ -206,13 +206,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void seg_apply(const int32_t *cnt, in
         }
 }
 
-int device_segment_rows(gg_ctx *ctx, const int32_t *cnt, int64_t n, int T, int32_t *off, int4 *list, int64_t *totals) {
+int device_segment_rows(gg_ctx *ctx, const int32_t *cnt, int64_t n, int T, int32_t *off, int4 *list, int64_t *totals, hipStream_t stream, DevBuf *scratch) {
     const int64_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
-    GG_HIP(ctx, ctx->scan_tmp.reserve(sizeof(int64_t) * (2 * tiles + 4)));
-    int64_t *tr = ctx->scan_tmp.as<int64_t>(), *to = tr + tiles + 1;
-    hipLaunchKernelGGL(seg_tile_sums, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, ctx->stream, cnt, n, T, tr, to);
-    hipLaunchKernelGGL(scan_tile_offsets2, dim3(2), dim3(SCAN_THREADS), 0, ctx->stream, tr, to, tiles, totals, totals + 1);
-    hipLaunchKernelGGL(seg_apply, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, ctx->stream, cnt, n, T, tr, to, off, list);
+    if (!scratch) scratch = &ctx->scan_tmp;  // (a launch beside the main stream's scans brings its own scratch)
+    if (!stream) stream = ctx->stream;
+    GG_HIP(ctx, scratch->reserve(sizeof(int64_t) * (2 * tiles + 4)));
+    int64_t *tr = scratch->as<int64_t>(), *to = tr + tiles + 1;
+    hipLaunchKernelGGL(seg_tile_sums, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, stream, cnt, n, T, tr, to);
+    hipLaunchKernelGGL(scan_tile_offsets2, dim3(2), dim3(SCAN_THREADS), 0, stream, tr, to, tiles, totals, totals + 1);
+    hipLaunchKernelGGL(seg_apply, dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, stream, cnt, n, T, tr, to, off, list);
     GG_HIP(ctx, hipGetLastError());
     return GG_OK;
 }

@@ -36,6 +36,7 @@ struct StepArgs {
     const int64_t *n_glob; // multi-GPU G step: pairs of ALL ranks in this step (device word) -> inv_n = 1 / *n_glob
     int is_d;
     int ppg;               // consecutive pairs handled by one 16-lane group
+    unsigned long long *prof;  // GG_DET_PROFILE: 100 MHz clock stamps of the small-batch kernel (wave 0 and the last wave), else null
     // STAGED (large fused batches on one replica, see path_count_kernel): stage row of the v-side gradient of pair p, and of
     // the u-side gradient of the run that ends at pair p (-2: no run ends there); -1 = hub row, atomics as before
     const int32_t *slot_v, *slot_u;
@@ -322,21 +323,23 @@ struct PathArgs {
 // differs from run to run; the sum does not: every stage row carries the path position it came from (sg_key) and the
 // reducing group adds its segment in ascending key order -- a deterministic sum for those rows.  Hub rows (> T gradients)
 // keep the atomic path (run-dependent fp32 order) and the flag -> list -> sparse_opt_kernel update.
+// `flag` (early launches behind the walk, enqueue_path_slots): the walk launch's status word; 2 = the launch is being rerun, its
+// paths are not final -> count nothing (the rerun brings its own launch of these kernels)
 __global__ __launch_bounds__(256) void path_count_kernel(const int32_t *paths, const int32_t *path_len, int stride, int64_t n_walks,
-                                                         int32_t *cnt, int32_t *slot) {
+                                                         int32_t *cnt, int32_t *slot, const unsigned long long *flag) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t w = idx / stride;
-    if (w >= n_walks) return;
+    if (w >= n_walks || (flag && *flag == 2ull)) return;
     const int c = (int)(idx - w * stride), L = path_len[w] - 1;
     if (L <= 1 || c >= L) return;  // walks without pairs flush nothing
     slot[idx] = atomicAdd(&cnt[paths[idx]], 1);
 }
 
 __global__ __launch_bounds__(256) void path_slot_kernel(const int32_t *paths, const int32_t *path_len, int stride, int64_t n_walks,
-                                                        const int32_t *cnt, const int32_t *off, int T, int32_t *slot, int32_t *key) {
+                                                        const int32_t *cnt, const int32_t *off, int T, int32_t *slot, int32_t *key, const unsigned long long *flag) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t w = idx / stride;
-    if (w >= n_walks) return;
+    if (w >= n_walks || (flag && *flag == 2ull)) return;
     const int c = (int)(idx - w * stride), L = path_len[w] - 1;
     if (L <= 1 || c >= L) return;
     const int nd = paths[idx];
@@ -664,7 +667,14 @@ __device__ __forceinline__ unsigned group16_ballot(bool pred) {  // the 16 predi
     return (unsigned)(m >> (threadIdx.x & 48)) & 0xffffu;
 }
 
-template <int NF, bool ROWS_IN_LDS, int OPT>  // OPT: 0 = store the gradient rows, 1 = lazy Adam, 2 = SGD
+// (What the kernel's time is made of -- it is ONE chain on ONE compute unit: pair ids -> the two rows -> coefficient -> barrier ->
+// owners' sums -> stores.  The first version read the ids through LDS in front of the row loads, tested ownership and collected a
+// row's contributions with one LDS read per step of a loop, and added the contributions one at a time, each behind its own LDS
+// round trip: 10.8 us per launch against 5.9 for the atomic kernel -- a discriminator batch names its centre 64 times.  Now the
+// groups take their pair's ids straight from global memory, the slot ids sit in registers (ownership and the contribution masks
+// are ballots over them), and a row is summed by a whole wavefront, a lane per feature, four contributions at a time: see phase 2.)
+// SMALLN: n <= 64 (the reference's batch): the 128 slot ids are two registers per lane; up to 256 pairs: eight.
+template <int NF, bool ROWS_IN_LDS, int OPT, bool SMALLN>  // OPT: 0 = store the gradient rows, 1 = lazy Adam, 2 = SGD
 __global__ __launch_bounds__(DET_THREADS) void pair_grad_det_kernel(const StepArgs a, const OptArgs o) {
     static_assert(OPT == 0 || ROWS_IN_LDS, "the fused update needs every table read in front of the barrier");
     extern __shared__ float det_rows[];  // [2 n][ld] when ROWS_IN_LDS
@@ -673,10 +683,14 @@ __global__ __launch_bounds__(DET_THREADS) void pair_grad_det_kernel(const StepAr
     const int t = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int n = a.n, ld = a.ld, nchunk = ld >> 2;
     const float inv_n = a.n_glob ? 1.0f / (float)(*a.n_glob) : a.inv_n;
+    const bool stamp = a.prof && (threadIdx.x == 0 || threadIdx.x == DET_THREADS - 64);
+    unsigned long long *const pw = a.prof + (threadIdx.x ? 8 : 0);
+    if (stamp) pw[0] = wall_clock64();
     for (int s = threadIdx.x; s < 2 * n; s += DET_THREADS) ids[s] = s < n ? a.u[s] : a.v[s - n];
-    __syncthreads();
     for (int p = g; p < n; p += DET_GROUPS) {
-        const int iu = ids[p], iv = ids[n + p];
+        const int iu = a.u[p], iv = a.v[p];  // (the group's own pair: not through the LDS copy, which is for phase 2)
+        const float xp = a.x[p];
+        const float bv = a.b[iv];
         const float4 *ru = (const float4 *)(a.E + (int64_t)iu * ld);
         const float4 *rv = (const float4 *)(a.E + (int64_t)iv * ld);
         float acc = 0.f;
@@ -695,96 +709,140 @@ __global__ __launch_bounds__(DET_THREADS) void pair_grad_det_kernel(const StepAr
         acc += __shfl_xor(acc, 4, 64);
         acc += __shfl_xor(acc, 2, 64);
         acc += __shfl_xor(acc, 1, 64);
-        const float bv = a.b[iv];
         const float sc = acc + bv;
         const float sg = 1.0f / (1.0f + expf(-sc));
         float ds;
         if (a.is_d) {
-            ds = sg - a.x[p];
+            ds = sg - xp;
         } else {
             const bool inside = (sg >= 1e-5f) && (sg <= 1.0f);
-            ds = inside ? -(a.x[p] * inv_n) * (1.0f - sg) : 0.0f;
+            ds = inside ? -(xp * inv_n) * (1.0f - sg) : 0.0f;
         }
         if (t == 0) {
             coef[p] = ds;
             coefb[p] = a.is_d ? ds + a.lambda * bv : ds;
         }
     }
+    if (stamp) pw[1] = wall_clock64();
     __syncthreads();
-    for (int s = g; s < 2 * n; s += DET_GROUPS) {  // (uniform per group: the ballots below see whole rows of 16 lanes)
-        const int r = ids[s];
-        unsigned earlier = 0;
-        for (int base = 0; base < s; base += 16) earlier |= group16_ballot(base + t < s && ids[base + t] == r);
-        if (earlier) continue;  // not the first slot of this row
-        float own[NF], acc[NF], accb = 0.f;
+    if (stamp) pw[2] = wall_clock64();
+    // ---- phase 2: ONE WAVEFRONT per slot (wave w: slots w, w + 16, ...), everything about the slot wave-uniform (scalar code);
+    // lane L owns the features L, L + 64, ...  The first slot that names a row owns it and adds the row's contributions in
+    // ascending slot order, four at a time (their LDS reads in flight together): the fp32 operation sequence per element is the
+    // same whatever the hardware does.
+    // (Measured on the way here, CA-GrQc batches: a 16-lane group per slot, the other three groups of its wavefront masked off while
+    // it summed a centre row named by 20 - 64 pairs: 5.4 us of the kernel's 9.4 -- a wave64 instruction costs four cycles however
+    // few lanes are alive; the four groups sharing a row's contributions and merging partial sums with 4 NF + 4 permutes: 2.9 us.)
+    constexpr int NW = SMALLN ? 2 : 2 * DET_MAX_PAIRS / 64;  // 64-slot words of the id list
+    constexpr int NFW = (NF + 3) / 4;                          // features per lane: ceil(ld / 64)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int idr[NW];
 #pragma unroll
-        for (int i = 0; i < NF; ++i) {
-            const int f = t + 16 * i;
+    for (int j = 0; j < NW; ++j) idr[j] = (64 * j + lane < 2 * n) ? ids[64 * j + lane] : -1;
+    for (int s = wave; s < 2 * n; s += DET_THREADS / 64) {
+        // (slot s sits in lane s & 63 of register word s >> 6: a lane read, not an LDS round trip per slot)
+        int r = __builtin_amdgcn_readlane(idr[0], s & 63);
+#pragma unroll
+        for (int j = 1; j < NW; ++j) r = (s >> 6) == j ? __builtin_amdgcn_readlane(idr[j], s & 63) : r;
+        uint64_t m[NW];  // bit = slot: the slots that name row r
+        bool earlier = false;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            m[j] = __ballot(idr[j] == r);
+            if (64 * j + 63 < s) earlier |= m[j] != 0ull;
+            else if (64 * j <= s) earlier |= (m[j] & ((1ull << (s & 63)) - 1ull)) != 0ull;
+        }
+        if (earlier) continue;  // not the first slot of this row
+        float own[NFW], lown[NFW], acc[NFW], accb = 0.f;
+#pragma unroll
+        for (int i = 0; i < NFW; ++i) {
+            const int f = lane + 64 * i;
             own[i] = f < ld ? (ROWS_IN_LDS ? det_rows[(size_t)s * ld + f] : a.E[(int64_t)r * ld + f]) : 0.f;
+            lown[i] = a.lambda * own[i];  // the l2 term of one occurrence
             acc[i] = 0.f;
         }
-        for (int base = s & ~15; base < 2 * n; base += 16) {
-            unsigned m = group16_ballot(base + t >= s && base + t < 2 * n && ids[base + t] == r);
-            while (m) {  // ascending slot order
-                const int s2 = base + __builtin_ctz(m);
-                m &= m - 1;
-                const int p = s2 < n ? s2 : s2 - n;
-                const int ps = s2 < n ? n + p : p;  // the partner's slot
-                const float c = coef[p];
-                const float *prow = ROWS_IN_LDS ? det_rows + (size_t)ps * ld : a.E + (int64_t)ids[ps] * ld;
 #pragma unroll
-                for (int i = 0; i < NF; ++i) {
-                    const int f = t + 16 * i;
-                    if (f < ld) acc[i] += c * prow[f] + a.lambda * own[i];
+        for (int j = 0; j < NW; ++j) {
+            uint64_t cur = m[j];  // (no slot before s names r: the words in front of s are empty)
+            while (cur) {
+                int sq[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (cur) { sq[k] = 64 * j + __builtin_ctzll(cur); cur &= cur - 1ull; }
+                    else sq[k] = -1;
                 }
-                if (s2 >= n) accb += coefb[p];
+                float c[4], cb[4], pr[4][NFW];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int sk = sq[k] >= 0 ? sq[k] : s;
+                    const int p = sk < n ? sk : sk - n;
+                    const int ps = sk < n ? n + p : p;  // the partner's slot
+                    c[k] = coef[p];
+                    cb[k] = coefb[p];
+                    const float *prow = ROWS_IN_LDS ? det_rows + (size_t)ps * ld : a.E + (int64_t)ids[ps] * ld;
+#pragma unroll
+                    for (int i = 0; i < NFW; ++i) {
+                        const int f = lane + 64 * i;
+                        pr[k][i] = f < ld ? prow[f] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (sq[k] >= 0) {  // (uniform)
+#pragma unroll
+                        for (int i = 0; i < NFW; ++i) acc[i] += c[k] * pr[k][i] + lown[i];
+                        if (sq[k] >= n) accb += cb[k];
+                    }
+                }
             }
         }
         if (OPT == 0) {
             float *gr = a.gE + (int64_t)r * ld;
 #pragma unroll
-            for (int i = 0; i < NF; ++i) {
-                const int f = t + 16 * i;
+            for (int i = 0; i < NFW; ++i) {
+                const int f = lane + 64 * i;
                 if (f < ld) gr[f] = acc[i];
             }
-            if (t == 0) {
+            if (lane == 0) {
                 a.gb[r] = accb;
                 if (a.track) a.touched[r] = 1;
             }
         } else {
             const int64_t ro = (int64_t)r * ld;
 #pragma unroll
-            for (int i = 0; i < NF; ++i) {
-                const int f = t + 16 * i;
+            for (int i = 0; i < NFW; ++i) {
+                const int f = lane + 64 * i;
                 if (f < ld) {
                     float var = own[i];
                     if (OPT == 2) {
                         var -= o.lr * acc[i];
                     } else {
-                        float m = o.mE[ro + f], v = o.vE[ro + f];
-                        adam_elem(var, m, v, acc[i], o);
-                        o.mE[ro + f] = m;
-                        o.vE[ro + f] = v;
+                        float m1 = o.mE[ro + f], v1 = o.vE[ro + f];
+                        adam_elem(var, m1, v1, acc[i], o);
+                        o.mE[ro + f] = m1;
+                        o.vE[ro + f] = v1;
                     }
                     if (!__builtin_isfinite(var)) *o.bad = 1ull;
                     o.E[ro + f] = var;
                 }
             }
-            if (t == 0) {
+            if (lane == 0) {
                 float var = o.b[r];
                 if (OPT == 2) {
                     var -= o.lr * accb;
                 } else {
-                    float m = o.mb[r], v = o.vb[r];
-                    adam_elem(var, m, v, accb, o);
-                    o.mb[r] = m;
-                    o.vb[r] = v;
+                    float m1 = o.mb[r], v1 = o.vb[r];
+                    adam_elem(var, m1, v1, accb, o);
+                    o.mb[r] = m1;
+                    o.vb[r] = v1;
                 }
                 if (!__builtin_isfinite(var)) *o.bad = 1ull;
                 o.b[r] = var;
             }
         }
     }
+    if (stamp) pw[3] = wall_clock64();  // (one clock read per phase: s_memrealtime is itself a slow scalar memory operation -- a read per owner round measured itself)
 }
 
 static bool det_rows_fit_lds(const StepArgs &s) { return (size_t)2 * s.n * s.ld * sizeof(float) <= DET_LDS_ROW_BYTES; }
@@ -793,11 +851,14 @@ template <int NF, int OPT>
 static hipError_t launch_pair_grad_det_lds(gg_ctx *ctx, const StepArgs &s, const OptArgs &o) {
     static bool raised = false;  // (the attribute belongs to the function, not to a context)
     if (!raised) {
-        hipError_t e = hipFuncSetAttribute((const void *)pair_grad_det_kernel<NF, true, OPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DET_LDS_ROW_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void *)pair_grad_det_kernel<NF, true, OPT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DET_LDS_ROW_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)pair_grad_det_kernel<NF, true, OPT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DET_LDS_ROW_BYTES);
         if (e != hipSuccess) return e;
         raised = true;
     }
-    hipLaunchKernelGGL((pair_grad_det_kernel<NF, true, OPT>), dim3(1), dim3(DET_THREADS), (size_t)2 * s.n * s.ld * sizeof(float), ctx->stream, s, o);
+    const size_t dyn = (size_t)2 * s.n * s.ld * sizeof(float);
+    if (s.n <= 64) hipLaunchKernelGGL((pair_grad_det_kernel<NF, true, OPT, true>), dim3(1), dim3(DET_THREADS), dyn, ctx->stream, s, o);
+    else hipLaunchKernelGGL((pair_grad_det_kernel<NF, true, OPT, false>), dim3(1), dim3(DET_THREADS), dyn, ctx->stream, s, o);
     return hipSuccess;
 }
 
@@ -805,7 +866,8 @@ static hipError_t launch_pair_grad_det_lds(gg_ctx *ctx, const StepArgs &s, const
 template <int NF>
 static hipError_t launch_pair_grad_det(gg_ctx *ctx, const StepArgs &s, const OptArgs &o, int opt) {
     if (!det_rows_fit_lds(s)) {
-        hipLaunchKernelGGL((pair_grad_det_kernel<NF, false, 0>), dim3(1), dim3(DET_THREADS), 0, ctx->stream, s, o);
+        if (s.n <= 64) hipLaunchKernelGGL((pair_grad_det_kernel<NF, false, 0, true>), dim3(1), dim3(DET_THREADS), 0, ctx->stream, s, o);
+        else hipLaunchKernelGGL((pair_grad_det_kernel<NF, false, 0, false>), dim3(1), dim3(DET_THREADS), 0, ctx->stream, s, o);
         return hipSuccess;
     }
     if (opt == 1) return launch_pair_grad_det_lds<NF, 1>(ctx, s, o);
@@ -1021,6 +1083,26 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(float *gE, float *gb, in
     }
 }
 
+// Exchange rows as fp32 words ((ld + 1) per row: gradient row + bias gradient) or, GG_COMM_BF16=1, as bf16 halves ((ld + 2) / 2
+// words per row: ld is a multiple of 4; one half of padding): half the bytes on xGMI.  Sums are ALWAYS accumulated in fp32.
+__device__ __forceinline__ uint16_t f32_to_bf16(float x) {  // round to nearest even; NaN stays NaN
+    uint32_t u = __builtin_bit_cast(uint32_t, x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+static inline size_t pack_row_words(int ld, bool bf16) { return bf16 ? (size_t)(ld + 2) / 2 : (size_t)ld + 1; }
+template <bool BF16> __device__ __forceinline__ float pack_get(const float *rows, int64_t r, int ld, int f) {
+    if (BF16) return bf16_to_f32(((const uint16_t *)rows)[r * (ld + 2) + f]);
+    return rows[r * (ld + 1) + f];
+}
+template <bool BF16> __device__ __forceinline__ void pack_put(float *rows, int64_t r, int ld, int f, float v) {
+    if (BF16) ((uint16_t *)rows)[r * (ld + 2) + f] = f32_to_bf16(v);
+    else rows[r * (ld + 1) + f] = v;
+}
+
+template <bool BF16 = false>
 __global__ __launch_bounds__(256) void add_rows_kernel(float *gE, float *gb, int32_t *touched, const int32_t *ids, const float *rows, int64_t cnt,
                                                        int ld) {
     const int t = threadIdx.x & 15;
@@ -1029,9 +1111,8 @@ __global__ __launch_bounds__(256) void add_rows_kernel(float *gE, float *gb, int
         const int row = ids[r];
         if (row < 0) continue;  // padding behind the source rank's rows
         float *dst = gE + (int64_t)row * ld;
-        const float *src = rows + r * (ld + 1);
-        for (int f = t; f < ld; f += 16) dst[f] += src[f];
-        if (t == 0) { gb[row] += src[ld]; touched[row] = 1; }
+        for (int f = t; f < ld; f += 16) dst[f] += pack_get<BF16>(rows, r, ld, f);
+        if (t == 0) { gb[row] += pack_get<BF16>(rows, r, ld, ld); touched[row] = 1; }
     }
 }
 
@@ -1112,11 +1193,14 @@ static int staged_reserve(gg_ctx *ctx, int64_t n_occ, int64_t n_stage) {
 
 // ... and the update behind the gradient kernel: the small rows by the reducing optimizer, the hub rows through the flag
 // list and sparse_opt_kernel (apply_optimizer, which also advances the step count), the updated-row total for the timing
-static int staged_finish(gg_ctx *ctx, int which, int64_t n, int64_t n_occ) {
+static int staged_finish(gg_ctx *ctx, int which, int64_t n, int64_t n_occ, bool early_index = false) {
     const int opt = ctx->cfg.optimizer;
     OptArgs o = make_opt_args(ctx, which);  // before apply_optimizer advances the step count and the beta powers
-    o.sg_cnt = ctx->sg_cnt.as<int32_t>(); o.sg_list = ctx->sg_list.as<int4>(); o.sg_tot = ctx->sg_tot.as<int64_t>();
-    o.stage = ctx->sg_rows.as<float>(); o.stage_b = ctx->sg_bias.as<float>(); o.stage_key = ctx->sg_key.as<int32_t>();
+    // the staging index: the pass's own (sg_*), or the one built on the side stream behind the G-mode walks (sgp_*)
+    DevBuf &b_cnt = early_index ? ctx->sgp_cnt : ctx->sg_cnt, &b_list = early_index ? ctx->sgp_list : ctx->sg_list;
+    DevBuf &b_tot = early_index ? ctx->sgp_tot : ctx->sg_tot, &b_key = early_index ? ctx->sgp_key : ctx->sg_key;
+    o.sg_cnt = b_cnt.as<int32_t>(); o.sg_list = b_list.as<int4>(); o.sg_tot = b_tot.as<int64_t>();
+    o.stage = ctx->sg_rows.as<float>(); o.stage_b = ctx->sg_bias.as<float>(); o.stage_key = b_key.as<int32_t>();
     int nb = cdiv((int64_t)std::min<int64_t>(n_occ, ctx->n_node) * 16, 256);
     if (nb > 4096) nb = 4096;
     if (nb < 1) nb = 1;
@@ -1125,14 +1209,16 @@ static int staged_finish(gg_ctx *ctx, int which, int64_t n, int64_t n_occ) {
     else if (opt == GG_OPT_SGD) hipLaunchKernelGGL(staged_opt_kernel<1>, dim3(nb), dim3(256), 0, ctx->stream, o);
     else hipLaunchKernelGGL(staged_opt_kernel<0>, dim3(nb), dim3(256), 0, ctx->stream, o);
     ctx->sg_active = true;  // the hub rows: flags -> list -> sparse_opt_kernel, which also resets their counts
+    ctx->sg_cnt_active = o.sg_cnt;
     const int rc = apply_optimizer(ctx, which, n);
     ctx->sg_active = false;
     if (rc != GG_OK) return rc;
     // rows this pass updated (read back by the timing harvest): hub rows + small rows
     if (!replicas)
-        hipLaunchKernelGGL(add_word_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->touched_ptr.as<int64_t>() + ctx->n_node, ctx->sg_tot.as<int64_t>());
+        hipLaunchKernelGGL(add_word_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->touched_ptr.as<int64_t>() + ctx->n_node, b_tot.as<int64_t>());
     GG_HIP(ctx, hipGetLastError());
-    ctx->sg_cnt_dirty = false;
+    if (early_index) ctx->sgp_cnt_clean = true;  // every counted row was applied and reset
+    else ctx->sg_cnt_dirty = false;
     return GG_OK;
 }
 
@@ -1176,12 +1262,32 @@ int run_step(gg_ctx *ctx, int which, const int32_t *d_u, const int32_t *d_v, con
         const bool replicas = ctx->comm || ctx->fake_world > 1;
         const int fused = (!replicas && opt != GG_OPT_ADAM_DENSE && det_rows_fit_lds(s) && !getenv("GG_NO_FUSED_SMALL_STEP")) ? (opt == GG_OPT_SGD ? 2 : 1) : 0;
         const OptArgs o = make_opt_args(ctx, which);
+        static unsigned long long *det_prof = nullptr;
+        static const bool det_prof_on = getenv("GG_DET_PROFILE") != nullptr;
+        if (det_prof_on) {
+            if (!det_prof) GG_HIP(ctx, hipMalloc((void **)&det_prof, 16 * sizeof(unsigned long long)));
+            GG_HIP(ctx, hipMemsetAsync(det_prof, 0, 16 * sizeof(unsigned long long), ctx->stream));
+            s.prof = det_prof;
+        }
         hipError_t e;
         if (nfd <= 4) e = launch_pair_grad_det<4>(ctx, s, o, fused);
         else if (nfd <= 8) e = launch_pair_grad_det<8>(ctx, s, o, fused);
         else if (nfd <= 16) e = launch_pair_grad_det<16>(ctx, s, o, fused);
         else e = launch_pair_grad_det<32>(ctx, s, o, fused);
         GG_HIP(ctx, e);
+        if (det_prof_on) {  // debugging aid: one synchronisation per step; sums of the phase times per model, printed every 1 000 steps
+            static double acc_t[2][2][4] = {};
+            static long cnt[2] = {};
+            unsigned long long h[16];
+            GG_HIP(ctx, hipMemcpyAsync(h, det_prof, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+            GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            for (int w = 0; w < 2; ++w)
+                for (int k = 0; k < 3; ++k) acc_t[which][w][k] += h[8 * w + k + 1] > h[8 * w + k] ? 10.0 * (double)(h[8 * w + k + 1] - h[8 * w + k]) : 0.0;
+            if (++cnt[which] % 1000 == 0)
+                for (int w = 0; w < 2; ++w)
+                    fprintf(stderr, "[det] model %d n=%d wave %s: loads+coef %.0f ns, barrier %.0f, owners' sums + stores issued %.0f (means over %ld steps)\n", which, n, w ? "15" : "0",
+                            acc_t[which][w][0] / cnt[which], acc_t[which][w][1] / cnt[which], acc_t[which][w][2] / cnt[which], cnt[which]);
+        }
         if (fused) {
             GG_HIP(ctx, hipGetLastError());
             step_done(ctx, which, n);
@@ -1287,17 +1393,62 @@ int run_path_step(gg_ctx *ctx) {
     int rc;
     int32_t *cnt = ctx->sg_cnt.as<int32_t>(), *off = ctx->sg_off.as<int32_t>(), *slot = ctx->sg_slot.as<int32_t>();
     const dim3 pgrid((unsigned)cdiv(n_pos, 256));
-    hipLaunchKernelGGL(path_count_kernel, pgrid, dim3(256), 0, ctx->stream, p.paths, p.path_len, p.stride, p.n_walks, cnt, slot);
-    rc = device_segment_rows(ctx, cnt, ctx->n_node, ctx->sg_threshold, off, ctx->sg_list.as<int4>(), ctx->sg_tot.as<int64_t>());
-    if (rc != GG_OK) return rc;
-    hipLaunchKernelGGL(path_slot_kernel, pgrid, dim3(256), 0, ctx->stream, p.paths, p.path_len, p.stride, p.n_walks, cnt, off, ctx->sg_threshold, slot,
-                       ctx->sg_key.as<int32_t>());
+    // the index of these walks may already be on its way (side stream, behind the walks: enqueue_path_slots)
+    const bool early = ctx->g_slots_ready && ctx->g_slots_walks == p.n_walks && ctx->g_slots_stride == p.stride;
+    ctx->g_slots_ready = false;
+    if (early) {
+        ctx->sg_cnt_dirty = false;  // (staged_reserve left the pass's own count array clean, and this pass does not use it)
+        GG_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_slots_done, 0));
+        slot = ctx->sgp_slot.as<int32_t>();
+    } else {
+        hipLaunchKernelGGL(path_count_kernel, pgrid, dim3(256), 0, ctx->stream, p.paths, p.path_len, p.stride, p.n_walks, cnt, slot, (const unsigned long long *)nullptr);
+        rc = device_segment_rows(ctx, cnt, ctx->n_node, ctx->sg_threshold, off, ctx->sg_list.as<int4>(), ctx->sg_tot.as<int64_t>());
+        if (rc != GG_OK) return rc;
+        hipLaunchKernelGGL(path_slot_kernel, pgrid, dim3(256), 0, ctx->stream, p.paths, p.path_len, p.stride, p.n_walks, cnt, off, ctx->sg_threshold, slot,
+                           ctx->sg_key.as<int32_t>(), (const unsigned long long *)nullptr);
+    }
     p.slot = slot;
     p.stage = ctx->sg_rows.as<float>();
     p.stage_b = ctx->sg_bias.as<float>();
     launch_path_grad<true>(ctx, p, blocks, nf);
     if (ctx->tm_cur >= 0) GG_HIP(ctx, hipEventRecord(ctx->tm_ev[ctx->tm_cur][1], ctx->stream));  // gradient | optimizer
-    return staged_finish(ctx, 0, n, n_pos);
+    return staged_finish(ctx, 0, n, n_pos, early);
+}
+
+// The staging index of the G-mode walks that were just enqueued on the side stream, right behind them on that stream: per-row
+// counts of the path nodes, segments of the small rows, the nodes' slots and keys (what run_path_step used to launch in front
+// of its gradient kernel: ~0.12 ms of the step's critical path at the bench batch; here it runs beside the reward kernels).
+// The index has buffers of its own: the discriminator pass is using sg_* on the main stream at this very time.
+int enqueue_path_slots(gg_ctx *ctx) {
+    ctx->g_slots_ready = false;
+    if (ctx->walk_stream == ctx->stream || ctx->in_epoch_add || getenv("GG_NO_EARLY_SLOTS")) return GG_OK;
+    const int64_t n_walks = ctx->w_total, n_pos = n_walks * (int64_t)ctx->w_stride;
+    if (!staged_allowed(ctx) || ctx->cfg.window_size > 2 || n_walks == 0 || n_pos >= (1ll << 31)) return GG_OK;
+    hipStream_t st = ctx->walk_stream;
+    const size_t cnt_before = ctx->sgp_cnt.bytes;
+    GG_HIP(ctx, ctx->sgp_cnt.reserve(sizeof(int32_t) * (size_t)ctx->n_node));
+    if (ctx->sgp_cnt.bytes != cnt_before || !ctx->sgp_cnt_clean) GG_HIP(ctx, hipMemsetAsync(ctx->sgp_cnt.p, 0, ctx->sgp_cnt.bytes, st));
+    ctx->sgp_cnt_clean = false;
+    GG_HIP(ctx, ctx->sgp_off.reserve(sizeof(int32_t) * (size_t)ctx->n_node));
+    GG_HIP(ctx, ctx->sgp_list.reserve(sizeof(int4) * (size_t)ctx->n_node));
+    GG_HIP(ctx, ctx->sgp_slot.reserve(sizeof(int32_t) * (size_t)n_pos));
+    GG_HIP(ctx, ctx->sgp_key.reserve(sizeof(int32_t) * (size_t)n_pos));  // (staged rows <= path positions)
+    GG_HIP(ctx, ctx->sgp_tot.reserve(sizeof(int64_t) * 4));
+    if (!ctx->ev_slots_done) GG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_slots_done, hipEventDisableTiming));
+    const unsigned long long *flag = ctx->dev_ctr + 3;
+    const dim3 pgrid((unsigned)cdiv(n_pos, 256));
+    int32_t *cnt = ctx->sgp_cnt.as<int32_t>(), *off = ctx->sgp_off.as<int32_t>(), *slot = ctx->sgp_slot.as<int32_t>();
+    hipLaunchKernelGGL(path_count_kernel, pgrid, dim3(256), 0, st, ctx->w_paths.as<int32_t>(), ctx->w_len.as<int32_t>(), ctx->w_stride, n_walks, cnt, slot, flag);
+    int rc = device_segment_rows(ctx, cnt, ctx->n_node, ctx->sg_threshold, off, ctx->sgp_list.as<int4>(), ctx->sgp_tot.as<int64_t>(), st, &ctx->sgp_scan);
+    if (rc != GG_OK) return rc;
+    hipLaunchKernelGGL(path_slot_kernel, pgrid, dim3(256), 0, st, ctx->w_paths.as<int32_t>(), ctx->w_len.as<int32_t>(), ctx->w_stride, n_walks, cnt, off,
+                       ctx->sg_threshold, slot, ctx->sgp_key.as<int32_t>(), flag);
+    GG_HIP(ctx, hipGetLastError());
+    GG_HIP(ctx, hipEventRecord(ctx->ev_slots_done, st));
+    ctx->g_slots_ready = true;
+    ctx->g_slots_walks = n_walks;
+    ctx->g_slots_stride = ctx->w_stride;
+    return GG_OK;
 }
 
 __global__ void normalize_flags_kernel(int32_t *f, int n) {  // after the cross-rank sum: counts -> 0/1
@@ -1337,6 +1488,7 @@ __global__ __launch_bounds__(256) void owner_count_kernel(const int32_t *list, c
 
 // touched rows -> per-owner segments of the send buffer (slots inside a segment by arrival: a rank names a row once, so the
 // owner's sum does not depend on the slot order)
+template <bool BF16>
 __global__ __launch_bounds__(256) void owner_pack_kernel(const float *gE, const float *gb, const int32_t *list, const int64_t *cnt_ptr, int world,
                                                          const long long *seg_off, long long *fill, int ld, int32_t *out_ids, float *out_rows) {
     const int t = threadIdx.x & 15;
@@ -1349,14 +1501,18 @@ __global__ __launch_bounds__(256) void owner_pack_kernel(const float *gE, const 
         if (t == 0) slot = seg_off[q] + (long long)atomicAdd((unsigned long long *)&fill[q], 1ull);
         slot = __shfl(slot, (threadIdx.x & 63) & ~15, 64);
         const float *src = gE + (int64_t)row * ld;
-        float *dst = out_rows + slot * (ld + 1);
-        for (int f = t; f < ld; f += 16) dst[f] = src[f];
-        if (t == 0) { dst[ld] = gb[row]; out_ids[slot] = row; }
+        for (int f = t; f < ld; f += 16) pack_put<BF16>(out_rows, slot, ld, f, src[f]);
+        if (t == 0) {
+            pack_put<BF16>(out_rows, slot, ld, ld, gb[row]);
+            if (BF16) pack_put<BF16>(out_rows, slot, ld, ld + 1, 0.f);
+            out_ids[slot] = row;
+        }
     }
 }
 
 // owner side, after the adds: the flagged rows this rank owns -> gather pack (ids -1 behind them up to the capacity)
-__global__ __launch_bounds__(256) void owner_gather_pack_kernel(const float *gE, const float *gb, const int32_t *list, const int64_t *cnt_ptr, int world,
+template <bool BF16>
+__global__ __launch_bounds__(256) void owner_gather_pack_kernel(float *gE, float *gb, const int32_t *list, const int64_t *cnt_ptr, int world,
                                                                 int me, long long *fill, int64_t cap, int ld, int32_t *out_ids, float *out_rows) {
     const int t = threadIdx.x & 15;
     const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4, ng = ((int64_t)gridDim.x * blockDim.x) >> 4;
@@ -1368,10 +1524,16 @@ __global__ __launch_bounds__(256) void owner_gather_pack_kernel(const float *gE,
         if (t == 0) slot = (long long)atomicAdd((unsigned long long *)fill, 1ull);
         slot = __shfl(slot, (threadIdx.x & 63) & ~15, 64);
         if (slot >= cap) continue;  // (cannot happen: the capacity is the largest owner's count)
-        const float *src = gE + (int64_t)row * ld;
-        float *dst = out_rows + slot * (ld + 1);
-        for (int f = t; f < ld; f += 16) dst[f] = src[f];
-        if (t == 0) { dst[ld] = gb[row]; out_ids[slot] = row; }
+        float *src = gE + (int64_t)row * ld;
+        for (int f = t; f < ld; f += 16) {
+            pack_put<BF16>(out_rows, slot, ld, f, src[f]);
+            if (BF16) src[f] = pack_get<BF16>(out_rows, slot, ld, f);  // the owner keeps what the others receive: the rounded sum
+        }
+        if (t == 0) {
+            pack_put<BF16>(out_rows, slot, ld, ld, gb[row]);
+            if (BF16) { gb[row] = pack_get<BF16>(out_rows, slot, ld, ld); pack_put<BF16>(out_rows, slot, ld, ld + 1, 0.f); }
+            out_ids[slot] = row;
+        }
     }
 }
 
@@ -1388,6 +1550,7 @@ __global__ void fill_ids_kernel(int32_t *ids, int64_t n, int32_t v) {
 }
 
 // receivers of the gather: the owner's sum REPLACES whatever this rank had accumulated for the row
+template <bool BF16>
 __global__ __launch_bounds__(256) void set_rows_kernel(float *gE, float *gb, int32_t *touched, const int32_t *ids, const float *rows, int64_t cnt, int ld) {
     const int t = threadIdx.x & 15;
     const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4, ng = ((int64_t)gridDim.x * blockDim.x) >> 4;
@@ -1395,9 +1558,8 @@ __global__ __launch_bounds__(256) void set_rows_kernel(float *gE, float *gb, int
         const int row = ids[r];
         if (row < 0) continue;
         float *dst = gE + (int64_t)row * ld;
-        const float *src = rows + r * (ld + 1);
-        for (int f = t; f < ld; f += 16) dst[f] = src[f];
-        if (t == 0) { gb[row] = src[ld]; touched[row] = 1; }
+        for (int f = t; f < ld; f += 16) dst[f] = pack_get<BF16>(rows, r, ld, f);
+        if (t == 0) { gb[row] = pack_get<BF16>(rows, r, ld, ld); touched[row] = 1; }
     }
 }
 
@@ -1407,7 +1569,8 @@ static int exchange_owner(gg_ctx *ctx, OptArgs &o, int world, bool *taken) {
     const int n = ctx->n_node, ld = ctx->ld;
     const bool fake = !ctx->comm;
     if (!ctx->owner_exchange || world < 2 || world > 64 || !comm_has_p2p(ctx)) return GG_OK;
-    const size_t row_f = (size_t)ld + 1;
+    const bool bf16 = ctx->comm_bf16;
+    const size_t row_f = pack_row_words(ld, bf16);  // 4-byte words per packed row
     // ---- 1. this rank's touched rows, counted per owner; the P x P matrix on every host
     int rc = device_compact_flags(ctx, ctx->touched, n, ctx->touched_list, ctx->touched_ptr.as<int64_t>() + n);
     if (rc != GG_OK) return rc;
@@ -1440,8 +1603,10 @@ static int exchange_owner(gg_ctx *ctx, OptArgs &o, int world, bool *taken) {
     GG_HIP(ctx, ctx->x_send_rows.reserve(sizeof(float) * (size_t)std::max<long long>(T, 1) * row_f));
     int nb = cdiv(std::max<long long>(T, 1) * 16, 256);
     if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(owner_pack_kernel, dim3(nb), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, ctx->touched_list, o.touched_total, world, seg, fill, ld,
-                       ctx->x_send_ids.as<int32_t>(), ctx->x_send_rows.as<float>());
+    if (bf16) hipLaunchKernelGGL(owner_pack_kernel<true>, dim3(nb), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, ctx->touched_list, o.touched_total, world, seg, fill, ld,
+                                 ctx->x_send_ids.as<int32_t>(), ctx->x_send_rows.as<float>());
+    else hipLaunchKernelGGL(owner_pack_kernel<false>, dim3(nb), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, ctx->touched_list, o.touched_total, world, seg, fill, ld,
+                            ctx->x_send_ids.as<int32_t>(), ctx->x_send_rows.as<float>());
     long long bytes = 0;
     const int owners = fake ? world : 1;  // simulated ranks: this GPU plays every owner in turn
     for (int oi = 0; oi < owners; ++oi) {
@@ -1477,8 +1642,10 @@ static int exchange_owner(gg_ctx *ctx, OptArgs &o, int world, bool *taken) {
             if (r == me || !ri_cnt[r]) continue;
             int nbr = cdiv(ri_cnt[r] * 16, 256);
             if (nbr > 4096) nbr = 4096;
-            hipLaunchKernelGGL(add_rows_kernel, dim3(nbr), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, ctx->touched, ctx->x_recv_ids.as<int32_t>() + ri_off[r],
-                               ctx->x_recv_rows.as<float>() + r_off[r], (int64_t)ri_cnt[r], ld);
+            if (bf16) hipLaunchKernelGGL(add_rows_kernel<true>, dim3(nbr), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, ctx->touched, ctx->x_recv_ids.as<int32_t>() + ri_off[r],
+                                         ctx->x_recv_rows.as<float>() + r_off[r], (int64_t)ri_cnt[r], ld);
+            else hipLaunchKernelGGL(add_rows_kernel<false>, dim3(nbr), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, ctx->touched, ctx->x_recv_ids.as<int32_t>() + ri_off[r],
+                                    ctx->x_recv_rows.as<float>() + r_off[r], (int64_t)ri_cnt[r], ld);
         }
     }
     // ---- 4. gather the owners' reduced rows
@@ -1500,21 +1667,25 @@ static int exchange_owner(gg_ctx *ctx, OptArgs &o, int world, bool *taken) {
         GG_HIP(ctx, hipMemsetAsync(own + 1, 0, sizeof(long long), ctx->stream));
         int nbg = cdiv((int64_t)cap * 16, 256);
         if (nbg > 4096) nbg = 4096;
-        hipLaunchKernelGGL(owner_gather_pack_kernel, dim3(nbg), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, ctx->touched_list, o.touched_total, world, ctx->rank,
-                           own + 1, (int64_t)cap, ld, ctx->x_send_ids.as<int32_t>(), ctx->x_send_rows.as<float>());
+        if (bf16) hipLaunchKernelGGL(owner_gather_pack_kernel<true>, dim3(nbg), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, ctx->touched_list, o.touched_total, world, ctx->rank,
+                                     own + 1, (int64_t)cap, ld, ctx->x_send_ids.as<int32_t>(), ctx->x_send_rows.as<float>());
+        else hipLaunchKernelGGL(owner_gather_pack_kernel<false>, dim3(nbg), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, ctx->touched_list, o.touched_total, world, ctx->rank,
+                                own + 1, (int64_t)cap, ld, ctx->x_send_ids.as<int32_t>(), ctx->x_send_rows.as<float>());
         rc = comm_allgather(ctx, ctx->x_send_ids.p, ctx->x_recv_ids.p, cap, 4);
         if (rc == GG_OK) rc = comm_allgather(ctx, ctx->x_send_rows.p, ctx->x_recv_rows.p, cap * row_f, 4);
         if (rc != GG_OK) return rc;
         for (int r = 0; r < world; ++r) {
             if (r == ctx->rank) continue;
-            hipLaunchKernelGGL(set_rows_kernel, dim3(nbg), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, ctx->touched, ctx->x_recv_ids.as<int32_t>() + (size_t)r * cap,
-                               ctx->x_recv_rows.as<float>() + (size_t)r * cap * row_f, (int64_t)cap, ld);
+            if (bf16) hipLaunchKernelGGL(set_rows_kernel<true>, dim3(nbg), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, ctx->touched, ctx->x_recv_ids.as<int32_t>() + (size_t)r * cap,
+                                         ctx->x_recv_rows.as<float>() + (size_t)r * cap * row_f, (int64_t)cap, ld);
+            else hipLaunchKernelGGL(set_rows_kernel<false>, dim3(nbg), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, ctx->touched, ctx->x_recv_ids.as<int32_t>() + (size_t)r * cap,
+                                    ctx->x_recv_rows.as<float>() + (size_t)r * cap * row_f, (int64_t)cap, ld);
         }
         bytes += (long long)(world - 1) * (long long)cap * (long long)(row_f + 1) * 4;
     } else {
         // simulated: every owner's rows are already in this GPU's accumulators; run the pack / overwrite kernels once (owner 0)
         // so that they are exercised: overwriting a row with itself changes nothing
-        hipLaunchKernelGGL(owner_count_owned_kernel, dim3(256), dim3(256), 0, ctx->stream, ctx->touched_list, o.touched_total, world, 0, own);
+        hipLaunchKernelGGL(owner_count_owned_kernel, dim3(256), dim3(256), 0, ctx->stream, ctx->touched_list, o.touched_total, bf16 ? 1 : world, 0, own);
         GG_HIP(ctx, hipMemcpyAsync(&umax, own, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
         GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         const size_t cap = (size_t)std::max<long long>(umax, 1);
@@ -1524,10 +1695,19 @@ static int exchange_owner(gg_ctx *ctx, OptArgs &o, int world, bool *taken) {
         GG_HIP(ctx, hipMemsetAsync(own + 1, 0, sizeof(long long), ctx->stream));
         int nbg = cdiv((int64_t)cap * 16, 256);
         if (nbg > 4096) nbg = 4096;
-        hipLaunchKernelGGL(owner_gather_pack_kernel, dim3(nbg), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, ctx->touched_list, o.touched_total, world, 0, own + 1,
-                           (int64_t)cap, ld, ctx->x_send_ids.as<int32_t>(), ctx->x_send_rows.as<float>());
-        hipLaunchKernelGGL(set_rows_kernel, dim3(nbg), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, ctx->touched, ctx->x_send_ids.as<int32_t>(),
-                           ctx->x_send_rows.as<float>(), (int64_t)cap, ld);
+        // (bf16 packs: every owner rounds the sums it hands out, so the simulation rounds ALL touched rows -- world = 1 makes every row "owned")
+        const int wsim = bf16 ? 1 : world;
+        if (bf16) {
+            hipLaunchKernelGGL(owner_gather_pack_kernel<true>, dim3(nbg), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, ctx->touched_list, o.touched_total, wsim, 0, own + 1,
+                               (int64_t)cap, ld, ctx->x_send_ids.as<int32_t>(), ctx->x_send_rows.as<float>());
+            hipLaunchKernelGGL(set_rows_kernel<true>, dim3(nbg), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, ctx->touched, ctx->x_send_ids.as<int32_t>(),
+                               ctx->x_send_rows.as<float>(), (int64_t)cap, ld);
+        } else {
+            hipLaunchKernelGGL(owner_gather_pack_kernel<false>, dim3(nbg), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, ctx->touched_list, o.touched_total, wsim, 0, own + 1,
+                               (int64_t)cap, ld, ctx->x_send_ids.as<int32_t>(), ctx->x_send_rows.as<float>());
+            hipLaunchKernelGGL(set_rows_kernel<false>, dim3(nbg), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, ctx->touched, ctx->x_send_ids.as<int32_t>(),
+                               ctx->x_send_rows.as<float>(), (int64_t)cap, ld);
+        }
     }
     GG_HIP(ctx, hipGetLastError());
     ctx->comm_steps_sparse += 1;
@@ -1588,7 +1768,7 @@ static int exchange_sparse(gg_ctx *ctx, OptArgs &o, int world, int64_t bound) {
     rc = comm_allgather(ctx, ctx->x_send_rows.p, ctx->x_recv_rows.p, (size_t)cap * row_f, 4);
     if (rc != GG_OK) return rc;
     for (int r = 0; r < world; ++r)
-        hipLaunchKernelGGL(add_rows_kernel, dim3(nb), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, ctx->touched,
+        hipLaunchKernelGGL(add_rows_kernel<false>, dim3(nb), dim3(256), 0, ctx->stream, ctx->gradE, ctx->gradb, ctx->touched,
                            ctx->x_recv_ids.as<int32_t>() + (size_t)r * cap, ctx->x_recv_rows.as<float>() + (size_t)r * cap * row_f, cap, ld);
     GG_HIP(ctx, hipGetLastError());
     ctx->comm_steps_sparse += 1;
@@ -1624,7 +1804,7 @@ int apply_optimizer(gg_ctx *ctx, int which, int64_t n) {
     if (rc != GG_OK) return rc;
 
     OptArgs o = make_opt_args(ctx, which);
-    if (ctx->sg_active) o.sg_cnt = ctx->sg_cnt.as<int32_t>();  // hub rows of a staged G pass: the row's count is reset with its flag
+    if (ctx->sg_active) o.sg_cnt = ctx->sg_cnt_active;  // hub rows of a staged pass: the row's count is reset with its flag
     if (opt == GG_OPT_ADAM_DENSE) {
         int64_t nb = (o.nE / 4 + 255) / 256;
         if (nb > 2048) nb = 2048;

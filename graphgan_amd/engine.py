@@ -474,10 +474,13 @@ class Engine:
         self._ck(lib.gg_comm_init(self._ctx, buf, rank, world))
 
     def comm_stats(self):
-        """Gradient-exchange statistics of this rank: dict(sparse_steps, dense_steps, bytes_sent, world)."""
-        out = np.zeros(4, dtype=np.int64)
-        self._ck(lib.gg_comm_stats(self._ctx, _ptr(out)))
-        return dict(sparse_steps=int(out[0]), dense_steps=int(out[1]), bytes_sent=int(out[2]), world=int(out[3]))
+        """Gradient-exchange statistics of this rank: dict(sparse_steps, dense_steps, bytes_sent, world) + what kind the sparse
+        steps were (pack_steps: all-gather of fixed-capacity row packs; owner_steps: owner-partitioned send / recv + gather) and
+        whether the owner-partitioned exchange moves bf16 rows."""
+        out = np.zeros(8, dtype=np.int64)
+        self._ck(lib.gg_comm_stats_ex(self._ctx, _ptr(out)))
+        return dict(sparse_steps=int(out[0] + out[1]), dense_steps=int(out[2]), bytes_sent=int(out[3]), world=int(out[4]),
+                    pack_steps=int(out[0]), owner_steps=int(out[1]), bf16_rows=bool(out[5]))
 
     def comm_barrier(self):
         self._ck(lib.gg_comm_barrier(self._ctx))

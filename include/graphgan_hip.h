@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GG_ABI_VERSION 5  /* round 4: epoch over root batches (gg_epoch_*, gg_q3_*); round 3: gg_counters extended, gg_prepare_g_begin */
+#define GG_ABI_VERSION 6  /* round 5: gg_comm_stats_ex; round 4: epoch over root batches (gg_epoch_*, gg_q3_*); round 3: gg_counters extended, gg_prepare_g_begin */
 
 enum {
     GG_OK = 0,
@@ -331,6 +331,10 @@ int gg_comm_barrier(gg_ctx *ctx);
 /* gg_comm_stats: out4 = {optimizer steps that exchanged row packs (sparse), steps that exchanged the whole accumulators
  * (dense: reduce-scatter + all-gather), bytes this rank has sent for gradient exchanges so far, world size}. */
 int gg_comm_stats(gg_ctx *ctx, int64_t *out4);
+/* gg_comm_stats_ex (ABI 6): out8 = {steps that all-gathered fixed-capacity row packs, steps that took the owner-partitioned
+ * exchange (send / recv to the rows' owners + all-gather of the reduced rows), dense steps, bytes sent, world size,
+ * 1 if the owner-partitioned exchange moves bf16 rows (GG_COMM_BF16=1), 0, 0}.  The first two add up to out4[0]. */
+int gg_comm_stats_ex(gg_ctx *ctx, int64_t *out8);
 
 /* ---- edge-list ingest: utils.read_edges (utils.py:12-54) natively -- adjacency CSR in the reference's
  * list order from the train file (+ node ids of the test file); buffers are malloc'ed by the library and

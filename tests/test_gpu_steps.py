@@ -633,27 +633,50 @@ def test_sparse_exchange_with_simulated_ranks(ga, mode, monkeypatch):
 
 
 @pytest.mark.parametrize("world", [2, 3, 8])
-@pytest.mark.parametrize("mode", ["sgd", "lazy"])
+@pytest.mark.parametrize("mode", ["sgd", "lazy", "sgd-bf16", "lazy-bf16"])
 def test_owner_partitioned_exchange_with_simulated_ranks(ga, mode, world, monkeypatch):
     """The owner-partitioned sparse exchange (round 4): touched rows travel to their owner (row mod P), the owner adds the
     sources in rank order, the reduced rows are gathered back and OVERWRITE the receivers' accumulator rows.  One GPU here:
     GG_COMM_FAKE_WORLD = P makes this rank play every owner in turn with P - 1 copies of its own rows as the other sources,
     so the applied gradient must be exactly P x the local one -- per-owner counting, segment offsets, slot assignment, the
     rank-order adds, the gather pack and the overwrite kernel all run.  The branch is forced (dense ratio 0: the row packs are
-    ruled out) and must really be taken (statistics)."""
+    ruled out) and must really be taken (statistics).
+    -bf16 (GG_COMM_BF16=1, round 5): the rows travel as bf16 -- half the bytes on xGMI -- and are summed in fp32 at the owner:
+    own fp32 contribution + (P - 1) x bf16(contribution) in rank order, the sum rounded to bf16 once more for the way back (the
+    owner keeps the rounded sum too: all replicas hold the same bits).  The oracle restates exactly that; the engine's LOCAL
+    gradient is an atomic sum whose last fp32 bit may differ from numpy's, which moves a bf16 rounding in a few elements: those may
+    be off by one bf16 step (2^-8 relative), everything else agrees to the fp32 tolerances."""
+    bf16 = mode.endswith("-bf16")
+    mode = mode.split("-")[0]
     monkeypatch.setenv("GG_COMM_FAKE_WORLD", str(world))
     monkeypatch.setenv("GG_COMM_DENSE_RATIO", "0")
     monkeypatch.setenv("GG_COMM_OWNER_MIN", "0")
+    if bf16:
+        monkeypatch.setenv("GG_COMM_BF16", "1")
     n, d = 1200, 64
     Eg, Ed, bg, bd = make_models(n, d, 33)
     opt = ga.GG_OPT_SGD if mode == "sgd" else ga.GG_OPT_ADAM_LAZY
     eng = engine_with(ga, Eg, Ed, bg, bd, optimizer=opt)
     for k in ("GG_COMM_FAKE_WORLD", "GG_COMM_DENSE_RATIO", "GG_COMM_OWNER_MIN"):
         monkeypatch.delenv(k)
+    if bf16:
+        monkeypatch.delenv("GG_COMM_BF16")
     dis = orc.Discriminator(Ed, 1e-3, lazy=True)
     dis.b[:] = bd
     rs = np.random.RandomState(world)
     B = 700
+
+    def exchanged(local):  # what every replica holds after the exchange, from this rank's fp32 gradient
+        if not bf16:
+            return (world * local).astype(np.float32)
+        local = local.astype(np.float32)
+        piece = _bf16_round(local)
+        tot = local.copy()
+        for _ in range(world - 1):
+            tot = (tot + piece).astype(np.float32)
+        return _bf16_round(tot).reshape(local.shape)
+
+    moved = 0.0
     for t in range(3):
         u, v = rs.randint(0, n // 4, B), rs.randint(0, n // 4, B)   # ~ 270 of the 1 200 rows touched: P x that stays below the table
         lab = (rs.rand(B) < 0.5).astype(np.float32)
@@ -662,7 +685,9 @@ def test_owner_partitioned_exchange_with_simulated_ranks(ga, mode, world, monkey
         np.add.at(GE, u, gu)
         np.add.at(GE, v, gv)
         np.add.at(Gb, v, gb)
-        GE, Gb = (world * GE).astype(np.float32), (world * Gb).astype(np.float32)
+        plain = (world * GE).astype(np.float32)
+        GE, Gb = exchanged(GE), exchanged(Gb)
+        moved = max(moved, float(np.abs(GE - plain).max()))
         rows = np.flatnonzero((np.abs(GE).sum(1) > 0) | (Gb != 0))
         if mode == "sgd":
             dis.E -= np.float32(1e-3) * GE
@@ -670,8 +695,18 @@ def test_owner_partitioned_exchange_with_simulated_ranks(ga, mode, world, monkey
         else:
             dis.opt.step([dis.E, dis.b], [(rows, GE[rows]), (rows, Gb[rows])])
         eng.d_step(u, v, lab)
-        assert np.allclose(eng.get_embeddings(1), dis.E, rtol=3e-5, atol=2e-6), t
-        assert np.allclose(eng.get_bias(1), dis.b, rtol=3e-5, atol=2e-6), t
+        for got, want, gmax in ((eng.get_embeddings(1), dis.E, np.abs(GE).max()), (eng.get_bias(1), dis.b, np.abs(Gb).max())):
+            if not bf16:
+                assert np.allclose(got, want, rtol=3e-5, atol=2e-6), t
+            else:
+                off = np.abs(got - want) > 3e-5 * np.abs(want) + 2e-6
+                assert off.mean() < 0.02, (t, off.mean())
+                # one bf16 step of the largest gradient through the step size (lazy Adam's first steps move by ~lr whatever the size)
+                assert np.abs(got - want).max() <= (1e-3 * gmax * 2.0 ** -7 if mode == "sgd" else 2.5e-3), t
+        if bf16:   # later steps start from the engine's own tables: rounding flips do not accumulate into the comparison
+            dis.E[:] = eng.get_embeddings(1)
+            dis.b[:] = eng.get_bias(1)
+    assert (moved > 1e-3) == bf16          # the rounding is really there (and only there)
     assert np.array_equal(eng.get_embeddings(1)[n // 4:], Ed[n // 4:])
     st = eng.comm_stats()
     assert st["sparse_steps"] == 3 and st["dense_steps"] == 0   # the owner path ran every time (it counts as a sparse step)
