@@ -683,7 +683,7 @@ __global__ __launch_bounds__(DET_THREADS) void pair_grad_det_kernel(const StepAr
     const int t = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int n = a.n, ld = a.ld, nchunk = ld >> 2;
     const float inv_n = a.n_glob ? 1.0f / (float)(*a.n_glob) : a.inv_n;
-    const bool stamp = a.prof && (threadIdx.x == 0 || threadIdx.x == DET_THREADS - 64);
+    const bool stamp = a.prof && blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == DET_THREADS - 64);
     unsigned long long *const pw = a.prof + (threadIdx.x ? 8 : 0);
     if (stamp) pw[0] = wall_clock64();
     for (int s = threadIdx.x; s < 2 * n; s += DET_THREADS) ids[s] = s < n ? a.u[s] : a.v[s - n];
@@ -728,19 +728,24 @@ __global__ __launch_bounds__(DET_THREADS) void pair_grad_det_kernel(const StepAr
     if (stamp) pw[2] = wall_clock64();
     // ---- phase 2: ONE WAVEFRONT per slot (wave w: slots w, w + 16, ...), everything about the slot wave-uniform (scalar code);
     // lane L owns the features L, L + 64, ...  The first slot that names a row owns it and adds the row's contributions in
-    // ascending slot order, four at a time (their LDS reads in flight together): the fp32 operation sequence per element is the
+    // ascending slot order, CB at a time (their LDS reads in flight together): the fp32 operation sequence per element is the
     // same whatever the hardware does.
     // (Measured on the way here, CA-GrQc batches: a 16-lane group per slot, the other three groups of its wavefront masked off while
     // it summed a centre row named by 20 - 64 pairs: 5.4 us of the kernel's 9.4 -- a wave64 instruction costs four cycles however
     // few lanes are alive; the four groups sharing a row's contributions and merging partial sums with 4 NF + 4 permutes: 2.9 us.)
     constexpr int NW = SMALLN ? 2 : 2 * DET_MAX_PAIRS / 64;  // 64-slot words of the id list
     constexpr int NFW = (NF + 3) / 4;                          // features per lane: ceil(ld / 64)
+    constexpr int CB = 4;                                      // contributions fetched together (8: measured slower -- single-contribution rows pay for the empty reads)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int idr[NW];
 #pragma unroll
     for (int j = 0; j < NW; ++j) idr[j] = (64 * j + lane < 2 * n) ? ids[64 * j + lane] : -1;
-    for (int s = wave; s < 2 * n; s += DET_THREADS / 64) {
+    // OPT == 0: the kernel only READS the table, so several workgroups may run it side by side -- each redoes phase 1 for itself
+    // (128 rows out of the L2: no more latency than one workgroup's) and takes every gridDim.x-th round of slots in phase 2: a
+    // wavefront's chain of owner rounds shrinks from eight to one without any synchronisation between workgroups.  (The fused
+    // variants write the table in phase 2 and stay one workgroup: another workgroup could still be reading those rows.)
+    for (int s = (int)blockIdx.x * (DET_THREADS / 64) + wave; s < 2 * n; s += (int)gridDim.x * (DET_THREADS / 64)) {
         // (slot s sits in lane s & 63 of register word s >> 6: a lane read, not an LDS round trip per slot)
         int r = __builtin_amdgcn_readlane(idr[0], s & 63);
 #pragma unroll
@@ -766,15 +771,15 @@ __global__ __launch_bounds__(DET_THREADS) void pair_grad_det_kernel(const StepAr
         for (int j = 0; j < NW; ++j) {
             uint64_t cur = m[j];  // (no slot before s names r: the words in front of s are empty)
             while (cur) {
-                int sq[4];
+                int sq[CB];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < CB; ++k) {
                     if (cur) { sq[k] = 64 * j + __builtin_ctzll(cur); cur &= cur - 1ull; }
                     else sq[k] = -1;
                 }
-                float c[4], cb[4], pr[4][NFW];
+                float c[CB], cb[CB], pr[CB][NFW];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < CB; ++k) {
                     const int sk = sq[k] >= 0 ? sq[k] : s;
                     const int p = sk < n ? sk : sk - n;
                     const int ps = sk < n ? n + p : p;  // the partner's slot
@@ -788,7 +793,7 @@ __global__ __launch_bounds__(DET_THREADS) void pair_grad_det_kernel(const StepAr
                     }
                 }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < CB; ++k) {
                     if (sq[k] >= 0) {  // (uniform)
 #pragma unroll
                         for (int i = 0; i < NFW; ++i) acc[i] += c[k] * pr[k][i] + lown[i];
@@ -845,6 +850,12 @@ __global__ __launch_bounds__(DET_THREADS) void pair_grad_det_kernel(const StepAr
     if (stamp) pw[3] = wall_clock64();  // (one clock read per phase: s_memrealtime is itself a slow scalar memory operation -- a read per owner round measured itself)
 }
 
+// workgroups of the table-read-only variant: one round of slots (16 wavefronts) each, at most 8
+static unsigned det_workgroups(int n) {
+    static const int cap = [] { const char *e = getenv("GG_DET_WORKGROUPS"); return e ? std::max(1, atoi(e)) : 8; }();
+    return (unsigned)std::min(cap, std::max(1, (2 * n + DET_THREADS / 64 - 1) / (DET_THREADS / 64)));
+}
+
 static bool det_rows_fit_lds(const StepArgs &s) { return (size_t)2 * s.n * s.ld * sizeof(float) <= DET_LDS_ROW_BYTES; }
 
 template <int NF, int OPT>
@@ -857,8 +868,9 @@ static hipError_t launch_pair_grad_det_lds(gg_ctx *ctx, const StepArgs &s, const
         raised = true;
     }
     const size_t dyn = (size_t)2 * s.n * s.ld * sizeof(float);
-    if (s.n <= 64) hipLaunchKernelGGL((pair_grad_det_kernel<NF, true, OPT, true>), dim3(1), dim3(DET_THREADS), dyn, ctx->stream, s, o);
-    else hipLaunchKernelGGL((pair_grad_det_kernel<NF, true, OPT, false>), dim3(1), dim3(DET_THREADS), dyn, ctx->stream, s, o);
+    const dim3 grid(OPT == 0 ? det_workgroups(s.n) : 1);
+    if (s.n <= 64) hipLaunchKernelGGL((pair_grad_det_kernel<NF, true, OPT, true>), grid, dim3(DET_THREADS), dyn, ctx->stream, s, o);
+    else hipLaunchKernelGGL((pair_grad_det_kernel<NF, true, OPT, false>), grid, dim3(DET_THREADS), dyn, ctx->stream, s, o);
     return hipSuccess;
 }
 
@@ -866,8 +878,9 @@ static hipError_t launch_pair_grad_det_lds(gg_ctx *ctx, const StepArgs &s, const
 template <int NF>
 static hipError_t launch_pair_grad_det(gg_ctx *ctx, const StepArgs &s, const OptArgs &o, int opt) {
     if (!det_rows_fit_lds(s)) {
-        if (s.n <= 64) hipLaunchKernelGGL((pair_grad_det_kernel<NF, false, 0, true>), dim3(1), dim3(DET_THREADS), 0, ctx->stream, s, o);
-        else hipLaunchKernelGGL((pair_grad_det_kernel<NF, false, 0, false>), dim3(1), dim3(DET_THREADS), 0, ctx->stream, s, o);
+        const dim3 grid(det_workgroups(s.n));
+        if (s.n <= 64) hipLaunchKernelGGL((pair_grad_det_kernel<NF, false, 0, true>), grid, dim3(DET_THREADS), 0, ctx->stream, s, o);
+        else hipLaunchKernelGGL((pair_grad_det_kernel<NF, false, 0, false>), grid, dim3(DET_THREADS), 0, ctx->stream, s, o);
         return hipSuccess;
     }
     if (opt == 1) return launch_pair_grad_det_lds<NF, 1>(ctx, s, o);
