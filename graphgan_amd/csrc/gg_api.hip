@@ -400,7 +400,16 @@ int gg_create(int32_t n_node, int32_t n_emb, const float *emb_gen, const float *
     } while (0)
     auto body = [&]() -> int {
         GG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-        GG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        {
+            // GG_WALK_PRIORITY=1: the side stream (G-mode walks beside the discriminator pass) at the highest stream priority --
+            // those walks are the longer of the two branches the step joins behind
+            int lo = 0, hi = 0;
+            const char *wp = getenv("GG_WALK_PRIORITY");
+            if (wp && atoi(wp) != 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
+                GG_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, atoi(wp) > 0 ? hi : lo));
+            else
+                GG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        }
         GG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
         GG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
         GG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));

@@ -731,8 +731,8 @@ __global__ __launch_bounds__(DET_THREADS) void pair_grad_det_kernel(const StepAr
     // ascending slot order, CB at a time (their LDS reads in flight together): the fp32 operation sequence per element is the
     // same whatever the hardware does.
     // (Measured on the way here, CA-GrQc batches: a 16-lane group per slot, the other three groups of its wavefront masked off while
-    // it summed a centre row named by 20 - 64 pairs: 5.4 us of the kernel's 9.4 -- a wave64 instruction costs four cycles however
-    // few lanes are alive; the four groups sharing a row's contributions and merging partial sums with 4 NF + 4 permutes: 2.9 us.)
+    // it summed a centre row named by 20 - 64 pairs: 5.4 us of the kernel's 9.4 -- a wave64 instruction takes its issue cycles
+    // however few lanes are alive; the four groups sharing a row's contributions and merging partial sums with 4 NF + 4 permutes: 2.9 us.)
     constexpr int NW = SMALLN ? 2 : 2 * DET_MAX_PAIRS / 64;  // 64-slot words of the id list
     constexpr int NFW = (NF + 3) / 4;                          // features per lane: ceil(ld / 64)
     constexpr int CB = 4;                                      // contributions fetched together (8: measured slower -- single-contribution rows pay for the empty reads)
