@@ -860,7 +860,8 @@ static bool det_rows_fit_lds(const StepArgs &s) { return (size_t)2 * s.n * s.ld 
 
 template <int NF, int OPT>
 static hipError_t launch_pair_grad_det_lds(gg_ctx *ctx, const StepArgs &s, const OptArgs &o) {
-    static bool raised = false;  // (the attribute belongs to the function, not to a context)
+    static bool raised_dev[64] = {};  // (the attribute belongs to the function on a device, not to a context)
+    bool &raised = raised_dev[ctx->device & 63];
     if (!raised) {
         hipError_t e = hipFuncSetAttribute((const void *)pair_grad_det_kernel<NF, true, OPT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DET_LDS_ROW_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)pair_grad_det_kernel<NF, true, OPT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DET_LDS_ROW_BYTES);
