@@ -261,7 +261,10 @@ static int score_blocks() {
     }();
     return v;
 }
-constexpr int BIG_TASK = 256;   // owner tasks with more candidates get a whole workgroup for their prefix sums
+#ifndef GG_BIG_TASK
+#define GG_BIG_TASK 256
+#endif
+constexpr int BIG_TASK = GG_BIG_TASK;   // owner tasks with more candidates get a whole workgroup for their prefix sums
 constexpr int CTR_NONFINITE = 6; // ctr[6]: a distribution had total weight 0 (non-finite generator scores) -> GG_EINVAL
 constexpr int CTR_FIN = 7;      // ctr[7]: walks still alive behind the last streamed level = entries of the finisher's walk list
 constexpr int CTR_ALIVE = 8;    // ctr[CTR_ALIVE + level]: walks alive when hop `level` was set up
@@ -969,7 +972,10 @@ __device__ __forceinline__ void weights_small_blocks(const WalkArgs &a, const in
 // barrier pairs per tile; lane-strided rows of 256 cost a barrier pair per row, sixteen per tile), the thread's own prefix
 // is a register loop, and it stores 64 contiguous bytes.  A task of up to one tile keeps its scores in registers between
 // the max and the scan pass; larger ones read them twice.
-constexpr int BIG_PT = 8;
+#ifndef GG_BIG_PT
+#define GG_BIG_PT 8
+#endif
+constexpr int BIG_PT = GG_BIG_PT;
 constexpr int BIG_TILE = 256 * BIG_PT;
 constexpr int BIG_BLOCKS = 2048;  // workgroups of the weights launch that serve the big-task list
 __device__ __forceinline__ void weights_big_blocks(const WalkArgs &a) {
