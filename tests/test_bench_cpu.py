@@ -56,3 +56,25 @@ def test_gpus_n_launches_its_own_ranks(tmp_path, monkeypatch):
     # main() takes that path exactly when no launcher exported WORLD_SIZE
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert 'if "WORLD_SIZE" not in os.environ and args.gpus > 1:' in src and "must be launched with" not in src
+
+
+def test_comm_model_prices_the_exchange_on_xgmi():
+    """bench.comm_model: bytes per strategy, the time they take over P - 1 point-to-point links, what stays exposed and the
+    weak-scaling efficiency that follows (a MODEL: no multi-GPU run exists).  Sanity of its arithmetic on the bench's counts."""
+    import bench
+    m = bench.comm_model(1_000_000, 128, 445_000, 488_000, 646_000, 3_630_000, step_ms=4.05, d_pass_ms=1.1, g_walk_ms=1.34)
+    row = 4.0 * 130
+    for P in (2, 4, 8):
+        e = m["P=%d" % P]
+        f = (P - 1.0) / P
+        want = sum(f * t * row + f * min(1_000_000, P * t) * row for t in (445_000, 488_000))
+        assert abs(e["owner_partitioned_sparse"] - want) < 1.0
+        assert e["owner_partitioned_sparse_bf16"] < 0.52 * e["owner_partitioned_sparse"]           # half the row bytes (+ the ids)
+        t32, t16 = e["modelled_time_owner_fp32"], e["modelled_time_owner_bf16"]
+        rate = (P - 1) * bench.XGMI_LINK_GBS * 1e9 * bench.XGMI_EFFICIENCY
+        assert abs(t32["d_exchange_ms"] + t32["g_exchange_ms"] - (1e3 * want / rate + 4 * bench.HOST_ROUND_TRIP_MS)) < 1e-9
+        # the D exchange hides behind the G-mode walks as far as they reach; the G exchange is exposed in full
+        assert abs(t32["exposed_ms_per_step"] - (max(0.0, 1.1 + t32["d_exchange_ms"] - 1.34) + t32["g_exchange_ms"])) < 1e-12
+        assert 0.0 < t32["weak_scaling_efficiency_estimate"] < t16["weak_scaling_efficiency_estimate"] < 1.0
+    assert m["P=8"]["modelled_time_owner_fp32"]["weak_scaling_efficiency_estimate"] < 0.8     # not near-linear at this batch: said so in DESIGN section 7
+    assert m["assumptions"]["xgmi_link_GBs"] == 153.0
