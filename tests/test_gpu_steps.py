@@ -780,6 +780,47 @@ def test_atomic_free_kernel_row_widths(ga, d):
     eng.close()
 
 
+@pytest.mark.parametrize("opt", ["dense", "lazy"])
+def test_atomic_free_kernel_batch_shapes(ga, opt):
+    """Edge shapes of the reference's batches through the atomic-free kernel, each against the oracle's step: every size around the
+    16-slot words and the 64-pair boundary of the register-resident id list (1 .. 256 pairs), one centre for the whole batch (a
+    discriminator slice: graph_gan.py:193-201), one neighbour for the whole batch, SELF pairs (u == v: the reference's self-loop
+    positives, utils.py:36-37 -- both slots of the pair name one row), and a batch in which every pair is the same pair."""
+    n, d = 400, 50
+    Eg, Ed, bg, bd = make_models(n, d, 17)
+    lazy = opt == "lazy"
+    eng = engine_with(ga, Eg, Ed, bg, bd, optimizer=ga.GG_OPT_ADAM_LAZY if lazy else ga.GG_OPT_ADAM_DENSE)
+    gen, dis = orc.Generator(Eg, 1e-3, lazy=lazy), orc.Discriminator(Ed, 1e-3, lazy=lazy)
+    gen.b[:] = bg
+    dis.b[:] = bd
+    rs = np.random.RandomState(12)
+    shapes = []
+    for B in (1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256):
+        shapes.append((rs.randint(0, n, B), rs.randint(0, n, B)))
+    shapes.append((np.full(64, 7), rs.randint(0, n, 64)))            # one centre
+    shapes.append((rs.randint(0, n, 64), np.full(64, 9)))            # one neighbour
+    u = rs.randint(0, n, 64)
+    shapes.append((u, u.copy()))                                     # self pairs only
+    u = rs.randint(0, 20, 200)
+    v = rs.randint(0, 20, 200)
+    v[::5] = u[::5]                                                  # a fifth of them self pairs, heavy duplication
+    shapes.append((u, v))
+    shapes.append((np.full(37, 3), np.full(37, 5)))                  # the same pair 37 times
+    shapes.append((np.full(64, 11), np.full(64, 11)))                # the same SELF pair 64 times
+    for t, (u, v) in enumerate(shapes):
+        B = len(u)
+        lab = (rs.rand(B) < 0.5).astype(np.float32)
+        rew = (rs.rand(B) * 2).astype(np.float32)
+        dis.d_step(u, v, lab, 1e-5)
+        gen.g_step(v, u, rew, 1e-5)
+        eng.d_step(u, v, lab)
+        eng.g_step(v, u, rew)
+        for which, model in ((1, dis), (0, gen)):
+            assert np.allclose(eng.get_embeddings(which), model.E, rtol=3e-5, atol=3e-6), (t, B, which)
+            assert np.allclose(eng.get_bias(which), model.b, rtol=3e-5, atol=3e-6), (t, B, which)
+    eng.close()
+
+
 @pytest.mark.parametrize("mode", ["lazy", "sgd"])
 def test_small_batch_steps_apply_the_optimizer_in_the_gradient_kernel(ga, mode, monkeypatch):
     """The strict schedule at scale (batch 64 with lazy Adam / SGD on one replica): ONE launch per step -- the owner of a row in the
