@@ -29,3 +29,26 @@ def test_auditor_accepts_the_build_and_rejects_a_touched_register(tmp_path):
     p.write_text("\n".join(bad))
     res = subprocess.run([sys.executable, AUDIT, str(p)], capture_output=True, text=True)
     assert res.returncode != 0 and "in flight" in res.stderr
+
+
+def test_product_path_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under graphgan_amd/ may import, load or execute it (a product path that routed
+    through the CPU restatement would void every parity claim), and bench.py may name it only inside its cpu_baseline legs."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pat = re.compile(r"(from\s+oracle\b|import\s+oracle\b|oracle[/\\.]|walk_oracle|libwalk_oracle)")
+    for dirpath, _, files in os.walk(os.path.join(root, "graphgan_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".sh")) or f == "Makefile":
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                hits = [ln for ln in src.splitlines() if pat.search(ln) and not ln.lstrip().startswith(("#", "//", "*"))]
+                # comments may cite the oracle (what a kernel is checked against); code may not use it
+                hits = [ln for ln in hits if "import" in ln or "CDLL" in ln or "dlopen" in ln or "open(" in ln]
+                assert not hits, (os.path.join(dirpath, f), hits[:3])
+    bench = open(os.path.join(root, "bench.py")).read()
+    for m in re.finditer(r"^\s*from oracle import|^\s*import oracle", bench, flags=re.M):
+        # every import sits inside one of the two CPU-baseline functions
+        head = bench[:m.start()]
+        fn = re.findall(r"^def (\w+)\(", head, flags=re.M)[-1]
+        assert fn in ("cpu_baseline", "cpu_baseline_faithful"), fn
