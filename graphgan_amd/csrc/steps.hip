@@ -741,24 +741,24 @@ __global__ __launch_bounds__(DET_THREADS) void pair_grad_det_kernel(const StepAr
     int idr[NW];
 #pragma unroll
     for (int j = 0; j < NW; ++j) idr[j] = (64 * j + lane < 2 * n) ? ids[64 * j + lane] : -1;
-    // OPT == 0: the kernel only READS the table, so several workgroups may run it side by side -- each redoes phase 1 for itself
-    // (128 rows out of the L2: no more latency than one workgroup's) and takes every gridDim.x-th round of slots in phase 2: a
-    // wavefront's chain of owner rounds shrinks from eight to one without any synchronisation between workgroups.  (The fused
-    // variants write the table in phase 2 and stay one workgroup: another workgroup could still be reading those rows.)
-    for (int s = (int)blockIdx.x * (DET_THREADS / 64) + wave; s < 2 * n; s += (int)gridDim.x * (DET_THREADS / 64)) {
+    // is slot s the first that names its row?  (row id and the row's slot masks come back with the answer: all wave-uniform)
+    auto leader_of = [&](const int s, int &r, uint64_t (&m)[NW]) -> bool {
         // (slot s sits in lane s & 63 of register word s >> 6: a lane read, not an LDS round trip per slot)
-        int r = __builtin_amdgcn_readlane(idr[0], s & 63);
+        r = __builtin_amdgcn_readlane(idr[0], s & 63);
 #pragma unroll
         for (int j = 1; j < NW; ++j) r = (s >> 6) == j ? __builtin_amdgcn_readlane(idr[j], s & 63) : r;
-        uint64_t m[NW];  // bit = slot: the slots that name row r
         bool earlier = false;
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
-            m[j] = __ballot(idr[j] == r);
+            m[j] = __ballot(idr[j] == r);  // bit = slot: the slots that name row r
             if (64 * j + 63 < s) earlier |= m[j] != 0ull;
             else if (64 * j <= s) earlier |= (m[j] & ((1ull << (s & 63)) - 1ull)) != 0ull;
         }
-        if (earlier) continue;  // not the first slot of this row
+        return !earlier;
+    };
+    // the owner's work for row r (first named by slot s): the sum, then the gradient store (OPT == 0) or the optimizer.  PRE: the
+    // row's moments and bias words were requested earlier (pm / pv per feature; pb = {bias, its m, its v} in lane 0)
+    auto own_row = [&](const int s, const int r, const uint64_t (&m)[NW], const bool PRE, const float (&pm)[NFW], const float (&pv)[NFW], const float (&pb)[3]) {
         float own[NFW], lown[NFW], acc[NFW], accb = 0.f;
 #pragma unroll
         for (int i = 0; i < NFW; ++i) {
@@ -823,7 +823,7 @@ __global__ __launch_bounds__(DET_THREADS) void pair_grad_det_kernel(const StepAr
                     if (OPT == 2) {
                         var -= o.lr * acc[i];
                     } else {
-                        float m1 = o.mE[ro + f], v1 = o.vE[ro + f];
+                        float m1 = PRE ? pm[i] : o.mE[ro + f], v1 = PRE ? pv[i] : o.vE[ro + f];
                         adam_elem(var, m1, v1, acc[i], o);
                         o.mE[ro + f] = m1;
                         o.vE[ro + f] = v1;
@@ -833,11 +833,11 @@ __global__ __launch_bounds__(DET_THREADS) void pair_grad_det_kernel(const StepAr
                 }
             }
             if (lane == 0) {
-                float var = o.b[r];
+                float var = PRE ? pb[0] : o.b[r];
                 if (OPT == 2) {
                     var -= o.lr * accb;
                 } else {
-                    float m1 = o.mb[r], v1 = o.vb[r];
+                    float m1 = PRE ? pb[1] : o.mb[r], v1 = PRE ? pb[2] : o.vb[r];
                     adam_elem(var, m1, v1, accb, o);
                     o.mb[r] = m1;
                     o.vb[r] = v1;
@@ -845,6 +845,52 @@ __global__ __launch_bounds__(DET_THREADS) void pair_grad_det_kernel(const StepAr
                 if (!__builtin_isfinite(var)) *o.bad = 1ull;
                 o.b[r] = var;
             }
+        }
+    };
+    if constexpr (OPT != 0 && SMALLN && NFW <= 2) {
+        // The fused variants read a row's moments (lazy Adam) and bias words from the table behind the sum: one global round trip
+        // per owner round, eight rounds per wavefront one after the other (20 / 14 us per D / G step at d = 128 on the 1M graph).
+        // So the wavefront FIRST decides which of its eight slots own a row and requests all their words, THEN sums and updates.
+        constexpr int SPW = 2 * 64 / (DET_THREADS / 64);  // slots per wavefront: 8
+        float pm[SPW][NFW], pv[SPW][NFW], pb[SPW][3];
+#pragma unroll
+        for (int k = 0; k < SPW; ++k) {
+            const int s = wave + k * (DET_THREADS / 64);
+            int r = 0;
+            uint64_t m[NW];
+#pragma unroll
+            for (int i = 0; i < NFW; ++i) { pm[k][i] = 0.f; pv[k][i] = 0.f; }
+            pb[k][0] = pb[k][1] = pb[k][2] = 0.f;
+            if (s < 2 * n && leader_of(s, r, m)) {
+                const int64_t ro = (int64_t)r * ld;
+#pragma unroll
+                for (int i = 0; i < NFW; ++i) {
+                    const int f = lane + 64 * i;
+                    if (OPT == 1 && f < ld) { pm[k][i] = o.mE[ro + f]; pv[k][i] = o.vE[ro + f]; }
+                }
+                if (lane == 0) {
+                    pb[k][0] = o.b[r];
+                    if (OPT == 1) { pb[k][1] = o.mb[r]; pb[k][2] = o.vb[r]; }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < SPW; ++k) {
+            const int s = wave + k * (DET_THREADS / 64);
+            int r = 0;
+            uint64_t m[NW];
+            if (s < 2 * n && leader_of(s, r, m)) own_row(s, r, m, true, pm[k], pv[k], pb[k]);
+        }
+    } else {
+        // OPT == 0: the kernel only READS the table, so several workgroups may run it side by side -- each redoes phase 1 for itself
+        // (128 rows out of the L2: no more latency than one workgroup's) and takes every gridDim.x-th round of slots in phase 2: a
+        // wavefront's chain of owner rounds shrinks from eight to one without any synchronisation between workgroups.  (The fused
+        // variants write the table in phase 2 and stay one workgroup: another workgroup could still be reading those rows.)
+        const float none[NFW] = {}, none3[3] = {};
+        for (int s = (int)blockIdx.x * (DET_THREADS / 64) + wave; s < 2 * n; s += (int)gridDim.x * (DET_THREADS / 64)) {
+            int r = 0;
+            uint64_t m[NW];
+            if (leader_of(s, r, m)) own_row(s, r, m, false, none, none, none3);
         }
     }
     if (stamp) pw[3] = wall_clock64();  // (one clock read per phase: s_memrealtime is itself a slow scalar memory operation -- a read per owner round measured itself)
