@@ -850,36 +850,41 @@ __global__ __launch_bounds__(DET_THREADS) void pair_grad_det_kernel(const StepAr
     if constexpr (OPT != 0 && SMALLN && NFW <= 2) {
         // The fused variants read a row's moments (lazy Adam) and bias words from the table behind the sum: one global round trip
         // per owner round, eight rounds per wavefront one after the other (20 / 14 us per D / G step at d = 128 on the 1M graph).
-        // So the wavefront FIRST decides which of its eight slots own a row and requests all their words, THEN sums and updates.
-        constexpr int SPW = 2 * 64 / (DET_THREADS / 64);  // slots per wavefront: 8
-        float pm[SPW][NFW], pv[SPW][NFW], pb[SPW][3];
+        // So the wavefront FIRST decides which of its next four slots own a row and requests all their words, THEN sums and updates.
+        constexpr int SPW = 2 * 64 / (DET_THREADS / 64);  // slots per wavefront: 8 ...
+        constexpr int SPH = SPW / 2;                       // ... requested and processed four at a time: all eight at once measured the same and
+                                                           // sat at the edge of the register allocator (125 VGPRs; 650+ bytes of scratch per lane with three more live values)
+#pragma clang loop unroll(full)
+        for (int h0 = 0; h0 < SPW; h0 += SPH) {
+            float pm[SPH][NFW], pv[SPH][NFW], pb[SPH][3];  // (the k loops MUST unroll: an index that survives puts these arrays into scratch memory)
+#pragma clang loop unroll(full)
+            for (int k = 0; k < SPH; ++k) {
+                const int s = wave + (h0 + k) * (DET_THREADS / 64);
+                int r = 0;
+                uint64_t m[NW];
 #pragma unroll
-        for (int k = 0; k < SPW; ++k) {
-            const int s = wave + k * (DET_THREADS / 64);
-            int r = 0;
-            uint64_t m[NW];
+                for (int i = 0; i < NFW; ++i) { pm[k][i] = 0.f; pv[k][i] = 0.f; }
+                pb[k][0] = pb[k][1] = pb[k][2] = 0.f;
+                if (s < 2 * n && leader_of(s, r, m)) {
+                    const int64_t ro = (int64_t)r * ld;
 #pragma unroll
-            for (int i = 0; i < NFW; ++i) { pm[k][i] = 0.f; pv[k][i] = 0.f; }
-            pb[k][0] = pb[k][1] = pb[k][2] = 0.f;
-            if (s < 2 * n && leader_of(s, r, m)) {
-                const int64_t ro = (int64_t)r * ld;
-#pragma unroll
-                for (int i = 0; i < NFW; ++i) {
-                    const int f = lane + 64 * i;
-                    if (OPT == 1 && f < ld) { pm[k][i] = o.mE[ro + f]; pv[k][i] = o.vE[ro + f]; }
-                }
-                if (lane == 0) {
-                    pb[k][0] = o.b[r];
-                    if (OPT == 1) { pb[k][1] = o.mb[r]; pb[k][2] = o.vb[r]; }
+                    for (int i = 0; i < NFW; ++i) {
+                        const int f = lane + 64 * i;
+                        if (OPT == 1 && f < ld) { pm[k][i] = o.mE[ro + f]; pv[k][i] = o.vE[ro + f]; }
+                    }
+                    if (lane == 0) {
+                        pb[k][0] = o.b[r];
+                        if (OPT == 1) { pb[k][1] = o.mb[r]; pb[k][2] = o.vb[r]; }
+                    }
                 }
             }
-        }
-#pragma unroll
-        for (int k = 0; k < SPW; ++k) {
-            const int s = wave + k * (DET_THREADS / 64);
-            int r = 0;
-            uint64_t m[NW];
-            if (s < 2 * n && leader_of(s, r, m)) own_row(s, r, m, true, pm[k], pv[k], pb[k]);
+#pragma clang loop unroll(full)
+            for (int k = 0; k < SPH; ++k) {
+                const int s = wave + (h0 + k) * (DET_THREADS / 64);
+                int r = 0;
+                uint64_t m[NW];
+                if (s < 2 * n && leader_of(s, r, m)) own_row(s, r, m, true, pm[k], pv[k], pb[k]);
+            }
         }
     } else {
         // OPT == 0: the kernel only READS the table, so several workgroups may run it side by side -- each redoes phase 1 for itself
