@@ -99,6 +99,60 @@ def cpu_baseline(args, n, rowptr, col, emb, bias, roots, seconds):
         args.n_sample_gen, len(rts), stream // 2, hops, t)
 
 
+def cpu_baseline_threads(args, n, rowptr, col, emb, bias, roots, seconds, threads):
+    """The same C port on MANY host cores: `threads` Python threads, each with four roots of its own (trees built by the thread,
+    not timed), each calling the C walk sampler in a loop until the deadline -- ctypes releases the GIL inside the call, the
+    library keeps no state, G-mode walks only read the trees.  Whole-host rate = hops of all threads / wall time.  No fork and no
+    subprocess: the HIP runtime is live in this process."""
+    import threading
+    from oracle import graphgan_oracle as orc
+    Ep = orc.pad_rows(emb)
+    per = 4
+    pick = np.ascontiguousarray(roots[:: max(1, len(roots) // (threads * per))][: threads * per])
+    threads = max(1, len(pick) // per)
+    state = [None] * threads
+    ready = threading.Barrier(threads + 1)
+    hops = [0] * threads
+    err = []
+    deadline = [0.0]
+
+    def work(i):
+        try:
+            rts = np.ascontiguousarray(pick[i * per:(i + 1) * per])
+            off, nbr, base, dmax = orc.c_build_trees(n, rowptr, col, rts)
+            slots = np.arange(len(rts), dtype=np.int32)
+            nw = np.full(len(rts), args.n_sample_gen, dtype=np.int32)
+            state[i] = True
+        except Exception as e:  # noqa: BLE001  (reported, never fatal for the bench line)
+            err.append(repr(e))
+            state[i] = False
+        ready.wait()
+        ready.wait()  # the main thread has set the deadline
+        if not state[i]:
+            return
+        stream = 1 + 2 * i
+        while time.perf_counter() < deadline[0]:
+            res = orc.c_walk_sample(Ep, bias, off, nbr, base, rts, slots, nw, False, args.seed, stream, dmax + 3)
+            hops[i] += int(res["hops"])
+            stream += 2 * threads
+
+    ts = [threading.Thread(target=work, args=(i,), daemon=True) for i in range(threads)]
+    for t in ts:
+        t.start()
+    ready.wait()
+    t0 = time.perf_counter()
+    deadline[0] = t0 + seconds
+    ready.wait()
+    for t in ts:
+        t.join(timeout=seconds + 60)
+    dt = time.perf_counter() - t0
+    if err:
+        return {"error": err[0]}
+    return {"value": sum(hops) / dt, "unit": "edges/s", "cores": threads, "host_cores_on_box": os.cpu_count(), "kind": "port",
+            "sample": "G-mode walks (%d per root) from %d roots (%d per thread) of the same graph, every thread looping over RNG streams for %.1f s: %d hops"
+                      % (args.n_sample_gen, threads * per, per, dt, sum(hops))}
+
+
 def cpu_baseline_faithful(n_roots=24):
     """The 'faithful' flavour of SURVEY.md section 8d on BASELINE configs[0..1] (CA-GrQc, n_emb = 50): like the reference,
     EVERY sample() call first recomputes the full N x N score matrix (graph_gan.py:238, generator.py:21: E.E^T + b, numpy on
@@ -664,6 +718,10 @@ def main():
         v, sample = cpu_baseline(args, n, rowptr, col, embg, bias, roots, args.cpu_baseline_seconds)
         out["cpu_baseline"] = {"value": v, "unit": "edges/s", "cores": 1, "host_cores_on_box": os.cpu_count(), "kind": "port", "sample": sample}
         out["walk_kernel_vs_cpu"] = out["walk_kernel_edges_per_sec"] / v if v > 0 and out["walk_kernel_edges_per_sec"] else None
+        try:  # the same port on many cores (a reported baseline like the one above; a failure here never costs the bench line)
+            out["cpu_baseline_all_cores"] = cpu_baseline_threads(args, n, rowptr, col, embg, bias, roots, 8.0, min(64, max(1, (os.cpu_count() or 2) // 2)))
+        except Exception as e:  # noqa: BLE001
+            out["cpu_baseline_all_cores"] = {"error": repr(e)}
         out["cpu_baseline_faithful"] = cpu_baseline_faithful()
     eng.close()
     print(json.dumps(out))
