@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgraphgan_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "graphgan_hip.h")
-ABI_VERSION = 6  # == GG_ABI_VERSION of include/graphgan_hip.h (tests/test_host_cpu.py keeps header, binding and library in step)
+ABI_VERSION = 7  # == GG_ABI_VERSION of include/graphgan_hip.h (tests/test_host_cpu.py keeps header, binding and library in step)
 
 
 def header_abi_version(path=HEADER_PATH):
@@ -81,6 +81,9 @@ SIGNATURES = {
     "gg_host_build_trees": (_i64, [_i32, _P, _P, _P, _i32, _P, _P, _P, _i64, _i32, _P]),
     "gg_build_trees": (ctypes.c_int, [_P, _P, _i32, _i32]),
     "gg_build_trees_device": (ctypes.c_int, [_P, _P, _i32]),
+    "gg_set_tree_mode": (ctypes.c_int, [_P, _i32, _i64]),
+    "gg_lazy_stats": (ctypes.c_int, [_P, _P]),
+    "gg_get_lazy_trees": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "gg_set_trees": (ctypes.c_int, [_P, _P, _i32, _P, _P, _P, _i32]),
     "gg_tree_info": (ctypes.c_int, [_P, _P, _P, _P]),
     "gg_tree_roots": (ctypes.c_int, [_P, _P]),

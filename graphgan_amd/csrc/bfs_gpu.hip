@@ -71,6 +71,14 @@ struct BfsArgs {
     uint32_t *sp_vis;          // [grid][bm_words] the visited bitmap while the LDS holds a bucket's
     uint32_t *sp_mark;         // [grid][bm_words] candidate fathers by node id (all-zero between uses)
     unsigned long long *sp_mask;  // [grid][n_node / 64 + 32] the same by rank: one ballot per 64 ranks of the level
+    // whole trees outside the slots' own segments (the arena of lazy builds) / LAZY trees (bfs_order2_kernel<.., .., true>)
+    const int32_t *expect;     // [n_roots] nodes of the root's component (NULL: base[r + 1] - base[r])
+    const int32_t *slot_ids;   // [n_roots] tree slot of launch item r (NULL: r): offsets the cstart row, indexes the lz_* rows
+    const int32_t *lz_limit;   // [n_roots] LAZY: node limit of the exact part (>= the component: the tree is built whole)
+    int4 *lz_info;             // [slots]   LAZY: {first rank without a children list, exact ranks, level of those ranks, capacity of the segment}
+    uint2 *lz_bm;              // [slots][bm_words] LAZY: {visited word, members below the word}
+    int32_t *lz_rank;          // [tree nodes] LAZY: BFS rank by member index, at base[r]
+    int32_t *lz_cursor;        // [slots]   LAZY: first free rank of the pool
 };
 
 __device__ __forceinline__ int lanes_below(unsigned long long m) {  // popcount of m restricted to the lanes below this one
@@ -726,7 +734,11 @@ __device__ __forceinline__ int sparse_fathers(unsigned long long *sph, lds_u32_t
 }
 
 // INSTR: the phase clocks (GG_BFS_PROFILE), event counts and ablation switches (GG_BFS_EXPERIMENT) live in a second instance only.
-template <bool LDS_BM, bool INSTR>
+// LAZY (round 6): the tree is built exactly only through the last level whose expansion is KNOWN to fit the slot's node limit
+// (nodes so far + adjacency entries of the level's nodes <= limit: every entry could append a node); the children lists of that
+// level and below are resolved by the walks that need them (walk_sample.hip, "LAZY").  The kernel then leaves what resolution
+// needs: the visited set of the exact levels with a popcount index, and the BFS rank of every member by that index.
+template <bool LDS_BM, bool INSTR, bool LAZY = false>
 __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
     extern __shared__ uint32_t lds_bm[];              // [bm_words] when LDS_BM
     __shared__ uint32_t e0s[B2_NB];                   // first CSR entry of each window node (of the segment, for a partial node)
@@ -765,10 +777,12 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
         const int r = s_root;
         if (r >= a.n_roots) return;
         const int root = a.roots[r];
+        const int slot = a.slot_ids ? a.slot_ids[r] : r;
         int32_t *const order = a.order + a.base[r];
-        int32_t *const cstart = a.cstart + a.base[r] + r;
+        int32_t *const cstart = a.cstart + a.base[r] + slot;
         int32_t *const tedge = a.edge + a.base[r];
-        const int expect = (int)(a.base[r + 1] - a.base[r]);
+        const int expect = a.expect ? a.expect[r] : (int)(a.base[r + 1] - a.base[r]);
+        const int limit = LAZY ? a.lz_limit[r] : expect;
         for (int i = tid; i < a.bm_words; i += B2_T) bm[i] = 0u;
         __syncthreads();
         if (tid == 0) {
@@ -876,6 +890,35 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
                     level_end = tail;
                     ++depth;
                     const int F = tail - head, Un = expect - tail;
+                    if (LAZY && expect > limit) {
+                        // may this level be expanded?  Only if even an append per adjacency entry fits the limit.
+                        __syncthreads();  // (the level's queue entries have landed)
+                        fenced = tail;
+                        uint32_t dsum = 0;
+                        for (int i0 = head + tid; i0 < tail; i0 += 8 * B2_T) {
+                            int vv[8];
+                            uint2u rp[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) vv[u] = i0 + u * B2_T < tail ? ldi(&order[i0 + u * B2_T]) : -1;
+#pragma unroll
+                            for (int u = 0; u < 8; ++u)
+                                if (vv[u] >= 0) rp[u] = *reinterpret_cast<const uint2u *>(a.rowptr32 + vv[u]);
+#pragma unroll
+                            for (int u = 0; u < 8; ++u)
+                                if (vv[u] >= 0) dsum += rp[u].y - rp[u].x;
+                        }
+                        dsum = (uint32_t)wave_incl_scan((int)dsum, lane);
+                        if (lane == 63) wtot[0][wv] = (int32_t)dsum;
+                        lds_barrier();
+                        unsigned long long D = 0;
+#pragma unroll
+                        for (int i = 0; i < B2_WAVES; ++i) D += (unsigned long long)(uint32_t)wtot[0][i];
+                        lds_barrier();  // (wtot is reused by the windows)
+                        if ((unsigned long long)tail + D > (unsigned long long)limit) {
+                            why = 4;
+                            break;
+                        }
+                    }
                     if (LDS_BM && a.sp_k >= 0 && Un > 0 && F >= a.sp_min && (long long)Un * a.sp_k <= (long long)F) {
                         why = 1;
                         break;
@@ -1224,7 +1267,7 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
                 break;
             }
           }
-          if (why == 0) break;
+          if (why == 0 || why == 4) break;
           if (why == 1) {
               __syncthreads();  // the level's queue entries have landed: the search reads them back
               fenced = tail;
@@ -1279,16 +1322,60 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
             for (int k = 0; k < 7; ++k) atomicAdd(&a.prof[21 + k], sph[k]);
         }
 #undef B2_TICK
+        const bool lazy_stop = LAZY && why == 4;  // ranks [head, tail) are level `depth`: exact queue entries without children lists
+        if (LAZY) {
+            if (lazy_stop) {
+                // the visited set of the exact levels with its popcount index: {word, members below the word}
+                uint2 *const zb = a.lz_bm + (size_t)slot * a.bm_words;
+                int32_t *const zr = a.lz_rank + a.base[r];
+                const int W = a.bm_words, wpt = (W + B2_T - 1) / B2_T;
+                const int w0 = min(tid * wpt, W), w1 = min(w0 + wpt, W);
+                int cnt = 0;
+                for (int i = w0; i < w1; ++i) cnt += (int)__popc(LDS_BM ? bm[i] : ldu(&bm[i]));
+                const int inc = wave_incl_scan(cnt, lane);
+                if (lane == 63) wtot[0][wv] = inc;
+                lds_barrier();
+                int run = inc - cnt;
+#pragma unroll
+                for (int i = 0; i < B2_WAVES; ++i)
+                    if (i < wv) run += wtot[0][i];
+                for (int i = w0; i < w1; ++i) {
+                    const uint32_t wd = LDS_BM ? bm[i] : ldu(&bm[i]);
+                    zb[i] = make_uint2(wd, (uint32_t)run);
+                    run += (int)__popc(wd);
+                }
+                __syncthreads();  // (the index has landed: the ranks below read it back)
+                // rank of every member by its index
+                for (int i0 = tid; i0 < tail; i0 += 8 * B2_T) {
+                    int vv[8];
+                    unsigned long long wq[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) vv[u] = i0 + u * B2_T < tail ? ldi(&order[i0 + u * B2_T]) : -1;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) wq[u] = vv[u] >= 0 ? ldq(reinterpret_cast<const unsigned long long *>(zb + (vv[u] >> 5))) : 0ull;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (vv[u] >= 0) zr[(int)(wq[u] >> 32) + (int)__popc((uint32_t)wq[u] & ((1u << (vv[u] & 31)) - 1u))] = i0 + u * B2_T;
+                }
+            }
+            if (tid == 0) {
+                const int seg = (int)(a.base[r + 1] - a.base[r]);  // capacity of the slot's segment: exact ranks + pool
+                a.lz_info[slot] = lazy_stop ? make_int4(head, tail, depth, seg) : make_int4(expect, expect, depth, seg);
+                a.lz_cursor[slot] = lazy_stop ? tail : expect;
+                if (lazy_stop) atomicMax(&a.stats[3], 1024 - depth);  // (smallest lazy level of the launch: 1024 - stats[3])
+            }
+        }
         // ---- per-root results: node count check, depth, longest list (1 + most children)
         int mc = 0;
-        if (tail == expect && !(INSTR && (a.exp & 32)))
-            for (int i0 = tid; i0 < tail; i0 += 8 * B2_T) {  // (eight positions per thread in flight: 977 one-load iterations otherwise)
+        const int n_lists = lazy_stop ? head : tail;  // ranks whose children lists are built
+        if ((tail == expect || lazy_stop) && !(INSTR && (a.exp & 32)))
+            for (int i0 = tid; i0 < n_lists; i0 += 8 * B2_T) {  // (eight positions per thread in flight: 977 one-load iterations otherwise)
                 int c0[8], c1[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int i = i0 + u * B2_T;
-                    c0[u] = i < tail ? cstart[i] : 0;
-                    c1[u] = i < tail ? cstart[i + 1] : 0;
+                    c0[u] = i < n_lists ? cstart[i] : 0;
+                    c1[u] = i < n_lists ? cstart[i + 1] : 0;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) mc = max(mc, c1[u] - c0[u]);
@@ -1298,8 +1385,8 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
         if (lane == 0) atomicMax(&s_max, mc);
         __syncthreads();
         if (tid == 0) {
-            if (tail != expect) a.stats[2] = 1;
-            atomicMax(&a.stats[0], depth);
+            if (tail != expect && !lazy_stop) a.stats[2] = 1;
+            atomicMax(&a.stats[0], lazy_stop ? depth + 2 : depth);  // (walks on a lazy tree end two levels below the exact ones, or raise the slot's flag)
             atomicMax(&a.stats[1], s_max + 1);
         }
         __syncthreads();
@@ -1310,22 +1397,17 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
 
 using namespace gg;
 
-extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t n_roots) {
-    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
-    GG_CHECK(ctx, ctx->g_rowptr && !ctx->h_rowptr.empty(), GG_EINVAL, "gg_build_trees_device: call gg_set_graph_csr first");
-    GG_CHECK(ctx, n_roots >= 0 && (roots || n_roots == 0), GG_EINVAL, "gg_build_trees_device: bad roots");
-    const int n = ctx->n_node;
-    for (int r = 0; r < n_roots; ++r) GG_CHECK(ctx, roots[r] >= 0 && roots[r] < n, GG_EINVAL, "gg_build_trees_device: root %d out of range", roots[r]);
-    GG_CHECK(ctx, ctx->g_nnz < (1ll << 31), GG_EINVAL, "gg_build_trees_device: %lld adjacency entries (limit 2^31 - 1)", (long long)ctx->g_nnz);
-    GG_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = alloc_trees(ctx, roots, n_roots, nullptr, nullptr);  // node counts from the (cached) component sweep
-    if (rc != GG_OK) return rc;
-    if (n_roots == 0) return GG_OK;
+namespace gg {
 
-    const int grid = std::min<int>(n_roots, ctx->n_cus);
+// Scratch, kernel choice, launch and read-back shared by the three builds: whole trees into the slots' segments, lazy trees
+// (gg_build_trees_device), whole trees of single slots into the arena (lazy_fallback_rebuild).  The caller has set the roots /
+// base / output pointers of `a`; stats = {deepest level, longest list, error, 1024 - smallest lazy level}.
+static int bfs_run(gg_ctx *ctx, BfsArgs &a, int n_items, bool lazy, int32_t *stats /*[4]*/) {
+    const int n = ctx->n_node;
+    const int grid = std::min<int>(n_items, ctx->n_cus);
     const int bm_words = (n + 31) / 32;
     // static LDS of the kernel (eoff, e0s, duplicate list, mask, counters) ~ 21.5 KB; the CU has 160 KB
-    const bool v1 = getenv("GG_BFS_V1") != nullptr;  // the chunk kernel of rounds 2-3 (kept for A/B timing and as a second witness in the tests)
+    const bool v1 = getenv("GG_BFS_V1") != nullptr && !lazy && !a.expect;  // the chunk kernel of rounds 2-3 (kept for A/B timing and as a second witness in the tests)
     hipFuncAttributes fa;
     GG_HIP(ctx, hipFuncGetAttributes(&fa, v1 ? (const void *)bfs_order_kernel<true, false> : (const void *)bfs_order2_kernel<true, false>));
     const size_t lds_total = 160 * 1024;
@@ -1342,13 +1424,12 @@ extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t 
         GG_HIP(ctx, hipMemcpy(ctx->bfs_rowptr32.p, r32.data(), sizeof(uint32_t) * r32.size(), hipMemcpyHostToDevice));
         ctx->bfs_rowptr32_valid = true;
     }
-    auto cleanup = [&]() {};
     const size_t key_bytes_before = gkey.bytes;
     hipError_t e = gkey.reserve(sizeof(uint32_t) * (size_t)grid * n);
     if (e == hipSuccess && !lds_bm) e = gbm.reserve(sizeof(uint32_t) * (size_t)grid * bm_words);
     constexpr size_t misc_bytes = sizeof(int32_t) * 8 + sizeof(unsigned long long) * 32;
     if (e == hipSuccess) e = misc.reserve(misc_bytes);
-    if (e != hipSuccess) { cleanup(); return fail(ctx, GG_ENOMEM, "gg_build_trees_device: scratch: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) return fail(ctx, GG_ENOMEM, "gg_build_trees_device: scratch: %s", hipGetErrorString(e));
     // sparse levels (bfs_order2_kernel, LDS bitmap): GG_BFS_SPARSE=0 switches them off; _K / _MIN / _BUCKETS tune the choice
     int sp_k = -1, sp_min = 0, sp_buckets = 16, sp_cap = 0;
     size_t sp_off[6] = {0, 0, 0, 0, 0, 0};
@@ -1370,24 +1451,18 @@ extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t 
             sp_k = -1;
         }
     }
-    BfsArgs a{};
     a.n_node = n;
-    a.n_roots = n_roots;
+    a.n_roots = n_items;
     a.rowptr = ctx->g_rowptr;
     a.rowptr32 = ctx->bfs_rowptr32.as<uint32_t>();
     a.col = ctx->g_col;
-    a.roots = ctx->t_root;
-    a.base = ctx->t_base;
-    a.order = ctx->t_order;
-    a.cstart = ctx->t_cstart;
-    a.edge = ctx->t_edge;
     a.ticket = misc.as<unsigned int>();
     a.stats = misc.as<int32_t>() + 1;
     a.gbitmap = gbm.as<uint32_t>();
     a.gkey = gkey.as<uint32_t>();
     a.bm_words = bm_words;
-    const bool prof = getenv("GG_BFS_PROFILE") != nullptr;
-    a.exp = getenv("GG_BFS_EXPERIMENT") ? atoi(getenv("GG_BFS_EXPERIMENT")) : 0;
+    const bool prof = getenv("GG_BFS_PROFILE") != nullptr && !lazy;
+    a.exp = (getenv("GG_BFS_EXPERIMENT") && !lazy) ? atoi(getenv("GG_BFS_EXPERIMENT")) : 0;
     a.prof = prof ? (unsigned long long *)(misc.as<int32_t>() + 8) : nullptr;
     a.sp_k = sp_k;
     a.sp_min = sp_min;
@@ -1410,13 +1485,16 @@ extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t 
     if (!v1) {
         const size_t dyn = lds_bm ? (size_t)bm_words * 4 : 0;
         const bool instr = prof || a.exp != 0;
-        const void *fn = lds_bm ? (instr ? (const void *)bfs_order2_kernel<true, true> : (const void *)bfs_order2_kernel<true, false>)
-                                : (instr ? (const void *)bfs_order2_kernel<false, true> : (const void *)bfs_order2_kernel<false, false>);
+        const void *fn = lazy ? (lds_bm ? (const void *)bfs_order2_kernel<true, false, true> : (const void *)bfs_order2_kernel<false, false, true>)
+                         : lds_bm ? (instr ? (const void *)bfs_order2_kernel<true, true> : (const void *)bfs_order2_kernel<true, false>)
+                                  : (instr ? (const void *)bfs_order2_kernel<false, true> : (const void *)bfs_order2_kernel<false, false>);
         if (lds_bm) {
             e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-            if (e != hipSuccess) { cleanup(); return fail(ctx, GG_EHIP, "gg_build_trees_device: %zu bytes of LDS: %s", dyn, hipGetErrorString(e)); }
+            if (e != hipSuccess) return fail(ctx, GG_EHIP, "gg_build_trees_device: %zu bytes of LDS: %s", dyn, hipGetErrorString(e));
         }
-        if (lds_bm && instr) hipLaunchKernelGGL((bfs_order2_kernel<true, true>), dim3(grid), dim3(B2_T), dyn, ctx->stream, a);
+        if (lazy && lds_bm) hipLaunchKernelGGL((bfs_order2_kernel<true, false, true>), dim3(grid), dim3(B2_T), dyn, ctx->stream, a);
+        else if (lazy) hipLaunchKernelGGL((bfs_order2_kernel<false, false, true>), dim3(grid), dim3(B2_T), 0, ctx->stream, a);
+        else if (lds_bm && instr) hipLaunchKernelGGL((bfs_order2_kernel<true, true>), dim3(grid), dim3(B2_T), dyn, ctx->stream, a);
         else if (lds_bm) hipLaunchKernelGGL((bfs_order2_kernel<true, false>), dim3(grid), dim3(B2_T), dyn, ctx->stream, a);
         else if (instr) hipLaunchKernelGGL((bfs_order2_kernel<false, true>), dim3(grid), dim3(B2_T), 0, ctx->stream, a);
         else hipLaunchKernelGGL((bfs_order2_kernel<false, false>), dim3(grid), dim3(B2_T), 0, ctx->stream, a);
@@ -1425,7 +1503,7 @@ extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t 
         const bool instr = prof || a.exp != 0;
         const void *fn = instr ? (const void *)bfs_order_kernel<true, true> : (const void *)bfs_order_kernel<true, false>;
         e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-        if (e != hipSuccess) { cleanup(); return fail(ctx, GG_EHIP, "gg_build_trees_device: %zu bytes of LDS: %s", dyn, hipGetErrorString(e)); }
+        if (e != hipSuccess) return fail(ctx, GG_EHIP, "gg_build_trees_device: %zu bytes of LDS: %s", dyn, hipGetErrorString(e));
         if (instr) hipLaunchKernelGGL((bfs_order_kernel<true, true>), dim3(grid), dim3(BFS_T), dyn, ctx->stream, a);
         else hipLaunchKernelGGL((bfs_order_kernel<true, false>), dim3(grid), dim3(BFS_T), dyn, ctx->stream, a);
     } else if (prof || a.exp != 0) {
@@ -1434,11 +1512,12 @@ extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t 
         hipLaunchKernelGGL((bfs_order_kernel<false, false>), dim3(grid), dim3(BFS_T), 0, ctx->stream, a);
     }
     (void)hipEventRecord(ctx->ev1, ctx->stream);
-    int32_t stats[3] = {0, 0, 0};
+    stats[0] = stats[1] = stats[2] = stats[3] = 0;
     e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(stats, a.stats, sizeof(stats), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(stats, a.stats, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess && prof && !v1) {
+        const int n_roots = n_items;
         unsigned long long pc[32];
         if (hipMemcpy(pc, a.prof, sizeof(pc), hipMemcpyDeviceToHost) == hipSuccess) {
             fprintf(stderr, "[bfs2 profile] %d roots, grid %d: per root %.0f windows (%.0f without a candidate, %.0f with in-window duplicates, %.0f through the key array), "
@@ -1467,21 +1546,223 @@ extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t 
             const char *names[8] = {"nodes+scan", "batch form", "map+load+test", "empty chunk", "claim", "dup resolve", "compaction", "stores"};
             double tot = 0;
             for (int k = 0; k < 8; ++k) tot += (double)pc[k];
-            fprintf(stderr, "[bfs profile] %d roots, grid %d: batches %llu chunks %llu (empty %llu, with dups %llu); wave-0 shader-clock share:", n_roots, grid, pc[8], pc[9], pc[10], pc[11]);
+            fprintf(stderr, "[bfs profile] %d roots, grid %d: batches %llu chunks %llu (empty %llu, with dups %llu); wave-0 shader-clock share:", n_items, grid, pc[8], pc[9], pc[10], pc[11]);
             for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.1f%%", names[k], 100.0 * (double)pc[k] / (tot > 0 ? tot : 1));
             fprintf(stderr, "; cycles per chunk %.0f\n", tot / (double)(pc[9] ? pc[9] : 1));
         }
     }
     float ms = 0.f;
     if (e == hipSuccess) (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
-    cleanup();
     if (e != hipSuccess) return fail(ctx, GG_EHIP, "gg_build_trees_device: %s", hipGetErrorString(e));
-    if (a.exp) fprintf(stderr, "[bfs experiment %d] kernel %.1f ms for %d roots (results invalid)\n", a.exp, ms, n_roots);
+    if (a.exp) fprintf(stderr, "[bfs experiment %d] kernel %.1f ms for %d roots (results invalid)\n", a.exp, ms, n_items);
     GG_CHECK(ctx, stats[2] == 0 || (a.exp & ~(8 | 64 | 128)), GG_EINVAL, "gg_build_trees_device: a BFS reached a different number of nodes than the component sweep of the graph");
+    ctx->ctr.bfs_kernel_ms += ms;
+    ctx->ctr.bfs_trees += n_items;
+    return GG_OK;
+}
+
+// Is the next build lazy?  gg_set_tree_mode / GG_TREE_LAZY decide; by default graphs from GG_LZ_AUTO_NODES (2^18) nodes on.
+// Lazy trees need what the walks' resolution reads: a symmetric adjacency (g_rev), degrees that fit the 20 count bits of a pair.
+bool lazy_build_wanted(const gg_ctx *ctx) {
+    int mode = ctx->tree_mode;
+    if (const char *e = getenv("GG_TREE_LAZY")) mode = atoi(e);
+    if (mode < 0) {
+        const long long auto_nodes = getenv("GG_LZ_AUTO_NODES") ? atoll(getenv("GG_LZ_AUTO_NODES")) : (1ll << 18);
+        mode = ctx->n_node >= auto_nodes ? 1 : 0;
+    }
+    return mode > 0 && !ctx->lz_force_whole && ctx->g_rev && ctx->g_max_deg < 0xFFFFF && !getenv("GG_BFS_V1");
+}
+
+static int64_t lazy_node_cap(const gg_ctx *ctx) {
+    int64_t cap = ctx->lz_cap;
+    if (const char *e = getenv("GG_LZ_CAP")) cap = atoll(e);
+    if (cap <= 0) cap = std::max<int64_t>(65536, (int64_t)ctx->n_node * 3 / 8);
+    return cap;
+}
+
+static int build_trees_lazy(gg_ctx *ctx, const int32_t *roots, int32_t n_roots) {
+    const int n = ctx->n_node;
+    if (ctx->h_comp_size.empty()) component_sizes(n, ctx->h_rowptr.data(), ctx->h_col.data(), ctx->h_comp_size);
+    const int64_t cap = lazy_node_cap(ctx);
+    // per slot: node limit of the exact part, pool behind it.  A component that fits the limit is built whole (no pool); a root
+    // whose own children already exceed it gets a whole segment.  The pool takes what a resolution reserves -- one entry per
+    // candidate of the node's adjacency -- for the walks a root can have: ~3 lazy hops each.
+    std::vector<int64_t> seg(n_roots);
+    std::vector<int32_t> limit(n_roots), expect(n_roots);
+    int64_t max_c = 1;
+    for (int r = 0; r < n_roots; ++r) {
+        const int64_t C = ctx->h_comp_size[roots[r]], deg = ctx->h_rowptr[roots[r] + 1] - ctx->h_rowptr[roots[r]];
+        expect[r] = (int32_t)C;
+        max_c = std::max(max_c, C);
+        if (C <= cap || deg + 1 > cap) {
+            limit[r] = (int32_t)C;
+            seg[r] = C;
+        } else {
+            const int64_t pool_env = getenv("GG_LZ_POOL") ? atoll(getenv("GG_LZ_POOL")) : 0;
+            const int64_t pool = pool_env > 0 ? pool_env : std::min<int64_t>(std::max<int64_t>(16384, 192 * (deg + 64)), cap);
+            limit[r] = (int32_t)cap;
+            seg[r] = cap + pool;
+        }
+    }
+    // the arena: whole trees of the slots whose walks need more than a lazy tree gives (lazy_fallback_rebuild)
+    const int64_t arena_roots = getenv("GG_LZ_ARENA") ? atoll(getenv("GG_LZ_ARENA")) : std::min<int64_t>(1024, std::max<int64_t>(8, n_roots / 16));
+    const int64_t arena = arena_roots * (max_c + 1) + 16 * ((int64_t)n_roots + 1);  // (+ the spacing of up to 16 rounds of rebuilds, lazy_fallback_rebuild)
+    int rc = alloc_trees(ctx, roots, n_roots, seg.data(), nullptr, arena);
+    if (rc != GG_OK) return rc;
+    if (n_roots == 0) return GG_OK;
+    ctx->h_lz_seg.resize(n_roots);
+    for (int r = 0; r < n_roots; ++r) ctx->h_lz_seg[r] = (int32_t)seg[r];
+    const int bm_words = (n + 31) / 32;
+    const size_t pair_before = ctx->lz_pair.bytes;
+    hipError_t e = ctx->lz_info.reserve(sizeof(int4) * (size_t)n_roots);
+    if (e == hipSuccess) e = ctx->lz_pair.reserve(sizeof(unsigned long long) * (size_t)ctx->t_cap_nodes);
+    if (e == hipSuccess) e = ctx->lz_rank.reserve(sizeof(int32_t) * (size_t)ctx->t_cap_nodes);
+    if (e == hipSuccess) e = ctx->lz_bm.reserve(sizeof(uint2) * (size_t)n_roots * bm_words);
+    if (e == hipSuccess) e = ctx->lz_cursor.reserve(sizeof(int32_t) * (size_t)n_roots);
+    if (e == hipSuccess) e = ctx->lz_flag.reserve(sizeof(int32_t) * (size_t)n_roots);
+    if (e == hipSuccess) e = ctx->lz_limit.reserve(sizeof(int32_t) * (size_t)n_roots);
+    if (e == hipSuccess) e = ctx->lz_expect.reserve(sizeof(int32_t) * (size_t)n_roots);
+    if (e != hipSuccess) return fail(ctx, GG_ENOMEM, "gg_build_trees_device: lazy-tree arrays: %s", hipGetErrorString(e));
+    // a pair is valid iff it carries the build's stamp: nothing to initialise per build; cleared when the 12 bits wrap (and when new)
+    ctx->lz_stamp = ctx->lz_stamp % 4095u + 1u;
+    if (ctx->lz_stamp == 1u || ctx->lz_pair.bytes != pair_before) GG_HIP(ctx, hipMemsetAsync(ctx->lz_pair.p, 0, ctx->lz_pair.bytes, ctx->stream));
+    GG_HIP(ctx, hipMemsetAsync(ctx->lz_flag.p, 0, sizeof(int32_t) * (size_t)n_roots, ctx->stream));
+    GG_HIP(ctx, hipMemcpyAsync(ctx->lz_limit.p, limit.data(), sizeof(int32_t) * (size_t)n_roots, hipMemcpyHostToDevice, ctx->stream));
+    GG_HIP(ctx, hipMemcpyAsync(ctx->lz_expect.p, expect.data(), sizeof(int32_t) * (size_t)n_roots, hipMemcpyHostToDevice, ctx->stream));
+    BfsArgs a{};
+    a.roots = ctx->t_root;
+    a.base = ctx->t_base;
+    a.order = ctx->t_order;
+    a.cstart = ctx->t_cstart;
+    a.edge = ctx->t_edge;
+    a.expect = ctx->lz_expect.as<int32_t>();
+    a.lz_limit = ctx->lz_limit.as<int32_t>();
+    a.lz_info = ctx->lz_info.as<int4>();
+    a.lz_bm = ctx->lz_bm.as<uint2>();
+    a.lz_rank = ctx->lz_rank.as<int32_t>();
+    a.lz_cursor = ctx->lz_cursor.as<int32_t>();
+    int32_t stats[4];
+    rc = bfs_run(ctx, a, n_roots, /*lazy=*/true, stats);  // (copies and memsets above: same stream, done when it returns)
+    if (rc != GG_OK) return rc;
+    ctx->t_lazy = true;
+    ctx->lz_min_level = stats[3] > 0 ? 1024 - stats[3] : 0x7fffffff;
+    ctx->tree_max_depth = stats[0];
+    ctx->tree_max_list = std::max(stats[1], ctx->g_max_deg + 1);  // (a resolved list holds up to the node's degree)
+    ctx->t_edge_valid = true;
+    return GG_OK;
+}
+
+// Whole trees for the slots whose lazy tree did not suffice (lz_flag raised by the walks of the launch that has just finished),
+// built into the arena; the slots' bases move there.  Returns the number of slots rebuilt in *n_out; GG_ECAPACITY when the arena
+// is full (the caller rebuilds the batch whole).
+int lazy_fallback_rebuild(gg_ctx *ctx, int *n_out) {
+    *n_out = 0;
+    const int R = ctx->n_tree_roots;
+    std::vector<int32_t> flag(R);
+    GG_HIP(ctx, hipMemcpy(flag.data(), ctx->lz_flag.p, sizeof(int32_t) * (size_t)R, hipMemcpyDeviceToHost));
+    std::vector<int32_t> slots, roots, expect;
+    std::vector<int64_t> base;
+    int64_t next = ctx->arena_next + R + 1;  // (the cstart row of a slot starts at base + slot: rounds are spaced by the slot range)
+    for (int s = 0; s < R; ++s) {
+        if (!flag[s]) continue;
+        const int64_t C = ctx->h_comp_size[ctx->h_troot[s]];
+        if (next + C + 1 > ctx->arena_end) return fail(ctx, GG_ECAPACITY, "lazy trees: the arena of whole trees is full");
+        slots.push_back(s);
+        roots.push_back(ctx->h_troot[s]);
+        expect.push_back((int32_t)C);
+        base.push_back(next);
+        next += C + 1;  // (ascending slots: the cstart rows, shifted by their slot, cannot overlap)
+    }
+    const int m = (int)slots.size();
+    if (m == 0) return GG_OK;
+    base.push_back(next);
+    DevBuf d_slots, d_roots, d_expect, d_base;
+    hipError_t e = d_slots.reserve(sizeof(int32_t) * m);
+    if (e == hipSuccess) e = d_roots.reserve(sizeof(int32_t) * m);
+    if (e == hipSuccess) e = d_expect.reserve(sizeof(int32_t) * m);
+    if (e == hipSuccess) e = d_base.reserve(sizeof(int64_t) * (m + 1));
+    auto release = [&]() { d_slots.release(); d_roots.release(); d_expect.release(); d_base.release(); };
+    if (e != hipSuccess) { release(); return fail(ctx, GG_ENOMEM, "lazy trees: %s", hipGetErrorString(e)); }
+    (void)hipMemcpy(d_slots.p, slots.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_roots.p, roots.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_expect.p, expect.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_base.p, base.data(), sizeof(int64_t) * (m + 1), hipMemcpyHostToDevice);
+    BfsArgs a{};
+    a.roots = d_roots.as<int32_t>();
+    a.base = d_base.as<int64_t>();
+    a.order = ctx->t_order;
+    a.cstart = ctx->t_cstart;
+    a.edge = ctx->t_edge;
+    a.expect = d_expect.as<int32_t>();
+    a.slot_ids = d_slots.as<int32_t>();
+    int32_t stats[4];
+    int rc = bfs_run(ctx, a, m, /*lazy=*/false, stats);
+    release();
+    if (rc != GG_OK) return rc;
+    // the slots now point into the arena and have no lazy ranks
+    std::vector<int4> info(m);
+    for (int i = 0; i < m; ++i) {
+        const int s = slots[i];
+        GG_HIP(ctx, hipMemcpy(ctx->t_base + s, &base[i], sizeof(int64_t), hipMemcpyHostToDevice));
+        const int4 v = make_int4(expect[i], expect[i], 0, 0);
+        GG_HIP(ctx, hipMemcpy(ctx->lz_info.as<int4>() + s, &v, sizeof(int4), hipMemcpyHostToDevice));
+    }
+    GG_HIP(ctx, hipMemset(ctx->lz_flag.p, 0, sizeof(int32_t) * (size_t)R));
+    ctx->arena_next = next;
+    ctx->tree_max_depth = std::max(ctx->tree_max_depth, stats[0]);
+    ctx->tree_max_list = std::max(ctx->tree_max_list, stats[1]);
+    ctx->lz_fallback_roots += m;
+    ctx->lz_fallback_rounds += 1;
+    *n_out = m;
+    return GG_OK;
+}
+
+// The arena is full: the resident lazy batch is rebuilt as whole trees (the Q3 bits of the slots survive).
+int lazy_rebuild_whole(gg_ctx *ctx) {
+    const int R = ctx->n_tree_roots;
+    const std::vector<int32_t> roots = ctx->h_troot;
+    std::vector<uint32_t> q3((size_t)std::max<int64_t>(ctx->h_q3off[R], 1));
+    GG_HIP(ctx, hipMemcpy(q3.data(), ctx->t_q3, sizeof(uint32_t) * (size_t)ctx->h_q3off[R], hipMemcpyDeviceToHost));
+    ctx->lz_pair.release();
+    ctx->lz_rank.release();
+    ctx->lz_bm.release();
+    ctx->lz_force_whole = true;
+    const int rc = gg_build_trees_device(ctx, roots.data(), R);
+    ctx->lz_force_whole = false;
+    if (rc != GG_OK) return rc;
+    if (ctx->h_q3off[R]) GG_HIP(ctx, hipMemcpy(ctx->t_q3, q3.data(), sizeof(uint32_t) * (size_t)ctx->h_q3off[R], hipMemcpyHostToDevice));
+    ctx->lz_fallback_roots += R;
+    ctx->lz_fallback_rounds += 1;
+    return GG_OK;
+}
+
+}  // namespace gg
+
+extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t n_roots) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    GG_CHECK(ctx, ctx->g_rowptr && !ctx->h_rowptr.empty(), GG_EINVAL, "gg_build_trees_device: call gg_set_graph_csr first");
+    GG_CHECK(ctx, n_roots >= 0 && (roots || n_roots == 0), GG_EINVAL, "gg_build_trees_device: bad roots");
+    const int n = ctx->n_node;
+    for (int r = 0; r < n_roots; ++r) GG_CHECK(ctx, roots[r] >= 0 && roots[r] < n, GG_EINVAL, "gg_build_trees_device: root %d out of range", roots[r]);
+    GG_CHECK(ctx, ctx->g_nnz < (1ll << 31), GG_EINVAL, "gg_build_trees_device: %lld adjacency entries (limit 2^31 - 1)", (long long)ctx->g_nnz);
+    GG_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->t_lazy = false;
+    ctx->lz_min_level = 0x7fffffff;
+    if (lazy_build_wanted(ctx)) return build_trees_lazy(ctx, roots, n_roots);
+    int rc = alloc_trees(ctx, roots, n_roots, nullptr, nullptr);  // node counts from the (cached) component sweep
+    if (rc != GG_OK) return rc;
+    if (n_roots == 0) return GG_OK;
+    BfsArgs a{};
+    a.roots = ctx->t_root;
+    a.base = ctx->t_base;
+    a.order = ctx->t_order;
+    a.cstart = ctx->t_cstart;
+    a.edge = ctx->t_edge;
+    int32_t stats[4];
+    rc = bfs_run(ctx, a, n_roots, /*lazy=*/false, stats);
+    if (rc != GG_OK) return rc;
     ctx->tree_max_depth = stats[0];
     ctx->tree_max_list = stats[1];
     ctx->t_edge_valid = (a.exp & ~(8 | 64 | 128)) == 0;
-    ctx->ctr.bfs_kernel_ms += ms;
-    ctx->ctr.bfs_trees += n_roots;
     return GG_OK;
 }

@@ -29,6 +29,15 @@ __global__ __launch_bounds__(256) void reverse_edges_kernel(const int64_t *rowpt
     if (r < 0) *ok = 0;
 }
 
+// does some adjacency list hold a node twice?  e is the FIRST occurrence of its target in its list iff rev[rev[e]] == e (rev names
+// first occurrences); the lazy trees' resolution (walk_sample.hip) skips its first-occurrence tests on a graph without duplicates
+__global__ __launch_bounds__(256) void multi_edge_kernel(const int32_t *rev, int64_t nnz, int32_t *multi) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    const int32_t r = rev[e];
+    if (r >= 0 && rev[r] != (int32_t)e) *multi = 1;
+}
+
 // one thread per tree node (slot r, rank i): match its children -- consecutive ranks, in adjacency order -- against
 // adj(order[i]) from the left; the first occurrence of each child is the edge the BFS appended it at.
 __global__ __launch_bounds__(256) void tree_edges_kernel(const int32_t *order, const int32_t *cstart, const int64_t *base, int32_t n_roots,
@@ -73,7 +82,15 @@ int compute_reverse_edges(gg_ctx *ctx) {
     if (!h_ok) {  // not a symmetric adjacency: the cache cannot serve father candidates -> every distribution scores privately
         (void)hipFree(ctx->g_rev);
         ctx->g_rev = nullptr;
+        return GG_OK;
     }
+    int32_t h_multi = 0;
+    GG_HIP(ctx, hipMemcpy(ok, &h_multi, sizeof(int32_t), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(multi_edge_kernel, dim3((unsigned)cdiv(ctx->g_nnz, 256)), dim3(256), 0, ctx->stream, ctx->g_rev, ctx->g_nnz, ok);
+    GG_HIP(ctx, hipGetLastError());
+    GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GG_HIP(ctx, hipMemcpy(&h_multi, ok, sizeof(int32_t), hipMemcpyDeviceToHost));
+    ctx->g_multi = h_multi != 0;
     return GG_OK;
 }
 

@@ -41,6 +41,8 @@ static void free_trees(gg_ctx *ctx) {
     ctx->n_tree_roots = 0;
     ctx->tree_nodes = ctx->tree_entries = 0;
     ctx->tree_max_depth = ctx->tree_max_list = 0;
+    ctx->t_lazy = false;
+    ctx->lz_min_level = 0x7fffffff;
     ctx->h_troot.clear();
     ctx->h_tbase.clear();
     ctx->h_q3off.clear();
@@ -48,10 +50,12 @@ static void free_trees(gg_ctx *ctx) {
 
 // Device arrays for the BFS-order trees of `roots`: node counts C_r (NULL: component sizes from a cached host sweep of
 // the graph), Q3 bit rows sized by the roots' child counts (NULL: their degrees, an upper bound), zero-initialised.
-int alloc_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int64_t *node_counts, const int64_t *root_children) {
+int alloc_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int64_t *node_counts, const int64_t *root_children, int64_t extra_nodes) {
     discard_begun_walk(ctx);
     (void)hipDeviceSynchronize();  // walks of calls that returned early may still read the old trees
     ctx->dc_valid = false;
+    ctx->t_lazy = false;  // (set by the lazy build once its arrays are filled)
+    ctx->lz_min_level = 0x7fffffff;
     ctx->t_edge_valid = false;  // set by whoever fills the arrays (GPU BFS: in the same pass; otherwise derive_tree_edges)
     const int n = ctx->n_node;
     if (!node_counts && ctx->h_comp_size.empty()) component_sizes(n, ctx->h_rowptr.data(), ctx->h_col.data(), ctx->h_comp_size);
@@ -62,8 +66,11 @@ int alloc_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int64_
         const int64_t deg = root_children ? root_children[r] : ctx->h_rowptr[roots[r] + 1] - ctx->h_rowptr[roots[r]];
         ctx->h_q3off[r + 1] = ctx->h_q3off[r] + (deg + 31) / 32;
     }
-    const int64_t nodes = ctx->h_tbase[n_roots], q3w = ctx->h_q3off[n_roots];
+    const int64_t seg_nodes = ctx->h_tbase[n_roots], q3w = ctx->h_q3off[n_roots];
+    const int64_t nodes = seg_nodes + extra_nodes;  // (extra: the arena of whole trees behind the segments of a lazy build)
     const int nr = std::max(n_roots, 1);
+    ctx->arena_next = seg_nodes;
+    ctx->arena_end = nodes;
     // Trees are rebuilt per root batch when they cannot all stay resident (an epoch over 10^6 roots): keep the arrays
     // of the previous batch when they are large enough instead of returning 64 GB to the driver and asking for it again.
     auto regrow = [&](void **p, size_t bytes) -> hipError_t {
@@ -76,7 +83,7 @@ int alloc_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int64_
         const int64_t cn = std::max<int64_t>(nodes, 1), cr = std::max<int64_t>(nr, ctx->t_cap_roots);
         GG_HIP(ctx, regrow((void **)&ctx->t_order, sizeof(int32_t) * (size_t)cn));
         GG_HIP(ctx, regrow((void **)&ctx->t_edge, sizeof(int32_t) * (size_t)cn));
-        GG_HIP(ctx, regrow((void **)&ctx->t_cstart, sizeof(int32_t) * (size_t)(cn + cr)));
+        GG_HIP(ctx, regrow((void **)&ctx->t_cstart, sizeof(int32_t) * (size_t)(cn + 2 * cr + 2)));  // (a slot's row starts at base + slot; arena rows too)
         GG_HIP(ctx, regrow((void **)&ctx->t_root, sizeof(int32_t) * (size_t)cr));
         GG_HIP(ctx, regrow((void **)&ctx->t_base, sizeof(int64_t) * (size_t)(cr + 1)));
         GG_HIP(ctx, regrow((void **)&ctx->t_q3off, sizeof(int64_t) * (size_t)(cr + 1)));
@@ -95,8 +102,8 @@ int alloc_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int64_
     GG_HIP(ctx, hipMemsetAsync(ctx->t_q3, 0, sizeof(uint32_t) * (size_t)std::max<int64_t>(q3w, 1), ctx->stream));
     GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->n_tree_roots = n_roots;
-    ctx->tree_nodes = nodes;
-    ctx->tree_entries = 2 * nodes - n_roots;
+    ctx->tree_nodes = seg_nodes;
+    ctx->tree_entries = 2 * seg_nodes - n_roots;
     ctx->h_troot.assign(roots, roots + n_roots);
     return GG_OK;
 }
@@ -264,10 +271,24 @@ int gg::walk_finalize(gg_ctx *ctx, bool *retried) {
     GG_HIP(ctx, hipMemcpyAsync(c, ctx->dev_ctr, sizeof(unsigned long long) * 2 * CW, hipMemcpyDeviceToHost, ctx->stream));
     GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     harvest_timings(ctx);
-    if (c[3] == 2ull) {
-        // nothing the overflowed launch wrote or counted is final (the D-mode post-pass is gated by the same flag,
+    for (int attempt = 0; c[3] == 2ull || (c[2] != 0ull && ctx->t_lazy); ++attempt) {
+        // nothing the voided launch wrote or counted is final (the D-mode post-pass is gated by the same flag,
         // the counter words are zeroed again by the new launch)
-        ctx->walk_force_sized = true;
+        GG_CHECK(ctx, attempt < 16, GG_EHIP, "walk: the launch was voided %d times in a row", attempt);
+        if (c[2] != 0ull && ctx->t_lazy) {
+            // LAZY trees: walks of some slots needed more than their lazy tree gives (lz_flag): those slots get their whole trees
+            // (arena), everything is walked again -- the other slots' walks come out the same, theirs now complete
+            int rebuilt = 0;
+            int rc = lazy_fallback_rebuild(ctx, &rebuilt);
+            if (rc == GG_ECAPACITY) rc = lazy_rebuild_whole(ctx);  // the arena is full: the whole batch as whole trees
+            if (rc != GG_OK) return rc;
+            if (ctx->tree_max_depth + 3 > ctx->w_stride) {  // a whole tree may be deeper than the lazy bound
+                ctx->w_stride = ctx->tree_max_depth + 3;
+                GG_HIP(ctx, ctx->w_paths.reserve(sizeof(int32_t) * ((size_t)total * ctx->w_stride + 1)));
+            }
+        } else {
+            ctx->walk_force_sized = true;
+        }
         ctx->ctr.walk_reruns += 1;
         generator_changed(ctx);  // nodes the aborted launch claimed were never scored: no stamp of it may stay valid
         int rc = launch_and_join(ctx, ctx->w_nslots, total, ctx->w_args.for_d, ctx->w_args.seed, ctx->w_args.stream, ctx->w_stride);
@@ -546,6 +567,9 @@ int gg_set_graph_csr(gg_ctx *ctx, const int64_t *rowptr, const int32_t *col) {
     GG_HIP(ctx, hipMemcpy(ctx->g_rowptr, rowptr, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
     if (nnz) GG_HIP(ctx, hipMemcpy(ctx->g_col, col, sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
     ctx->g_nnz = nnz;
+    ctx->g_max_deg = 0;
+    for (int v = 0; v < n; ++v) ctx->g_max_deg = (int32_t)std::min<int64_t>(std::max<int64_t>(ctx->g_max_deg, rowptr[v + 1] - rowptr[v]), 0x7fffffff);
+    ctx->g_multi = true;
     ctx->h_rowptr.assign(rowptr, rowptr + n + 1);
     ctx->h_col.assign(col, col + nnz);
     ctx->h_comp_size.clear();
@@ -689,6 +713,7 @@ int gg_tree_roots(const gg_ctx *ctx, int32_t *roots) {
 // Download the resident trees in the reference's shape, including the D-mode mutations (removed father entries = -1).
 int gg_get_trees(gg_ctx *ctx, int32_t *off, int32_t *nbr, int64_t *nbr_base) {
     if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    GG_CHECK(ctx, !ctx->t_lazy, GG_EINVAL, "gg_get_trees: the resident trees are lazy (exact through a level only): build them whole (gg_set_tree_mode(ctx, 0, 0)) to export them");
     GG_CHECK(ctx, ctx->n_tree_roots > 0, GG_EINVAL, "gg_get_trees: no trees loaded");
     GG_HIP(ctx, hipSetDevice(ctx->device));
     GG_HIP(ctx, hipDeviceSynchronize());
@@ -722,6 +747,7 @@ int gg_get_trees(gg_ctx *ctx, int32_t *off, int32_t *nbr, int64_t *nbr_base) {
 
 int gg_get_tree_order(gg_ctx *ctx, int64_t *base, int32_t *order, int32_t *cstart, int32_t *edge, int32_t *edges_valid) {
     if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    GG_CHECK(ctx, !ctx->t_lazy, GG_EINVAL, "gg_get_tree_order: the resident trees are lazy (exact through a level only): build them whole (gg_set_tree_mode(ctx, 0, 0)) to export them");
     GG_CHECK(ctx, ctx->n_tree_roots > 0, GG_EINVAL, "gg_get_tree_order: no trees loaded");
     GG_HIP(ctx, hipSetDevice(ctx->device));
     GG_HIP(ctx, hipDeviceSynchronize());
@@ -790,6 +816,7 @@ int stream_dev(gg_ctx *ctx, FILE *f, int32_t *dev, size_t count, bool save) {
 
 int gg_save_trees(gg_ctx *ctx, const char *path) {
     if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    GG_CHECK(ctx, !ctx->t_lazy, GG_EINVAL, "gg_save_trees: the resident trees are lazy (exact through a level only): build them whole (gg_set_tree_mode(ctx, 0, 0)) to export them");
     GG_CHECK(ctx, path, GG_EINVAL, "gg_save_trees: path is NULL");
     GG_CHECK(ctx, ctx->n_tree_roots > 0, GG_EINVAL, "gg_save_trees: no trees loaded");
     GG_HIP(ctx, hipSetDevice(ctx->device));
@@ -890,8 +917,65 @@ int gg_walk_sample(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, in
     const int64_t total = ctx->w_total;
     if (samples && total) GG_HIP(ctx, hipMemcpy(samples, ctx->w_samples.p, sizeof(int32_t) * total, hipMemcpyDeviceToHost));
     if (path_len && total) GG_HIP(ctx, hipMemcpy(path_len, ctx->w_len.p, sizeof(int32_t) * total, hipMemcpyDeviceToHost));
-    if (paths && total) GG_HIP(ctx, hipMemcpy(paths, ctx->w_paths.p, sizeof(int32_t) * (size_t)total * stride, hipMemcpyDeviceToHost));
+    if (paths && total && ctx->w_stride == stride) GG_HIP(ctx, hipMemcpy(paths, ctx->w_paths.p, sizeof(int32_t) * (size_t)total * stride, hipMemcpyDeviceToHost));
+    if (ctx->w_stride != stride && total) {
+        // LAZY trees: slots that were rebuilt whole may hold deeper trees than the bound the caller sized its rows by
+        std::vector<int32_t> len((size_t)total);
+        GG_HIP(ctx, hipMemcpy(len.data(), ctx->w_len.p, sizeof(int32_t) * total, hipMemcpyDeviceToHost));
+        for (int64_t w = 0; w < total; ++w)
+            GG_CHECK(ctx, len[w] <= stride, GG_ECAPACITY, "walk: a path needed %d entries, stride is %d (gg_tree_info reports the depth of the trees as rebuilt)", len[w], stride);
+        if (paths) GG_HIP(ctx, hipMemcpy2D(paths, sizeof(int32_t) * (size_t)stride, ctx->w_paths.p, sizeof(int32_t) * (size_t)ctx->w_stride, sizeof(int32_t) * (size_t)stride, (size_t)total, hipMemcpyDeviceToHost));
+    }
     if (root_status && n_slots) GG_HIP(ctx, hipMemcpy(root_status, ctx->w_status.p, sizeof(int32_t) * n_slots, hipMemcpyDeviceToHost));
+    return GG_OK;
+}
+
+int gg_set_tree_mode(gg_ctx *ctx, int32_t mode, int64_t node_cap) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    GG_CHECK(ctx, mode >= -1 && mode <= 1 && node_cap >= 0, GG_EINVAL, "gg_set_tree_mode: mode must be -1 (auto), 0 (whole trees) or 1 (lazy), node_cap >= 0");
+    ctx->tree_mode = mode;
+    ctx->lz_cap = node_cap;
+    return GG_OK;
+}
+
+int gg_lazy_stats(gg_ctx *ctx, int64_t *out8) {
+    if (!ctx || !out8) return fail(ctx, GG_EINVAL, "gg_lazy_stats: NULL argument");
+    GG_HIP(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    out8[0] = ctx->t_lazy ? 1 : 0;
+    out8[1] = ctx->t_lazy ? ctx->lz_min_level : 0;
+    out8[2] = ctx->lz_fallback_roots;
+    out8[3] = ctx->lz_fallback_rounds;
+    if (ctx->t_lazy && ctx->n_tree_roots > 0) {
+        GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const int R = ctx->n_tree_roots;
+        std::vector<int4> info((size_t)R);
+        std::vector<int32_t> cur((size_t)R);
+        GG_HIP(ctx, hipMemcpy(info.data(), ctx->lz_info.p, sizeof(int4) * (size_t)R, hipMemcpyDeviceToHost));
+        GG_HIP(ctx, hipMemcpy(cur.data(), ctx->lz_cursor.p, sizeof(int32_t) * (size_t)R, hipMemcpyDeviceToHost));
+        for (int r = 0; r < R; ++r) {
+            out8[4] += info[r].y;                                  // exact nodes written by the BFS
+            out8[5] += std::max(0, cur[r] - info[r].y);            // pool entries reserved by resolutions
+            out8[6] += info[r].x < info[r].y ? 1 : 0;              // slots that are lazy (not built whole)
+            out8[7] = std::max<int64_t>(out8[7], info[r].z);       // deepest exact level
+        }
+    }
+    return GG_OK;
+}
+
+int gg_get_lazy_trees(gg_ctx *ctx, int64_t *n_entries, int32_t *info4, int64_t *base, int32_t *order, int32_t *cstart, int32_t *edge, uint64_t *pair) {
+    if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
+    GG_CHECK(ctx, ctx->t_lazy, GG_EINVAL, "gg_get_lazy_trees: the resident trees are not lazy");
+    GG_HIP(ctx, hipSetDevice(ctx->device));
+    GG_HIP(ctx, hipDeviceSynchronize());
+    const size_t R = (size_t)ctx->n_tree_roots, nodes = (size_t)ctx->arena_end;  // (segments and arena)
+    if (n_entries) *n_entries = (int64_t)nodes;
+    if (info4) GG_HIP(ctx, hipMemcpy(info4, ctx->lz_info.p, sizeof(int4) * R, hipMemcpyDeviceToHost));
+    if (base) GG_HIP(ctx, hipMemcpy(base, ctx->t_base, sizeof(int64_t) * R, hipMemcpyDeviceToHost));
+    if (order) GG_HIP(ctx, hipMemcpy(order, ctx->t_order, sizeof(int32_t) * nodes, hipMemcpyDeviceToHost));
+    if (cstart) GG_HIP(ctx, hipMemcpy(cstart, ctx->t_cstart, sizeof(int32_t) * (nodes + R), hipMemcpyDeviceToHost));
+    if (edge) GG_HIP(ctx, hipMemcpy(edge, ctx->t_edge, sizeof(int32_t) * nodes, hipMemcpyDeviceToHost));
+    if (pair) GG_HIP(ctx, hipMemcpy(pair, ctx->lz_pair.p, sizeof(uint64_t) * std::min(nodes, ctx->lz_pair.bytes / sizeof(uint64_t)), hipMemcpyDeviceToHost));
     return GG_OK;
 }
 

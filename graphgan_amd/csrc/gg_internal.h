@@ -137,6 +137,31 @@ struct gg_ctx {
     std::vector<int64_t> h_tbase, h_q3off;
     std::vector<int32_t> h_comp_size;  // |component| of every node (one host sweep per graph, cached): C_r before any BFS runs
 
+    // LAZY trees (round 6; bfs_gpu.hip "LAZY", walk_sample.hip "LAZY"): gg_build_trees_device builds a root's tree exactly only
+    // THROUGH A LEVEL L_r -- the last level whose expansion is known to fit the slot's node limit -- and the walks resolve the
+    // children list of a deeper node the first time one of them stands on it.  Slot r then holds
+    //   ranks [0, lzs)        levels < L_r: exact, children through t_cstart as always
+    //   ranks [lzs, P)        level L_r: exact queue entries (t_order / t_edge) whose children lists are NOT built
+    //   ranks [P, seg)        the POOL: children lists resolved on demand, appended by an atomic cursor (lz_cursor)
+    // and for a rank >= lzs the children range is lz_pair[t_base[r] + rank] = start << 32 | count << 12 | stamp (valid iff its
+    // stamp is the build's; count 0xFFFFF = being resolved).  Resolution needs, per slot, the visited set of levels <= L_r with
+    // the BFS rank of every member: lz_bm[r][w] = {bitmap word w, members below word w} and lz_rank[t_base[r] + index] = rank,
+    // index = members below the node (popcount) -- a node's rank is two loads, the second only for members.
+    // A slot whose walks need more than that (a level L_r + 3 node, a full pool) raises lz_flag[r]: walk_finalize rebuilds those
+    // roots whole in the ARENA behind the slots' segments (t_base[r] moves there, lz_info[r].x = its node count) and reruns.
+    int32_t tree_mode = -1;            // gg_set_tree_mode / GG_TREE_LAZY: 0 = whole trees, 1 = lazy, -1 = lazy from GG_LZ_AUTO_NODES nodes on
+    int64_t lz_cap = 0;                // node limit of a slot's exact part (0 = 3/8 of the nodes, at least 65 536; GG_LZ_CAP)
+    bool t_lazy = false;               // the resident trees are lazy
+    bool lz_force_whole = false;       // (the rebuild of a lazy batch as whole trees is under way)
+    int32_t lz_min_level = 0x7fffffff; // smallest L_r of the resident lazy slots (levels below it need no resolve step)
+    uint32_t lz_stamp = 0;             // stamp of the resident build (1 .. 4095; the pair array is cleared when it wraps)
+    gg::DevBuf lz_info, lz_pair, lz_rank, lz_bm, lz_cursor, lz_flag, lz_limit, lz_expect, lz_list;
+    std::vector<int32_t> h_lz_seg;     // capacity (nodes) of every slot's segment
+    int64_t arena_next = 0, arena_end = 0;  // the arena of whole trees behind the segments: [arena_next, arena_end) is free
+    int64_t lz_fallback_roots = 0, lz_fallback_rounds = 0, lz_resolved = 0;  // statistics (gg_lazy_stats)
+    bool g_multi = true;               // the adjacency holds a node twice in some list (first-occurrence tests needed)
+    int32_t g_max_deg = 0;
+
     // walk outputs (device resident)
     // walk inputs (slot list, walk offsets): one resident copy per mode (index 1 = D-mode, 0 = anything else) with the host
     // shadow that tells whether the next call brings the same lists -- the trainer alternates D and G calls over the same
@@ -293,7 +318,10 @@ int device_segment_rows(gg_ctx *ctx, const int32_t *cnt, int64_t n, int T, int32
                         DevBuf *scratch = nullptr);  // prepare.hip (defaults: the main stream and its scan scratch)
 
 // trees (gg_api.hip / tree_builder.cpp)
-int alloc_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int64_t *node_counts, const int64_t *root_children);
+int alloc_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int64_t *node_counts, const int64_t *root_children, int64_t extra_nodes = 0);
+bool lazy_build_wanted(const gg_ctx *ctx);            // bfs_gpu.hip: is the next gg_build_trees_device lazy?
+int lazy_rebuild_whole(gg_ctx *ctx);                  // bfs_gpu.hip: the resident lazy batch again, as whole trees
+int lazy_fallback_rebuild(gg_ctx *ctx, int *n_out);   // bfs_gpu.hip: whole trees (arena) for the slots whose walks raised lz_flag
 void component_sizes(int n, const int64_t *rowptr, const int32_t *col, std::vector<int32_t> &comp_size);
 // FIFO BFS of one root into BFS-order form; returns C (order[0..C), cstart[0..C]); scratch: n-entry stamp array + epoch
 int32_t host_bfs_order(const int64_t *rowptr, const int32_t *col, int32_t root, int32_t *order, int32_t *cstart,

@@ -634,7 +634,12 @@ int gg_prepare_g(gg_ctx *ctx, const int32_t *slots, int32_t n_slots, int32_t n_s
     if (rc != GG_OK) return rc;
     if (nw > 0) {
         if (retried) {
-            rc = enqueue_g_pairs(ctx, nw, cap);
+            // (LAZY trees: slots rebuilt whole may have deepened the paths -- the launch was repeated with a longer stride)
+            const int64_t cap2 = std::max<int64_t>(cap, nw * 2 * ctx->cfg.window_size * (ctx->w_stride - 1));
+            GG_HIP(ctx, ctx->g_node1.reserve(sizeof(int32_t) * (cap2 + 1)));
+            GG_HIP(ctx, ctx->g_node2.reserve(sizeof(int32_t) * (cap2 + 1)));
+            GG_HIP(ctx, ctx->g_reward.reserve(sizeof(float) * (cap2 + 1)));
+            rc = enqueue_g_pairs(ctx, nw, cap2);
             if (rc != GG_OK) return rc;
             GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }

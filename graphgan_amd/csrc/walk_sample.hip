@@ -105,6 +105,20 @@ struct WalkArgs {
     int32_t es_ratio, es_hub;
     int32_t *lv_fe;          // [total_walks] es index of the father candidate's score (gather tasks with a father entry)
     int32_t exp;             // GG_WALK_EXPERIMENT: timing ablations (results are then WRONG): 1 / 2 = the weights kernel skips its big / small tasks, 64 / 32 = runs them twice (results stay right), 8 = per-level row counts
+    // LAZY trees (gg_internal.h "LAZY trees", bfs_gpu.hip): slot r is exact through level L_r; the children list of a rank >= lzs_r
+    // is resolved by the first walk that stands on it ("LAZY RESOLUTION" below) and appended to the slot's pool
+    int32_t lazy;
+    const int4 *lz_info;          // [slots] {lzs: first rank without a built children list, exact ranks, their level L, capacity of the segment}
+    unsigned long long *lz_pair;  // at t_base[r] + rank: start << 32 | count << 12 | stamp
+    const int32_t *lz_rank;       // at t_base[r] + member index: BFS rank
+    const uint2 *lz_bm;           // [slots][lz_words] {visited word, members below the word}
+    int32_t lz_words;
+    int32_t *lz_cursor;           // [slots] first free rank of the pool
+    int32_t *lz_flag;             // [slots] the walks need the whole tree of this slot
+    uint32_t lz_stamp;
+    int32_t g_multi;              // some adjacency list holds a node twice: first-occurrence tests needed
+    int32_t *lz_list;             // [total_walks] walks whose node waits for the resolve kernel (count: lc[CTR_LZ + level])
+    int32_t *t_order_w, *t_edge_w;  // the tree arrays, writable (pool appends)
 };
 
 // ---- cross-lane moves without an LDS round trip (DPP): shifts / rotations inside a row of 16 lanes, row broadcasts across rows.
@@ -245,6 +259,221 @@ __device__ __forceinline__ int sample_index(Load sbuf, int k, float mx, uint64_t
 }
 
 // ------------------------------------------------------------------------------------------
+// LAZY RESOLUTION (round 6): children lists the BFS did not build, identical to the ones it would have built.
+//
+// Slot r is exact through level L: the visited set V (levels <= L) with the BFS rank of every member.  The FIFO BFS
+// (graph_gan.py:96-107) appends a node when the first queue node adjacent to it is popped, at the first occurrence of
+// the node in that adjacency; a level's queue order is (rank of the father, index of the appending edge).  So for a walk
+// standing on `cur`:
+//   depth 0 (cur in level L, rank known): w in adj(cur) is a child iff w is not in V (then all its neighbours in V are in
+//           level L) and no neighbour of w in V has a smaller rank than cur;
+//   depth 1 (cur in level L + 1, a pool node; its key = (rank of its father f, index of the edge f -> cur)): x in adj(cur) is
+//           a child iff x is not in V, has no neighbour in V (else it is in level L + 1) and no neighbour y of x that is in
+//           level L + 1 -- y has a neighbour in V; its key = (smallest rank among them, index of that father's edge to y,
+//           through the reverse-edge index) -- has a smaller key;
+//   depth 2 (cur in level L + 2): only "is it a leaf": a neighbour that is not in V, has no neighbour in V and no neighbour
+//           in level L + 1 would be a child -- then the slot asks for its whole tree (lz_flag; walk_finalize rebuilds it in
+//           the arena and reruns the launch); so does a pool that is full.
+// Children are entries of adj(cur) in adjacency order, first occurrences only: the list the BFS builds, bit for bit.
+// One WAVEFRONT per node: 64 adjacency entries per round are tested, the candidates among them judged four at a time by
+// the wave's four 16-lane groups (every loop is wave-uniform: a group that is through idles along).
+// ------------------------------------------------------------------------------------------
+constexpr unsigned long long LZ_CLAIMED = 0xFFFFFull;  // count field of a pair whose list is being resolved
+constexpr int CTR_LZ_FB = 2;                           // ctr[2]: a slot raised its flag: the launch is void, the host rebuilds the flagged slots whole and repeats it
+__device__ __forceinline__ unsigned long long lz_make(int start, unsigned long long count, uint32_t stamp) {
+    return ((unsigned long long)(uint32_t)start << 32) | (count << 12) | (unsigned long long)stamp;
+}
+__device__ __forceinline__ bool lz_in(const uint2 *bm, int x) { return (bm[x >> 5].x >> (x & 31)) & 1u; }
+__device__ __forceinline__ unsigned long long grp16_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(uint32_t)v, off, 64), hi = (unsigned)__shfl_xor((int)(uint32_t)(v >> 32), off, 64);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        v = o < v ? o : v;
+    }
+    return v;
+}
+// per group: does node xn (-1: idle group) have a neighbour in V?  (group-uniform result)
+__device__ __forceinline__ bool lz_grp_touches(const WalkArgs &a, const uint2 *bm, int xn, int t, int g) {
+    int64_t q = xn >= 0 ? a.rowptr[xn] : 0;
+    const int64_t qe = xn >= 0 ? a.rowptr[xn + 1] : 0;
+    bool hit = false;
+    while (__ballot(q < qe && !hit)) {
+        bool v = false;
+        if (!hit && q + t < qe) v = lz_in(bm, a.col[q + t]);
+        if ((__ballot(v) >> (16 * g)) & 0xFFFFull) hit = true;
+        q += 16;
+    }
+    return hit;
+}
+// per group: the smallest (rank << 32 | index in adj(xn)) over the neighbours of xn in V; ~0 if it has none.  With `below`:
+// stops as soon as a rank smaller than it was seen (the caller only asks "is there one")
+__device__ __forceinline__ unsigned long long lz_grp_min_rank(const WalkArgs &a, const uint2 *bm, const int32_t *rk, int xn, int below, int t, int g) {
+    int64_t q = xn >= 0 ? a.rowptr[xn] : 0;
+    const int64_t qe = xn >= 0 ? a.rowptr[xn + 1] : 0;
+    unsigned long long best = ~0ull;
+    while (__ballot(q < qe && (long long)(best >> 32) >= (long long)below)) {
+        unsigned long long key = ~0ull;
+        if (q + t < qe) {
+            const int u = a.col[q + t];
+            const uint2 wd = bm[u >> 5];
+            if ((wd.x >> (u & 31)) & 1u) key = ((unsigned long long)(uint32_t)rk[wd.y + __popc(wd.x & ((1u << (u & 31)) - 1u))] << 32) | (unsigned long long)(uint32_t)(q + t);
+        }
+        key = grp16_min_u64(key);
+        best = key < best ? key : best;
+        q += 16;
+    }
+    return best;
+}
+
+// Resolve the children list of (slot, rank) = node `cur` on tree level `level` (its father on the walk: `prev`) and publish it;
+// the caller has claimed the pair.  Returns the published pair.  All 64 lanes take part; everything returned is wave-uniform.
+__device__ __noinline__ unsigned long long lazy_resolve_wave(const WalkArgs &a, int slot, int64_t tbase, int rank, int cur, int prev, int level, int lane) {
+    const int4 info = a.lz_info[slot];
+    const int depth = level - info.z, seg = info.w;
+    const uint2 *const bm = a.lz_bm + (size_t)slot * a.lz_words;
+    const int32_t *const rk = a.lz_rank + tbase;
+    unsigned long long *const pair = a.lz_pair + tbase + rank;
+    const int64_t e0 = a.rowptr[cur], e1 = a.rowptr[cur + 1];
+    const int g = lane >> 4, t = lane & 15;
+    bool fallback = depth < 0 || depth > 2;
+    // the key of cur inside its level
+    int my_rank = rank, my_edge = 0;
+    if (depth == 1) {
+        const uint2 wd = bm[prev >> 5];
+        my_rank = rk[wd.y + __popc(wd.x & ((1u << (prev & 31)) - 1u))];  // (the father of a level L + 1 node is in V)
+        my_edge = a.t_edge[tbase + rank];
+    }
+    auto candidate = [&](int64_t e, int &x) -> bool {  // entry e of adj(cur): a node outside V, at its first occurrence in the list
+        x = -1;
+        if (e >= e1) return false;
+        x = a.col[e];
+        if (x == cur || lz_in(bm, x)) return false;
+        return !a.g_multi || a.rev[a.rev[e]] == (int32_t)e;
+    };
+    // candidates of the whole adjacency: what the list can hold at most -> its place in the pool
+    int x0 = -1, ncand = 0;
+    bool c0 = false;
+    if (!fallback) {
+        c0 = candidate(e0 + lane, x0);
+        ncand = (int)__popcll(__ballot(c0));
+        for (int64_t b = e0 + 64; b < e1; b += 64) {
+            int x;
+            ncand += (int)__popcll(__ballot(candidate(b + lane, x)));
+        }
+    }
+    int start = 0;
+    if (depth <= 1 && ncand > 0) {
+        if (lane == 0) start = atomicAdd(&a.lz_cursor[slot], ncand);
+        start = __shfl(start, 0, 64);
+        if ((long long)start + ncand > (long long)seg) fallback = true;  // the pool is full
+    }
+    int count = 0;
+    if (!fallback && ncand > 0) {
+        for (int64_t b = e0; b < e1; b += 64) {
+            int x = x0;
+            bool c = c0;
+            if (b != e0) c = candidate(b + lane, x);
+            unsigned long long m = __ballot(c), kids = 0;
+            while (m) {
+                int p[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    p[i] = m ? __ffsll((long long)m) - 1 : -1;
+                    if (m) m &= m - 1;
+                }
+                const int pg = g == 0 ? p[0] : g == 1 ? p[1] : g == 2 ? p[2] : p[3];
+                const int xn = __shfl(x, pg < 0 ? 0 : pg, 64);
+                const int xg = pg < 0 ? -1 : xn;  // this group's candidate
+                bool child = false;
+                if (depth == 0) {
+                    const unsigned long long best = lz_grp_min_rank(a, bm, rk, xg, my_rank, t, g);
+                    child = xg >= 0 && (long long)(best >> 32) >= (long long)my_rank;  // (~0: no neighbour in V cannot happen -- cur is one)
+                } else {
+                    const bool touches = lz_grp_touches(a, bm, xg, t, g);
+                    // x is one level below cur.  depth 1: is cur its first neighbour of level L + 1?  depth 2: any such x means cur has children
+                    int64_t qx = (xg >= 0 && !touches) ? a.rowptr[xg] : 0;
+                    const int64_t qxe = (xg >= 0 && !touches) ? a.rowptr[xg + 1] : 0;
+                    bool open = xg >= 0 && !touches;  // verdict still open
+                    bool verdict = true;               // depth 1: child unless a neighbour precedes cur; depth 2: "deeper" unless a neighbour is in level L + 1
+                    while (__ballot(open)) {
+                        int y = -1;
+                        if (open) {
+                            if (qx >= qxe) open = false;
+                            else {
+                                y = a.col[qx++];
+                                if (y == cur && depth == 1) y = -1;
+                            }
+                        }
+                        const unsigned long long best = lz_grp_min_rank(a, bm, rk, open ? y : -1, depth == 1 ? -1 : 0x7fffffff, t, g);
+                        if (open && y >= 0 && best != ~0ull) {  // y is in level L + 1
+                            if (depth == 1) {
+                                const int ry = (int)(best >> 32);
+                                if (ry < my_rank || (ry == my_rank && a.rev[(int)(uint32_t)best] < my_edge)) { verdict = false; open = false; }
+                            } else {
+                                verdict = false;  // x is in level L + 2, like cur: no child of cur
+                                open = false;
+                            }
+                        }
+                    }
+                    if (depth == 1) child = xg >= 0 && !touches && verdict;
+                    else if (xg >= 0 && !touches && verdict) fallback = true;  // (group-uniform so far; made wave-uniform below)
+                }
+                const unsigned long long cb = __ballot(child && t == 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (p[i] >= 0 && ((cb >> (16 * i)) & 1ull)) kids |= 1ull << p[i];
+            }
+            if ((kids >> lane) & 1ull) {
+                const int64_t at = tbase + start + count + (int)__popcll(kids & ((1ull << lane) - 1ull));
+                a.t_order_w[at] = x;
+                a.t_edge_w[at] = (int32_t)(b + lane);
+            }
+            count += (int)__popcll(kids);
+        }
+    }
+    fallback = __ballot(fallback) != 0ull;
+    if (fallback) {
+        count = 0;
+        if (lane == 0) {
+            a.lz_flag[slot] = 1;
+            // the launch is void -- the host rebuilds the flagged slots whole and repeats it -- but it runs to its end: every slot
+            // whose walks need the whole tree is found in ONE pass (cut short, each repeat would find one level's worth)
+            a.ctr[CTR_LZ_FB] = 1ull;
+        }
+    }
+    const unsigned long long v = lz_make(start, (unsigned long long)count, a.lz_stamp);
+    __threadfence();  // the list before the pair that names it
+    if (lane == 0) __hip_atomic_store(pair, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+}
+
+// The children range of a rank >= lzs for a whole wavefront (the finisher): resolved on the spot if nobody has, waited for if
+// another wave is at it (that wave is running: claims are only ever taken by running waves).
+__device__ __forceinline__ unsigned long long lazy_children_wave(const WalkArgs &a, int slot, int64_t tbase, int rank, int cur, int prev, int level, int lane) {
+    unsigned long long *const pair = a.lz_pair + tbase + rank;
+    for (int spins = 0;; ++spins) {
+        const unsigned long long v = __hip_atomic_load(pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(v & 0xFFFull) == a.lz_stamp) {
+            if (((v >> 12) & 0xFFFFFull) != LZ_CLAIMED) {
+                __threadfence();
+                return v;
+            }
+            if (spins > (1 << 20)) {  // (a claim nobody is working on -- cannot happen; if it does, the slot gets its whole tree)
+                if (lane == 0) { a.lz_flag[slot] = 1; a.ctr[CTR_LZ_FB] = 1ull; }
+                return lz_make(0, 0ull, a.lz_stamp);
+            }
+            __builtin_amdgcn_s_sleep(16);
+            continue;
+        }
+        unsigned long long old = v;
+        if (lane == 0) old = atomicCAS(pair, v, lz_make(0, LZ_CLAIMED, a.lz_stamp));
+        old = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(old >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)old, 0, 64);
+        if (old == v) return lazy_resolve_wave(a, slot, tbase, rank, cur, prev, level, lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Level kernels (streaming front end)
 // ------------------------------------------------------------------------------------------
 constexpr int SINGLE_CHUNK = 0x100;  // descriptor flag: the task has one chunk -> the score kernel finishes its prefix sums itself
@@ -337,6 +566,12 @@ __device__ __forceinline__ void write_node_desc(int4 *desc, int64_t c, int cur, 
 // three lanes at once instead of one after the other: 6-7 round trips.
 __device__ __forceinline__ uint32_t dc_hash(unsigned long long key, uint32_t mask) { return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & mask; }
 
+// LAZY (trees exact through a level only, see "LAZY RESOLUTION"): on a level where a walk may stand on a node without a built
+// children list the kernel runs as two launches around the resolve kernel -- do_setup == 0: finish hop level-1 only, store the
+// walk state, claim the picked node's list if nobody has resolved it (the claimed walks go to lz_list); do_sample == 2: the
+// walk state is read back and hop `level` is set up as always, its children range taken from the node's pair.
+constexpr int CTR_LZ = 456;  // lc[CTR_LZ + level]: walks listed for the resolve kernel of `level` (the spare words of CTR_TINY)
+template <bool LAZY>
 __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, const int do_sample, const int do_setup, const int write_desc,
                                                             const int64_t cap_chunks) {
     __shared__ int blk_skip;
@@ -353,17 +588,22 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     int alive_w = 1, kraw = 0, len = 0, cur0 = -1, prev0 = -1, fe0 = -1;
     int4 sc = make_int4(0, 0, 0, 0), sc2 = make_int4(0, 0, 0, 0);
     int64_t pfx0 = 0, beg0 = 0;
+    int rank0 = 0;
     if (in_range && do_sample) {
         alive_w = a.st_alive[w];
         sc = a.st_const[w];
         sc2 = a.st_const2[w];
-        kraw = a.lv_k[w];
-        pfx0 = a.lv_pfx[w];
-        beg0 = a.lv_beg[w];
         len = a.st_len[w];
         cur0 = a.st_cur[w];
         prev0 = a.st_prev[w];
-        if (a.es_mode) fe0 = a.lv_fe[w];
+        if (!LAZY || do_sample == 1) {
+            kraw = a.lv_k[w];
+            pfx0 = a.lv_pfx[w];
+            beg0 = a.lv_beg[w];
+            if (a.es_mode) fe0 = a.lv_fe[w];
+        } else {
+            rank0 = a.st_rank[w];
+        }
     }
     // Block-uniform early exit: other blocks of this very launch may raise flag 2 (speculative overflow below, a walk
     // still alive after the last level), so every thread testing the global word itself could split a workgroup in
@@ -414,6 +654,12 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
             a.st_len[w] = 1;
             a.paths[w * (int64_t)a.stride] = root;
             if (a.for_d) a.first_child[w] = -1;
+        } else if (LAZY && do_sample == 2) {  // hop level-1 was finished by the launch in front of the resolve kernel
+            alive = true;
+            cur = cur0;
+            father = prev0;
+            rank = rank0;
+            len -= 1;  // (entries of the path before that hop's append, as the fused kernel counts below)
         } else {
             alive = true;
             sampled = true;
@@ -515,9 +761,32 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
                 }
             }
         }
+        int4 lzi = make_int4(0x7fffffff, 0, 0, 0);
+        if (LAZY && alive) lzi = a.lz_info[slot];
+        if (LAZY && alive && do_setup == 0 && rank >= lzi.x) {
+            // the picked node has no built children list: claim it unless somebody has (resolved or claimed)
+            unsigned long long *const pair = a.lz_pair + tbase + rank;
+            const unsigned long long v = __hip_atomic_load(pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint32_t)(v & 0xFFFull) != a.lz_stamp && atomicCAS(pair, v, lz_make(0, LZ_CLAIMED, a.lz_stamp)) == v)
+                a.lz_list[atomicAdd(&a.lc[CTR_LZ + a.level], 1ull)] = (int32_t)w;
+        }
         if (alive && do_setup) {
             const int32_t *const cs = a.t_cstart + tbase + slot;
-            const int cbeg = cs[rank], cend = cs[rank + 1];  // children of cur = ranks [cbeg, cend)
+            int cbeg, cend;  // children of cur = ranks [cbeg, cend)
+            if (LAZY && rank >= lzi.x) {
+                const unsigned long long v = __hip_atomic_load(a.lz_pair + tbase + rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long cnt = (v >> 12) & 0xFFFFFull;
+                cbeg = (int)(v >> 32);
+                cend = cbeg + (int)cnt;
+                if ((uint32_t)(v & 0xFFFull) != a.lz_stamp || cnt == LZ_CLAIMED) {  // (not resolved: cannot happen -- the slot gets its whole tree)
+                    a.lz_flag[slot] = 1;
+                    a.ctr[CTR_LZ_FB] = 1ull;
+                    cbeg = cend = 0;
+                }
+            } else {
+                cbeg = cs[rank];
+                cend = cs[rank + 1];
+            }
             unsigned q3w = 0u;
             if (a.level == 1) q3w = a.t_q3[q3off + ((rank - 1) >> 5)];
             if (a.es_mode) {
@@ -597,6 +866,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
             atomicAdd(&a.lc[CTR_READS_V + (blockIdx.x & 63)], my_k);
         }
     }
+    if (LAZY && do_setup == 0) return;  // (the resolve kernel and the set-up launch follow)
     if (do_setup != 1) {
         // behind the last streamed level: the walks that are still going, as a compact list for the finisher (it used to
         // draw one ticket per WALK, finished or not: 160 k same-address atomics, ~2 ms, to find a few thousand live walks)
@@ -779,6 +1049,20 @@ __global__ void level_expand_kernel(const WalkArgs a) {
     const int father = hf ? a.st_prev[w] : -1;
     const int64_t beg = a.lv_beg[w], pfx = a.lv_pfx[w];
     for (int i = 0; i < n; ++i) write_chunk_desc(a.lv_chunk_desc, c0 + i, cur, k, hf, father, beg, i, pfx);
+}
+
+// LAZY: one wavefront per listed walk resolves the children list its node was claimed for ("LAZY RESOLUTION").  Runs whatever
+// the launch's flags say: a claim that stayed unresolved would stall every later reader of the pair.
+__global__ __launch_bounds__(256) void lazy_resolve_kernel(const WalkArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)a.lc[CTR_LZ + a.level];
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += n_waves) {
+        const int64_t w = a.lz_list[i];
+        const int4 sc = a.st_const[w], sc2 = a.st_const2[w];
+        const int64_t tbase = ((int64_t)sc2.y << 32) | (unsigned)sc2.x;
+        (void)lazy_resolve_wave(a, sc.y, tbase, a.st_rank[w], a.st_cur[w], a.st_prev[w], a.level, lane);
+    }
 }
 
 __device__ __forceinline__ uint64_t group16_incl_scan_u64(uint64_t v, int /*t*/) { return group16_incl_scan_u64_dpp(v); }
@@ -1060,7 +1344,7 @@ __global__ __launch_bounds__(256) void level_weights_kernel(const WalkArgs a, co
 // ------------------------------------------------------------------------------------------
 // Finisher: one wavefront per walk, from hop a.level to the end of the walk.
 // ------------------------------------------------------------------------------------------
-template <int NCH>
+template <int NCH, bool LAZY>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void walk_sample_kernel(const WalkArgs a) {
     __shared__ float lds_scores[WAVES_PER_BLOCK][SCORE_CAP];
     __shared__ unsigned long long blk_ctr[2];
@@ -1097,6 +1381,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void walk_sample_kernel(const
             const int32_t *const cs = a.t_cstart + tbase + slot;
             const int32_t *const order = a.t_order + tbase;
             int32_t *const path = a.paths + w * (int64_t)a.stride;
+            const int lzs = LAZY ? a.lz_info[slot].x : 0x7fffffff;  // first rank without a built children list
 
             int cur = root, prev = -1, len = 1, rank = 0;
             uint32_t hop = 0;  // = depth of cur: a walk only moves down the tree until its back-step
@@ -1113,7 +1398,15 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void walk_sample_kernel(const
             bool aborted = false, overflow = false;
 
             for (;;) {
-                const int cbeg = cs[rank], cend = cs[rank + 1];
+                int cbeg, cend;
+                if (LAZY && rank >= lzs) {  // resolved on the spot if no walk has stood here before
+                    const unsigned long long v = lazy_children_wave(a, slot, tbase, rank, cur, prev, (int)hop, lane);
+                    cbeg = (int)(v >> 32);
+                    cend = cbeg + (int)((v >> 12) & 0xFFFFFull);
+                } else {
+                    cbeg = cs[rank];
+                    cend = cs[rank + 1];
+                }
                 const int nchild = cend - cbeg;
                 int hf = 1;                                 // list = [father] ++ children ...
                 if (hop == 0) hf = 0;                       // ... tree[root][1:]  (graph_gan.py:250)
@@ -1207,7 +1500,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void walk_sample_kernel(const
 // walk (graph_gan.py:255-257); only walks before it have mutated the tree (:258-259).
 __global__ void walk_d_postpass_kernel(const WalkArgs a) {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= a.total_walks || a.ctr[3] == 2ull) return;  // flag 2: the launch is being rerun, mutate nothing
+    if (w >= a.total_walks || a.ctr[3] == 2ull || a.ctr[CTR_LZ_FB] != 0ull) return;  // the launch is being rerun, mutate nothing
     const int item = find_item(a.walk_ptr, a.n_slots, w);
     const int j = (int)(w - a.walk_ptr[item]);
     const int ab = a.abort_walk[item];
@@ -1289,7 +1582,7 @@ __global__ __launch_bounds__(256) void fill_ones_kernel(uint4 *p, int64_t n16) {
 
 // end of a D launch that registered its distributions: chunks now in the prefix buffer = where the G launch appends
 __global__ void dc_finish_kernel(const WalkArgs a, int64_t *words, int n_levels) {
-    if (a.ctr[3] == 2ull) { words[1] = 0; return; }  // the launch is being rerun
+    if (a.ctr[3] == 2ull || a.ctr[CTR_LZ_FB] != 0ull) { words[1] = 0; return; }  // the launch is being rerun
     words[1] = (int64_t)a.lc[CTR_BASE + n_levels];  // (written by the score kernel of hop n_levels - 1)
 }
 
@@ -1309,6 +1602,10 @@ __global__ void dc_finish_kernel(const WalkArgs a, int64_t *words, int n_levels)
 // 1.81 ms unsplit, the step 4.62 against 4.42 ms -- the advance / weights rounds do hide (about -0.2 ms per call), but a
 // half-size score launch runs at 0.55-0.59 of the HBM peak instead of 0.68-0.70 (the persistent grid's ramp-up and tail are
 // paid twice per level, and the kernel shares the chip with the other half's latency-bound kernels), which costs more.
+
+static unsigned lazy_resolve_blocks(int64_t walks) {  // four wavefronts per workgroup, one listed walk per wavefront and round
+    return (unsigned)std::max<int64_t>(1, std::min<int64_t>(4096, (walks + 3) / 4));
+}
 
 template <int NCH>
 static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_levels, bool sized, bool finisher_follows, bool *any_alive) {
@@ -1363,7 +1660,15 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
             x.level = level;
             x.es_now = a.es_now + 2 * level + k;  // the tick of this half's score kernel of this level (MAX_LEVELS = 64: < 256 per launch)
             const unsigned wblocks = (unsigned)cdiv(x.w_end - x.w0, 256);
-            hipLaunchKernelGGL(level_advance_kernel, dim3(wblocks), dim3(256), 0, hs[k], x, level > 0 ? 1 : 0, 1, sized ? 0 : 1, cap);
+            if (!a.lazy) {
+                hipLaunchKernelGGL(level_advance_kernel<false>, dim3(wblocks), dim3(256), 0, hs[k], x, level > 0 ? 1 : 0, 1, sized ? 0 : 1, cap);
+            } else if (level == 0 || level < ctx->lz_min_level) {  // every node of these levels has its children list built
+                hipLaunchKernelGGL(level_advance_kernel<true>, dim3(wblocks), dim3(256), 0, hs[k], x, level > 0 ? 1 : 0, 1, sized ? 0 : 1, cap);
+            } else {  // finish hop level - 1 | resolve the lists of the picked nodes nobody has stood on before | set hop `level` up
+                hipLaunchKernelGGL(level_advance_kernel<true>, dim3(wblocks), dim3(256), 0, hs[k], x, 1, 0, 0, cap);
+                hipLaunchKernelGGL(lazy_resolve_kernel, dim3(lazy_resolve_blocks(x.w_end - x.w0)), dim3(256), 0, hs[k], x);
+                hipLaunchKernelGGL(level_advance_kernel<true>, dim3(wblocks), dim3(256), 0, hs[k], x, 2, 1, sized ? 0 : 1, cap);
+            }
             if (sized) {
                 unsigned long long total_chunks = 0, alive = 0;
                 GG_HIP(ctx, hipMemcpyAsync(&total_chunks, ctx->dev_ctr + CTR_CHUNKS + level, sizeof(total_chunks), hipMemcpyDeviceToHost, ctx->walk_stream));
@@ -1418,7 +1723,16 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
         WalkArgs &x = h[k];
         x.level = level;
         const unsigned wblocks = (unsigned)cdiv(x.w_end - x.w0, 256);
-        hipLaunchKernelGGL(level_advance_kernel, dim3(wblocks), dim3(256), 0, hs[k], x, 1, 2, (!sized && all_levels && !finisher_follows) ? 2 : 0, 0);
+        const int wd_last = (!sized && all_levels && !finisher_follows) ? 2 : 0;
+        if (!a.lazy) {
+            hipLaunchKernelGGL(level_advance_kernel<false>, dim3(wblocks), dim3(256), 0, hs[k], x, 1, 2, wd_last, 0);
+        } else if (level < ctx->lz_min_level) {
+            hipLaunchKernelGGL(level_advance_kernel<true>, dim3(wblocks), dim3(256), 0, hs[k], x, 1, 2, wd_last, 0);
+        } else {
+            hipLaunchKernelGGL(level_advance_kernel<true>, dim3(wblocks), dim3(256), 0, hs[k], x, 1, 0, 0, 0);
+            hipLaunchKernelGGL(lazy_resolve_kernel, dim3(lazy_resolve_blocks(x.w_end - x.w0)), dim3(256), 0, hs[k], x);
+            hipLaunchKernelGGL(level_advance_kernel<true>, dim3(wblocks), dim3(256), 0, hs[k], x, 2, 2, wd_last, 0);
+        }
         if (a.dc_mode == 1) hipLaunchKernelGGL(dc_finish_kernel, dim3(1), dim3(1), 0, hs[k], x, ctx->dc_words.as<int64_t>() + 2 * k, level);
     }
     if (split) {
@@ -1512,7 +1826,8 @@ static int run_levels_and_finish(gg_ctx *ctx, WalkArgs &a, int64_t total_walks) 
         GG_HIP(ctx, ctx->w_scratch.reserve((size_t)need_stride * blocks * WAVES_PER_BLOCK * sizeof(float) + 16));
         a.scratch = ctx->w_scratch.as<float>();
         a.scratch_stride = need_stride;
-        hipLaunchKernelGGL(walk_sample_kernel<NCH>, dim3((unsigned)blocks), blk, 0, ctx->walk_stream, a);
+        if (a.lazy) hipLaunchKernelGGL((walk_sample_kernel<NCH, true>), dim3((unsigned)blocks), blk, 0, ctx->walk_stream, a);
+        else hipLaunchKernelGGL((walk_sample_kernel<NCH, false>), dim3((unsigned)blocks), blk, 0, ctx->walk_stream, a);
     }
     GG_HIP(ctx, hipGetLastError());
     return GG_OK;
@@ -1567,6 +1882,22 @@ int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int fo
     a.w0 = 0;
     a.w_end = total_walks;
     a.lv_big_cap = total_walks;
+    a.lazy = ctx->t_lazy ? 1 : 0;
+    a.t_order_w = ctx->t_order;
+    a.t_edge_w = ctx->t_edge;
+    if (a.lazy) {
+        GG_HIP(ctx, ctx->lz_list.reserve(sizeof(int32_t) * (size_t)(total_walks + 1)));
+        a.lz_info = ctx->lz_info.as<int4>();
+        a.lz_pair = ctx->lz_pair.as<unsigned long long>();
+        a.lz_rank = ctx->lz_rank.as<int32_t>();
+        a.lz_bm = ctx->lz_bm.as<uint2>();
+        a.lz_words = (ctx->n_node + 31) / 32;
+        a.lz_cursor = ctx->lz_cursor.as<int32_t>();
+        a.lz_flag = ctx->lz_flag.as<int32_t>();
+        a.lz_stamp = ctx->lz_stamp;
+        a.g_multi = ctx->g_multi ? 1 : 0;
+        a.lz_list = ctx->lz_list.as<int32_t>();
+    }
     GG_HIP(ctx, ctx->fin_list.reserve(sizeof(int32_t) * (size_t)(total_walks + 1)));
     a.fin_list = ctx->fin_list.as<int32_t>();
     // distribution cache: mode requested by gg_prepare_d (register) / gg_prepare_g (look up); anything else runs without it
@@ -1591,7 +1922,7 @@ int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int fo
     // hipMemcpyAsync + hipMemsetAsync pair these were blit kernels with system-scope fences: the copy took ~130 us on the side
     // stream while the discriminator's gradient kernel was filling the L2 with atomics.)
     const bool will_size = ctx->lv_cap_chunks == 0 || ctx->walk_force_sized;
-    ctx->w_split = ctx->split_enabled && ctx->walk_levels > 0 && !will_size && total_walks >= ctx->split_min_walks;
+    ctx->w_split = ctx->split_enabled && ctx->walk_levels > 0 && !will_size && total_walks >= ctx->split_min_walks && !ctx->t_lazy;
     // the edge-score cache needs the trees' edge indices (and a symmetric adjacency: g_rev)
     if (ctx->es && ctx->es_stamp && ctx->g_rev && ctx->t_edge_valid && ctx->walk_levels > 0) a.es_mode = ctx->es_mode;
     hipLaunchKernelGGL(walk_reset_kernel, dim3(cdiv(2 * CTR_WORDS, 256)), dim3(256), 0, ctx->walk_stream, ctx->dev_ctr, 2 * (int)CTR_WORDS,

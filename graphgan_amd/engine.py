@@ -188,6 +188,28 @@ class Engine:
         """Upper bound of the HBM bytes ``n_roots`` resident trees need (every root reaching every node)."""
         return float(n_roots) * 12.0 * (self.n_node + 1)  # pop order + first-child ranks + edge indices
 
+    def set_tree_mode(self, mode, node_cap=0):
+        """gg_set_tree_mode: 0 = whole trees, 1 = lazy trees (exact through a level, children lists below it resolved by the
+        walks that need them -- same walks, bit for bit), -1 = lazy from 2^18 nodes on (the default)."""
+        self._ck(lib.gg_set_tree_mode(self._ctx, int(mode), int(node_cap)))
+
+    def lazy_stats(self):
+        out = np.zeros(8, dtype=np.int64)
+        self._ck(lib.gg_lazy_stats(self._ctx, _ptr(out)))
+        return dict(lazy=bool(out[0]), min_level=int(out[1]), fallback_roots=int(out[2]), fallback_rounds=int(out[3]), exact_nodes=int(out[4]),
+                    pool_entries=int(out[5]), lazy_slots=int(out[6]), max_level=int(out[7]))
+
+    def get_lazy_trees(self):
+        """Raw arrays of the resident LAZY trees (tests): dict(info [R, 4], base [R], order, cstart, edge, pair)."""
+        R = len(self.tree_roots)
+        n = ctypes.c_int64()
+        self._ck(lib.gg_get_lazy_trees(self._ctx, ctypes.byref(n), None, None, None, None, None, None))
+        n = n.value
+        info, base = np.zeros((R, 4), np.int32), np.zeros(R, np.int64)
+        order, cstart, edge, pair = np.zeros(n, np.int32), np.zeros(n + R, np.int32), np.zeros(n, np.int32), np.zeros(n, np.uint64)
+        self._ck(lib.gg_get_lazy_trees(self._ctx, None, _ptr(info), _ptr(base), _ptr(order), _ptr(cstart), _ptr(edge), _ptr(pair)))
+        return dict(info=info, base=base, order=order, cstart=cstart, edge=edge, pair=pair)
+
     def set_trees(self, roots, off, nbr, nbr_base, max_depth=0):
         roots, off, nbr = _i32(roots), _i32(off), _i32(nbr)
         nbr_base = np.ascontiguousarray(nbr_base, dtype=np.int64)
@@ -249,6 +271,7 @@ class Engine:
         status = np.zeros(len(slots), dtype=np.int32)
         self._ck(lib.gg_walk_sample(self._ctx, _ptr(slots), _ptr(n_walks), len(slots), int(bool(for_d)), seed, stream,
                                     _ptr(samples), _ptr(paths), _ptr(plen), stride, _ptr(status)))
+        self._after_trees(self.tree_roots)  # (lazy trees: slots rebuilt whole may have raised the depth)
         return dict(samples=samples, paths=paths, path_len=plen, root_status=status)
 
     def get_walks(self):

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GG_ABI_VERSION 6  /* round 5: gg_comm_stats_ex; round 4: epoch over root batches (gg_epoch_*, gg_q3_*); round 3: gg_counters extended, gg_prepare_g_begin */
+#define GG_ABI_VERSION 7  /* round 6: lazy trees (gg_set_tree_mode, gg_lazy_stats, gg_get_lazy_trees); round 5: gg_comm_stats_ex; round 4: epoch over root batches (gg_epoch_*, gg_q3_*); round 3: gg_counters extended, gg_prepare_g_begin */
 
 enum {
     GG_OK = 0,
@@ -156,6 +156,25 @@ int gg_build_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, int32_t n
 int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t n_roots);
 /* gg_set_trees / gg_get_trees: upload / download trees in the reference's shape (tests, foreign caches; the
  * download shows the in-place D-mode mutations, graph_gan.py:258-259, as father entries of -1). */
+/* LAZY trees (ABI 7).  The walks of one prepare call read a few hundred of a tree's children lists (graph_gan.py:249-250: the
+ * list of the node the walk stands on) -- 5e-5 of what construct_trees (:84-108) writes per root on the 10^6-node bench graph --
+ * and the tree of a root that cannot stay resident is built, walked twice and dropped.  In lazy mode gg_build_trees_device builds
+ * a root's tree exactly only THROUGH the last level whose expansion is known to fit a node limit (nodes so far + adjacency entries
+ * of the level <= limit); the children list of a deeper node is resolved by the first walk that stands on it, from the visited
+ * set of the exact levels and their BFS ranks (a child of v = a neighbour outside the set whose first queue neighbour is v, in
+ * adjacency order: the list the BFS would have appended, entry for entry) up to two levels below the exact ones.  A root whose
+ * walks go deeper -- or whose pool of resolved lists is full -- gets its whole tree behind the scenes and the launch is repeated:
+ * every gg_walk_sample / gg_prepare_* result is the whole trees' result, bit for bit (tested against the oracle's).
+ * mode: 0 = whole trees (gg_get_trees / gg_save_trees / gg_get_tree_order need them), 1 = lazy, -1 (default) = lazy for graphs of
+ * 2^18 nodes and more (GG_LZ_AUTO_NODES); GG_TREE_LAZY overrides.  node_cap: the limit per root (0 = 3/8 of the nodes, at least
+ * 65 536; GG_LZ_CAP).  gg_tree_info reports, for lazy trees, a depth no walk exceeds.
+ * gg_lazy_stats: out8 = {resident trees are lazy, smallest exact level of the lazy slots, slots rebuilt whole so far, launches
+ * repeated for it, exact nodes the BFS wrote, pool entries reserved by resolutions, lazy slots, deepest exact level}.
+ * gg_get_lazy_trees (tests): the raw arrays -- info4[slot] = {first rank without a built list, exact ranks, their level,
+ * capacity of the segment}, base[slot], then order / cstart / edge / pair over *n_entries entries (cstart: + n_roots). */
+int gg_set_tree_mode(gg_ctx *ctx, int32_t mode, int64_t node_cap);
+int gg_lazy_stats(gg_ctx *ctx, int64_t *out8);
+int gg_get_lazy_trees(gg_ctx *ctx, int64_t *n_entries, int32_t *info4, int64_t *base, int32_t *order, int32_t *cstart, int32_t *edge, uint64_t *pair);
 int gg_set_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int32_t *off,
                  const int32_t *nbr, const int64_t *nbr_base, int32_t max_depth);
 int gg_tree_info(const gg_ctx *ctx, int32_t *n_roots, int64_t *n_entries, int32_t *max_depth);
