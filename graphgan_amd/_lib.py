@@ -82,6 +82,7 @@ SIGNATURES = {
     "gg_build_trees": (ctypes.c_int, [_P, _P, _i32, _i32]),
     "gg_build_trees_device": (ctypes.c_int, [_P, _P, _i32]),
     "gg_set_tree_mode": (ctypes.c_int, [_P, _i32, _i64]),
+    "gg_debug_words": (ctypes.c_int, [_P, _i32, _i32, _P]),
     "gg_lazy_stats": (ctypes.c_int, [_P, _P]),
     "gg_get_lazy_trees": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "gg_set_trees": (ctypes.c_int, [_P, _P, _i32, _P, _P, _P, _i32]),

@@ -79,6 +79,15 @@ struct BfsArgs {
     uint2 *lz_bm;              // [slots][bm_words] LAZY: {visited word, members below the word}
     int32_t *lz_rank;          // [tree nodes] LAZY: BFS rank by member index, at base[r]
     int32_t *lz_cursor;        // [slots]   LAZY: first free rank of the pool
+    // LAZY: the BFS runs in a per-workgroup scratch tree; what it keeps -- the exact ranks, the built lists, a pool behind them --
+    // gets its place in the tree arrays from ONE cursor when the size is known (a slot costs what its tree needs, not a worst case)
+    int32_t *scr_order, *scr_edge, *scr_cstart;  // [grid][scr_cap] ([grid][scr_cap + 1])
+    int scr_cap;
+    const int32_t *lz_pool;    // [n_roots] pool entries behind the exact ranks of a lazy slot
+    unsigned long long *lz_alloc;  // the cursor (entries)
+    long long lz_alloc_end;    // entries the segments may take; a slot that does not fit raises lz_flag (whole tree in the arena) and stats[4]
+    int64_t *base_w;           // [slots]   LAZY: t_base, written here
+    int32_t *lz_flag;          // [slots]
 };
 
 __device__ __forceinline__ int lanes_below(unsigned long long m) {  // popcount of m restricted to the lanes below this one
@@ -751,6 +760,7 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
     __shared__ int32_t wtot[2][B2_WAVES];
     __shared__ int32_t s_root, s_any, s_Lcount, s_cap, s_max, s_deg, s_live;
     __shared__ uint32_t s_e0;
+    __shared__ long long s_off;
     uint16_t *const emap = reinterpret_cast<uint16_t *>(scratch);
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -778,9 +788,9 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
         if (r >= a.n_roots) return;
         const int root = a.roots[r];
         const int slot = a.slot_ids ? a.slot_ids[r] : r;
-        int32_t *const order = a.order + a.base[r];
-        int32_t *const cstart = a.cstart + a.base[r] + slot;
-        int32_t *const tedge = a.edge + a.base[r];
+        int32_t *const order = LAZY ? a.scr_order + (size_t)blockIdx.x * a.scr_cap : a.order + a.base[r];
+        int32_t *const cstart = LAZY ? a.scr_cstart + (size_t)blockIdx.x * (a.scr_cap + 1) : a.cstart + a.base[r] + slot;
+        int32_t *const tedge = LAZY ? a.scr_edge + (size_t)blockIdx.x * a.scr_cap : a.edge + a.base[r];
         const int expect = a.expect ? a.expect[r] : (int)(a.base[r + 1] - a.base[r]);
         const int limit = LAZY ? a.lz_limit[r] : expect;
         for (int i = tid; i < a.bm_words; i += B2_T) bm[i] = 0u;
@@ -890,7 +900,7 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
                     level_end = tail;
                     ++depth;
                     const int F = tail - head, Un = expect - tail;
-                    if (LAZY && expect > limit) {
+                    if (LAZY && a.lz_pool[r] > 0) {  // (a lazy candidate: the host gave it a pool)
                         // may this level be expanded?  Only if even an append per adjacency entry fits the limit.
                         __syncthreads();  // (the level's queue entries have landed)
                         fenced = tail;
@@ -1324,10 +1334,39 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
 #undef B2_TICK
         const bool lazy_stop = LAZY && why == 4;  // ranks [head, tail) are level `depth`: exact queue entries without children lists
         if (LAZY) {
-            if (lazy_stop) {
+            // the slot's place in the tree arrays: exact ranks (+ pool), built lists; then the copy out of the scratch tree
+            const int n_keep = lazy_stop ? tail : expect, n_built = lazy_stop ? head : expect;
+            const int seg = n_keep + 1 + (lazy_stop ? a.lz_pool[r] : 0);  // (+ 1: the row of first-child ranks has one entry more than ranks)
+            const bool complete = tail == expect || lazy_stop;
+            if (tid == 0) {
+                long long off = complete ? (long long)atomicAdd(a.lz_alloc, (unsigned long long)seg) : -1;
+                if (off >= 0 && off + seg > a.lz_alloc_end) off = -1;
+                s_off = off;
+            }
+            __syncthreads();  // (also: every queue / cstart store of the scratch tree has landed)
+            const long long off = s_off;
+            if (off >= 0) {
+                int32_t *const o_out = a.order + off, *const e_out = a.edge + off, *const c_out = a.cstart + off;
+                for (int i0 = tid; i0 < n_keep; i0 += 4 * B2_T) {
+                    int vo[4], ve[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = i0 + u * B2_T;
+                        vo[u] = i < n_keep ? ldi(&order[i]) : 0;
+                        ve[u] = i < n_keep ? ldi(&tedge[i]) : 0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = i0 + u * B2_T;
+                        if (i < n_keep) { o_out[i] = vo[u]; e_out[i] = ve[u]; }
+                    }
+                }
+                for (int i = tid; i <= n_built; i += B2_T) c_out[i] = ldi(&cstart[i]);
+            }
+            if (lazy_stop && off >= 0) {
                 // the visited set of the exact levels with its popcount index: {word, members below the word}
                 uint2 *const zb = a.lz_bm + (size_t)slot * a.bm_words;
-                int32_t *const zr = a.lz_rank + a.base[r];
+                int32_t *const zr = a.lz_rank + off;
                 const int W = a.bm_words, wpt = (W + B2_T - 1) / B2_T;
                 const int w0 = min(tid * wpt, W), w1 = min(w0 + wpt, W);
                 int cnt = 0;
@@ -1359,16 +1398,26 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
                 }
             }
             if (tid == 0) {
-                const int seg = (int)(a.base[r + 1] - a.base[r]);  // capacity of the slot's segment: exact ranks + pool
-                a.lz_info[slot] = lazy_stop ? make_int4(head, tail, depth, seg) : make_int4(expect, expect, depth, seg);
-                a.lz_cursor[slot] = lazy_stop ? tail : expect;
-                if (lazy_stop) atomicMax(&a.stats[3], 1024 - depth);  // (smallest lazy level of the launch: 1024 - stats[3])
+                if (off >= 0) {
+                    a.base_w[slot] = off;
+                    a.lz_info[slot] = lazy_stop ? make_int4(head, tail, depth, seg) : make_int4(expect, expect, depth, seg);
+                    a.lz_cursor[slot] = lazy_stop ? tail : expect;
+                    if (lazy_stop) atomicMax(&a.stats[3], 1024 - depth);  // (smallest lazy level of the launch: 1024 - stats[3])
+                } else if (complete) {
+                    // no room among the segments: the slot gets its whole tree in the arena before anything walks on it
+                    a.base_w[slot] = 0;
+                    a.lz_info[slot] = make_int4(1, 1, 0, 1);
+                    a.lz_cursor[slot] = 1;
+                    a.lz_flag[slot] = 1;
+                    atomicAdd(&a.stats[4], 1);
+                }
             }
+            __syncthreads();  // (the scratch tree is free for the next root)
         }
         // ---- per-root results: node count check, depth, longest list (1 + most children)
         int mc = 0;
         const int n_lists = lazy_stop ? head : tail;  // ranks whose children lists are built
-        if ((tail == expect || lazy_stop) && !(INSTR && (a.exp & 32)))
+        if ((tail == expect || lazy_stop) && !(INSTR && (a.exp & 32)) && !LAZY)  // (LAZY: a resolved list is as long as a degree; the host takes the graph's largest)
             for (int i0 = tid; i0 < n_lists; i0 += 8 * B2_T) {  // (eight positions per thread in flight: 977 one-load iterations otherwise)
                 int c0[8], c1[8];
 #pragma unroll
@@ -1402,7 +1451,7 @@ namespace gg {
 // Scratch, kernel choice, launch and read-back shared by the three builds: whole trees into the slots' segments, lazy trees
 // (gg_build_trees_device), whole trees of single slots into the arena (lazy_fallback_rebuild).  The caller has set the roots /
 // base / output pointers of `a`; stats = {deepest level, longest list, error, 1024 - smallest lazy level}.
-static int bfs_run(gg_ctx *ctx, BfsArgs &a, int n_items, bool lazy, int32_t *stats /*[4]*/) {
+static int bfs_run(gg_ctx *ctx, BfsArgs &a, int n_items, bool lazy, int32_t *stats /*[6]*/) {
     const int n = ctx->n_node;
     const int grid = std::min<int>(n_items, ctx->n_cus);
     const int bm_words = (n + 31) / 32;
@@ -1512,9 +1561,9 @@ static int bfs_run(gg_ctx *ctx, BfsArgs &a, int n_items, bool lazy, int32_t *sta
         hipLaunchKernelGGL((bfs_order_kernel<false, false>), dim3(grid), dim3(BFS_T), 0, ctx->stream, a);
     }
     (void)hipEventRecord(ctx->ev1, ctx->stream);
-    stats[0] = stats[1] = stats[2] = stats[3] = 0;
+    for (int i = 0; i < 6; ++i) stats[i] = 0;
     e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(stats, a.stats, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(stats, a.stats, sizeof(int32_t) * 6, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess && prof && !v1) {
         const int n_roots = n_items;
@@ -1573,46 +1622,57 @@ bool lazy_build_wanted(const gg_ctx *ctx) {
     return mode > 0 && !ctx->lz_force_whole && ctx->g_rev && ctx->g_max_deg < 0xFFFFF && !getenv("GG_BFS_V1");
 }
 
-static int64_t lazy_node_cap(const gg_ctx *ctx) {
-    int64_t cap = ctx->lz_cap;
-    if (const char *e = getenv("GG_LZ_CAP")) cap = atoll(e);
-    if (cap <= 0) cap = std::max<int64_t>(65536, (int64_t)ctx->n_node * 3 / 8);
-    return cap;
+// Node limit of a slot's exact part: a level is expanded only while (nodes so far + adjacency entries of the level) fit it.  The
+// default -- the node count -- stops in front of the level that holds the bulk of a small-world graph; components up to
+// `whole_max` nodes are built whole.  gg_set_tree_mode's node_cap (tests) sets both.
+static void lazy_limits(const gg_ctx *ctx, int64_t *cap, int64_t *whole_max) {
+    int64_t c = ctx->lz_cap;
+    if (const char *e = getenv("GG_LZ_CAP")) c = atoll(e);
+    *cap = c > 0 ? c : std::max<int64_t>(ctx->n_node, 2);
+    *whole_max = c > 0 ? c : 65536;
 }
 
 static int build_trees_lazy(gg_ctx *ctx, const int32_t *roots, int32_t n_roots) {
     const int n = ctx->n_node;
     if (ctx->h_comp_size.empty()) component_sizes(n, ctx->h_rowptr.data(), ctx->h_col.data(), ctx->h_comp_size);
-    const int64_t cap = lazy_node_cap(ctx);
-    // per slot: node limit of the exact part, pool behind it.  A component that fits the limit is built whole (no pool); a root
-    // whose own children already exceed it gets a whole segment.  The pool takes what a resolution reserves -- one entry per
-    // candidate of the node's adjacency -- for the walks a root can have: ~3 lazy hops each.
-    std::vector<int64_t> seg(n_roots);
-    std::vector<int32_t> limit(n_roots), expect(n_roots);
-    int64_t max_c = 1;
+    int64_t cap, whole_max;
+    lazy_limits(ctx, &cap, &whole_max);
+    // per root: node limit of the exact part, pool behind it.  The pool takes what a resolution reserves -- one entry per candidate
+    // of the node's adjacency -- for the walks a root can have, ~3 lazy hops each.
+    std::vector<int32_t> limit(n_roots), expect(n_roots), pool(n_roots);
+    int64_t max_c = 1, max_limit = 1, sure = 0;
     for (int r = 0; r < n_roots; ++r) {
         const int64_t C = ctx->h_comp_size[roots[r]], deg = ctx->h_rowptr[roots[r] + 1] - ctx->h_rowptr[roots[r]];
         expect[r] = (int32_t)C;
         max_c = std::max(max_c, C);
-        if (C <= cap || deg + 1 > cap) {
+        if (C <= whole_max || deg + 1 > cap) {  // (a root whose own children exceed the limit: whole as well)
             limit[r] = (int32_t)C;
-            seg[r] = C;
+            pool[r] = 0;
         } else {
             const int64_t pool_env = getenv("GG_LZ_POOL") ? atoll(getenv("GG_LZ_POOL")) : 0;
-            const int64_t pool = pool_env > 0 ? pool_env : std::min<int64_t>(std::max<int64_t>(16384, 192 * (deg + 64)), cap);
-            limit[r] = (int32_t)cap;
-            seg[r] = cap + pool;
+            limit[r] = (int32_t)std::min<int64_t>(cap, C);
+            pool[r] = (int32_t)(pool_env > 0 ? pool_env : std::min<int64_t>(std::max<int64_t>(16384, 192 * (deg + 64)), std::max<int64_t>(cap, 16384)));
         }
+        max_limit = std::max<int64_t>(max_limit, limit[r]);
+        sure += (int64_t)limit[r] + pool[r] + 1;
     }
+    // entries for all segments: what the slots can need at most, but no more than an average of a sixth of the nodes (+ pool) per
+    // slot -- a slot that finds no room is rebuilt whole in the arena right away
+    const int64_t avg_env = getenv("GG_LZ_AVG") ? atoll(getenv("GG_LZ_AVG")) : 0;
+    const int64_t avg = avg_env > 0 ? avg_env : std::max<int64_t>(65536, n / 6) + 16384;
+    const int64_t budget = std::max<int64_t>(1, std::min<int64_t>(sure, (int64_t)n_roots * avg));
     // the arena: whole trees of the slots whose walks need more than a lazy tree gives (lazy_fallback_rebuild)
     const int64_t arena_roots = getenv("GG_LZ_ARENA") ? atoll(getenv("GG_LZ_ARENA")) : std::min<int64_t>(1024, std::max<int64_t>(8, n_roots / 16));
-    const int64_t arena = arena_roots * (max_c + 1) + 16 * ((int64_t)n_roots + 1);  // (+ the spacing of up to 16 rounds of rebuilds, lazy_fallback_rebuild)
-    int rc = alloc_trees(ctx, roots, n_roots, seg.data(), nullptr, arena);
+    const int64_t arena = arena_roots * (max_c + 1);
+    std::vector<int64_t> zeros(n_roots, 0);
+    int rc = alloc_trees(ctx, roots, n_roots, zeros.data(), nullptr, budget + arena);
     if (rc != GG_OK) return rc;
     if (n_roots == 0) return GG_OK;
-    ctx->h_lz_seg.resize(n_roots);
-    for (int r = 0; r < n_roots; ++r) ctx->h_lz_seg[r] = (int32_t)seg[r];
+    ctx->arena_next = budget;
+    ctx->arena_end = budget + arena;
     const int bm_words = (n + 31) / 32;
+    const int grid = std::min<int>(n_roots, ctx->n_cus);
+    const size_t scr = (size_t)max_limit + 1;
     const size_t pair_before = ctx->lz_pair.bytes;
     hipError_t e = ctx->lz_info.reserve(sizeof(int4) * (size_t)n_roots);
     if (e == hipSuccess) e = ctx->lz_pair.reserve(sizeof(unsigned long long) * (size_t)ctx->t_cap_nodes);
@@ -1620,35 +1680,56 @@ static int build_trees_lazy(gg_ctx *ctx, const int32_t *roots, int32_t n_roots) 
     if (e == hipSuccess) e = ctx->lz_bm.reserve(sizeof(uint2) * (size_t)n_roots * bm_words);
     if (e == hipSuccess) e = ctx->lz_cursor.reserve(sizeof(int32_t) * (size_t)n_roots);
     if (e == hipSuccess) e = ctx->lz_flag.reserve(sizeof(int32_t) * (size_t)n_roots);
-    if (e == hipSuccess) e = ctx->lz_limit.reserve(sizeof(int32_t) * (size_t)n_roots);
+    if (e == hipSuccess) e = ctx->lz_limit.reserve(sizeof(int32_t) * (size_t)n_roots * 2);  // limits, pools
     if (e == hipSuccess) e = ctx->lz_expect.reserve(sizeof(int32_t) * (size_t)n_roots);
+    if (e == hipSuccess) e = ctx->lz_list.reserve(sizeof(int32_t) * 4 * (size_t)n_roots + 64);  // (walk launches: items listed + claims per item; a launch may name a slot twice)
+    if (e == hipSuccess) e = ctx->lz_scratch.reserve(sizeof(int32_t) * (size_t)grid * (3 * scr + 1) + 64);
     if (e != hipSuccess) return fail(ctx, GG_ENOMEM, "gg_build_trees_device: lazy-tree arrays: %s", hipGetErrorString(e));
     // a pair is valid iff it carries the build's stamp: nothing to initialise per build; cleared when the 12 bits wrap (and when new)
     ctx->lz_stamp = ctx->lz_stamp % 4095u + 1u;
     if (ctx->lz_stamp == 1u || ctx->lz_pair.bytes != pair_before) GG_HIP(ctx, hipMemsetAsync(ctx->lz_pair.p, 0, ctx->lz_pair.bytes, ctx->stream));
     GG_HIP(ctx, hipMemsetAsync(ctx->lz_flag.p, 0, sizeof(int32_t) * (size_t)n_roots, ctx->stream));
+    GG_HIP(ctx, hipMemsetAsync(ctx->lz_list.p, 0, ctx->lz_list.bytes, ctx->stream));
+    GG_HIP(ctx, hipMemsetAsync(ctx->dev_ctr + 1500, 0, sizeof(unsigned long long) * 10, ctx->stream));  // resolution statistics of this build (walk_sample.hip, lz_ctr) + [8] the segment cursor
     GG_HIP(ctx, hipMemcpyAsync(ctx->lz_limit.p, limit.data(), sizeof(int32_t) * (size_t)n_roots, hipMemcpyHostToDevice, ctx->stream));
+    GG_HIP(ctx, hipMemcpyAsync(ctx->lz_limit.as<int32_t>() + n_roots, pool.data(), sizeof(int32_t) * (size_t)n_roots, hipMemcpyHostToDevice, ctx->stream));
     GG_HIP(ctx, hipMemcpyAsync(ctx->lz_expect.p, expect.data(), sizeof(int32_t) * (size_t)n_roots, hipMemcpyHostToDevice, ctx->stream));
     BfsArgs a{};
     a.roots = ctx->t_root;
     a.base = ctx->t_base;
+    a.base_w = ctx->t_base;
     a.order = ctx->t_order;
     a.cstart = ctx->t_cstart;
     a.edge = ctx->t_edge;
     a.expect = ctx->lz_expect.as<int32_t>();
     a.lz_limit = ctx->lz_limit.as<int32_t>();
+    a.lz_pool = ctx->lz_limit.as<int32_t>() + n_roots;
     a.lz_info = ctx->lz_info.as<int4>();
     a.lz_bm = ctx->lz_bm.as<uint2>();
     a.lz_rank = ctx->lz_rank.as<int32_t>();
     a.lz_cursor = ctx->lz_cursor.as<int32_t>();
-    int32_t stats[4];
+    a.lz_flag = ctx->lz_flag.as<int32_t>();
+    a.lz_alloc = ctx->dev_ctr + 1508;
+    a.lz_alloc_end = budget;
+    a.scr_cap = (int)scr;
+    a.scr_order = ctx->lz_scratch.as<int32_t>();
+    a.scr_edge = a.scr_order + (size_t)grid * scr;
+    a.scr_cstart = a.scr_edge + (size_t)grid * scr;
+    int32_t stats[6];
     rc = bfs_run(ctx, a, n_roots, /*lazy=*/true, stats);  // (copies and memsets above: same stream, done when it returns)
     if (rc != GG_OK) return rc;
     ctx->t_lazy = true;
+    ctx->tree_entries = 0;
     ctx->lz_min_level = stats[3] > 0 ? 1024 - stats[3] : 0x7fffffff;
     ctx->tree_max_depth = stats[0];
-    ctx->tree_max_list = std::max(stats[1], ctx->g_max_deg + 1);  // (a resolved list holds up to the node's degree)
+    ctx->tree_max_list = ctx->g_max_deg + 1;  // (a resolved list holds up to the node's degree)
     ctx->t_edge_valid = true;
+    if (stats[4] > 0) {  // slots that found no room among the segments: whole trees in the arena, now
+        int rebuilt = 0;
+        rc = lazy_fallback_rebuild(ctx, &rebuilt);
+        if (rc == GG_ECAPACITY) rc = lazy_rebuild_whole(ctx);
+        if (rc != GG_OK) return rc;
+    }
     return GG_OK;
 }
 
@@ -1662,7 +1743,7 @@ int lazy_fallback_rebuild(gg_ctx *ctx, int *n_out) {
     GG_HIP(ctx, hipMemcpy(flag.data(), ctx->lz_flag.p, sizeof(int32_t) * (size_t)R, hipMemcpyDeviceToHost));
     std::vector<int32_t> slots, roots, expect;
     std::vector<int64_t> base;
-    int64_t next = ctx->arena_next + R + 1;  // (the cstart row of a slot starts at base + slot: rounds are spaced by the slot range)
+    int64_t next = ctx->arena_next;  // (lazy builds: a slot's row of first-child ranks starts at its base -- no shift by the slot)
     for (int s = 0; s < R; ++s) {
         if (!flag[s]) continue;
         const int64_t C = ctx->h_comp_size[ctx->h_troot[s]];
@@ -1671,7 +1752,7 @@ int lazy_fallback_rebuild(gg_ctx *ctx, int *n_out) {
         roots.push_back(ctx->h_troot[s]);
         expect.push_back((int32_t)C);
         base.push_back(next);
-        next += C + 1;  // (ascending slots: the cstart rows, shifted by their slot, cannot overlap)
+        next += C + 1;
     }
     const int m = (int)slots.size();
     if (m == 0) return GG_OK;
@@ -1683,7 +1764,7 @@ int lazy_fallback_rebuild(gg_ctx *ctx, int *n_out) {
     if (e == hipSuccess) e = d_base.reserve(sizeof(int64_t) * (m + 1));
     auto release = [&]() { d_slots.release(); d_roots.release(); d_expect.release(); d_base.release(); };
     if (e != hipSuccess) { release(); return fail(ctx, GG_ENOMEM, "lazy trees: %s", hipGetErrorString(e)); }
-    (void)hipMemcpy(d_slots.p, slots.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice);
+    (void)hipMemset(d_slots.p, 0, sizeof(int32_t) * m);
     (void)hipMemcpy(d_roots.p, roots.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice);
     (void)hipMemcpy(d_expect.p, expect.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice);
     (void)hipMemcpy(d_base.p, base.data(), sizeof(int64_t) * (m + 1), hipMemcpyHostToDevice);
@@ -1694,8 +1775,8 @@ int lazy_fallback_rebuild(gg_ctx *ctx, int *n_out) {
     a.cstart = ctx->t_cstart;
     a.edge = ctx->t_edge;
     a.expect = d_expect.as<int32_t>();
-    a.slot_ids = d_slots.as<int32_t>();
-    int32_t stats[4];
+    a.slot_ids = d_slots.as<int32_t>();  // (all zero: the rows are not shifted)
+    int32_t stats[6];
     int rc = bfs_run(ctx, a, m, /*lazy=*/false, stats);
     release();
     if (rc != GG_OK) return rc;
@@ -1758,7 +1839,7 @@ extern "C" int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t 
     a.order = ctx->t_order;
     a.cstart = ctx->t_cstart;
     a.edge = ctx->t_edge;
-    int32_t stats[4];
+    int32_t stats[6];
     rc = bfs_run(ctx, a, n_roots, /*lazy=*/false, stats);
     if (rc != GG_OK) return rc;
     ctx->tree_max_depth = stats[0];

@@ -930,6 +930,18 @@ int gg_walk_sample(gg_ctx *ctx, const int32_t *slots, const int32_t *n_walks, in
     return GG_OK;
 }
 
+int gg_debug_words(gg_ctx *ctx, int32_t first, int32_t n, uint64_t *out) {
+    if (!ctx || !out || first < 0 || n < 0 || first + n > gg_ctx::PIN_WORDS) return fail(ctx, GG_EINVAL, "gg_debug_words: bad argument");
+    GG_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s;  // (its own stream: readable while a kernel of the context hangs)
+    GG_HIP(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    hipError_t e = hipMemcpyAsync(out, ctx->dev_ctr + first, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipStreamDestroy(s);
+    GG_HIP(ctx, e);
+    return GG_OK;
+}
+
 int gg_set_tree_mode(gg_ctx *ctx, int32_t mode, int64_t node_cap) {
     if (!ctx) return fail(nullptr, GG_EINVAL, "ctx is NULL");
     GG_CHECK(ctx, mode >= -1 && mode <= 1 && node_cap >= 0, GG_EINVAL, "gg_set_tree_mode: mode must be -1 (auto), 0 (whole trees) or 1 (lazy), node_cap >= 0");
@@ -941,7 +953,7 @@ int gg_set_tree_mode(gg_ctx *ctx, int32_t mode, int64_t node_cap) {
 int gg_lazy_stats(gg_ctx *ctx, int64_t *out8) {
     if (!ctx || !out8) return fail(ctx, GG_EINVAL, "gg_lazy_stats: NULL argument");
     GG_HIP(ctx, hipSetDevice(ctx->device));
-    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    for (int i = 0; i < 24; ++i) out8[i] = 0;
     out8[0] = ctx->t_lazy ? 1 : 0;
     out8[1] = ctx->t_lazy ? ctx->lz_min_level : 0;
     out8[2] = ctx->lz_fallback_roots;
@@ -958,7 +970,11 @@ int gg_lazy_stats(gg_ctx *ctx, int64_t *out8) {
             out8[5] += std::max(0, cur[r] - info[r].y);            // pool entries reserved by resolutions
             out8[6] += info[r].x < info[r].y ? 1 : 0;              // slots that are lazy (not built whole)
             out8[7] = std::max<int64_t>(out8[7], info[r].z);       // deepest exact level
+            if (info[r].x < info[r].y && info[r].z >= 0 && info[r].z < 8) out8[16 + info[r].z] += 1;  // lazy slots by exact level
         }
+        unsigned long long c[8];
+        GG_HIP(ctx, hipMemcpy(c, ctx->dev_ctr + 1500, sizeof(c), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 8; ++i) out8[8 + i] = (int64_t)c[i];   // lists resolved at depth 0 / 1 / 2, candidates, scan rounds, most rounds of one list, longest adjacency resolved
     }
     return GG_OK;
 }

@@ -150,13 +150,12 @@ struct gg_ctx {
     // A slot whose walks need more than that (a level L_r + 3 node, a full pool) raises lz_flag[r]: walk_finalize rebuilds those
     // roots whole in the ARENA behind the slots' segments (t_base[r] moves there, lz_info[r].x = its node count) and reruns.
     int32_t tree_mode = -1;            // gg_set_tree_mode / GG_TREE_LAZY: 0 = whole trees, 1 = lazy, -1 = lazy from GG_LZ_AUTO_NODES nodes on
-    int64_t lz_cap = 0;                // node limit of a slot's exact part (0 = 3/8 of the nodes, at least 65 536; GG_LZ_CAP)
+    int64_t lz_cap = 0;                // node limit of a slot's exact part (0 = the node count, components up to 65 536 nodes whole; GG_LZ_CAP)
     bool t_lazy = false;               // the resident trees are lazy
     bool lz_force_whole = false;       // (the rebuild of a lazy batch as whole trees is under way)
     int32_t lz_min_level = 0x7fffffff; // smallest L_r of the resident lazy slots (levels below it need no resolve step)
     uint32_t lz_stamp = 0;             // stamp of the resident build (1 .. 4095; the pair array is cleared when it wraps)
-    gg::DevBuf lz_info, lz_pair, lz_rank, lz_bm, lz_cursor, lz_flag, lz_limit, lz_expect, lz_list;
-    std::vector<int32_t> h_lz_seg;     // capacity (nodes) of every slot's segment
+    gg::DevBuf lz_info, lz_pair, lz_rank, lz_bm, lz_cursor, lz_flag, lz_limit, lz_expect, lz_list, lz_scratch;
     int64_t arena_next = 0, arena_end = 0;  // the arena of whole trees behind the segments: [arena_next, arena_end) is free
     int64_t lz_fallback_roots = 0, lz_fallback_rounds = 0, lz_resolved = 0;  // statistics (gg_lazy_stats)
     bool g_multi = true;               // the adjacency holds a node twice in some list (first-occurrence tests needed)

@@ -117,8 +117,10 @@ struct WalkArgs {
     int32_t *lz_flag;             // [slots] the walks need the whole tree of this slot
     uint32_t lz_stamp;
     int32_t g_multi;              // some adjacency list holds a node twice: first-occurrence tests needed
-    int32_t *lz_list;             // [total_walks] walks whose node waits for the resolve kernel (count: lc[CTR_LZ + level])
+    int32_t *lz_list;             // [n_slots] launch items with claimed walks at this level, then [n_slots] claims per item (zero between launches)
     int32_t *t_order_w, *t_edge_w;  // the tree arrays, writable (pool appends)
+    int32_t lz_budget;            // 256-entry scan batches one list may cost; a list that needs more sends its slot to the whole-tree rebuild (bounds a launch's tail)
+    unsigned long long *lz_ctr;   // statistics: [depth] lists resolved at depth 0 / 1 / 2, [3] candidates judged, [4] 16-entry scan rounds, [5] most rounds of one list
 };
 
 // ---- cross-lane moves without an LDS round trip (DPP): shifts / rotations inside a row of 16 lanes, row broadcasts across rows.
@@ -275,67 +277,142 @@ __device__ __forceinline__ int sample_index(Load sbuf, int k, float mx, uint64_t
 //           in level L + 1 would be a child -- then the slot asks for its whole tree (lz_flag; walk_finalize rebuilds it in
 //           the arena and reruns the launch); so does a pool that is full.
 // Children are entries of adj(cur) in adjacency order, first occurrences only: the list the BFS builds, bit for bit.
-// One WAVEFRONT per node: 64 adjacency entries per round are tested, the candidates among them judged four at a time by
-// the wave's four 16-lane groups (every loop is wave-uniform: a group that is through idles along).
+// One WAVEFRONT per node: 64 adjacency entries of cur per round; the adjacencies of the candidates among them (and, below cur's
+// own level, of THEIR neighbours) are tested as one flat stream of entries, 256 at a time (lz_flat_scan).
 // ------------------------------------------------------------------------------------------
 constexpr unsigned long long LZ_CLAIMED = 0xFFFFFull;  // count field of a pair whose list is being resolved
 constexpr int CTR_LZ_FB = 2;                           // ctr[2]: a slot raised its flag: the launch is void, the host rebuilds the flagged slots whole and repeats it
 __device__ __forceinline__ unsigned long long lz_make(int start, unsigned long long count, uint32_t stamp) {
     return ((unsigned long long)(uint32_t)start << 32) | (count << 12) | (unsigned long long)stamp;
 }
-__device__ __forceinline__ bool lz_in(const uint2 *bm, int x) { return (bm[x >> 5].x >> (x & 31)) & 1u; }
-__device__ __forceinline__ unsigned long long grp16_min_u64(unsigned long long v) {
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) {
-        const unsigned lo = (unsigned)__shfl_xor((int)(uint32_t)v, off, 64), hi = (unsigned)__shfl_xor((int)(uint32_t)(v >> 32), off, 64);
-        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-        v = o < v ? o : v;
-    }
+// where the visited words of the slot come from: the index in global memory (any kernel), or the copy a workgroup of the
+// resolve kernel holds in LDS for the slot it is working on -- a list costs ~1 000 membership tests, each a random sector of a
+// 250 KB index of ITS slot; 16 384 slots' indices share no cache line: from HBM that was the whole run time of the kernel
+struct LzBitsGlobal {
+    const uint2 *bm;
+    __device__ __forceinline__ uint32_t operator()(int i) const { return bm[i].x; }
+};
+struct LzBitsLds {
+    const uint32_t *w;
+    __device__ __forceinline__ uint32_t operator()(int i) const { return w[i]; }
+};
+template <class Bits>
+__device__ __forceinline__ bool lz_in(const Bits &bits, int x) { return (bits(x >> 5) >> (x & 31)) & 1u; }
+// Per-wavefront LDS workspace of a resolution.
+struct LzWork {
+    int32_t pre[64], q0[64];          // inner segments: inclusive prefix of their lengths, first CSR entry
+    int32_t xpre[64], xq0[64];        // outer segments (the candidates whose neighbours become pairs)
+    unsigned long long best[64];      // per pair: smallest (rank << 32 | CSR entry) over the pair node's neighbours in V
+    unsigned long long mask[2];       // per candidate lane: [0] ruled out / touches V, [1] has a neighbour in level L + 1
+};
+__device__ __forceinline__ void wave_lds_sync() {  // LDS writes (stores and atomics, through the generic workspace pointer) of this wavefront's lanes are visible to its other lanes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (a wavefront-scope fence emits no wait at all: with the statistics' atomics gone, reads overtook the writes they depend on)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ int wave_incl_scan_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
     return v;
 }
-// per group: does node xn (-1: idle group) have a neighbour in V?  (group-uniform result)
-__device__ __forceinline__ bool lz_grp_touches(const WalkArgs &a, const uint2 *bm, int xn, int t, int g) {
-    int64_t q = xn >= 0 ? a.rowptr[xn] : 0;
-    const int64_t qe = xn >= 0 ? a.rowptr[xn + 1] : 0;
-    bool hit = false;
-    while (__ballot(q < qe && !hit)) {
-        bool v = false;
-        if (!hit && q + t < qe) v = lz_in(bm, a.col[q + t]);
-        if ((__ballot(v) >> (16 * g)) & 0xFFFFull) hit = true;
-        q += 16;
+// element `flat` of the concatenation of 64 segments (inclusive length prefix in LDS): its segment
+__device__ __forceinline__ int lz_owner(const int32_t *pre, int flat) {
+    int lo = 0, hi = 63;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int mid = (lo + hi) >> 1;
+        if (pre[mid] > flat) hi = mid; else lo = mid + 1;
     }
-    return hit;
+    return lo;
 }
-// per group: the smallest (rank << 32 | index in adj(xn)) over the neighbours of xn in V; ~0 if it has none.  With `below`:
-// stops as soon as a rank smaller than it was seen (the caller only asks "is there one")
-__device__ __forceinline__ unsigned long long lz_grp_min_rank(const WalkArgs &a, const uint2 *bm, const int32_t *rk, int xn, int below, int t, int g) {
-    int64_t q = xn >= 0 ? a.rowptr[xn] : 0;
-    const int64_t qe = xn >= 0 ? a.rowptr[xn + 1] : 0;
-    unsigned long long best = ~0ull;
-    while (__ballot(q < qe && (long long)(best >> 32) >= (long long)below)) {
-        unsigned long long key = ~0ull;
-        if (q + t < qe) {
-            const int u = a.col[q + t];
-            const uint2 wd = bm[u >> 5];
-            if ((wd.x >> (u & 31)) & 1u) key = ((unsigned long long)(uint32_t)rk[wd.y + __popc(wd.x & ((1u << (u & 31)) - 1u))] << 32) | (unsigned long long)(uint32_t)(q + t);
+// Every lane brings one segment of adjacency (first CSR entry, length; 0 = none).  ALL entries of all 64 segments are tested
+// against V, 64 x U at a time with the U batches' loads in flight together -- a list's latency no longer grows with the number
+// or the degrees of its candidates (judged one 16-entry round at a time, a list was a chain of ~70 memory round trips):
+//   MODE 0  owners with a neighbour in V whose rank is below `below`  -> bit in ws->mask[0]
+//   MODE 1  owners with any neighbour in V                            -> bit in ws->mask[0]
+//   MODE 2  per owner the smallest (rank << 32 | CSR entry) over its neighbours in V -> ws->best[owner]
+// The caller initialises mask / best.  `work` counts the batches (the list's budget).
+template <int MODE, class Bits>
+__device__ __forceinline__ void lz_flat_scan(const WalkArgs &a, const Bits &bits, const uint2 *bm, const int32_t *rk, LzWork *ws, int lane, int my_q0, int my_len,
+                                             int below, int &work) {
+    constexpr int U = 4;
+    const int incl = wave_incl_scan_i32(my_len);
+    ws->pre[lane] = incl;
+    ws->q0[lane] = my_q0;
+    const int T = __builtin_amdgcn_readlane(incl, 63);
+    wave_lds_sync();
+    for (int f0 = 0; f0 < T && work <= a.lz_budget; f0 += 64 * U) {
+        int own[U], e[U], u[U];
+        uint32_t wx[U], pr[U];
+        bool vis[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int flat = f0 + 64 * k + lane;
+            own[k] = -1;
+            e[k] = 0;
+            if (flat < T) {
+                own[k] = lz_owner(ws->pre, flat);
+                e[k] = ws->q0[own[k]] + (flat - (own[k] ? ws->pre[own[k] - 1] : 0));
+            }
         }
-        key = grp16_min_u64(key);
-        best = key < best ? key : best;
-        q += 16;
+#pragma unroll
+        for (int k = 0; k < U; ++k) u[k] = own[k] >= 0 ? a.col[e[k]] : 0;
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            wx[k] = own[k] >= 0 ? bits(u[k] >> 5) : 0u;
+            vis[k] = (wx[k] >> (u[k] & 31)) & 1u;
+        }
+        if (MODE == 1) {
+#pragma unroll
+            for (int k = 0; k < U; ++k)
+                if (vis[k]) atomicOr(&ws->mask[0], 1ull << own[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < U; ++k) pr[k] = vis[k] ? bm[u[k] >> 5].y : 0u;
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                if (vis[k]) {
+                    const int r = rk[pr[k] + __popc(wx[k] & ((1u << (u[k] & 31)) - 1u))];
+                    if (MODE == 0) {
+                        if (r < below) atomicOr(&ws->mask[0], 1ull << own[k]);
+                    } else {
+                        atomicMin(&ws->best[own[k]], ((unsigned long long)(uint32_t)r << 32) | (unsigned long long)(uint32_t)e[k]);
+                    }
+                }
+            }
+        }
+        work += 1;
     }
-    return best;
+    wave_lds_sync();
 }
 
 // Resolve the children list of (slot, rank) = node `cur` on tree level `level` (its father on the walk: `prev`) and publish it;
 // the caller has claimed the pair.  Returns the published pair.  All 64 lanes take part; everything returned is wave-uniform.
-__device__ __noinline__ unsigned long long lazy_resolve_wave(const WalkArgs &a, int slot, int64_t tbase, int rank, int cur, int prev, int level, int lane) {
+template <class Bits>
+__device__ __forceinline__ unsigned long long lazy_resolve_wave(const WalkArgs &a, const Bits &bits, LzWork *ws, int slot, int64_t tbase, int rank, int cur, int prev,
+                                                                int level, int lane) {
+    // Every argument is wave-uniform; as scalars the loops below branch on scalar conditions.
+    // NO "if (lane == 0)" BRANCHES in this function or around its call: inlined into the resolve kernel's loop over the listed
+    // walks, the lane-0-only store of the pair at its end was merged with the loop's latch -- lane 0 LEFT the loop after its first
+    // list while lanes 1-63 went round for ever on entry 0 (EXEC = ...fffe at the function's entry, its LDS stores missing; found
+    // on the GPU, in the disassembly).  Uniform stores are made by every lane (same address, same value: one store), counters
+    // are added to with (lane == 0 ? value : 0).
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    rank = __builtin_amdgcn_readfirstlane(rank);
+    cur = __builtin_amdgcn_readfirstlane(cur);
+    prev = __builtin_amdgcn_readfirstlane(prev);
+    level = __builtin_amdgcn_readfirstlane(level);
+    tbase = ((int64_t)__builtin_amdgcn_readfirstlane((int)(tbase >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tbase);
     const int4 info = a.lz_info[slot];
     const int depth = level - info.z, seg = info.w;
     const uint2 *const bm = a.lz_bm + (size_t)slot * a.lz_words;
     const int32_t *const rk = a.lz_rank + tbase;
     unsigned long long *const pair = a.lz_pair + tbase + rank;
     const int64_t e0 = a.rowptr[cur], e1 = a.rowptr[cur + 1];
-    const int g = lane >> 4, t = lane & 15;
     bool fallback = depth < 0 || depth > 2;
     // the key of cur inside its level
     int my_rank = rank, my_edge = 0;
@@ -348,7 +425,7 @@ __device__ __noinline__ unsigned long long lazy_resolve_wave(const WalkArgs &a, 
         x = -1;
         if (e >= e1) return false;
         x = a.col[e];
-        if (x == cur || lz_in(bm, x)) return false;
+        if (x == cur || lz_in(bits, x)) return false;
         return !a.g_multi || a.rev[a.rev[e]] == (int32_t)e;
     };
     // candidates of the whole adjacency: what the list can hold at most -> its place in the pool
@@ -364,65 +441,70 @@ __device__ __noinline__ unsigned long long lazy_resolve_wave(const WalkArgs &a, 
     }
     int start = 0;
     if (depth <= 1 && ncand > 0) {
-        if (lane == 0) start = atomicAdd(&a.lz_cursor[slot], ncand);
-        start = __shfl(start, 0, 64);
+        start = __builtin_amdgcn_readfirstlane(atomicAdd(&a.lz_cursor[slot], lane == 0 ? ncand : 0));
         if ((long long)start + ncand > (long long)seg) fallback = true;  // the pool is full
     }
-    int count = 0;
+    int count = 0, work = 0;
     if (!fallback && ncand > 0) {
-        for (int64_t b = e0; b < e1; b += 64) {
+        for (int64_t b = e0; b < e1 && work <= a.lz_budget; b += 64) {
             int x = x0;
             bool c = c0;
             if (b != e0) c = candidate(b + lane, x);
-            unsigned long long m = __ballot(c), kids = 0;
-            while (m) {
-                int p[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    p[i] = m ? __ffsll((long long)m) - 1 : -1;
-                    if (m) m &= m - 1;
-                }
-                const int pg = g == 0 ? p[0] : g == 1 ? p[1] : g == 2 ? p[2] : p[3];
-                const int xn = __shfl(x, pg < 0 ? 0 : pg, 64);
-                const int xg = pg < 0 ? -1 : xn;  // this group's candidate
-                bool child = false;
-                if (depth == 0) {
-                    const unsigned long long best = lz_grp_min_rank(a, bm, rk, xg, my_rank, t, g);
-                    child = xg >= 0 && (long long)(best >> 32) >= (long long)my_rank;  // (~0: no neighbour in V cannot happen -- cur is one)
-                } else {
-                    const bool touches = lz_grp_touches(a, bm, xg, t, g);
-                    // x is one level below cur.  depth 1: is cur its first neighbour of level L + 1?  depth 2: any such x means cur has children
-                    int64_t qx = (xg >= 0 && !touches) ? a.rowptr[xg] : 0;
-                    const int64_t qxe = (xg >= 0 && !touches) ? a.rowptr[xg + 1] : 0;
-                    bool open = xg >= 0 && !touches;  // verdict still open
-                    bool verdict = true;               // depth 1: child unless a neighbour precedes cur; depth 2: "deeper" unless a neighbour is in level L + 1
-                    while (__ballot(open)) {
-                        int y = -1;
-                        if (open) {
-                            if (qx >= qxe) open = false;
-                            else {
-                                y = a.col[qx++];
-                                if (y == cur && depth == 1) y = -1;
-                            }
-                        }
-                        const unsigned long long best = lz_grp_min_rank(a, bm, rk, open ? y : -1, depth == 1 ? -1 : 0x7fffffff, t, g);
-                        if (open && y >= 0 && best != ~0ull) {  // y is in level L + 1
-                            if (depth == 1) {
-                                const int ry = (int)(best >> 32);
-                                if (ry < my_rank || (ry == my_rank && a.rev[(int)(uint32_t)best] < my_edge)) { verdict = false; open = false; }
-                            } else {
-                                verdict = false;  // x is in level L + 2, like cur: no child of cur
-                                open = false;
-                            }
+            const unsigned long long m = __ballot(c);
+            if (m) {
+            // the candidates' adjacencies, one segment per lane
+            int64_t xq = 0, xe = 0;
+            if (c) { xq = a.rowptr[x]; xe = a.rowptr[x + 1]; }
+            ws->mask[0] = 0ull;
+            ws->mask[1] = 0ull;
+            wave_lds_sync();
+            unsigned long long kids;
+            if (depth == 0) {
+                // a child unless a neighbour in V precedes cur
+                lz_flat_scan<0>(a, bits, bm, rk, ws, lane, (int)xq, (int)(xe - xq), my_rank, work);
+                kids = m & ~ws->mask[0];
+            } else {
+                // candidates that touch V are in cur's own level; the others are one level below cur
+                lz_flat_scan<1>(a, bits, bm, rk, ws, lane, (int)xq, (int)(xe - xq), 0, work);
+                const unsigned long long below_m = m & ~ws->mask[0];
+                wave_lds_sync();  // (every lane has read the mask)
+                ws->mask[0] = 0ull;
+                // their neighbours y (PAIRS (x, y), 64 at a time): is y in level L + 1, and with which key?
+                const bool xb = (below_m >> lane) & 1ull;
+                const int xincl = wave_incl_scan_i32(xb ? (int)(xe - xq) : 0);
+                ws->xpre[lane] = xincl;
+                ws->xq0[lane] = (int)xq;
+                const int P = __builtin_amdgcn_readlane(xincl, 63);
+                wave_lds_sync();
+                for (int p0 = 0; p0 < P && work <= a.lz_budget; p0 += 64) {
+                    const int pi = p0 + lane;
+                    int xl = -1, y = -1;
+                    int64_t yq = 0, ye = 0;
+                    if (pi < P) {
+                        xl = lz_owner(ws->xpre, pi);
+                        y = a.col[ws->xq0[xl] + (pi - (xl ? ws->xpre[xl - 1] : 0))];
+                        if (y == cur) y = -1;  // (cur itself: level L + 1 with cur's own key at depth 1, not in level L + 1 at depth 2)
+                    }
+                    if (y >= 0) { yq = a.rowptr[y]; ye = a.rowptr[y + 1]; }
+                    ws->best[lane] = ~0ull;
+                    wave_lds_sync();
+                    lz_flat_scan<2>(a, bits, bm, rk, ws, lane, (int)yq, (int)(ye - yq), 0, work);
+                    const unsigned long long best = ws->best[lane];
+                    if (y >= 0 && best != ~0ull) {  // y is in level L + 1
+                        atomicOr(&ws->mask[1], 1ull << xl);
+                        if (depth == 1) {
+                            const int ry = (int)(best >> 32);
+                            if (ry < my_rank || (ry == my_rank && a.rev[(int)(uint32_t)best] < my_edge)) atomicOr(&ws->mask[0], 1ull << xl);  // y precedes cur in the queue
                         }
                     }
-                    if (depth == 1) child = xg >= 0 && !touches && verdict;
-                    else if (xg >= 0 && !touches && verdict) fallback = true;  // (group-uniform so far; made wave-uniform below)
+                    wave_lds_sync();
                 }
-                const unsigned long long cb = __ballot(child && t == 0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (p[i] >= 0 && ((cb >> (16 * i)) & 1ull)) kids |= 1ull << p[i];
+                if (depth == 1) {
+                    kids = below_m & ~ws->mask[0];
+                } else {
+                    kids = 0ull;
+                    if (below_m & ~ws->mask[1]) fallback = true;  // a neighbour two levels below the exact ones' children: cur is no leaf
+                }
             }
             if ((kids >> lane) & 1ull) {
                 const int64_t at = tbase + start + count + (int)__popcll(kids & ((1ull << lane) - 1ull));
@@ -430,27 +512,36 @@ __device__ __noinline__ unsigned long long lazy_resolve_wave(const WalkArgs &a, 
                 a.t_edge_w[at] = (int32_t)(b + lane);
             }
             count += (int)__popcll(kids);
+            wave_lds_sync();  // (the masks are read: the next round resets them)
+            }
         }
     }
-    fallback = __ballot(fallback) != 0ull;
+    // a list this expensive (a hub's adjacency judged through hubs) is not worth resolving: the slot gets its whole tree instead
+    fallback = fallback || work > a.lz_budget;
     if (fallback) {
         count = 0;
-        if (lane == 0) {
-            a.lz_flag[slot] = 1;
-            // the launch is void -- the host rebuilds the flagged slots whole and repeats it -- but it runs to its end: every slot
-            // whose walks need the whole tree is found in ONE pass (cut short, each repeat would find one level's worth)
-            a.ctr[CTR_LZ_FB] = 1ull;
-        }
+        a.lz_flag[slot] = 1;
+        // the launch is void -- the host rebuilds the flagged slots whole and repeats it -- but it runs to its end: every slot
+        // whose walks need the whole tree is found in ONE pass (cut short, each repeat would find one level's worth)
+        a.ctr[CTR_LZ_FB] = 1ull;
+    }
+    if (a.lz_ctr) {  // (GG_LZ_STATS=1: same-address atomics of every list of the launch -- ~40 ms per 16 384 roots)
+        const unsigned long long one = lane == 0 ? 1ull : 0ull;
+        atomicAdd(&a.lz_ctr[depth < 0 ? 0 : depth > 2 ? 2 : depth], one);
+        atomicAdd(&a.lz_ctr[3], one * (unsigned long long)ncand);
+        atomicAdd(&a.lz_ctr[4], one * (unsigned long long)work);
+        atomicMax(&a.lz_ctr[5], (unsigned long long)work);
+        atomicMax(&a.lz_ctr[6], (unsigned long long)(e1 - e0));
     }
     const unsigned long long v = lz_make(start, (unsigned long long)count, a.lz_stamp);
     __threadfence();  // the list before the pair that names it
-    if (lane == 0) __hip_atomic_store(pair, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(pair, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (every lane: the same word)
     return v;
 }
 
 // The children range of a rank >= lzs for a whole wavefront (the finisher): resolved on the spot if nobody has, waited for if
 // another wave is at it (that wave is running: claims are only ever taken by running waves).
-__device__ __forceinline__ unsigned long long lazy_children_wave(const WalkArgs &a, int slot, int64_t tbase, int rank, int cur, int prev, int level, int lane) {
+__device__ __forceinline__ unsigned long long lazy_children_wave(const WalkArgs &a, LzWork *ws, int slot, int64_t tbase, int rank, int cur, int prev, int level, int lane) {
     unsigned long long *const pair = a.lz_pair + tbase + rank;
     for (int spins = 0;; ++spins) {
         const unsigned long long v = __hip_atomic_load(pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -469,7 +560,7 @@ __device__ __forceinline__ unsigned long long lazy_children_wave(const WalkArgs 
         unsigned long long old = v;
         if (lane == 0) old = atomicCAS(pair, v, lz_make(0, LZ_CLAIMED, a.lz_stamp));
         old = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(old >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)old, 0, 64);
-        if (old == v) return lazy_resolve_wave(a, slot, tbase, rank, cur, prev, level, lane);
+        if (old == v) return lazy_resolve_wave(a, LzBitsGlobal{a.lz_bm + (size_t)slot * a.lz_words}, ws, slot, tbase, rank, cur, prev, level, lane);
     }
 }
 
@@ -621,7 +712,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     ho[tid] = 0x7fffffff; ho[tid + 256] = 0x7fffffff;
     __syncthreads();
     if (blk_skip) return;
-    bool alive = false, sampled = false, forced = false;
+    bool alive = false, sampled = false, forced = false, claimed = false;
     int item = 0, cur = -1, k = 0, hf = 0, father = -1, slot_w = 0, rank_w = 0, up_edge = -1;
     unsigned long long my_k = 0;
     int64_t beg_abs = 0;
@@ -767,11 +858,13 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
             // the picked node has no built children list: claim it unless somebody has (resolved or claimed)
             unsigned long long *const pair = a.lz_pair + tbase + rank;
             const unsigned long long v = __hip_atomic_load(pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((uint32_t)(v & 0xFFFull) != a.lz_stamp && atomicCAS(pair, v, lz_make(0, LZ_CLAIMED, a.lz_stamp)) == v)
-                a.lz_list[atomicAdd(&a.lc[CTR_LZ + a.level], 1ull)] = (int32_t)w;
+            if ((uint32_t)(v & 0xFFFull) != a.lz_stamp && atomicCAS(pair, v, lz_make(0, LZ_CLAIMED, a.lz_stamp)) == v) {
+                claimed = true;
+                // the first claim of a launch item lists the item for the resolve kernel (low half of the level's word: items listed)
+            }
         }
         if (alive && do_setup) {
-            const int32_t *const cs = a.t_cstart + tbase + slot;
+            const int32_t *const cs = a.t_cstart + tbase + (LAZY ? 0 : slot);  // (lazy builds place a slot's row at its base: the segments come from a cursor, in no slot order)
             int cbeg, cend;  // children of cur = ranks [cbeg, cend)
             if (LAZY && rank >= lzi.x) {
                 const unsigned long long v = __hip_atomic_load(a.lz_pair + tbase + rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -855,7 +948,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         // still going after the last one sends the launch to the sized rerun
         if (alive && do_setup != 1 && write_desc == 2) a.ctr[3] = 2ull;
     }
-    if (in_range) a.st_alive[w] = alive ? 1 : 0;
+    if (in_range) a.st_alive[w] = alive ? (claimed ? 2 : 1) : 0;  // (2: the resolve kernel owes this walk's node its children list)
     {
         const unsigned long long bal = __ballot(sampled), fbal = __ballot(forced);  // hops sampled here + leaf back-steps finished here
         my_k += forced ? 1ull : 0ull;
@@ -1051,17 +1144,66 @@ __global__ void level_expand_kernel(const WalkArgs a) {
     for (int i = 0; i < n; ++i) write_chunk_desc(a.lv_chunk_desc, c0 + i, cur, k, hf, father, beg, i, pfx);
 }
 
-// LAZY: one wavefront per listed walk resolves the children list its node was claimed for ("LAZY RESOLUTION").  Runs whatever
-// the launch's flags say: a claim that stayed unresolved would stall every later reader of the pair.
-__global__ __launch_bounds__(256) void lazy_resolve_kernel(const WalkArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int64_t n = (int64_t)a.lc[CTR_LZ + a.level];
-    const int64_t n_waves = (int64_t)gridDim.x * 4;
-    for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += n_waves) {
-        const int64_t w = a.lz_list[i];
-        const int4 sc = a.st_const[w], sc2 = a.st_const2[w];
-        const int64_t tbase = ((int64_t)sc2.y << 32) | (unsigned)sc2.x;
-        (void)lazy_resolve_wave(a, sc.y, tbase, a.st_rank[w], a.st_cur[w], a.st_prev[w], a.level, lane);
+// LAZY: the children lists the walks of this level were claimed for ("LAZY RESOLUTION").  One workgroup per launch item (a root
+// slot and its walks) at a time, items from a ticket: the claimed walks of the item (st_alive == 2) are listed in LDS, the slot's
+// visited words are copied into LDS (LDS_BITS: graphs up to ~1.2 M nodes; else the tests read the index in global memory), and
+// the workgroup's wavefronts take one listed walk each until the list is empty.  Runs whatever the launch's flags say: a claim
+// that stayed unresolved would stall every later reader of the pair.
+constexpr int LZ_T = 1024, LZ_LIST = 1024;
+template <bool LDS_BITS>
+__global__ __launch_bounds__(LZ_T) void lazy_resolve_kernel(const WalkArgs a) {
+    extern __shared__ uint32_t lz_lds[];  // [lz_words] when LDS_BITS
+    __shared__ int32_t s_list[LZ_LIST];
+    __shared__ LzWork s_ws[LZ_T / 64];
+    __shared__ int s_item, s_n, s_next;
+    const int tid = threadIdx.x, lane = tid & 63;
+    LzWork *const ws = &s_ws[tid >> 6];
+    for (;;) {
+        if (tid == 0) {
+            // the level's word: items listed (low half, final: the claiming launch is through) | ticket (high half)
+            int it = (int)atomicAdd(&a.lc[CTR_LZ + a.level], 1ull);
+            if (it >= a.n_slots) it = -1;
+            s_item = it;
+            s_n = 0;
+            s_next = 0;
+        }
+        __syncthreads();
+        const int item = s_item;
+        if (item < 0) return;
+        const int64_t w0 = a.walk_ptr[item], w1 = a.walk_ptr[item + 1];
+        for (;;) {  // (rounds of LZ_LIST claimed walks; one round unless the root has thousands of walks)
+            for (int64_t w = w0 + tid; w < w1; w += LZ_T)
+                if (a.st_alive[w] == 2) {
+                    const int i = atomicAdd(&s_n, 1);
+                    if (i < LZ_LIST) {
+                        s_list[i] = (int32_t)(w - w0);
+                        a.st_alive[w] = 1;
+                    }
+                }
+            __syncthreads();
+            const int found = s_n, n = min(found, LZ_LIST);
+            if (n > 0) {
+                const int slot = a.slots[item];
+                if (LDS_BITS) {
+                    const uint2 *const src = a.lz_bm + (size_t)slot * a.lz_words;
+                    for (int i = tid; i < a.lz_words; i += LZ_T) lz_lds[i] = src[i].x;
+                    __syncthreads();
+                }
+                for (;;) {
+                    const int i = __builtin_amdgcn_readfirstlane(atomicAdd(&s_next, lane == 0 ? 1 : 0));  // (a scalar: the loop branches on it; no lane-0 branch, see lazy_resolve_wave)
+                    if (i >= n) break;
+                    const int64_t w = w0 + s_list[i];
+                    const int4 sc2 = a.st_const2[w];
+                    const int64_t tbase = ((int64_t)sc2.y << 32) | (unsigned)sc2.x;
+                    if (LDS_BITS) (void)lazy_resolve_wave(a, LzBitsLds{lz_lds}, ws, slot, tbase, a.st_rank[w], a.st_cur[w], a.st_prev[w], a.level, lane);
+                    else (void)lazy_resolve_wave(a, LzBitsGlobal{a.lz_bm + (size_t)slot * a.lz_words}, ws, slot, tbase, a.st_rank[w], a.st_cur[w], a.st_prev[w], a.level, lane);
+                }
+            }
+            __syncthreads();  // (everyone is through with the list and the LDS words)
+            if (found <= LZ_LIST) break;
+            if (tid == 0) { s_n = 0; s_next = 0; }
+            __syncthreads();
+        }
     }
 }
 
@@ -1378,7 +1520,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void walk_sample_kernel(const
             const int slot = a.slots[item];
             const int root = a.t_root[slot];
             const int64_t tbase = a.t_base[slot];
-            const int32_t *const cs = a.t_cstart + tbase + slot;
+            const int32_t *const cs = a.t_cstart + tbase + (LAZY ? 0 : slot);  // (lazy builds place a slot's row at its base: the segments come from a cursor, in no slot order)
             const int32_t *const order = a.t_order + tbase;
             int32_t *const path = a.paths + w * (int64_t)a.stride;
             const int lzs = LAZY ? a.lz_info[slot].x : 0x7fffffff;  // first rank without a built children list
@@ -1400,7 +1542,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void walk_sample_kernel(const
             for (;;) {
                 int cbeg, cend;
                 if (LAZY && rank >= lzs) {  // resolved on the spot if no walk has stood here before
-                    const unsigned long long v = lazy_children_wave(a, slot, tbase, rank, cur, prev, (int)hop, lane);
+                    const unsigned long long v = lazy_children_wave(a, reinterpret_cast<LzWork *>(sbuf_lds), slot, tbase, rank, cur, prev, (int)hop, lane);  // (the score slots are free between hops)
                     cbeg = (int)(v >> 32);
                     cend = cbeg + (int)((v >> 12) & 0xFFFFFull);
                 } else {
@@ -1603,8 +1745,20 @@ __global__ void dc_finish_kernel(const WalkArgs a, int64_t *words, int n_levels)
 // half-size score launch runs at 0.55-0.59 of the HBM peak instead of 0.68-0.70 (the persistent grid's ramp-up and tail are
 // paid twice per level, and the kernel shares the chip with the other half's latency-bound kernels), which costs more.
 
-static unsigned lazy_resolve_blocks(int64_t walks) {  // four wavefronts per workgroup, one listed walk per wavefront and round
-    return (unsigned)std::max<int64_t>(1, std::min<int64_t>(4096, (walks + 3) / 4));
+// the resolve kernel of one lazy level: a persistent grid, one workgroup per CU when the slot's visited words go to LDS
+static void launch_lazy_resolve(gg_ctx *ctx, const WalkArgs &x, hipStream_t st) {
+    const size_t lds = sizeof(uint32_t) * (size_t)x.lz_words;
+    static const bool no_lds = getenv("GG_LZ_NO_LDS") != nullptr;
+    if (!no_lds && lds + sizeof(LzWork) * (LZ_T / 64) + sizeof(int32_t) * LZ_LIST + 256 <= 160 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void *)lazy_resolve_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 130 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(lazy_resolve_kernel<true>, dim3((unsigned)std::min<int64_t>(x.n_slots, ctx->n_cus)), dim3(LZ_T), lds, st, x);
+    } else {
+        hipLaunchKernelGGL(lazy_resolve_kernel<false>, dim3((unsigned)std::min<int64_t>(x.n_slots, 2 * ctx->n_cus)), dim3(LZ_T), 0, st, x);
+    }
 }
 
 template <int NCH>
@@ -1666,7 +1820,7 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
                 hipLaunchKernelGGL(level_advance_kernel<true>, dim3(wblocks), dim3(256), 0, hs[k], x, level > 0 ? 1 : 0, 1, sized ? 0 : 1, cap);
             } else {  // finish hop level - 1 | resolve the lists of the picked nodes nobody has stood on before | set hop `level` up
                 hipLaunchKernelGGL(level_advance_kernel<true>, dim3(wblocks), dim3(256), 0, hs[k], x, 1, 0, 0, cap);
-                hipLaunchKernelGGL(lazy_resolve_kernel, dim3(lazy_resolve_blocks(x.w_end - x.w0)), dim3(256), 0, hs[k], x);
+                launch_lazy_resolve(ctx, x, hs[k]);
                 hipLaunchKernelGGL(level_advance_kernel<true>, dim3(wblocks), dim3(256), 0, hs[k], x, 2, 1, sized ? 0 : 1, cap);
             }
             if (sized) {
@@ -1730,7 +1884,7 @@ static int run_levels(gg_ctx *ctx, WalkArgs &a, int64_t total_walks, int n_level
             hipLaunchKernelGGL(level_advance_kernel<true>, dim3(wblocks), dim3(256), 0, hs[k], x, 1, 2, wd_last, 0);
         } else {
             hipLaunchKernelGGL(level_advance_kernel<true>, dim3(wblocks), dim3(256), 0, hs[k], x, 1, 0, 0, 0);
-            hipLaunchKernelGGL(lazy_resolve_kernel, dim3(lazy_resolve_blocks(x.w_end - x.w0)), dim3(256), 0, hs[k], x);
+            launch_lazy_resolve(ctx, x, hs[k]);
             hipLaunchKernelGGL(level_advance_kernel<true>, dim3(wblocks), dim3(256), 0, hs[k], x, 2, 2, wd_last, 0);
         }
         if (a.dc_mode == 1) hipLaunchKernelGGL(dc_finish_kernel, dim3(1), dim3(1), 0, hs[k], x, ctx->dc_words.as<int64_t>() + 2 * k, level);
@@ -1886,7 +2040,10 @@ int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int fo
     a.t_order_w = ctx->t_order;
     a.t_edge_w = ctx->t_edge;
     if (a.lazy) {
-        GG_HIP(ctx, ctx->lz_list.reserve(sizeof(int32_t) * (size_t)(total_walks + 1)));
+        if (ctx->lz_list.bytes < sizeof(int32_t) * 2 * (size_t)n_slots) {  // (a launch that names slots more than once)
+            GG_HIP(ctx, ctx->lz_list.reserve(sizeof(int32_t) * 2 * (size_t)n_slots));
+            GG_HIP(ctx, hipMemset(ctx->lz_list.p, 0, ctx->lz_list.bytes));
+        }
         a.lz_info = ctx->lz_info.as<int4>();
         a.lz_pair = ctx->lz_pair.as<unsigned long long>();
         a.lz_rank = ctx->lz_rank.as<int32_t>();
@@ -1897,6 +2054,14 @@ int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int fo
         a.lz_stamp = ctx->lz_stamp;
         a.g_multi = ctx->g_multi ? 1 : 0;
         a.lz_list = ctx->lz_list.as<int32_t>();
+        {
+            static const bool stats_env = getenv("GG_LZ_STATS") != nullptr;
+            a.lz_ctr = stats_env ? ctx->dev_ctr + 1500 : nullptr;  // (behind the launches' counter words; zeroed by the build)
+        }
+        {
+            static const int budget_env = getenv("GG_LZ_BUDGET") ? atoi(getenv("GG_LZ_BUDGET")) : 2048;
+            a.lz_budget = budget_env > 0 ? budget_env : 0x7fffffff;
+        }
     }
     GG_HIP(ctx, ctx->fin_list.reserve(sizeof(int32_t) * (size_t)(total_walks + 1)));
     a.fin_list = ctx->fin_list.as<int32_t>();

@@ -194,10 +194,12 @@ class Engine:
         self._ck(lib.gg_set_tree_mode(self._ctx, int(mode), int(node_cap)))
 
     def lazy_stats(self):
-        out = np.zeros(8, dtype=np.int64)
+        out = np.zeros(24, dtype=np.int64)
         self._ck(lib.gg_lazy_stats(self._ctx, _ptr(out)))
         return dict(lazy=bool(out[0]), min_level=int(out[1]), fallback_roots=int(out[2]), fallback_rounds=int(out[3]), exact_nodes=int(out[4]),
-                    pool_entries=int(out[5]), lazy_slots=int(out[6]), max_level=int(out[7]))
+                    pool_entries=int(out[5]), lazy_slots=int(out[6]), max_level=int(out[7]), resolved=[int(x) for x in out[8:11]],
+                    candidates=int(out[11]), scan_rounds=int(out[12]), max_rounds=int(out[13]), max_degree_resolved=int(out[14]),
+                    slots_by_level=[int(x) for x in out[16:24]])
 
     def get_lazy_trees(self):
         """Raw arrays of the resident LAZY trees (tests): dict(info [R, 4], base [R], order, cstart, edge, pair)."""

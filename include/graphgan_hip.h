@@ -168,12 +168,16 @@ int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t n_roots);
  * mode: 0 = whole trees (gg_get_trees / gg_save_trees / gg_get_tree_order need them), 1 = lazy, -1 (default) = lazy for graphs of
  * 2^18 nodes and more (GG_LZ_AUTO_NODES); GG_TREE_LAZY overrides.  node_cap: the limit per root (0 = 3/8 of the nodes, at least
  * 65 536; GG_LZ_CAP).  gg_tree_info reports, for lazy trees, a depth no walk exceeds.
- * gg_lazy_stats: out8 = {resident trees are lazy, smallest exact level of the lazy slots, slots rebuilt whole so far, launches
- * repeated for it, exact nodes the BFS wrote, pool entries reserved by resolutions, lazy slots, deepest exact level}.
+ * gg_lazy_stats: out24 = {resident trees are lazy, smallest exact level of the lazy slots, slots rebuilt whole so far, launches
+ * repeated for it, exact nodes the BFS wrote, pool entries reserved by resolutions, lazy slots, deepest exact level; of the
+ * resident build: lists resolved at depth 0 / 1 / 2, candidates judged, 16-entry scan rounds, most rounds of one list, longest
+ * adjacency resolved, 0; lazy slots whose exact level is 0 .. 7}.
  * gg_get_lazy_trees (tests): the raw arrays -- info4[slot] = {first rank without a built list, exact ranks, their level,
  * capacity of the segment}, base[slot], then order / cstart / edge / pair over *n_entries entries (cstart: + n_roots). */
 int gg_set_tree_mode(gg_ctx *ctx, int32_t mode, int64_t node_cap);
-int gg_lazy_stats(gg_ctx *ctx, int64_t *out8);
+/* gg_debug_words (diagnostics): n of the context's 2 048 device counter words from `first` on. */
+int gg_debug_words(gg_ctx *ctx, int32_t first, int32_t n, uint64_t *out);
+int gg_lazy_stats(gg_ctx *ctx, int64_t *out24);
 int gg_get_lazy_trees(gg_ctx *ctx, int64_t *n_entries, int32_t *info4, int64_t *base, int32_t *order, int32_t *cstart, int32_t *edge, uint64_t *pair);
 int gg_set_trees(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, const int32_t *off,
                  const int32_t *nbr, const int64_t *nbr_base, int32_t max_depth);
