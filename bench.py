@@ -507,14 +507,35 @@ def main():
         barrier()
         dt3 = time.perf_counter() - t3
         c4 = delta(eng.counters(), c3)
-        e2e = (c4["hops"], dt3, c4["bfs_kernel_ms"], c4["bfs_trees"])
+        e2e_whole = (c4["hops"], dt3, c4["bfs_kernel_ms"], c4["bfs_trees"])
+        # ... and the same with LAZY trees (round 6; what gg_epoch_add builds by default on a graph of this size): exact through
+        # the last level that fits a node limit, deeper children lists resolved by the walks that stand on them -- same walks, bit
+        # for bit (tests/test_gpu_lazy.py, tools/lazy_time.py).  One untimed batch first: the lazy arrays are allocated there.
+        eng.set_tree_mode(1)
+        eng.build_trees(workloads.bench_roots(rowptr, args.roots, rank, world, args.seed + 201), device=True)
+        step(nxt + args.fresh_batches)
+        c3 = eng.counters()
+        barrier()
+        t3 = time.perf_counter()
+        lz = []
+        for k in range(args.fresh_batches):
+            fresh = workloads.bench_roots(rowptr, args.roots, rank, world, args.seed + 301 + k)
+            eng.build_trees(fresh, device=True)
+            step(nxt + args.fresh_batches + 1 + k)
+            lz.append(eng.lazy_stats())
+        barrier()
+        dt3 = time.perf_counter() - t3
+        c4 = delta(eng.counters(), c3)
+        e2e = (c4["hops"], dt3, c4["bfs_kernel_ms"], c4["bfs_trees"], lz)
+        eng.set_tree_mode(-1)
 
     hops, reads, rows_scored = c["hops"], c["nbr_reads"], c["rows_scored"]
     walk_ms, launches = c["walk_kernel_ms"], c["walk_launches"]  # HIP events of the profiled walk launches and how many that was
     calls = 2 * args.steps
-    sums = ctl.sum([hops, c["d_pairs"], c["g_pairs"], e2e[0] if e2e else 0.0])
+    sums = ctl.sum([hops, c["d_pairs"], c["g_pairs"], e2e[0] if e2e else 0.0, e2e_whole[0] if e2e else 0.0])
     tot = np.array([sums[0], sums[1], sums[2], ctl.max(dt)])
     e2e_dt = ctl.max(e2e[1]) if e2e else 0.0
+    e2e_whole_dt = ctl.max(e2e_whole[1]) if e2e else 0.0
     if rank != 0:
         eng.close()
         return
@@ -697,11 +718,21 @@ def main():
         out["comm"] = dict(comm, what="rank 0's gradient exchanges up to the end of the timed region (RCCL over xGMI): optimizer steps that exchanged "
                                       "fixed-capacity row packs (sparse) / reduce-scatter + all-gather of the accumulators (dense), bytes sent")
     if e2e:
+        lzs = e2e[4]
         out["end_to_end_with_tree_build"] = {
             "value": sums[3] / e2e_dt, "unit": "edges/s",
-            "what": "%d fresh batches of %d roots per GPU: gg_build_trees_device + one step each (trees not resident)" % (args.fresh_batches, R),
+            "what": "%d fresh batches of %d roots per GPU: gg_build_trees_device (LAZY trees: exact through the last level that fits the node "
+                    "limit, deeper children lists resolved by the walks) + one step each (trees not resident)" % (args.fresh_batches, R),
             "s_per_batch": e2e_dt / args.fresh_batches, "bfs_kernel_ms_per_batch": e2e[2] / args.fresh_batches,
-            "bfs_us_per_tree": 1e3 * e2e[2] / max(e2e[3], 1)}
+            "bfs_us_per_tree": 1e3 * e2e[2] / max(e2e[3], 1),
+            "slots_rebuilt_whole_per_batch": (lzs[-1]["fallback_roots"] - 0) / (args.fresh_batches + 1.0),
+            "exact_nodes_per_root": float(np.mean([z["exact_nodes"] for z in lzs])) / R, "pool_entries_per_root": float(np.mean([z["pool_entries"] for z in lzs])) / R,
+            "lazy_slots_by_exact_level": lzs[-1]["slots_by_level"]}
+        out["end_to_end_with_tree_build_whole_trees"] = {
+            "value": sums[4] / e2e_whole_dt, "unit": "edges/s",
+            "what": "the same with whole trees (rounds 2-5: every root's BFS to its last node)",
+            "s_per_batch": e2e_whole_dt / args.fresh_batches, "bfs_kernel_ms_per_batch": e2e_whole[2] / args.fresh_batches,
+            "bfs_us_per_tree": 1e3 * e2e_whole[2] / max(e2e_whole[3], 1)}
         # the number a user of this configuration sees when the trees are NOT resident (an epoch over all N roots is a
         # sequence of exactly these batches): beside the resident-trees headline, where the driver's record keeps it
         out["roofline"]["with_tree_build_edges_per_sec"] = sums[3] / e2e_dt

@@ -1402,7 +1402,7 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
                     a.base_w[slot] = off;
                     a.lz_info[slot] = lazy_stop ? make_int4(head, tail, depth, seg) : make_int4(expect, expect, depth, seg);
                     a.lz_cursor[slot] = lazy_stop ? tail : expect;
-                    if (lazy_stop) atomicMax(&a.stats[3], 1024 - depth);  // (smallest lazy level of the launch: 1024 - stats[3])
+                    if (lazy_stop) { atomicMax(&a.stats[3], 1024 - depth); atomicMax(&a.stats[5], depth); }  // (smallest lazy level of the launch: 1024 - stats[3]; deepest: stats[5])
                 } else if (complete) {
                     // no room among the segments: the slot gets its whole tree in the arena before anything walks on it
                     a.base_w[slot] = 0;
@@ -1610,14 +1610,16 @@ static int bfs_run(gg_ctx *ctx, BfsArgs &a, int n_items, bool lazy, int32_t *sta
     return GG_OK;
 }
 
-// Is the next build lazy?  gg_set_tree_mode / GG_TREE_LAZY decide; by default graphs from GG_LZ_AUTO_NODES (2^18) nodes on.
+// Is the next build lazy?  gg_set_tree_mode / GG_TREE_LAZY decide; by default (-1) the trees of an epoch's root batches
+// (gg_epoch_add: built, walked twice, dropped) on graphs from GG_LZ_AUTO_NODES (2^18) nodes on -- trees that stay resident for many
+// steps (gg_build_trees_device called directly) are built whole: every step would resolve its lists anew.
 // Lazy trees need what the walks' resolution reads: a symmetric adjacency (g_rev), degrees that fit the 20 count bits of a pair.
 bool lazy_build_wanted(const gg_ctx *ctx) {
     int mode = ctx->tree_mode;
     if (const char *e = getenv("GG_TREE_LAZY")) mode = atoi(e);
     if (mode < 0) {
         const long long auto_nodes = getenv("GG_LZ_AUTO_NODES") ? atoll(getenv("GG_LZ_AUTO_NODES")) : (1ll << 18);
-        mode = ctx->n_node >= auto_nodes ? 1 : 0;
+        mode = (ctx->in_epoch_add && ctx->n_node >= auto_nodes) ? 1 : 0;
     }
     return mode > 0 && !ctx->lz_force_whole && ctx->g_rev && ctx->g_max_deg < 0xFFFFF && !getenv("GG_BFS_V1");
 }
@@ -1626,9 +1628,11 @@ bool lazy_build_wanted(const gg_ctx *ctx) {
 // default -- the node count -- stops in front of the level that holds the bulk of a small-world graph; components up to
 // `whole_max` nodes are built whole.  gg_set_tree_mode's node_cap (tests) sets both.
 static void lazy_limits(const gg_ctx *ctx, int64_t *cap, int64_t *whole_max) {
-    int64_t c = ctx->lz_cap;
-    if (const char *e = getenv("GG_LZ_CAP")) c = atoll(e);
-    *cap = c > 0 ? c : std::max<int64_t>(ctx->n_node, 2);
+    const int64_t c = ctx->lz_cap;
+    // (default 3/8 of the nodes: on the 10^6-node bench graph the node count itself lets 7 % of the roots expand their third level
+    // -- up to 900 000 entries each, as dear as whole trees: 78 instead of 44 ms per 16 384 roots -- while 3/8 stops 2.4 % one level
+    // early; those get whole trees right away, below)
+    *cap = c > 0 ? c : getenv("GG_LZ_CAP") ? std::max<int64_t>(2, atoll(getenv("GG_LZ_CAP"))) : std::max<int64_t>(65536, (int64_t)ctx->n_node * 3 / 8);
     *whole_max = c > 0 ? c : 65536;
 }
 
@@ -1724,11 +1728,33 @@ static int build_trees_lazy(gg_ctx *ctx, const int32_t *roots, int32_t n_roots) 
     ctx->tree_max_depth = stats[0];
     ctx->tree_max_list = ctx->g_max_deg + 1;  // (a resolved list holds up to the node's degree)
     ctx->t_edge_valid = true;
-    if (stats[4] > 0) {  // slots that found no room among the segments: whole trees in the arena, now
+    // Slots that stopped a level (or more) before the batch's deepest exact level: their walks resolve through two levels of
+    // hubs and, more often than not, leave the resolvable levels -- the launch would be voided and repeated for them.  When they
+    // are few they get their whole trees now (gg_set_tree_mode with a node_cap: tests keep every slot as built).
+    int early = 0;
+    if (ctx->lz_cap == 0 && !getenv("GG_LZ_NO_EARLY") && stats[5] > ctx->lz_min_level && ctx->lz_min_level < 0x7fffffff) {
+        std::vector<int4> info((size_t)n_roots);
+        GG_HIP(ctx, hipMemcpy(info.data(), ctx->lz_info.p, sizeof(int4) * (size_t)n_roots, hipMemcpyDeviceToHost));
+        std::vector<int32_t> flag((size_t)n_roots, 0);
+        for (int r = 0; r < n_roots; ++r)
+            if (info[r].x < info[r].y && info[r].z < stats[5]) { flag[r] = 1; ++early; }
+        if (early > 0 && early <= std::min<int64_t>(arena_roots, n_roots / 8)) {
+            std::vector<int32_t> cur((size_t)n_roots);
+            GG_HIP(ctx, hipMemcpy(cur.data(), ctx->lz_flag.p, sizeof(int32_t) * (size_t)n_roots, hipMemcpyDeviceToHost));
+            for (int r = 0; r < n_roots; ++r) flag[r] |= cur[r];
+            GG_HIP(ctx, hipMemcpy(ctx->lz_flag.p, flag.data(), sizeof(int32_t) * (size_t)n_roots, hipMemcpyHostToDevice));
+        } else {
+            early = 0;
+        }
+    }
+    if (stats[4] > 0 || early > 0) {  // (and the slots that found no room among the segments): whole trees in the arena, now
         int rebuilt = 0;
         rc = lazy_fallback_rebuild(ctx, &rebuilt);
         if (rc == GG_ECAPACITY) rc = lazy_rebuild_whole(ctx);
         if (rc != GG_OK) return rc;
+        if (ctx->t_lazy) {  // the smallest exact level of what is still lazy
+            ctx->lz_min_level = early > 0 ? stats[5] : ctx->lz_min_level;
+        }
     }
     return GG_OK;
 }

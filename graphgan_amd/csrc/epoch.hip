@@ -118,7 +118,9 @@ int gg_epoch_add(gg_ctx *ctx, const int32_t *roots, int32_t n_roots, int32_t do_
     int rc = ensure_q3_store(ctx);
     if (rc != GG_OK) return rc;
     if (n_roots > 0 && (do_d || do_g)) {
+        ctx->in_epoch_add = true;   // (also tells the build that these trees are walked twice and dropped: lazy by default on large graphs)
         rc = gg_build_trees_device(ctx, roots, n_roots);  // (waits for everything in flight; Q3 rows of the slots zeroed)
+        ctx->in_epoch_add = false;
         if (rc != GG_OK) return rc;
         rc = q3_copy(ctx, n_roots, /*to_store=*/false);
         if (rc != GG_OK) return rc;

@@ -144,6 +144,10 @@ int rescan_table_finite(gg_ctx *ctx, int which) {
     const int64_t nE = (int64_t)ctx->n_node * ctx->ld;
     hipLaunchKernelGGL(table_finite_kernel, dim3((unsigned)std::min<int64_t>(2048, (nE + 255) / 256)), dim3(256), 0, ctx->stream, M.E, M.b, nE, (int64_t)ctx->n_node, w);
     GG_HIP(ctx, hipGetLastError());
+    // The scan is only ENQUEUED on the main stream.  A walk launch of the side stream (gg_prepare_g_begin) reads the generator's
+    // flag in its reset kernel and is ordered behind the main stream only through ev_gen_pass / gen_dirty: without this it could
+    // read the flag before the scan has written it (advisor, round 5).
+    if (which == 0) ctx->gen_dirty = true;
     return GG_OK;
 }
 
@@ -1219,7 +1223,10 @@ int state_io(gg_ctx *ctx, const char *path, bool save) {
     }
     fclose(f);
     generator_changed(ctx);
-    for (int m = 0; m < 2; ++m) (void)gg::rescan_table_finite(ctx, m);
+    for (int m = 0; m < 2; ++m) {  // (the load path only: a save returns above)
+        const int rs = gg::rescan_table_finite(ctx, m);
+        if (rc == GG_OK) rc = rs;  // an enqueue failure would leave the finiteness flags stale
+    }
     if (rc == GG_OK)  // step counts / beta powers only once every table arrived
         for (int m = 0; m < 2; ++m) { ctx->model[m].t = loaded[m].t; ctx->model[m].b1p = loaded[m].b1p; ctx->model[m].b2p = loaded[m].b2p; }
     return rc;

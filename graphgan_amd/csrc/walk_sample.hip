@@ -124,7 +124,11 @@ struct WalkArgs {
 };
 
 // ---- cross-lane moves without an LDS round trip (DPP): shifts / rotations inside a row of 16 lanes, row broadcasts across rows.
-// (UNVALIDATED ON HARDWARE in this branch: compiled and checked against a CPU model of the DPP controls only.)
+// (On the product path of every walk kernel since round 5: the bit-exact walk tests -- tests/test_gpu_walk.py, all seven
+// decompositions -- run through them.  row_bcast:15 / :31 and row_newbcast exist on gfx9-class targets only.)
+#if !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__) && defined(__HIP_DEVICE_COMPILE__)
+#error "walk_sample.hip uses gfx9 DPP row broadcasts: build for gfx950 (ARCH in the Makefile)"
+#endif
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ uint64_t dpp_u64(uint64_t v) {  // both halves moved by the same control; lanes without a source get 0
     const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, ROW_MASK, 0xf, false);
@@ -291,10 +295,15 @@ __device__ __forceinline__ unsigned long long lz_make(int start, unsigned long l
 struct LzBitsGlobal {
     const uint2 *bm;
     __device__ __forceinline__ uint32_t operator()(int i) const { return bm[i].x; }
+    // member index of node u (its visited word wx): members below its word + below its bit
+    __device__ __forceinline__ int index(int u, uint32_t wx) const { return (int)bm[u >> 5].y + __popc(wx & ((1u << (u & 31)) - 1u)); }
 };
 struct LzBitsLds {
-    const uint32_t *w;
+    const uint32_t *w;  // [lz_words] visited words in LDS
+    const uint2 *bm;    // (the index in global memory: members below a word.  Measured and dropped: members below every 16th word in
+                        // LDS as well + popcounts of up to 15 LDS words -- 72 instead of 61 ms per 16 384 roots: the LDS reads cost more than the one load)
     __device__ __forceinline__ uint32_t operator()(int i) const { return w[i]; }
+    __device__ __forceinline__ int index(int u, uint32_t wx) const { return (int)bm[u >> 5].y + __popc(wx & ((1u << (u & 31)) - 1u)); }
 };
 template <class Bits>
 __device__ __forceinline__ bool lz_in(const Bits &bits, int x) { return (bits(x >> 5) >> (x & 31)) & 1u; }
@@ -372,11 +381,11 @@ __device__ __forceinline__ void lz_flat_scan(const WalkArgs &a, const Bits &bits
                 if (vis[k]) atomicOr(&ws->mask[0], 1ull << own[k]);
         } else {
 #pragma unroll
-            for (int k = 0; k < U; ++k) pr[k] = vis[k] ? bm[u[k] >> 5].y : 0u;
+            for (int k = 0; k < U; ++k) pr[k] = vis[k] ? (uint32_t)bits.index(u[k], wx[k]) : 0u;
 #pragma unroll
             for (int k = 0; k < U; ++k) {
                 if (vis[k]) {
-                    const int r = rk[pr[k] + __popc(wx[k] & ((1u << (u[k] & 31)) - 1u))];
+                    const int r = rk[pr[k]];
                     if (MODE == 0) {
                         if (r < below) atomicOr(&ws->mask[0], 1ull << own[k]);
                     } else {
@@ -1184,18 +1193,26 @@ __global__ __launch_bounds__(LZ_T) void lazy_resolve_kernel(const WalkArgs a) {
             const int found = s_n, n = min(found, LZ_LIST);
             if (n > 0) {
                 const int slot = a.slots[item];
-                if (LDS_BITS) {
+                if (LDS_BITS && !(a.exp & 8192)) {  // (GG_WALK_EXPERIMENT & 8192 / 4096: timing ablations -- no copy / no resolution; results are WRONG)
                     const uint2 *const src = a.lz_bm + (size_t)slot * a.lz_words;
-                    for (int i = tid; i < a.lz_words; i += LZ_T) lz_lds[i] = src[i].x;
+                    for (int i0 = tid; i0 < a.lz_words; i0 += 8 * LZ_T) {  // (eight loads in flight per thread: one at a time this copy was 31 memory round trips per slot)
+                        uint32_t wv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) wv[u] = i0 + u * LZ_T < a.lz_words ? src[i0 + u * LZ_T].x : 0u;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (i0 + u * LZ_T < a.lz_words) lz_lds[i0 + u * LZ_T] = wv[u];
+                    }
                     __syncthreads();
                 }
                 for (;;) {
                     const int i = __builtin_amdgcn_readfirstlane(atomicAdd(&s_next, lane == 0 ? 1 : 0));  // (a scalar: the loop branches on it; no lane-0 branch, see lazy_resolve_wave)
                     if (i >= n) break;
+                    if (a.exp & 4096) continue;
                     const int64_t w = w0 + s_list[i];
                     const int4 sc2 = a.st_const2[w];
                     const int64_t tbase = ((int64_t)sc2.y << 32) | (unsigned)sc2.x;
-                    if (LDS_BITS) (void)lazy_resolve_wave(a, LzBitsLds{lz_lds}, ws, slot, tbase, a.st_rank[w], a.st_cur[w], a.st_prev[w], a.level, lane);
+                    if (LDS_BITS) (void)lazy_resolve_wave(a, LzBitsLds{lz_lds, a.lz_bm + (size_t)slot * a.lz_words}, ws, slot, tbase, a.st_rank[w], a.st_cur[w], a.st_prev[w], a.level, lane);
                     else (void)lazy_resolve_wave(a, LzBitsGlobal{a.lz_bm + (size_t)slot * a.lz_words}, ws, slot, tbase, a.st_rank[w], a.st_cur[w], a.st_prev[w], a.level, lane);
                 }
             }
