@@ -747,12 +747,17 @@ def main():
         bias = eng.get_bias(0)
         embg = eng.get_embeddings(0)
         v, sample = cpu_baseline(args, n, rowptr, col, embg, bias, roots, args.cpu_baseline_seconds)
-        out["cpu_baseline"] = {"value": v, "unit": "edges/s", "cores": 1, "host_cores_on_box": os.cpu_count(), "kind": "port", "sample": sample}
+        one_core = {"value": v, "unit": "edges/s", "cores": 1, "host_cores_on_box": os.cpu_count(), "kind": "port", "sample": sample}
         out["walk_kernel_vs_cpu"] = out["walk_kernel_edges_per_sec"] / v if v > 0 and out["walk_kernel_edges_per_sec"] else None
-        try:  # the same port on many cores (a reported baseline like the one above; a failure here never costs the bench line)
-            out["cpu_baseline_all_cores"] = cpu_baseline_threads(args, n, rowptr, col, embg, bias, roots, 8.0, min(64, max(1, (os.cpu_count() or 2) // 2)))
+        # `cpu_baseline` = the same port on MANY host cores (the north star's "timed on the same box's host cores, core count stated");
+        # the one-core figure stays beside it.  A failure of the threaded leg never costs the bench line: the one-core figure stands in.
+        try:
+            many = cpu_baseline_threads(args, n, rowptr, col, embg, bias, roots, 8.0, min(64, max(1, (os.cpu_count() or 2) // 2)))
         except Exception as e:  # noqa: BLE001
-            out["cpu_baseline_all_cores"] = {"error": repr(e)}
+            many = {"error": repr(e)}
+        out["cpu_baseline"] = many if "value" in many else one_core
+        out["cpu_baseline_one_core"] = one_core
+        out["cpu_baseline_all_cores"] = many  # (the key of round 5's records)
         out["cpu_baseline_faithful"] = cpu_baseline_faithful()
     eng.close()
     print(json.dumps(out))
