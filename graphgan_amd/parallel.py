@@ -4,8 +4,9 @@ is a single ``tf.Session``, graph_gan.py:57-61).
 Data path: walks shard by root with no collective (the walk RNG is keyed by root id, so any
 partition gives the same walks); the gradient exchange is an RCCL all-reduce inside
 ``libgraphgan_hip.so`` (``gg_comm_init``).  This module only (a) partitions roots, (b) carries
-the 128-byte RCCL unique id between processes over ``torch.distributed`` (gloo, CPU) and
-(c) provides the barrier / max-over-ranks used for timing.
+the 128-byte RCCL unique id between the processes and (c) provides the barrier / max-over-ranks used for
+timing -- over a TCP star of the node's ranks (standard library; ``torch.distributed`` / gloo stays
+available as ``Control(backend="gloo")`` or GG_CTL_BACKEND=gloo for launchers that bring it).
 """
 from __future__ import annotations
 
@@ -41,23 +42,108 @@ def shard_roots(roots, rank, world, weights=None):
     return roots[owner == rank].copy()
 
 
-class Control:
-    """Control plane over torch.distributed (gloo): never touches device memory."""
+class _SocketGroup:
+    """The ranks of one node as a star over TCP: rank 0 listens on MASTER_ADDR : (MASTER_PORT + 29, or GG_CTL_PORT), the others
+    connect; one primitive -- every rank contributes a picklable object, every rank gets the list of all of them in rank order --
+    carries the few hundred bytes the control plane ever moves (the 128-byte RCCL id, three scalars per timing, the 12 bytes per
+    row of the sharded all-pairs evaluation).  No torch: the engine's only tensors are its embedding tables."""
 
-    def __init__(self, rank=None, world=None, backend="gloo"):
+    _live = {}
+
+    @classmethod
+    def get(cls, rank, world):
+        import socket
+        addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = int(os.environ.get("GG_CTL_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 29))
+        key = (addr, port, rank, world)
+        if key not in cls._live:
+            cls._live[key] = cls(socket, addr, port, rank, world)
+        return cls._live[key]
+
+    def __init__(self, socket, addr, port, rank, world):
+        import time
+        self.rank, self.world, self.peers, self.sock = rank, world, {}, None
+        if rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(world)
+            srv.settimeout(300.0)
+            while len(self.peers) < world - 1:
+                c, _ = srv.accept()
+                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                self.peers[self._recv(c)] = c
+            srv.close()
+        else:
+            deadline = time.time() + 300.0
+            while True:
+                try:
+                    self.sock = socket.create_connection((addr, port), timeout=300.0)
+                    break
+                except OSError:
+                    if time.time() > deadline:
+                        raise
+                    time.sleep(0.05)
+            self.sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            self._send(self.sock, rank)
+
+    @staticmethod
+    def _send(c, obj):
+        import pickle
+        import struct
+        b = pickle.dumps(obj, protocol=4)
+        c.sendall(struct.pack("<Q", len(b)) + b)
+
+    @staticmethod
+    def _recv(c):
+        import pickle
+        import struct
+
+        def take(n):
+            out = bytearray()
+            while len(out) < n:
+                chunk = c.recv(min(1 << 20, n - len(out)))
+                if not chunk:
+                    raise ConnectionError("control plane: a rank closed its connection")
+                out += chunk
+            return bytes(out)
+        return pickle.loads(take(struct.unpack("<Q", take(8))[0]))
+
+    def all_gather(self, obj):
+        if self.rank == 0:
+            items = [obj] + [self._recv(self.peers[r]) for r in range(1, self.world)]
+            for r in range(1, self.world):
+                self._send(self.peers[r], items)
+            return items
+        self._send(self.sock, obj)
+        return self._recv(self.sock)
+
+
+class Control:
+    """Control plane of a multi-GPU run: never touches device memory.  backend "socket" (default): a TCP star of the node's
+    ranks, standard library only; "gloo": torch.distributed, for launchers that already initialised it."""
+
+    def __init__(self, rank=None, world=None, backend=None):
         r, w, lr = env_rank()
         self.rank = r if rank is None else rank
         self.world = w if world is None else world
         self.local_rank = lr
         self.dist = None
+        self.group = None
+        backend = backend or os.environ.get("GG_CTL_BACKEND", "socket")
         if self.world > 1:
-            import torch.distributed as dist
-            if not dist.is_initialized():
-                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                dist.init_process_group(backend, rank=self.rank, world_size=self.world)
-            self.dist = dist
+            if backend == "gloo":
+                import torch.distributed as dist
+                if not dist.is_initialized():
+                    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                    dist.init_process_group(backend, rank=self.rank, world_size=self.world)
+                self.dist = dist
+            else:
+                self.group = _SocketGroup.get(self.rank, self.world)
 
     def broadcast_bytes(self, payload, n, src=0):
+        if self.group is not None:
+            return bytes(self.group.all_gather(bytes(payload) if self.rank == src else b"")[src])
         if self.dist is None:
             return payload
         import torch
@@ -68,11 +154,15 @@ class Control:
         return bytes(buf.numpy().tobytes())
 
     def barrier(self):
-        if self.dist is not None:
+        if self.group is not None:
+            self.group.all_gather(None)
+        elif self.dist is not None:
             self.dist.barrier()
 
     def sum(self, values):
         values = np.asarray(values, dtype=np.float64)
+        if self.group is not None:
+            return np.sum(np.stack(self.group.all_gather(values)), axis=0)
         if self.dist is None:
             return values
         import torch
@@ -81,6 +171,8 @@ class Control:
         return t.numpy()
 
     def max(self, value):
+        if self.group is not None:
+            return float(max(self.group.all_gather(float(value))))
         if self.dist is None:
             return float(value)
         import torch
@@ -91,6 +183,8 @@ class Control:
     def all_gather_concat(self, arr):
         """Concatenation, in rank order, of every rank's 1-D array (lengths may differ)."""
         arr = np.ascontiguousarray(arr)
+        if self.group is not None:
+            return np.concatenate(self.group.all_gather(arr))
         if self.dist is None:
             return arr.copy()
         import torch

@@ -1,6 +1,6 @@
 """The committed 20-outer-epoch accuracy runs of DESIGN.md section 8 (reference schedule on CA-GrQc, 8 walk / shuffle seeds):
 oracle trainer (tests/golden/oracle_epochs20.json, tests/run_oracle_epochs.py: ~4 h on 8 cores) against the engine on an MI355X
-(profiles/r3_engine_epochs20.json, tests/run_engine_epochs.py: 2.8 s per epoch).  Neither can be re-run inside a CPU test
+(profiles/r6_engine_epochs20.json, tests/run_engine_epochs.py on the round-6 build -- the atomic-free batch-64 gradient kernel, bit-reproducible runs: ~2.8 s per epoch; profiles/r3_engine_epochs20.json is the round-3 build with fp32 atomics).  Neither can be re-run inside a CPU test
 run; this test re-derives, from the two files, every statement the design document makes about them."""
 import json
 import os
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_final_accuracy_of_the_full_schedule_agrees_within_half_a_percent_on_the_seed_mean():
     o = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_epochs20.json")))["epochs"]
-    e = json.load(open(os.path.join(ROOT, "profiles", "r3_engine_epochs20.json")))["epochs"]
+    e = json.load(open(os.path.join(ROOT, "profiles", "r6_engine_epochs20.json")))["epochs"]
     seeds = sorted(set(o) & set(e), key=int)
     assert len(seeds) == 8
     O = np.array([o[s] for s in seeds])   # [seed, before + 20 epochs, (gen, dis)]

@@ -23,7 +23,7 @@ def _free_port():
 
 def _worker(rank, world, port, out):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), GG_CTL_BACKEND="gloo")
     import torch.distributed as dist
     from graphgan_amd import parallel
     from oracle import graphgan_oracle as orc
@@ -183,7 +183,7 @@ class _ReplicaEngine(object):
 
 def _trainer_worker(rank, world, port, base, out):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), GG_CTL_BACKEND="gloo")
     import torch
     import torch.distributed as dist
     from graphgan_amd import engine as eng_mod, graph_gan
@@ -261,7 +261,7 @@ class _BatchedReplicaEngine(_ReplicaEngine):
 
 def _batched_trainer_worker(rank, world, port, base, out, update_ratio):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), GG_CTL_BACKEND="gloo")
     import torch
     import torch.distributed as dist
     from graphgan_amd import engine as eng_mod, graph_gan
@@ -320,7 +320,7 @@ class _ScoreEngine(object):
 
 def _allpairs_worker(rank, world, port, out):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), GG_CTL_BACKEND="gloo")
     import torch.distributed as dist
     from graphgan_amd import parallel
     ctl = parallel.Control()
@@ -350,3 +350,40 @@ def test_all_pairs_consumer_sharded_over_ranks(tmp_path):
     assert got["ms"] == 1.0 + 101                                            # the slowest rank's kernel time
     w2 = _ScoreEngine(E, b).all_score_reduce(np.array([7, 300]), logsumexp=False)
     assert np.array_equal(got["smax"], w2["max"]) and np.array_equal(got["sarg"], w2["argmax"])
+
+
+def _socket_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    os.environ.pop("GG_CTL_BACKEND", None)
+    from graphgan_amd import parallel
+    ctl = parallel.Control()  # the default control plane: a TCP star of the ranks, no torch.distributed
+    assert ctl.group is not None and ctl.dist is None and (ctl.rank, ctl.world) == (rank, world)
+    uid = ctl.broadcast_bytes(bytes(range(128)) if rank == 0 else b"", 128)
+    s = ctl.sum(np.arange(5, dtype=np.float64) * (rank + 1))
+    m = ctl.max(10.0 * rank)
+    cat = ctl.all_gather_concat(np.full(rank + 1, rank, dtype=np.int32))
+    ctl.barrier()
+    ctl2 = parallel.Control()  # a second control object of the process shares the connection
+    assert ctl2.group is ctl.group and ctl2.max(1.0) == 1.0
+    np.savez(out % rank, uid=np.frombuffer(uid, np.uint8), s=s, m=m, cat=cat)
+
+
+def test_socket_control_plane_three_ranks(tmp_path):
+    """parallel.Control without torch.distributed (north star: "no PyTorch-ROCm needed"): broadcast of the 128-byte RCCL id,
+    sum, max, ragged all-gather and barrier over three processes."""
+    import multiprocessing as mp
+    out = str(tmp_path / "rank%d.npz")
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ps = [ctx.Process(target=_socket_worker, args=(r, 3, port, out)) for r in range(3)]
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    for r in range(3):
+        got = np.load(out % r)
+        assert np.array_equal(got["uid"], np.arange(128, dtype=np.uint8))
+        assert np.array_equal(got["s"], np.arange(5) * 6.0) and got["m"] == 20.0
+        assert np.array_equal(got["cat"], np.array([0, 1, 1, 2, 2, 2], dtype=np.int32))
