@@ -238,7 +238,7 @@ XGMI_EFFICIENCY = 0.8   # assumed payload fraction of the link rate for RCCL sen
 HOST_ROUND_TRIP_MS = 0.03  # the owner exchange's two small host synchronisations (count matrix, largest owner), each
 
 
-def comm_model(n, ld, d_rows_touched, g_rows_touched, d_pairs, g_pairs, step_ms=None, d_pass_ms=None, g_walk_ms=None):
+def comm_model(n, ld, d_rows_touched, g_rows_touched, d_pairs, g_pairs, step_ms=None, d_pass_ms=None, g_walk_ms=None, epoch=None):
     """Bytes ONE rank sends per step (D exchange + G exchange) at P = 2 / 4 / 8 under each strategy, from this run's real
     per-rank counts (touched rows of the two passes, pairs of the two passes).  Weak scaling: every rank brings the same
     counts.  dense = reduce-scatter + all-gather of the [N, ld + 1] accumulators (+ the int32 row flags);
@@ -278,6 +278,21 @@ def comm_model(n, ld, d_rows_touched, g_rows_touched, d_pairs, g_pairs, step_ms=
         out["P=%d" % P] = entry
     out["assumptions"] = {"xgmi_link_GBs": XGMI_LINK_GBS, "links_used": "P - 1 (one per peer)", "link_efficiency": XGMI_EFFICIENCY,
                           "host_round_trip_ms": HOST_ROUND_TRIP_MS, "step_ms": step_ms, "d_pass_ms": d_pass_ms, "g_walk_ms": g_walk_ms}
+    if epoch:
+        # The OTHER metric that scales: one outer epoch of GraphGAN.train() over ALL roots (root batches, gg_epoch_*): its prepare
+        # phase -- tree build, D- and G-mode walks of every root batch -- has NO collective (roots are sharded, the walks' RNG is
+        # keyed by the root), the inner passes exchange once per optimizer step over fused batches of 2^22 rows (dense: at that
+        # size every row of the table is touched).  Strong scaling of a fixed epoch: T(P) = (prepare + passes) / P + steps x exchange.
+        nb, prep, pas = epoch["n_batches"], epoch["prepare_s_per_batch"], epoch["pass_s_per_batch"]
+        steps = -(-int(nb * d_pairs) // (1 << 22)) + -(-int(nb * g_pairs) // (1 << 22))
+        t1 = nb * (prep + pas)
+        ep = {"what": "MODELLED strong scaling of one outer epoch over all %d roots (%.0f root batches of this run's size): prepare phase "
+                      "without any collective, %d optimizer steps with a dense exchange each" % (epoch["n_roots"], nb, steps),
+              "one_gpu_s": t1, "prepare_share_one_gpu": nb * prep / t1}
+        for P in (2, 4, 8):
+            tp = t1 / P + steps * 1e-3 * out["P=%d" % P]["modelled_time_dense_ms"]
+            ep["P=%d" % P] = {"epoch_s": tp, "strong_scaling_efficiency_estimate": t1 / (P * tp)}
+        out["epoch_over_all_roots"] = ep
     return out
 
 
@@ -708,9 +723,13 @@ def main():
         out["batch_of_rounds_1_2"] = cont
     if c["d_passes_timed"] and c["g_passes_timed"]:
         d_pass_ms = (c["d_grad_ms"] + c["d_opt_ms"]) / c["d_passes_timed"]
+        g_pass_ms = (c["g_grad_ms"] + c["g_opt_ms"]) / c["g_passes_timed"] if c["g_passes_timed"] else None
         out["comm_model"] = dict(comm_model(n, eng.n_emb + (-eng.n_emb) % 4, c["d_rows_timed"] / c["d_passes_timed"], c["g_rows_timed"] / c["g_passes_timed"],
                                             c["d_pairs"] / args.steps, c["g_pairs"] / args.steps, step_ms=1e3 * dt / args.steps, d_pass_ms=d_pass_ms,
-                                            g_walk_ms=walk_ms / launches if launches else None),
+                                            g_walk_ms=walk_ms / launches if launches else None,
+                                            epoch=(dict(n_roots=n, n_batches=n / float(R), pass_s_per_batch=1e-3 * (d_pass_ms + g_pass_ms),
+                                                        prepare_s_per_batch=max(e2e_dt / args.fresh_batches - 1e-3 * (d_pass_ms + g_pass_ms), 0.0))
+                                                   if e2e and d_pass_ms is not None and g_pass_ms is not None else None)),
                                  what="bytes one rank would send per step for its two gradient exchanges, from this run's per-rank touched rows / pairs "
                                       "(unit B), the time they would take on xGMI and the weak-scaling efficiency that follows; a MODEL, NOT measured "
                                       "(no multi-GPU box has run this code)")
