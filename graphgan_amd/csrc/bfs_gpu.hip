@@ -88,6 +88,7 @@ struct BfsArgs {
     long long lz_alloc_end;    // entries the segments may take; a slot that does not fit raises lz_flag (whole tree in the arena) and stats[4]
     int64_t *base_w;           // [slots]   LAZY: t_base, written here
     int32_t *lz_flag;          // [slots]
+    int lz_ablate;             // GG_LZ_ABLATE (timing only, results WRONG): 1 = no rank scatter, 2 = no copy out of the scratch tree, 4 = no visited index
 };
 
 __device__ __forceinline__ int lanes_below(unsigned long long m) {  // popcount of m restricted to the lanes below this one
@@ -1345,7 +1346,7 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
             }
             __syncthreads();  // (also: every queue / cstart store of the scratch tree has landed)
             const long long off = s_off;
-            if (off >= 0) {
+            if (off >= 0 && !(a.lz_ablate & 2)) {
                 int32_t *const o_out = a.order + off, *const e_out = a.edge + off, *const c_out = a.cstart + off;
                 for (int i0 = tid; i0 < n_keep; i0 += 4 * B2_T) {
                     int vo[4], ve[4];
@@ -1363,7 +1364,7 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
                 }
                 for (int i = tid; i <= n_built; i += B2_T) c_out[i] = ldi(&cstart[i]);
             }
-            if (lazy_stop && off >= 0) {
+            if (lazy_stop && off >= 0 && !(a.lz_ablate & 4)) {
                 // the visited set of the exact levels with its popcount index: {word, members below the word}
                 uint2 *const zb = a.lz_bm + (size_t)slot * a.bm_words;
                 int32_t *const zr = a.lz_rank + off;
@@ -1384,8 +1385,14 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
                     run += (int)__popc(wd);
                 }
                 __syncthreads();  // (the index has landed: the ranks below read it back)
-                // rank of every member by its index
-                for (int i0 = tid; i0 < tail; i0 += 8 * B2_T) {
+                // rank of every member by its index.  A member's index is as good as random: written straight to memory every 4-byte
+                // store is a read-modify-write of its own line -- 25 of the kernel's 46 ms per 16 384 roots (timing ablation,
+                // GG_LZ_ABLATE=1; the PMC counters charge the kernel 17 MB of HBM traffic per root).  So: the indices once, in queue
+                // order, into the scratch row of first-child ranks (copied out above: free); then the index space through the LDS
+                // -- the bitmap's words are in `zb` now -- in blocks of W entries, each block one coalesced pass over the indices
+                // and one coalesced flush.  (Looking the index up again in every block pass instead: 61 ms.)
+                int32_t *const idxs = cstart;
+                for (int i0 = tid; i0 < tail && !(a.lz_ablate & 1); i0 += 8 * B2_T) {
                     int vv[8];
                     unsigned long long wq[8];
 #pragma unroll
@@ -1393,8 +1400,28 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
 #pragma unroll
                     for (int u = 0; u < 8; ++u) wq[u] = vv[u] >= 0 ? ldq(reinterpret_cast<const unsigned long long *>(zb + (vv[u] >> 5))) : 0ull;
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (vv[u] >= 0) zr[(int)(wq[u] >> 32) + (int)__popc((uint32_t)wq[u] & ((1u << (vv[u] & 31)) - 1u))] = i0 + u * B2_T;
+                    for (int u = 0; u < 8; ++u) {
+                        if (vv[u] < 0) continue;
+                        const int idx = (int)(wq[u] >> 32) + (int)__popc((uint32_t)wq[u] & ((1u << (vv[u] & 31)) - 1u));
+                        if (LDS_BM) idxs[i0 + u * B2_T] = idx;
+                        else zr[idx] = i0 + u * B2_T;
+                    }
+                }
+                if (LDS_BM && !(a.lz_ablate & 1)) {
+                    __syncthreads();
+                    for (int blk0 = 0; blk0 < tail; blk0 += W) {
+                        for (int i0 = tid; i0 < tail; i0 += 8 * B2_T) {
+                            int ix[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) ix[u] = i0 + u * B2_T < tail ? ldi(&idxs[i0 + u * B2_T]) : -1;
+#pragma unroll
+                            for (int u = 0; u < 8; ++u)
+                                if (ix[u] >= blk0 && ix[u] < blk0 + W) bm[ix[u] - blk0] = (uint32_t)(i0 + u * B2_T);
+                        }
+                        __syncthreads();
+                        for (int j = tid; j < min(W, tail - blk0); j += B2_T) zr[blk0 + j] = (int32_t)bm[j];
+                        __syncthreads();
+                    }
                 }
             }
             if (tid == 0) {
@@ -1716,6 +1743,7 @@ static int build_trees_lazy(gg_ctx *ctx, const int32_t *roots, int32_t n_roots) 
     a.lz_alloc = ctx->dev_ctr + 1508;
     a.lz_alloc_end = budget;
     a.scr_cap = (int)scr;
+    a.lz_ablate = getenv("GG_LZ_ABLATE") ? atoi(getenv("GG_LZ_ABLATE")) : 0;
     a.scr_order = ctx->lz_scratch.as<int32_t>();
     a.scr_edge = a.scr_order + (size_t)grid * scr;
     a.scr_cstart = a.scr_edge + (size_t)grid * scr;
@@ -1759,6 +1787,14 @@ static int build_trees_lazy(gg_ctx *ctx, const int32_t *roots, int32_t n_roots) 
     return GG_OK;
 }
 
+// the rebuilt slots' new bases and "no lazy ranks" records, in one launch (a synchronous 8-byte copy per slot was ~8 ms per batch)
+__global__ void lazy_move_slots_kernel(const int32_t *slots, const int64_t *base, const int32_t *expect, int m, int64_t *t_base, int4 *lz_info) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    t_base[slots[i]] = base[i];
+    lz_info[slots[i]] = make_int4(expect[i], expect[i], 0, 0);
+}
+
 // Whole trees for the slots whose lazy tree did not suffice (lz_flag raised by the walks of the launch that has just finished),
 // built into the arena; the slots' bases move there.  Returns the number of slots rebuilt in *n_out; GG_ECAPACITY when the arena
 // is full (the caller rebuilds the batch whole).
@@ -1783,38 +1819,35 @@ int lazy_fallback_rebuild(gg_ctx *ctx, int *n_out) {
     const int m = (int)slots.size();
     if (m == 0) return GG_OK;
     base.push_back(next);
-    DevBuf d_slots, d_roots, d_expect, d_base;
-    hipError_t e = d_slots.reserve(sizeof(int32_t) * m);
-    if (e == hipSuccess) e = d_roots.reserve(sizeof(int32_t) * m);
-    if (e == hipSuccess) e = d_expect.reserve(sizeof(int32_t) * m);
-    if (e == hipSuccess) e = d_base.reserve(sizeof(int64_t) * (m + 1));
-    auto release = [&]() { d_slots.release(); d_roots.release(); d_expect.release(); d_base.release(); };
-    if (e != hipSuccess) { release(); return fail(ctx, GG_ENOMEM, "lazy trees: %s", hipGetErrorString(e)); }
-    (void)hipMemset(d_slots.p, 0, sizeof(int32_t) * m);
-    (void)hipMemcpy(d_roots.p, roots.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice);
-    (void)hipMemcpy(d_expect.p, expect.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice);
-    (void)hipMemcpy(d_base.p, base.data(), sizeof(int64_t) * (m + 1), hipMemcpyHostToDevice);
+    // (one scratch allocation kept in the context: [zeros | roots | expect | slots] int32 then [base] int64)
+    DevBuf &scr = ctx->lz_fb_scratch;
+    const size_t i32n = 4 * (size_t)m + 4;
+    hipError_t e = scr.reserve(sizeof(int32_t) * i32n + sizeof(int64_t) * ((size_t)m + 2));
+    if (e != hipSuccess) return fail(ctx, GG_ENOMEM, "lazy trees: %s", hipGetErrorString(e));
+    int32_t *const d_zero = scr.as<int32_t>(), *const d_roots_p = d_zero + m, *const d_expect_p = d_roots_p + m, *const d_slots_p = d_expect_p + m;
+    int64_t *const d_base_p = reinterpret_cast<int64_t *>(scr.as<int32_t>() + ((i32n + 1) & ~(size_t)1));
+    auto release = [&]() {};
+    GG_HIP(ctx, hipMemsetAsync(d_zero, 0, sizeof(int32_t) * m, ctx->stream));
+    GG_HIP(ctx, hipMemcpyAsync(d_roots_p, roots.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, ctx->stream));
+    GG_HIP(ctx, hipMemcpyAsync(d_expect_p, expect.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, ctx->stream));
+    GG_HIP(ctx, hipMemcpyAsync(d_slots_p, slots.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, ctx->stream));
+    GG_HIP(ctx, hipMemcpyAsync(d_base_p, base.data(), sizeof(int64_t) * (m + 1), hipMemcpyHostToDevice, ctx->stream));
     BfsArgs a{};
-    a.roots = d_roots.as<int32_t>();
-    a.base = d_base.as<int64_t>();
+    a.roots = d_roots_p;
+    a.base = d_base_p;
     a.order = ctx->t_order;
     a.cstart = ctx->t_cstart;
     a.edge = ctx->t_edge;
-    a.expect = d_expect.as<int32_t>();
-    a.slot_ids = d_slots.as<int32_t>();  // (all zero: the rows are not shifted)
+    a.expect = d_expect_p;
+    a.slot_ids = d_zero;  // (all zero: the rows are not shifted)
     int32_t stats[6];
     int rc = bfs_run(ctx, a, m, /*lazy=*/false, stats);
     release();
     if (rc != GG_OK) return rc;
     // the slots now point into the arena and have no lazy ranks
-    std::vector<int4> info(m);
-    for (int i = 0; i < m; ++i) {
-        const int s = slots[i];
-        GG_HIP(ctx, hipMemcpy(ctx->t_base + s, &base[i], sizeof(int64_t), hipMemcpyHostToDevice));
-        const int4 v = make_int4(expect[i], expect[i], 0, 0);
-        GG_HIP(ctx, hipMemcpy(ctx->lz_info.as<int4>() + s, &v, sizeof(int4), hipMemcpyHostToDevice));
-    }
-    GG_HIP(ctx, hipMemset(ctx->lz_flag.p, 0, sizeof(int32_t) * (size_t)R));
+    hipLaunchKernelGGL(lazy_move_slots_kernel, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, d_slots_p, d_base_p, d_expect_p, m, ctx->t_base, ctx->lz_info.as<int4>());
+    GG_HIP(ctx, hipMemsetAsync(ctx->lz_flag.p, 0, sizeof(int32_t) * (size_t)R, ctx->stream));
+    GG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->arena_next = next;
     ctx->tree_max_depth = std::max(ctx->tree_max_depth, stats[0]);
     ctx->tree_max_list = std::max(ctx->tree_max_list, stats[1]);

@@ -155,7 +155,7 @@ struct gg_ctx {
     bool lz_force_whole = false;       // (the rebuild of a lazy batch as whole trees is under way)
     int32_t lz_min_level = 0x7fffffff; // smallest L_r of the resident lazy slots (levels below it need no resolve step)
     uint32_t lz_stamp = 0;             // stamp of the resident build (1 .. 4095; the pair array is cleared when it wraps)
-    gg::DevBuf lz_info, lz_pair, lz_rank, lz_bm, lz_cursor, lz_flag, lz_limit, lz_expect, lz_list, lz_scratch;
+    gg::DevBuf lz_info, lz_pair, lz_rank, lz_bm, lz_cursor, lz_flag, lz_limit, lz_expect, lz_list, lz_scratch, lz_fb_scratch;
     int64_t arena_next = 0, arena_end = 0;  // the arena of whole trees behind the segments: [arena_next, arena_end) is free
     int64_t lz_fallback_roots = 0, lz_fallback_rounds = 0, lz_resolved = 0;  // statistics (gg_lazy_stats)
     bool g_multi = true;               // the adjacency holds a node twice in some list (first-occurrence tests needed)

@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     // chunk offsets and task slots: in-wave exclusive scans, per-block totals through LDS, and the block's returning
     // atomics issued by three lanes AT ONCE (a single word serves only ~88 returning atomics per us, and three of them one
     // after the other were three round trips); the order of the blocks' regions in the buffers is irrelevant
-    __shared__ int wv_pch[4], wv_sch[4], wv_big[4], wv_own[4], wv_small[4], wv_gat[4], wv_node[4], wv_alive[4];
+    __shared__ int wv_pch[4], wv_sch[4], wv_big[4], wv_own[4], wv_small[4], wv_gat[4], wv_node[4], wv_alive[4], wv_p24[4];
     __shared__ unsigned long long blk_base[3];
     int inc_p = p_chunks, inc_s = s_chunks;
 #pragma unroll
@@ -1059,7 +1059,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         if (lane >= off) { inc_p += op; inc_s += os; }
     }
     const int wv = tid >> 6;
-    const unsigned long long big_bal = __ballot(big), small_bal = __ballot(small);
+    const unsigned long long big_bal = __ballot(big), small_bal = __ballot(small), p24_bal = __ballot(small && mode == 0 && p_chunks <= 4);
     const unsigned long long own_bal = __ballot(owns && mode != 1);  // tasks that read a current row: private owners + node scorings
     // distributions served from the cache: gather tasks of the weights kernel + walks that will gather themselves (counted per
     // walk: nothing dedups them; the walks behind a self-gathering owner are not counted)
@@ -1068,6 +1068,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
     if (lane == 0) {
         wv_big[wv] = __popcll(big_bal); wv_small[wv] = __popcll(small_bal);
         wv_own[wv] = __popcll(own_bal); wv_gat[wv] = __popcll(gat_bal); wv_node[wv] = __popcll(node_bal); wv_alive[wv] = __popcll(alive_bal);
+        wv_p24[wv] = __popcll(p24_bal);
     }
     __syncthreads();
     if (tid < 7) {
@@ -1076,7 +1077,7 @@ __global__ __launch_bounds__(256) void level_advance_kernel(const WalkArgs a, co
         unsigned long long val = 0;
         if (tid == 0) { word = &a.lc[CTR_CHUNKS + a.level]; val = tot(wv_pch) | (tot(wv_sch) << 32); }
         else if (tid == 1) { word = &a.lc[CTR_BIG + a.level]; val = tot(wv_big) | (tot(wv_small) << 32); }
-        else if (tid == 2) { word = &a.lc[CTR_TINY + a.level]; val = 0; }  // (spare)
+        else if (tid == 2) { word = &a.lc[CTR_TINY + a.level]; val = ((a.exp & 16) && !LAZY) ? tot(wv_p24) : 0; }  // (GG_WALK_EXPERIMENT & 16: small tasks that score their own 17..64 candidates -- what a "finish in the score kernel" wave task would take off the weights kernel's list; the word is the resolve ticket of lazy launches)
         else if (tid == 3) { word = &a.lc[CTR_DISTS + (blockIdx.x & 63)]; val = tot(wv_own); }
         else if (tid == 4) { word = &a.lc[CTR_GATHER + (blockIdx.x & 63)]; val = tot(wv_gat); }
         else if (tid == 5) { word = &a.lc[CTR_NODES + (blockIdx.x & 63)]; val = tot(wv_node); }
@@ -1765,7 +1766,7 @@ __global__ void dc_finish_kernel(const WalkArgs a, int64_t *words, int n_levels)
 // the resolve kernel of one lazy level: a persistent grid, one workgroup per CU when the slot's visited words go to LDS
 static void launch_lazy_resolve(gg_ctx *ctx, const WalkArgs &x, hipStream_t st) {
     const size_t lds = sizeof(uint32_t) * (size_t)x.lz_words;
-    static const bool no_lds = getenv("GG_LZ_NO_LDS") != nullptr;
+    const bool no_lds = getenv("GG_LZ_NO_LDS") != nullptr;  // (tests: the path of graphs whose visited words do not fit the LDS)
     if (!no_lds && lds + sizeof(LzWork) * (LZ_T / 64) + sizeof(int32_t) * LZ_LIST + 256 <= 160 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {

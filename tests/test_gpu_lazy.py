@@ -17,9 +17,14 @@ def ga():
     return graphgan_amd
 
 
-@pytest.fixture(params=["levels", "finisher", "hybrid2"])
+@pytest.fixture(params=["levels", "finisher", "hybrid2", "levels_global_bits"])
 def walk_mode(request, monkeypatch):
+    """The decompositions of the sampler a lazy tree must serve: the level pipeline with the resolve kernel between the two
+    halves of the advance kernel (visited words of the slot in LDS; "levels_global_bits": read from the index in global memory,
+    the path of graphs above ~1.2 M nodes), the per-walk finisher alone (it resolves inline), and two levels + the finisher."""
     monkeypatch.setenv("GG_WALK_LEVELS", {"finisher": "0", "hybrid2": "2"}.get(request.param, "64"))
+    if request.param == "levels_global_bits":
+        monkeypatch.setenv("GG_LZ_NO_LDS", "1")
     return request.param
 
 

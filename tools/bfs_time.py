@@ -16,6 +16,7 @@ d = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 rowptr, col, emb, ne = workloads.powerlaw_workload(n, 10, d)
 roots = workloads.bench_roots(rowptr, R)
 eng = ga.Engine(emb, emb, optimizer=ga.GG_OPT_SGD)
+eng.set_tree_mode(int(os.environ.get("BFS_TIME_MODE", "0")))  # 1: lazy trees
 eng.set_graph_csr(rowptr, col)
 for rep in range(3):
     c0 = eng.counters()
