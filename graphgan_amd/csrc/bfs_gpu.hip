@@ -88,6 +88,7 @@ struct BfsArgs {
     long long lz_alloc_end;    // entries the segments may take; a slot that does not fit raises lz_flag (whole tree in the arena) and stats[4]
     int64_t *base_w;           // [slots]   LAZY: t_base, written here
     int32_t *lz_flag;          // [slots]
+    int lz_easy, lz_limit_easy;  // levels 1 .. lz_easy are expanded while they fit lz_limit_easy (>= the root's own limit)
     int lz_ablate;             // GG_LZ_ABLATE (timing only, results WRONG): 1 = no rank scatter, 2 = no copy out of the scratch tree, 4 = no visited index
 };
 
@@ -925,7 +926,9 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
 #pragma unroll
                         for (int i = 0; i < B2_WAVES; ++i) D += (unsigned long long)(uint32_t)wtot[0][i];
                         lds_barrier();  // (wtot is reused by the windows)
-                        if ((unsigned long long)tail + D > (unsigned long long)limit) {
+                        // (the first lz_easy levels may take up to lz_limit_easy: a tree that stops before its third level sends its
+                        // walks through two levels of hub-heavy resolution and, mostly, to a whole rebuild)
+                        if ((unsigned long long)tail + D > (unsigned long long)(depth <= a.lz_easy ? max(limit, a.lz_limit_easy) : limit)) {
                             why = 4;
                             break;
                         }
@@ -1668,6 +1671,13 @@ static int build_trees_lazy(gg_ctx *ctx, const int32_t *roots, int32_t n_roots) 
     if (ctx->h_comp_size.empty()) component_sizes(n, ctx->h_rowptr.data(), ctx->h_col.data(), ctx->h_comp_size);
     int64_t cap, whole_max;
     lazy_limits(ctx, &cap, &whole_max);
+    // Two limits: a level is expanded while (nodes so far + its adjacency entries) fit `cap` -- 3/8 of the nodes: stops in front of
+    // the level that holds the bulk of a small-world graph --, but the first two levels below the root's children may take up to
+    // the node count: 2.4 % of the bench roots have a second level whose expansion exceeds 3/8 N; stopped there they resolve
+    // through two levels of hubs and mostly end as whole trees (19 ms per 16 384 roots), expanded they cost a fraction of one.
+    // (Raising `cap` itself to N lets 7 % of the roots expand their THIRD level, up to 900 000 entries each: 78 instead of 44 ms.)
+    const int easy_levels = ctx->lz_cap > 0 ? 0 : (getenv("GG_LZ_EASY") ? atoi(getenv("GG_LZ_EASY")) : 2);
+    const int64_t easy_cap = std::max<int64_t>(cap, n);
     // per root: node limit of the exact part, pool behind it.  The pool takes what a resolution reserves -- one entry per candidate
     // of the node's adjacency -- for the walks a root can have, ~3 lazy hops each.
     std::vector<int32_t> limit(n_roots), expect(n_roots), pool(n_roots);
@@ -1682,6 +1692,7 @@ static int build_trees_lazy(gg_ctx *ctx, const int32_t *roots, int32_t n_roots) 
         } else {
             const int64_t pool_env = getenv("GG_LZ_POOL") ? atoll(getenv("GG_LZ_POOL")) : 0;
             limit[r] = (int32_t)std::min<int64_t>(cap, C);
+            if (easy_levels > 0) max_limit = std::max<int64_t>(max_limit, std::min<int64_t>(easy_cap, C));  // (the scratch tree holds what the easy levels may append)
             pool[r] = (int32_t)(pool_env > 0 ? pool_env : std::min<int64_t>(std::max<int64_t>(16384, 192 * (deg + 64)), std::max<int64_t>(cap, 16384)));
         }
         max_limit = std::max<int64_t>(max_limit, limit[r]);
@@ -1744,6 +1755,8 @@ static int build_trees_lazy(gg_ctx *ctx, const int32_t *roots, int32_t n_roots) 
     a.lz_alloc_end = budget;
     a.scr_cap = (int)scr;
     a.lz_ablate = getenv("GG_LZ_ABLATE") ? atoi(getenv("GG_LZ_ABLATE")) : 0;
+    a.lz_easy = easy_levels;
+    a.lz_limit_easy = (int)easy_cap;
     a.scr_order = ctx->lz_scratch.as<int32_t>();
     a.scr_edge = a.scr_order + (size_t)grid * scr;
     a.scr_cstart = a.scr_edge + (size_t)grid * scr;

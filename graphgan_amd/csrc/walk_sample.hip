@@ -401,7 +401,10 @@ __device__ __forceinline__ void lz_flat_scan(const WalkArgs &a, const Bits &bits
 
 // Resolve the children list of (slot, rank) = node `cur` on tree level `level` (its father on the walk: `prev`) and publish it;
 // the caller has claimed the pair.  Returns the published pair.  All 64 lanes take part; everything returned is wave-uniform.
-template <class Bits>
+// FENCE: readers of the pair may run in the SAME kernel (the finisher's walks): the list is made visible before the pair that names
+// it.  The resolve kernel's readers are later kernels -- and an agent-scope release on this chip writes the XCD's L2 back
+// (buffer_wbl2) and invalidates it: per list, that was ~60 % of the resolve kernel's time.
+template <bool FENCE, class Bits>
 __device__ __forceinline__ unsigned long long lazy_resolve_wave(const WalkArgs &a, const Bits &bits, LzWork *ws, int slot, int64_t tbase, int rank, int cur, int prev,
                                                                 int level, int lane) {
     // Every argument is wave-uniform; as scalars the loops below branch on scalar conditions.
@@ -435,7 +438,7 @@ __device__ __forceinline__ unsigned long long lazy_resolve_wave(const WalkArgs &
         if (e >= e1) return false;
         x = a.col[e];
         if (x == cur || lz_in(bits, x)) return false;
-        return !a.g_multi || a.rev[a.rev[e]] == (int32_t)e;
+        return !a.g_multi || (a.exp & 32768) || a.rev[a.rev[e]] == (int32_t)e;  // (exp 16384 / 32768 / 65536: timing ablations of the resolution -- no pair stage / no first-occurrence tests / no scans; results WRONG)
     };
     // candidates of the whole adjacency: what the list can hold at most -> its place in the pool
     int x0 = -1, ncand = 0;
@@ -470,12 +473,12 @@ __device__ __forceinline__ unsigned long long lazy_resolve_wave(const WalkArgs &
             unsigned long long kids;
             if (depth == 0) {
                 // a child unless a neighbour in V precedes cur
-                lz_flat_scan<0>(a, bits, bm, rk, ws, lane, (int)xq, (int)(xe - xq), my_rank, work);
+                if (!(a.exp & 65536)) lz_flat_scan<0>(a, bits, bm, rk, ws, lane, (int)xq, (int)(xe - xq), my_rank, work);
                 kids = m & ~ws->mask[0];
             } else {
                 // candidates that touch V are in cur's own level; the others are one level below cur
-                lz_flat_scan<1>(a, bits, bm, rk, ws, lane, (int)xq, (int)(xe - xq), 0, work);
-                const unsigned long long below_m = m & ~ws->mask[0];
+                if (!(a.exp & 65536)) lz_flat_scan<1>(a, bits, bm, rk, ws, lane, (int)xq, (int)(xe - xq), 0, work);
+                const unsigned long long below_m = (a.exp & 16384) ? 0ull : m & ~ws->mask[0];
                 wave_lds_sync();  // (every lane has read the mask)
                 ws->mask[0] = 0ull;
                 // their neighbours y (PAIRS (x, y), 64 at a time): is y in level L + 1, and with which key?
@@ -543,7 +546,7 @@ __device__ __forceinline__ unsigned long long lazy_resolve_wave(const WalkArgs &
         atomicMax(&a.lz_ctr[6], (unsigned long long)(e1 - e0));
     }
     const unsigned long long v = lz_make(start, (unsigned long long)count, a.lz_stamp);
-    __threadfence();  // the list before the pair that names it
+    if (FENCE) __threadfence();  // the list before the pair that names it
     __hip_atomic_store(pair, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (every lane: the same word)
     return v;
 }
@@ -569,7 +572,7 @@ __device__ __forceinline__ unsigned long long lazy_children_wave(const WalkArgs 
         unsigned long long old = v;
         if (lane == 0) old = atomicCAS(pair, v, lz_make(0, LZ_CLAIMED, a.lz_stamp));
         old = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(old >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)old, 0, 64);
-        if (old == v) return lazy_resolve_wave(a, LzBitsGlobal{a.lz_bm + (size_t)slot * a.lz_words}, ws, slot, tbase, rank, cur, prev, level, lane);
+        if (old == v) return lazy_resolve_wave<true>(a, LzBitsGlobal{a.lz_bm + (size_t)slot * a.lz_words}, ws, slot, tbase, rank, cur, prev, level, lane);
     }
 }
 
@@ -1213,8 +1216,8 @@ __global__ __launch_bounds__(LZ_T) void lazy_resolve_kernel(const WalkArgs a) {
                     const int64_t w = w0 + s_list[i];
                     const int4 sc2 = a.st_const2[w];
                     const int64_t tbase = ((int64_t)sc2.y << 32) | (unsigned)sc2.x;
-                    if (LDS_BITS) (void)lazy_resolve_wave(a, LzBitsLds{lz_lds, a.lz_bm + (size_t)slot * a.lz_words}, ws, slot, tbase, a.st_rank[w], a.st_cur[w], a.st_prev[w], a.level, lane);
-                    else (void)lazy_resolve_wave(a, LzBitsGlobal{a.lz_bm + (size_t)slot * a.lz_words}, ws, slot, tbase, a.st_rank[w], a.st_cur[w], a.st_prev[w], a.level, lane);
+                    if (LDS_BITS) (void)lazy_resolve_wave<false>(a, LzBitsLds{lz_lds, a.lz_bm + (size_t)slot * a.lz_words}, ws, slot, tbase, a.st_rank[w], a.st_cur[w], a.st_prev[w], a.level, lane);
+                    else (void)lazy_resolve_wave<false>(a, LzBitsGlobal{a.lz_bm + (size_t)slot * a.lz_words}, ws, slot, tbase, a.st_rank[w], a.st_cur[w], a.st_prev[w], a.level, lane);
                 }
             }
             __syncthreads();  // (everyone is through with the list and the LDS words)
