@@ -253,6 +253,7 @@ int gg::walk_launch_async(gg_ctx *ctx, const int32_t *slots, const int32_t *n_wa
     if (ctx->g_slots_ready) {  // an index being built for the walks this launch overwrites: let its kernels finish reading them
         GG_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_slots_done, 0));
         ctx->g_slots_ready = false;
+        ctx->g_slots_unused++;  // nobody took it (the batch-64 schedule consumes the walks pair by pair: enqueue_path_slots)
     }
     if (n_slots == 0) {
         ctx->walk_stream = ctx->stream;

@@ -257,6 +257,7 @@ struct gg_ctx {
     hipEvent_t ev_slots_done = nullptr;
     bool g_slots_ready = false;        // the index of the resident G-mode walks is enqueued / done
     bool sgp_cnt_clean = false;        // sgp_cnt is all zero
+    int g_slots_unused = 0;            // early indexes in a row that no whole-walk generator pass consumed (2: stop building them)
     int64_t g_slots_walks = 0;
     int32_t g_slots_stride = 0;
     int32_t *sg_cnt_active = nullptr;  // the count array of the staged pass that is applying its hub rows (sg_active)

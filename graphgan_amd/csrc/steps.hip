@@ -907,7 +907,12 @@ static unsigned det_workgroups(int n) {
     return (unsigned)std::min(cap, std::max(1, (2 * n + DET_THREADS / 64 - 1) / (DET_THREADS / 64)));
 }
 
-static bool det_rows_fit_lds(const StepArgs &s) { return (size_t)2 * s.n * s.ld * sizeof(float) <= DET_LDS_ROW_BYTES; }
+// Whether this device grants a workgroup DET_LDS_ROW_BYTES of dynamic LDS (gfx950: yes).  Asked once per device with the call
+// that raises the limit; a device that refuses (an ARCH override with 64 KB of LDS) takes the variant with the rows in L2.
+static bool det_lds_granted(int device);
+static bool det_rows_fit_lds(const gg_ctx *ctx, const StepArgs &s) {
+    return (size_t)2 * s.n * s.ld * sizeof(float) <= DET_LDS_ROW_BYTES && det_lds_granted(ctx->device);
+}
 
 template <int NF, int OPT>
 static hipError_t launch_pair_grad_det_lds(gg_ctx *ctx, const StepArgs &s, const OptArgs &o) {
@@ -926,10 +931,21 @@ static hipError_t launch_pair_grad_det_lds(gg_ctx *ctx, const StepArgs &s, const
     return hipSuccess;
 }
 
+static bool det_lds_granted(int device) {
+    static int state[64] = {};  // 0 = not asked, 1 = granted, -1 = refused
+    int &s = state[device & 63];
+    if (s == 0) {
+        const hipError_t e = hipFuncSetAttribute((const void *)pair_grad_det_kernel<4, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DET_LDS_ROW_BYTES);
+        if (e != hipSuccess) (void)hipGetLastError();
+        s = e == hipSuccess ? 1 : -1;
+    }
+    return s > 0;
+}
+
 // opt: 0 = gradient rows to the accumulators (the optimizer kernels follow), 1 / 2 = lazy Adam / SGD applied by the row owners
 template <int NF>
 static hipError_t launch_pair_grad_det(gg_ctx *ctx, const StepArgs &s, const OptArgs &o, int opt) {
-    if (!det_rows_fit_lds(s)) {
+    if (!det_rows_fit_lds(ctx, s)) {
         const dim3 grid(det_workgroups(s.n));
         if (s.n <= 64) hipLaunchKernelGGL((pair_grad_det_kernel<NF, false, 0, true>), grid, dim3(DET_THREADS), 0, ctx->stream, s, o);
         else hipLaunchKernelGGL((pair_grad_det_kernel<NF, false, 0, false>), grid, dim3(DET_THREADS), 0, ctx->stream, s, o);
@@ -1325,7 +1341,7 @@ int run_step(gg_ctx *ctx, int which, const int32_t *d_u, const int32_t *d_v, con
         const int nfd = (ctx->ld + 15) / 16;
         // one replica, lazy Adam / SGD, the batch's rows in LDS: the row owners apply the optimizer themselves -- one launch per step
         const bool replicas = ctx->comm || ctx->fake_world > 1;
-        const int fused = (!replicas && opt != GG_OPT_ADAM_DENSE && det_rows_fit_lds(s) && !getenv("GG_NO_FUSED_SMALL_STEP")) ? (opt == GG_OPT_SGD ? 2 : 1) : 0;
+        const int fused = (!replicas && opt != GG_OPT_ADAM_DENSE && det_rows_fit_lds(ctx, s) && !getenv("GG_NO_FUSED_SMALL_STEP")) ? (opt == GG_OPT_SGD ? 2 : 1) : 0;
         const OptArgs o = make_opt_args(ctx, which);
         static unsigned long long *det_prof = nullptr;
         static const bool det_prof_on = getenv("GG_DET_PROFILE") != nullptr;
@@ -1461,6 +1477,7 @@ int run_path_step(gg_ctx *ctx) {
     // the index of these walks may already be on its way (side stream, behind the walks: enqueue_path_slots)
     const bool early = ctx->g_slots_ready && ctx->g_slots_walks == p.n_walks && ctx->g_slots_stride == p.stride;
     ctx->g_slots_ready = false;
+    ctx->g_slots_unused = 0;  // this caller takes whole-walk passes: keep (or resume) building the index early
     if (early) {
         ctx->sg_cnt_dirty = false;  // (staged_reserve left the pass's own count array clean, and this pass does not use it)
         GG_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_slots_done, 0));
@@ -1489,6 +1506,13 @@ int enqueue_path_slots(gg_ctx *ctx) {
     if (ctx->walk_stream == ctx->stream || ctx->in_epoch_add || getenv("GG_NO_EARLY_SLOTS")) return GG_OK;
     const int64_t n_walks = ctx->w_total, n_pos = n_walks * (int64_t)ctx->w_stride;
     if (!staged_allowed(ctx) || ctx->cfg.window_size > 2 || n_walks == 0 || n_pos >= (1ll << 31)) return GG_OK;
+    if (ctx->g_slots_unused >= 2) {  // the caller runs minibatch steps (run_step): the index would be built and dropped per prepare_g
+        if (ctx->sgp_slot.p) {       // (hipFree waits for the device: once, when the schedule is recognised)
+            for (DevBuf *b : {&ctx->sgp_cnt, &ctx->sgp_off, &ctx->sgp_slot, &ctx->sgp_list, &ctx->sgp_key, &ctx->sgp_scan}) b->release();
+            ctx->sgp_cnt_clean = false;
+        }
+        return GG_OK;
+    }
     hipStream_t st = ctx->walk_stream;
     const size_t cnt_before = ctx->sgp_cnt.bytes;
     GG_HIP(ctx, ctx->sgp_cnt.reserve(sizeof(int32_t) * (size_t)ctx->n_node));

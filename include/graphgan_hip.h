@@ -166,8 +166,10 @@ int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t n_roots);
  * walks go deeper -- or whose pool of resolved lists is full -- gets its whole tree behind the scenes and the launch is repeated:
  * every gg_walk_sample / gg_prepare_* result is the whole trees' result, bit for bit (tested against the oracle's).
  * mode: 0 = whole trees (gg_get_trees / gg_save_trees / gg_get_tree_order need them), 1 = lazy, -1 (default) = lazy for graphs of
- * 2^18 nodes and more (GG_LZ_AUTO_NODES); GG_TREE_LAZY overrides.  node_cap: the limit per root (0 = 3/8 of the nodes, at least
- * 65 536; GG_LZ_CAP).  gg_tree_info reports, for lazy trees, a depth no walk exceeds.
+ * 2^18 nodes and more (GG_LZ_AUTO_NODES); GG_TREE_LAZY overrides.  node_cap: the limit per root; 0 = the default rule: 3/8 of the nodes
+ * (at least 65 536; GG_LZ_CAP), except that the root's first two levels may expand up to the node count (GG_LZ_EASY levels), and a
+ * root whose component holds <= 65 536 nodes gets its whole tree; node_cap > 0 = exactly that limit for every level and as the
+ * whole-tree bound (tests).  gg_tree_info reports, for lazy trees, a depth no walk exceeds.
  * gg_lazy_stats: out24 = {resident trees are lazy, smallest exact level of the lazy slots, slots rebuilt whole so far, launches
  * repeated for it, exact nodes the BFS wrote, pool entries reserved by resolutions, lazy slots, deepest exact level; of the
  * resident build: lists resolved at depth 0 / 1 / 2, candidates judged, 16-entry scan rounds, most rounds of one list, longest
