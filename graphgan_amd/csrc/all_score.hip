@@ -264,11 +264,13 @@ __global__ __launch_bounds__(256) void all_score_reduce_bf16_kernel(const uint4 
         const int col = c0 + (lane & 31);
         const bool ok = col < cend;
         load_tile(bnxt, c0 + 128);
+        // (the accumulators START at the column's bias -- S = b + sum_k, the order the x32 kernel below computes in: same bits)
+        const float bj = ok ? bias[col] : 0.f;
         f32x16 acc[RB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[rb][i] = 0.f;
+            for (int i = 0; i < 16; ++i) acc[rb][i] = bj;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
 #pragma unroll
@@ -277,11 +279,10 @@ __global__ __launch_bounds__(256) void all_score_reduce_bf16_kernel(const uint4 
 #pragma unroll
         for (int s = 0; s < KS; ++s) bcur[s] = bnxt[s];
         if (ok) {
-            const float bj = bias[col];
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) run_update(run[rb * 16 + reg], acc[rb][reg] + bj, col, lse != 0);
+                for (int reg = 0; reg < 16; ++reg) run_update(run[rb * 16 + reg], acc[rb][reg], col, lse != 0);
         }
     }
     tile_finish<16 * RB>(run, lse != 0, r0, n_rows, split, gridDim.x, part_max, part_arg, part_sum, sh_m, sh_s, sh_a);
@@ -492,6 +493,263 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
+// Round 6: the many-rows consumer on v_mfma_f32_32x32x16_bf16 with the REQUESTED ROWS ON THE LANES.  The matrix instruction's A
+// operand is the table tile (32 nodes), its B operand a block of 32 requested rows, so a lane's 16 accumulator registers are 16
+// NODES of ONE requested row (row = lane & 31; nodes (i & 3) + 8 (i >> 2) + 4 (lane >> 5) of the tile): the running state of a
+// row block is one (max, argmax, sum) cell per lane instead of 16, and the consumer is per score
+//     y = x log2 e;  s += exp2(y);  half a v_max3
+// -- 3.5 vector instructions (the x16 kernel above: 9.2, SQ_INSTS_VALU / scores in profiles/r5_pmc_k7_sq.json), which is what fits
+// beside a 32-cycle matrix instruction on a SIMD that holds one wavefront (MI355X_MICROARCH.md: <= 5 single-issue instructions
+// hidden per v_mfma_f32_32x32x16_bf16).  What makes that possible:
+//  - the bias of a node is the INITIAL VALUE of its accumulator register (16-byte LDS reads straight into the accumulator
+//    tuple), not an addition per score; the narrow kernel above starts its accumulators at the bias as well, so both give the
+//    same bits;
+//  - max / argmax: the tile's 16 scores of a row fold into one maximum (v_max3 chain); only when that beats the running maximum
+//    in ANY lane (a few hundred times per sweep, ~ 64 ln(tiles / 64)) a uniform branch finds the first register that holds it;
+//  - the log-sum-exp is the reference-free sum of the x16 kernel (overflow flag -> the call is repeated with the narrow kernel).
+// Operands: a wavefront keeps RB blocks of 32 requested rows as B fragments in ACCUMULATION registers (RB KS 4 = all 256 of them
+// at d = 256) for the whole sweep; the table tile (KS KB) is staged ONCE per workgroup through LDS (each of the 4 wavefronts
+// loads a quarter of the next tile at the top of an iteration and stores it behind the matrix instructions; one barrier per
+// tile) -- a quarter of the L1 requests of four private streams, no hand-placed loads, nothing for the register allocator to
+// break.  A workgroup sweeps its column range once for 128 RB rows (512 at d = 256: 8 sweeps of the bf16 table for 4 096 rows,
+// and the row tiles of one column split sit on ONE XCD -- workgroup id mod 8 = split mod 8 -- so they share its L2).
+// Pipeline: iteration t multiplies tile t into accumulator set t & 1 and consumes tile t - 1 from the other set, one quad of
+// scores behind each group of matrix instructions; a consumed row block's registers are re-initialised with the bias of tile
+// t + 1 (a ring of 4 bias tiles in LDS, written two tiles ahead).  Tiles outside the split have a bias of -inf: x = -inf,
+// exp2 = 0, never a maximum -- the pipeline's first and last iterations need no special case.
+template <int KS, int RB, int NW, bool LSE, int DBG = 0>  // (DBG: timing ablations, results wrong -- 1 no barrier / no LDS store, 2 no global loads, 4 no slow path)
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void all_score_reduce_bf16_x32_kernel(
+    const uint4 *Eb, const float *bias, int n_node, const int32_t *rows, int n_rows, int cols_per_split, float *part_max, int32_t *part_arg,
+    float *part_sum, int32_t *overflow) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char x32_lds[];
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    union Frag { u32x4 q; bf16x8 v; };
+    constexpr int BUF = KS * 1024;                                      // a staged tile; behind the four of them a ring of 4 bias tiles
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int split = blockIdx.x, r0 = blockIdx.y * (32 * RB * NW) + wv * (32 * RB);
+    constexpr int G = KS >= NW ? KS / NW : 1;  // k-steps of a tile each wavefront stages (KS < NW: the first KS wavefronts one each)
+    const bool stager = KS >= NW || wv < KS;
+    constexpr float LOG2E = 1.44269504088896341f;
+    const int cbeg = split * cols_per_split, cend = min(n_node, cbeg + cols_per_split);
+    const int n_tiles = (cend - cbeg + 31) >> 5;
+    // requested rows: lane (row l31, k-half hi) of k-step s = the 16-byte piece the narrow kernel loads as its A fragment
+    Frag rf[RB][KS];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int r = r0 + 32 * rb + l31;
+        const int node = r < n_rows ? (rows ? rows[r] : r) : -1;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            rf[rb][s].q = node >= 0 ? *(const u32x4 *)&Eb[bf16_piece(node, s, hi, KS)] : z;
+        }
+    }
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) asm volatile("" : "+a"(rf[rb][s].q));  // (accumulation registers: see the x16 kernel)
+    float rm[RB], rs[RB], tmax[RB];
+    int rt[RB];  // the TILE that holds the row's maximum; which of its nodes is found after the sweep (below)
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) { rm[rb] = -INFINITY; rs[rb] = 0.f; rt[rb] = -1; tmax[rb] = -INFINITY; }
+    // Staging.  In the MIDDLE of iteration t, right behind the iteration's one barrier, every wavefront requests its k-steps
+    // (wv G .. wv G + G) of tile t + 3 straight into LDS (global_load_lds_dwordx4: no registers, no store instructions) -- into
+    // the buffer tile t - 1 has left: every wavefront that passed the barrier has finished iteration t - 1.  The tile is
+    // published by the barrier of iteration t + 1 (each wavefront waits for its own requests in front of it: a whole iteration
+    // old) and first read at the end of iteration t + 2.  Four buffers: tiles t, t + 1, t + 2 (in flight), t + 3.
+    // The barrier is a bare s_barrier in the middle of the matrix instructions (a barrier + register-staged store at the END of an
+    // iteration, with the drain of the LDS queue in front of it, cost 3.1 of 17.5 ms: the matrix pipe idles through it).
+    // The bias of tile t + 4 (thread tid < 32: node tid) is requested in iteration t and stored into ring slot (t + 4) & 3 in
+    // iteration t + 1; it initialises accumulators from the beginning of iteration t + 3 on.
+    auto tile_src = [&](int t) -> const u32x4 * {  // (a tile behind the split re-reads its first one: finite numbers, bias -inf)
+        return (const u32x4 *)Eb + ((int64_t)((cbeg >> 5) + (t < n_tiles ? t : 0)) * KS + (stager ? wv * G : 0)) * 64 + lane;
+    };
+    auto bias_of = [&](int t) -> float {
+        const int c = cbeg + 32 * t + tid;
+        return (tid < 32 && t < n_tiles && c < cend) ? bias[c] : -INFINITY;
+    };
+    u32x4 g[G];
+    float gb;
+    unsigned char *b_cur = x32_lds, *b_nxt = x32_lds + BUF, *b_n2 = x32_lds + 2 * BUF, *b_wr = x32_lds + 3 * BUF;  // tiles t .. t + 3
+    float *const ring = (float *)(x32_lds + 4 * BUF);
+#pragma unroll
+    for (int t0 = 0; t0 < 2; ++t0) {
+        const u32x4 *src = tile_src(t0);
+#pragma unroll
+        for (int k = 0; k < G; ++k) g[k] = src[64 * k];
+        unsigned char *dst = t0 ? b_nxt : b_cur;
+#pragma unroll
+        for (int k = 0; k < G; ++k) if (stager) ((u32x4 *)dst)[(wv * G + k) * 64 + lane] = g[k];
+    }
+    {
+        const float b0 = bias_of(0), b1 = bias_of(1), b2 = bias_of(2);
+        if (tid < 32) { ring[tid] = b0; ring[32 + tid] = b1; ring[64 + tid] = b2; }
+        const u32x4 *src = tile_src(2);
+#pragma unroll
+        for (int k = 0; k < G; ++k) g[k] = src[64 * k];
+#pragma unroll
+        for (int k = 0; k < G; ++k) if (stager) ((u32x4 *)b_n2)[(wv * G + k) * 64 + lane] = g[k];
+        gb = bias_of(3);  // (iteration 0 stores it)
+    }
+    __syncthreads();
+    f32x16 acc[2][RB];
+    {
+        const f32x4 *bq = (const f32x4 *)ring + hi;  // quad q of a lane: nodes 8 q + 4 hi .. + 4
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b = bq[2 * q];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { acc[0][rb][4 * q + j] = b[j]; acc[1][rb][4 * q + j] = -INFINITY; }
+            }
+    }
+    // The loop body is ONE basic block per tile, cut into KS RB SLOTS: one matrix instruction and what fits into its 32-cycle
+    // shadow (a wavefront issues in order: whatever sits between two matrix instructions and takes longer than that idles the
+    // pipe -- measured, one wavefront per SIMD, max / argmax only, of 15.8 ms: the 4 LDS-DMA requests issued back to back 2.2,
+    // the fragment read in FRONT of a k-step's first matrix instruction 1.7, the 4 bias reads of a row block back to back 1.2;
+    // the barrier itself: nothing).  So every slot gets at most one memory instruction: slot (s, 0) the next fragment's LDS
+    // read, slots (KS/2 + k, 1) the k-th LDS-DMA request, and the consumer is a queue of 16 RB ELEMENTS spread evenly over the
+    // slots -- element e (row block e / 16, register i = e % 16 of the finished tile): y = x log2 e, exp2(y); s += the PREVIOUS
+    // element's exponential (its latency passes in the other slot); v_max3 behind every second element; behind every fourth the
+    // LDS read that starts the quad's four registers at the next tile's bias; behind the 16th the row block's (max, tile) update.
+    // The consumer finishes one k-step early (CS slots): a quad's re-initialising read is issued in slot (s, 0) of the k-step AFTER
+    // the one that consumed its last element, in front of the fragment read -- both are then RB - 1 matrix instructions old when
+    // the next k-step waits for the fragment (the compiler waits with lgkmcnt(0) everywhere in this loop: an LDS-DMA request
+    // in flight makes it treat the LDS counter as out of order).
+    constexpr int SLOTS = KS * RB, ELEMS = 16 * RB, CS = SLOTS - RB;
+    Frag a_cur;
+    a_cur.q = ((const u32x4 *)b_cur)[lane];
+    float epend = 0.f;  // exponential of the last element, not yet added (row block RB - 1 at a tile's start)
+    float *const ring_dst = tid < 32 ? ring + tid : ring + 128 + tid;  // (every thread stores: no branch in the loop; 128 .. 128 + 64 NW: a dump)
+    for (int tt = 0; tt <= n_tiles; tt += 2) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int t = tt + p;
+            const u32x4 *const tl = (const u32x4 *)b_cur + lane, *const tl_next = (const u32x4 *)b_nxt + lane;
+            const f32x4 *const bq = (const f32x4 *)(ring + 32 * ((t + 1) & 3)) + hi;
+            const u32x4 *const dsrc = tile_src(t + 3);
+            const int bc = min(cbeg + 32 * (t + 4) + tid, cend - 1);  // bias of tile t + 4, clamped instead of predicated
+            const bool bok = tid < 32 && t + 4 < n_tiles && cbeg + 32 * (t + 4) + tid < cend;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                Frag a_nxt;
+#pragma unroll
+                for (int k = 0; k < RB; ++k) {
+                    const int slot = s * RB + k;
+                    if (s == KS / 2 && k == 0 && !(DBG & 1)) {
+                        // (the tile requested one iteration ago has landed: nothing to wait for; the wait makes it formal)
+                        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                    }
+                    acc[p][k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur.v, rf[k][s].v, acc[p][k], 0, 0, 0);
+                    if (k == 0) {
+#pragma unroll
+                        for (int e = 3; e < ELEMS; e += 4) {  // quads whose last element was consumed during the previous k-step
+                            if (s == 0 || e * CS / ELEMS < (s - 1) * RB || e * CS / ELEMS >= s * RB || (DBG & 16)) continue;
+                            const f32x4 b = bq[2 * ((e & 15) >> 2)];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[p ^ 1][e >> 4][(e & 12) + j] = b[j];
+                        }
+                        if (!(DBG & 8)) a_nxt.q = s + 1 < KS ? tl[64 * (s + 1)] : tl_next[0];
+                        else a_nxt.q = a_cur.q;
+                    }
+                    if (k == (RB > 1 ? 1 : 0) && s >= KS / 2 && s < KS / 2 + G && stager && !(DBG & 3)) {
+                        // tile t + 3 straight into the buffer tile t - 1 has left; lane l's 16 bytes land at M0 + 16 l
+                        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(dsrc + 64 * (s - KS / 2)),
+                                                         (void __attribute__((address_space(3))) *)(b_wr + (wv * G + s - KS / 2) * 1024), 16, 0, 0);
+                    }
+                    if (k == 0 && s == KS / 2 && !(DBG & 1)) ring_dst[32 * ((t + 3) & 3)] = gb;  // bias of tile t + 3 (in front of the DMA requests)
+                    if (k == RB - 1 && s == KS / 2 + 1 && !(DBG & 3)) gb = bok ? bias[bc] : -INFINITY;  // ... of tile t + 4
+#pragma unroll
+                    for (int e = 0; e < ELEMS; ++e) {
+                        if (e * CS / ELEMS != slot) continue;
+                        const int rb = e >> 4, i = e & 15, rbp = (e + ELEMS - 1) % ELEMS >> 4;
+                        f32x16 &c = acc[p ^ 1][rb];
+                        if (LSE) {
+                            rs[rbp] += epend;
+                            epend = __builtin_amdgcn_exp2f(c[i] * LOG2E);
+                        }
+                        if (i & 1) tmax[rb] = __builtin_fmaxf(__builtin_fmaxf(i == 1 ? -INFINITY : tmax[rb], c[i - 1]), c[i]);
+                        if (i == 15) {
+                            const bool up = tmax[rb] > rm[rb];  // (strictly: the first tile keeps a tie)
+                            rm[rb] = up ? tmax[rb] : rm[rb];
+                            rt[rb] = up ? t - 1 : rt[rb];
+                        }
+                        // (anchor: keeps the chain in its slot -- left alone, the machine-sink pass and the scheduler move pure
+                        // chains like s += exp2(..) to their last use)
+                        asm volatile("" : "+v"(rs[rbp]), "+v"(epend), "+v"(tmax[rb]));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                a_cur = a_nxt;
+            }
+            unsigned char *const o = b_cur;
+            b_cur = b_nxt;
+            b_nxt = b_n2;
+            b_n2 = b_wr;
+            b_wr = o;
+        }
+    }
+    if (LSE) rs[RB - 1] += epend;
+    // Which node of the winning tile?  The sweep kept no branch for it (a uniform branch per tile and row block that finds the
+    // register holding a new maximum cost 1.1 of 17.4 ms -- ~10 instructions when NOT taken, a basic-block cut per row block, and
+    // its per-wavefront variance in front of every barrier).  Now: for every lane that can still win its row, the tile is
+    // multiplied ONCE MORE -- same instruction, same operands, same order: the same bits -- and the first register equal to the
+    // maximum names the node.  ~34 lanes per row block (the two lanes of a row: the larger maximum, on a tie the earlier tile,
+    // on a tie of both, both) x KS matrix instructions: ~1 % of the sweep.
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const float m_o = __shfl_xor(rm[rb], 32, 64);
+        const int t_o = __shfl_xor(rt[rb], 32, 64);
+        const bool need = rt[rb] >= 0 && (rm[rb] > m_o || (rm[rb] == m_o && rt[rb] <= t_o));
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(need);
+        int arg = 0x7fffffff;
+        while (todo) {
+            const int j = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int tj = __builtin_amdgcn_readlane(rt[rb], j);
+            const u32x4 *src = (const u32x4 *)Eb + (int64_t)((cbeg >> 5) + tj) * KS * 64 + lane;
+            f32x16 c;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int nd = cbeg + 32 * tj + 4 * hi + (i & 3) + 8 * (i >> 2);
+                c[i] = nd < cend ? bias[nd] : -INFINITY;
+            }
+            constexpr int KC = KS < 16 ? KS : 16;  // fragments in flight
+#pragma unroll
+            for (int s0 = 0; s0 < KS; s0 += KC) {
+                Frag a[KC];
+#pragma unroll
+                for (int s2 = 0; s2 < KC; ++s2) a[s2].q = src[64 * (s0 + s2)];
+#pragma unroll
+                for (int s2 = 0; s2 < KC; ++s2) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s2].v, rf[rb][s0 + s2].v, c, 0, 0, 0);
+            }
+            int first = 0x7fffffff;
+#pragma unroll
+            for (int i = 15; i >= 0; --i) first = c[i] == rm[rb] ? (i & 3) + 8 * (i >> 2) : first;  // (first register = lowest node)
+            if (lane == j && first != 0x7fffffff) arg = cbeg + 32 * tj + 4 * hi + first;
+        }
+        // merge the two lanes of a row; lanes < 32 hold row l31 of the block
+        float sx = rs[rb];
+        if (LSE) {
+            if (!(sx <= 3.0e38f) || (sx == 0.f && rm[rb] > -INFINITY)) atomicOr(overflow, 1);
+            sx = rm[rb] > -INFINITY ? sx * __builtin_amdgcn_exp2f(-rm[rb] * LOG2E) : 0.f;
+        }
+        Running x{rm[rb], sx, arg};
+        const float m = __shfl_xor(x.m, 32, 64), so = __shfl_xor(x.s, 32, 64);
+        const int ar = __shfl_xor(x.arg, 32, 64);
+        run_merge(x, m, so, ar, LSE);
+        const int row = r0 + 32 * rb + l31;
+        if (hi == 0 && row < n_rows) {
+            const int64_t o = (int64_t)row * gridDim.x + split;
+            part_max[o] = x.m;
+            part_arg[o] = x.arg;
+            part_sum[o] = x.s;
+        }
+    }
+}
+
 }  // namespace gg
 
 using namespace gg;
@@ -547,10 +805,12 @@ extern "C" int gg_all_score_reduce(gg_ctx *ctx, const int32_t *rows, int32_t n_r
     const bool wide = precision == 1 && n_rows >= 512 && !getenv("GG_ALLPAIRS_NARROW") && !force_narrow;
     // 16-row blocks per wavefront of the wide kernel: as many as the registers of ONE wave per SIMD hold without a spill
     const int NRBW = KS <= 4 ? 6 : (KS <= 8 ? 5 : (KS <= 16 ? 4 : 2));
-    const int tile_rows = wide ? 64 * NRBW : 32 * RB;
+    // ... or (default, round 6) the x32 kernel: RBX blocks of 32 rows per wavefront, ONE workgroup per compute unit and sweep
+    const bool x16 = wide && getenv("GG_ALLPAIRS_X16");
+    const int tile_rows = wide ? (x16 ? 64 * NRBW : (KS <= 16 ? 512 : 256)) : 32 * RB;  // (x32: 32 RB NW rows)
     const int row_tiles = cdiv(n_rows, tile_rows);
     // enough workgroups for the chip: split the columns when there are few row tiles (multiples of 128 columns)
-    int splits = std::max(1, std::min(cdiv(n, 128), cdiv(wide ? 1024 : 2048, row_tiles)));
+    int splits = std::max(1, std::min(cdiv(n, 128), cdiv(wide ? (x16 ? 1024 : 256) : 2048, row_tiles)));
     int cps = cdiv(cdiv(n, splits), 128) * 128;
     splits = cdiv(n, cps);
     DevBuf d_rows, d_pm, d_pa, d_ps, d_bf, d_ovf;
@@ -591,7 +851,39 @@ extern "C" int gg_all_score_reduce(gg_ctx *ctx, const int32_t *rows, int32_t n_r
         else hipLaunchKernelGGL((all_score_reduce_bf16_x16_kernel<KSV, NRBV, false>), grid, dim3(256), 0, ctx->stream, Eb, G.b, n, dr, n_rows, cps,        \
                                 d_pm.as<float>(), d_pa.as<int32_t>(), d_ps.as<float>(), d_ovf.as<int32_t>());                                           \
     } while (0)
-        if (wide) {  // (NRBW above)
+#define GG_BF16_X32(KSV, RBV, NWV)                                                                                                                         \
+    do {                                                                                                                                               \
+        const size_t dyn = 4 * (KSV) * 1024 + 1024 + 256 * (NWV);                                                                                                   \
+        if (want_lse) {                                                                                                                                \
+            (void)hipFuncSetAttribute((const void *)all_score_reduce_bf16_x32_kernel<KSV, RBV, NWV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
+            hipLaunchKernelGGL((all_score_reduce_bf16_x32_kernel<KSV, RBV, NWV, true>), grid, dim3(64 * (NWV)), dyn, ctx->stream, Eb, G.b, n, dr, n_rows, cps, \
+                               d_pm.as<float>(), d_pa.as<int32_t>(), d_ps.as<float>(), d_ovf.as<int32_t>());                                             \
+        } else {                                                                                                                                       \
+            (void)hipFuncSetAttribute((const void *)all_score_reduce_bf16_x32_kernel<KSV, RBV, NWV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
+            hipLaunchKernelGGL((all_score_reduce_bf16_x32_kernel<KSV, RBV, NWV, false>), grid, dim3(64 * (NWV)), dyn, ctx->stream, Eb, G.b, n, dr, n_rows, cps, \
+                               d_pm.as<float>(), d_pa.as<int32_t>(), d_ps.as<float>(), d_ovf.as<int32_t>());                                             \
+        }                                                                                                                                              \
+    } while (0)
+        static const int k7dbg = getenv("GG_K7_DBG") ? atoi(getenv("GG_K7_DBG")) : 0;
+        if (wide && !x16 && k7dbg && KS == 16) {  // timing ablations (results wrong): the max / argmax consumer, one wavefront per SIMD
+            const size_t dyn = 4 * 16 * 1024 + 1024 + 256 * 4;
+#define GG_X32_DBG(D)                                                                                                                         \
+    case D:                                                                                                                                   \
+        (void)hipFuncSetAttribute((const void *)all_score_reduce_bf16_x32_kernel<16, 4, 4, false, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
+        hipLaunchKernelGGL((all_score_reduce_bf16_x32_kernel<16, 4, 4, false, D>), grid, dim3(256), dyn, ctx->stream, Eb, G.b, n, dr, n_rows, cps,    \
+                           d_pm.as<float>(), d_pa.as<int32_t>(), d_ps.as<float>(), d_ovf.as<int32_t>());                                        \
+        break;
+            switch (k7dbg) {
+                GG_X32_DBG(1) GG_X32_DBG(2) GG_X32_DBG(8) GG_X32_DBG(16) GG_X32_DBG(27) GG_X32_DBG(32) GG_X32_DBG(96) GG_X32_DBG(34)
+            }
+#undef GG_X32_DBG
+        } else if (wide && !x16) {  // (RBX above)
+            static const bool one_wave = getenv("GG_K7_NW4") != nullptr;  // (A/B: one wavefront per SIMD with 4 row blocks)
+            if (KS <= 4) { GG_BF16_X32(4, 2, 8); }
+            else if (KS <= 8) { GG_BF16_X32(8, 2, 8); }
+            else if (KS <= 16) { if (one_wave) { GG_BF16_X32(16, 4, 4); } else { GG_BF16_X32(16, 2, 8); } }
+            else { GG_BF16_X32(32, 1, 8); }
+        } else if (wide) {  // (NRBW above)
             if (KS <= 4) { GG_BF16_WIDE(4, 6); }
             else if (KS <= 8) { GG_BF16_WIDE(8, 5); }
             else if (KS <= 16) { GG_BF16_WIDE(16, 4); }
@@ -602,6 +894,7 @@ extern "C" int gg_all_score_reduce(gg_ctx *ctx, const int32_t *rows, int32_t n_r
         else { GG_BF16_LAUNCH(32, 1); }
 #undef GG_BF16_LAUNCH
 #undef GG_BF16_WIDE
+#undef GG_BF16_X32
     }
     (void)hipEventRecord(ctx->ev1, ctx->stream);
     std::vector<float> pm(np), ps(np);
