@@ -288,236 +288,42 @@ __global__ __launch_bounds__(256) void all_score_reduce_bf16_kernel(const uint4 
     tile_finish<16 * RB>(run, lse != 0, r0, n_rows, split, gridDim.x, part_max, part_arg, part_sum, sh_m, sh_s, sh_a);
 }
 
-// The same consumer for MANY rows (>= 512): the 4 wavefronts of a workgroup take 4 DIFFERENT row blocks (16 NRB rows each) and walk
-// the SAME 32-column tiles, so one sweep of the table serves 64 NRB rows instead of 32 or 64 -- in the kernel above every
-// row tile re-streams the whole bf16 table from HBM (4 096 rows x 10^7 nodes: 128 sweeps of 5 GB = 8.3 TB/s at 266 TFLOP/s:
-// it ran at the HBM roofline, not the matrix cores').  No cross-wave merge: a wave owns its rows.  One wavefront per SIMD
-// (all 512 registers), so everything below is about what that single instruction stream looks like:
-//  - v_mfma_f32_16x16x32_bf16: a wavefront owns NRB blocks of 16 rows x 2 halves of the 32-column tile = 2 NRB independent
-//    16x16 accumulators (4 registers each), walked k-step by k-step (32 k): 2 NRB instructions between two uses of one
-//    accumulator.  A 16 x 32 fragment is 4 runs of 256 bytes of the table's 32-row tiles (to_bf16_kernel).  The running state
-//    is 4 NRB cells per lane (lane = column, registers = rows; both column halves of a tile feed the same row cells).
-//  - the A fragments live in ACCUMULATION registers (a matrix instruction reads A from either file).  As ordinary values
-//    they overflow the 256 architectural registers together with b[] and the running state, and the compiler's way out is to
-//    park them in accumulation registers anyway and COPY four registers back in front of every second matrix instruction.
-//  - the B fragments are requested and awaited BY HAND (inline assembly): where these loads sit decides everything with one
-//    wavefront per SIMD, and the compiler moved them with every edit of the loop (to the top of the next iteration = no
-//    prefetch; into a second register set = 64 copies per tile; behind a bias load whose wait drained the whole queue).
-//    ONE set of B registers: step t of the NEXT tile is requested into b[t] right behind the matrix instructions that read
-//    the current b[t]; the memory counter retires in order and a request pair has exactly KS - 2 younger requests when its
-//    step is multiplied, so `s_waitcnt vmcnt(KS - 2)` there is exact.  Each b[t] is a read-write operand of both
-//    statements: it stays in one register quadruple and nothing moves across the wait.  THE KERNEL MUST NOT SPILL OR COPY them: a b[t] moved
-//    while its data is in flight is stale.  The build checks both on the generated code: csrc/check_no_scratch.sh (no scratch,
-//    no spill in any instantiation) and csrc/audit_inflight_regs.py (no instruction names a destination register between a
-//    load statement and the wait that covers it, around the loop and from the prologue).
-//  - the bias of the columns comes through LDS, 2 048 columns at a time and private to the wave: a global bias load per tile
-//    sits in the same in-order memory counter as the B prefetch.  The refill is the only compiler-issued load in the loop;
-//    its compiler-placed wait drains the queue (over-waiting is safe), once per 64 tiles, all 32 requests in flight at once.
-//  - software pipeline over TWO accumulator sets: the iteration that multiplies tile t consumes the finished accumulators
-//    of tile t - 1 between its matrix instructions (8 NRB / KT scores behind each k-step, pinned with scheduling barriers: left
-//    alone the scheduler lumps the consumer behind the matrix instructions).  One extra iteration drains the pipe;
-//    iterations in front of the first / behind the last tile of the split see a bias of -inf and change nothing (their
-//    matrix instructions re-read the split's first tile: finite numbers).
-//  - a 7-instruction consumer: the log-sum-exp is accumulated WITHOUT a running reference, s += exp2(x log2 e) -- one fused
-//    multiply-add and one exponential per score, no rescale, no select -- and brought to the (max, sum exp(x - max)) form
-//    once, at the end; max / argmax compare the scores themselves (bit-identical to the other kernels).  The reference-free
-//    sum is finite and accurate while the scores stay inside (-85, 85) -- embedding dot products are a few units --; a
-//    cell whose sum overflows, or underflows to 0, raises `overflow` and the host repeats the call with the kernel above.
-// Measured at 4 096 rows x 10^7 nodes x d = 256 (ms per call on one box; DESIGN.md section 5 has the table): this kernel 21.1
-// (max / argmax only: 17.5; both with the accumulators in architectural registers, Makefile); without the software pipeline, 32x32x16 instructions: 22.2; the same before the A fragments
-// moved to accumulation registers and the refill issued its 32 loads one by one: 25.3; before the hand-placed loads: 30.6.
-// Its matrix instructions alone (no loads, no consumer) take 13.4 ms = 1.56 PFLOP/s: the clocks this chip sustains under
-// dense matrix work, not the 2.5 PFLOP/s of the data sheet, are what "1.0" would be.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-template <int KS, int NRB, bool LSE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void all_score_reduce_bf16_x16_kernel(const uint4 *Eb, const float *bias, int n_node, const int32_t *rows,
-                                                                        int n_rows, int cols_per_split, float *part_max,
-                                                                        int32_t *part_arg, float *part_sum, int32_t *overflow) {
-    constexpr int KT = KS / 2;  // k-steps of 32
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kg = lane >> 4;
-    const int split = blockIdx.x, r0 = blockIdx.y * (64 * NRB) + wv * (16 * NRB);
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    union FragA { u32x4 q; bf16x8 v; };
-    union FragB { u32x4 q; bf16x8 v; };
-    // lane (row l15, k-group kg) of a 16 x 32 fragment: 8 consecutive k = 16-slice 2t + (kg >> 1), half kg & 1 of the table
-    FragA afrag[NRB][KT];
-#pragma unroll
-    for (int rbk = 0; rbk < NRB; ++rbk) {
-        const int r = r0 + 16 * rbk + l15;
-        const int node = r < n_rows ? (rows ? rows[r] : r) : -1;
-#pragma unroll
-        for (int t = 0; t < KT; ++t) {
-            const u32x4 z = {0u, 0u, 0u, 0u};
-            afrag[rbk][t].q = node >= 0 ? *(const u32x4 *)&Eb[bf16_piece(node, 2 * t + (kg >> 1), kg & 1, KS)] : z;
-        }
-    }
-    float rm[NRB][4], rs[NRB][4];
-    int ra[NRB][4];
-#pragma unroll
-    for (int rbk = 0; rbk < NRB; ++rbk)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { rm[rbk][i] = -INFINITY; rs[rbk][i] = 0.f; ra[rbk][i] = 0x7fffffff; }
-    const int cbeg = split * cols_per_split, cend = min(n_node, cbeg + cols_per_split);
-    auto tile_of = [&](int c0t) -> const char * {  // (the prefetch behind the split's end re-reads its first tile)
-        return (const char *)(Eb + (int64_t)((c0t < cend ? c0t : cbeg) >> 5) * KS * 64);
-    };
-    constexpr float LOG2E = 1.44269504088896341f;
-    // B fragments by hand, as above: step t, column half h at byte (t & 1) * 2048 + h * 256 behind voff[t >> 1]; every request
-    // pair has KS - 2 younger requests when its step is multiplied
-    int voff[(KT + 1) / 2];
-#pragma unroll
-    for (int k = 0; k < (KT + 1) / 2; ++k) voff[k] = (((kg >> 1) * 64 + 32 * (kg & 1) + l15) << 4) + 4096 * k;
-    FragB b[KT][2];
-#define GG_B16_LOAD(T, H, BASE, CONSTRAINT)                                                                                       \
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : CONSTRAINT(b[T][H].q) : "v"(voff[(T) >> 1]), "s"(BASE), "n"(((T) & 1) * 2048 + (H) * 256))
-    {
-        // The A fragments live in ACCUMULATION registers from here on (a matrix instruction reads its A operand from either file).
-        // As ordinary values they overflow the 256 architectural registers together with b[] and the running state, and the
-        // compiler's way out is to park them in accumulation registers anyway and COPY four registers back in front of every
-        // second matrix instruction: 128 extra vector instructions per tile, each pair a write-after-read on the operand the
-        // matrix core is still reading.  (It also puts their compiler-placed wait in front of the loop.)
-#pragma unroll
-        for (int rbk = 0; rbk < NRB; ++rbk)
-#pragma unroll
-            for (int t = 0; t < KT; ++t) asm volatile("" : "+a"(afrag[rbk][t].q));
-        const char *const first = tile_of(cbeg);
-#pragma unroll
-        for (int t = 0; t < KT; ++t) {
-            GG_B16_LOAD(t, 0, first, "=v");
-            GG_B16_LOAD(t, 1, first, "=v");
-        }
-    }
-    constexpr int BIAS_CHUNK = 2048;
-    __shared__ float bias_lds[4][BIAS_CHUNK];
-    float *const wb = bias_lds[wv];
-    f32x4 acc[2][NRB][2];
-#pragma unroll
-    for (int rbk = 0; rbk < NRB; ++rbk)
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[1][rbk][h][i] = 0.f;
-    constexpr int VALS = NRB * 8;  // scores per lane and tile: consumed VALS / KT behind each k-step of the next tile
-    for (int cc = cbeg; cc < cend + 32; cc += 64) {
-        // bias of the two tiles consumed in this iteration (cc - 32 and cc): only the second can open a new LDS chunk (refilled
-        // after the first one's read), and the two halves below stay one basic block
-        float bjs[2][2];
-        const int wprev = (cc - 32 - cbeg) & (BIAS_CHUNK - 1);
-        bjs[0][0] = cc > cbeg ? wb[wprev + l15] : -INFINITY;
-        bjs[0][1] = cc > cbeg ? wb[wprev + 16 + l15] : -INFINITY;
-        const int within = (cc - cbeg) & (BIAS_CHUNK - 1);
-        if (within == 0) {  // (all requests first, clamped instead of predicated: one memory latency per refill, not 32)
-            float bv[BIAS_CHUNK / 64];
-#pragma unroll
-            for (int i = 0; i < BIAS_CHUNK / 64; ++i) bv[i] = bias[min(cc + i * 64 + lane, cend - 1)];
-#pragma unroll
-            for (int i = 0; i < BIAS_CHUNK / 64; ++i) wb[i * 64 + lane] = cc + i * 64 + lane < cend ? bv[i] : -INFINITY;
-        }
-        bjs[1][0] = wb[within + l15];
-        bjs[1][1] = wb[within + 16 + l15];
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int c0 = cc + 32 * p, cprev = c0 - 32;  // multiplied now / consumed now
-            const int col0 = cprev + l15;
-            const float bj2[2] = {bjs[p][0] * LOG2E, bjs[p][1] * LOG2E};
-            const char *const nxt = tile_of(c0 + 32);
-#pragma unroll
-            for (int rbk = 0; rbk < NRB; ++rbk)
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[p][rbk][h][i] = 0.f;
-#pragma unroll
-            for (int t = 0; t < KT; ++t) {
-                asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b[t][0].q), "+v"(b[t][1].q) : "n"(KS - 2));
-#pragma unroll
-                for (int rbk = 0; rbk < NRB; ++rbk)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h)
-                        acc[p][rbk][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[rbk][t].v, b[t][h].v, acc[p][rbk][h], 0, 0, 0);
-                GG_B16_LOAD(t, 0, nxt, "+v");
-                GG_B16_LOAD(t, 1, nxt, "+v");
-#pragma unroll
-                for (int v = t * VALS / KT; v < (t + 1) * VALS / KT; ++v) {
-                    // (column half 0 of every row cell before half 1: ties keep the lower column)
-                    const int h = v / (NRB * 4), rbk = (v >> 2) % NRB, i = v & 3;
-                    const float a = acc[p ^ 1][rbk][h][i];
-                    const float x = a + bjs[p][h];
-                    if (LSE) rs[rbk][i] += __builtin_amdgcn_exp2f(__builtin_fmaf(a, LOG2E, bj2[h]));
-                    const bool up = x > rm[rbk][i];
-                    rm[rbk][i] = up ? x : rm[rbk][i];
-                    ra[rbk][i] = up ? col0 + 16 * h : ra[rbk][i];
-                }
-                // one matrix instruction, then the vector instructions that fit beside it (a wave issues in order: 2 NRB matrix
-                // instructions back to back hold the issue port until the last one is accepted, and the consumer runs after them)
-#pragma unroll
-                for (int k = 0; k < 2 * NRB; ++k) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);  // (left alone, the scheduler lumps the consumer behind the matrix instructions)
-            }
-        }
-    }
-    // (the last prefetch is still in flight INTO b[]: drain it before the registers are anyone else's)
-#pragma unroll
-    for (int t = 0; t < KT; ++t) asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[t][0].q), "+v"(b[t][1].q));
-#undef GG_B16_LOAD
-    // merge a row's 16 column lanes; lanes with l15 == 0 then hold rows 16 rbk + 4 kg + i
-#pragma unroll
-    for (int rbk = 0; rbk < NRB; ++rbk) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float sx = rs[rbk][i];
-            if (LSE) {
-                if (!(sx <= 3.0e38f) || (sx == 0.f && rm[rbk][i] > -INFINITY)) atomicOr(overflow, 1);
-                sx = rm[rbk][i] > -INFINITY ? sx * __builtin_amdgcn_exp2f(-rm[rbk][i] * LOG2E) : 0.f;
-            }
-            Running x{rm[rbk][i], sx, ra[rbk][i]};
-#pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) {
-                const float m = __shfl_xor(x.m, off, 64), so = __shfl_xor(x.s, off, 64);
-                const int ar = __shfl_xor(x.arg, off, 64);
-                run_merge(x, m, so, ar, LSE);
-            }
-            if (l15 == 0) {
-                const int row = r0 + 16 * rbk + 4 * kg + i;
-                if (row < n_rows) {
-                    const int64_t o = (int64_t)row * gridDim.x + split;
-                    part_max[o] = x.m;
-                    part_arg[o] = x.arg;
-                    part_sum[o] = x.s;
-                }
-            }
-        }
-    }
-}
 
-// Round 6: the many-rows consumer on v_mfma_f32_32x32x16_bf16 with the REQUESTED ROWS ON THE LANES.  The matrix instruction's A
-// operand is the table tile (32 nodes), its B operand a block of 32 requested rows, so a lane's 16 accumulator registers are 16
-// NODES of ONE requested row (row = lane & 31; nodes (i & 3) + 8 (i >> 2) + 4 (lane >> 5) of the tile): the running state of a
-// row block is one (max, argmax, sum) cell per lane instead of 16, and the consumer is per score
+// The same consumer for MANY rows (>= 512), round 6: v_mfma_f32_32x32x16_bf16 with the REQUESTED ROWS ON THE LANES.  The matrix
+// instruction's A operand is the table tile (32 nodes), its B operand a block of 32 requested rows, so a lane's 16 accumulator
+// registers are 16 NODES of ONE requested row (row = lane & 31; nodes (i & 3) + 8 (i >> 2) + 4 (lane >> 5) of the tile): the
+// running state of a row block is one (max, tile, sum) cell per lane instead of 16, and the consumer is per score
 //     y = x log2 e;  s += exp2(y);  half a v_max3
-// -- 3.5 vector instructions (the x16 kernel above: 9.2, SQ_INSTS_VALU / scores in profiles/r5_pmc_k7_sq.json), which is what fits
-// beside a 32-cycle matrix instruction on a SIMD that holds one wavefront (MI355X_MICROARCH.md: <= 5 single-issue instructions
-// hidden per v_mfma_f32_32x32x16_bf16).  What makes that possible:
+// -- 3.5 vector instructions (rounds 3-5's kernel on v_mfma_f32_16x16x32_bf16, rows on the registers: 9.2, SQ_INSTS_VALU / scores
+// in profiles/r5_pmc_k7_sq.json; that kernel and its hand-placed loads are in profiles/HISTORY.md), which is about what fits
+// beside a 32-cycle matrix instruction (MI355X_MICROARCH.md: <= 5 single-issue instructions hidden per
+// v_mfma_f32_32x32x16_bf16 and wavefront).  What makes that possible:
 //  - the bias of a node is the INITIAL VALUE of its accumulator register (16-byte LDS reads straight into the accumulator
-//    tuple), not an addition per score; the narrow kernel above starts its accumulators at the bias as well, so both give the
-//    same bits;
-//  - max / argmax: the tile's 16 scores of a row fold into one maximum (v_max3 chain); only when that beats the running maximum
-//    in ANY lane (a few hundred times per sweep, ~ 64 ln(tiles / 64)) a uniform branch finds the first register that holds it;
-//  - the log-sum-exp is the reference-free sum of the x16 kernel (overflow flag -> the call is repeated with the narrow kernel).
-// Operands: a wavefront keeps RB blocks of 32 requested rows as B fragments in ACCUMULATION registers (RB KS 4 = all 256 of them
-// at d = 256) for the whole sweep; the table tile (KS KB) is staged ONCE per workgroup through LDS (each of the 4 wavefronts
-// loads a quarter of the next tile at the top of an iteration and stores it behind the matrix instructions; one barrier per
-// tile) -- a quarter of the L1 requests of four private streams, no hand-placed loads, nothing for the register allocator to
-// break.  A workgroup sweeps its column range once for 128 RB rows (512 at d = 256: 8 sweeps of the bf16 table for 4 096 rows,
-// and the row tiles of one column split sit on ONE XCD -- workgroup id mod 8 = split mod 8 -- so they share its L2).
-// Pipeline: iteration t multiplies tile t into accumulator set t & 1 and consumes tile t - 1 from the other set, one quad of
-// scores behind each group of matrix instructions; a consumed row block's registers are re-initialised with the bias of tile
-// t + 1 (a ring of 4 bias tiles in LDS, written two tiles ahead).  Tiles outside the split have a bias of -inf: x = -inf,
-// exp2 = 0, never a maximum -- the pipeline's first and last iterations need no special case.
-template <int KS, int RB, int NW, bool LSE, int DBG = 0>  // (DBG: timing ablations, results wrong -- 1 no barrier / no LDS store, 2 no global loads, 4 no slow path)
+//    tuple), not an addition per score; the narrow kernel above starts its accumulators at the bias as well: same bits;
+//  - max / argmax: the tile's 16 scores of a row fold into one maximum (v_max3 chain), and a row block's running cell keeps
+//    (max, TILE) by one compare and two selects per tile; WHICH node of the winning tile is found after the sweep by
+//    multiplying that tile once more (below) -- the sweep has no branch;
+//  - the log-sum-exp is accumulated WITHOUT a running reference, s += exp2(x log2 e), and brought to the (max, sum exp(x - max))
+//    form once, at the end: finite and accurate while the scores stay inside (-85, 85) -- embedding dot products are a few
+//    units --; a cell whose sum overflows, or underflows to 0, raises `overflow` and the host repeats the call with the
+//    narrow kernel above (running maximum per cell).
+// Operands: a wavefront keeps RB blocks of 32 requested rows as B fragments in ACCUMULATION registers for the whole sweep
+// (RB KS 4 registers: 128 at d = 256 with RB = 2); the table tile (KS KB) is staged ONCE per workgroup through LDS -- every
+// wavefront requests 1 / NW of tile t + 3 by LDS-DMA in the middle of iteration t; four buffers; one bare s_barrier per tile
+// -- and read from there as A fragments, one k-step ahead of its matrix instructions.  NW = 8 wavefronts (two per SIMD) of
+// RB = 2 row blocks: a workgroup sweeps its column range once for 512 rows (8 sweeps of the bf16 table for 4 096 rows; the row
+// tiles of one column split sit on ONE XCD -- workgroup id mod 8 = split mod 8 -- and share its L2); one workgroup per
+// compute unit, 256 in all.  (One wavefront per SIMD with RB = 4, GG_K7_NW4: the same without the log-sum-exp, 3 % slower with it.)
+// Pipeline: iteration t multiplies tile t into accumulator set t & 1 and consumes tile t - 1 from the other set; a consumed
+// quad's registers are re-initialised with the bias of tile t + 1 (a ring of 4 bias tiles in LDS).  Tiles outside the split
+// have a bias of -inf: x = -inf, exp2 = 0, never a maximum -- the pipeline's first and last iterations need no special case.
+// Measured, 4 096 rows x 10^7 nodes x d = 256 (ms per call): 15.6 - 16.0 with the log-sum-exp (the 16x16x32 kernel: 21.2),
+// 14.3 - 14.6 without; its matrix instructions alone (ablation 27: no staging, no LDS reads) 11.2 -- the chip sustains ~1.9 GHz
+// under this load (SQ_BUSY_CYCLES / duration), at which 6.4 10^8 matrix instructions x 32 cycles are 10.5 ms.
+// DBG (builds with -DGG_K7_ABLATIONS only; results WRONG): 1 no barrier / staging, 2 no table loads, 4 no argmax resolution, 8 no
+// fragment reads, 16 no bias reads, 128 staging through registers instead of LDS-DMA
+template <int KS, int RB, int NW, bool LSE, int DBG = 0>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void all_score_reduce_bf16_x32_kernel(
     const uint4 *Eb, const float *bias, int n_node, const int32_t *rows, int n_rows, int cols_per_split, float *part_max, int32_t *part_arg,
     float *part_sum, int32_t *overflow) {
@@ -547,7 +353,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int s = 0; s < KS; ++s) asm volatile("" : "+a"(rf[rb][s].q));  // (accumulation registers: see the x16 kernel)
+        for (int s = 0; s < KS; ++s) asm volatile("" : "+a"(rf[rb][s].q));  // (into ACCUMULATION registers: a matrix instruction reads B from either file)
     float rm[RB], rs[RB], tmax[RB];
     int rt[RB];  // the TILE that holds the row's maximum; which of its nodes is found after the sweep (below)
 #pragma unroll
@@ -568,6 +374,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
         const int c = cbeg + 32 * t + tid;
         return (tid < 32 && t < n_tiles && c < cend) ? bias[c] : -INFINITY;
     };
+    constexpr bool DMA = (DBG & 128) == 0;  // LDS-DMA requests (default) or registers (measured: the same speed, 8 G registers more)
     u32x4 g[G];
     float gb;
     unsigned char *b_cur = x32_lds, *b_nxt = x32_lds + BUF, *b_n2 = x32_lds + 2 * BUF, *b_wr = x32_lds + 3 * BUF;  // tiles t .. t + 3
@@ -588,7 +395,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
 #pragma unroll
         for (int k = 0; k < G; ++k) g[k] = src[64 * k];
 #pragma unroll
-        for (int k = 0; k < G; ++k) if (stager) ((u32x4 *)b_n2)[(wv * G + k) * 64 + lane] = g[k];
+        for (int k = 0; k < G; ++k) if (stager && DMA) ((u32x4 *)b_n2)[(wv * G + k) * 64 + lane] = g[k];  // (!DMA: iteration 0 stores it)
         gb = bias_of(3);  // (iteration 0 stores it)
     }
     __syncthreads();
@@ -640,7 +447,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
                     const int slot = s * RB + k;
                     if (s == KS / 2 && k == 0 && !(DBG & 1)) {
                         // (the tile requested one iteration ago has landed: nothing to wait for; the wait makes it formal)
-                        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                        if (DMA) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                        else asm volatile("s_barrier" ::: "memory");
                     }
                     acc[p][k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur.v, rf[k][s].v, acc[p][k], 0, 0, 0);
                     if (k == 0) {
@@ -654,10 +462,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
                         if (!(DBG & 8)) a_nxt.q = s + 1 < KS ? tl[64 * (s + 1)] : tl_next[0];
                         else a_nxt.q = a_cur.q;
                     }
-                    if (k == (RB > 1 ? 1 : 0) && s >= KS / 2 && s < KS / 2 + G && stager && !(DBG & 3)) {
+                    if (DMA && k == (RB > 1 ? 1 : 0) && s >= KS / 2 && s < KS / 2 + G && stager && !(DBG & 3)) {
                         // tile t + 3 straight into the buffer tile t - 1 has left; lane l's 16 bytes land at M0 + 16 l
                         __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(dsrc + 64 * (s - KS / 2)),
                                                          (void __attribute__((address_space(3))) *)(b_wr + (wv * G + s - KS / 2) * 1024), 16, 0, 0);
+                    }
+                    if (!DMA && s >= KS / 2 && s < KS / 2 + G && stager && !(DBG & 1)) {
+                        // tile t + 2 (requested one iteration ago) into its buffer, and the same registers take tile t + 3
+                        if (k == (RB > 1 ? 1 : 0)) ((u32x4 *)b_n2)[(wv * G + s - KS / 2) * 64 + lane] = g[s - KS / 2];
+                        if (k == RB - 1 && !(DBG & 2)) g[s - KS / 2] = dsrc[64 * (s - KS / 2)];
                     }
                     if (k == 0 && s == KS / 2 && !(DBG & 1)) ring_dst[32 * ((t + 3) & 3)] = gb;  // bias of tile t + 3 (in front of the DMA requests)
                     if (k == RB - 1 && s == KS / 2 + 1 && !(DBG & 3)) gb = bok ? bias[bc] : -INFINITY;  // ... of tile t + 4
@@ -703,7 +516,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
         const float m_o = __shfl_xor(rm[rb], 32, 64);
         const int t_o = __shfl_xor(rt[rb], 32, 64);
         const bool need = rt[rb] >= 0 && (rm[rb] > m_o || (rm[rb] == m_o && rt[rb] <= t_o));
-        unsigned long long todo = __builtin_amdgcn_ballot_w64(need);
+        unsigned long long todo = (DBG & 4) ? 0ull : __builtin_amdgcn_ballot_w64(need);
         int arg = 0x7fffffff;
         while (todo) {
             const int j = __builtin_ctzll(todo);
@@ -800,17 +613,15 @@ extern "C" int gg_all_score_reduce(gg_ctx *ctx, const int32_t *rows, int32_t n_r
     const int KS = ks_need <= 4 ? 4 : ks_need <= 8 ? 8 : ks_need <= 16 ? 16 : 32;
     const int ld16 = 16 * KS;
     const int RB = (precision == 1 && KS <= 8) ? 2 : 1;
-    // bf16, many rows: a workgroup's four wavefronts take four row blocks and share the table sweep (all_score_reduce_bf16_x16_kernel)
+    // bf16, many rows: the x32 kernel -- a workgroup's wavefronts take 32 RB rows each and share ONE sweep of the table, one
+    // workgroup per compute unit (all_score_reduce_bf16_x32_kernel)
     static thread_local bool force_narrow = false;  // set for the repeat of a call whose wide kernel reported an overflowing sum
     const bool wide = precision == 1 && n_rows >= 512 && !getenv("GG_ALLPAIRS_NARROW") && !force_narrow;
-    // 16-row blocks per wavefront of the wide kernel: as many as the registers of ONE wave per SIMD hold without a spill
-    const int NRBW = KS <= 4 ? 6 : (KS <= 8 ? 5 : (KS <= 16 ? 4 : 2));
-    // ... or (default, round 6) the x32 kernel: RBX blocks of 32 rows per wavefront, ONE workgroup per compute unit and sweep
-    const bool x16 = wide && getenv("GG_ALLPAIRS_X16");
-    const int tile_rows = wide ? (x16 ? 64 * NRBW : (KS <= 16 ? 512 : 256)) : 32 * RB;  // (x32: 32 RB NW rows)
+    static const bool one_wave = getenv("GG_K7_NW4") != nullptr;  // (A/B at d <= 256: one wavefront per SIMD with 4 row blocks)
+    const int tile_rows = wide ? (KS <= 16 ? 512 : 256) : 32 * RB;  // (x32: 32 RB NW rows)
     const int row_tiles = cdiv(n_rows, tile_rows);
     // enough workgroups for the chip: split the columns when there are few row tiles (multiples of 128 columns)
-    int splits = std::max(1, std::min(cdiv(n, 128), cdiv(wide ? (x16 ? 1024 : 256) : 2048, row_tiles)));
+    int splits = std::max(1, std::min(cdiv(n, 128), cdiv(wide ? 256 : 2048, row_tiles)));
     int cps = cdiv(cdiv(n, splits), 128) * 128;
     splits = cdiv(n, cps);
     DevBuf d_rows, d_pm, d_pa, d_ps, d_bf, d_ovf;
@@ -844,13 +655,6 @@ extern "C" int gg_all_score_reduce(gg_ctx *ctx, const int32_t *rows, int32_t n_r
 #define GG_BF16_LAUNCH(KSV, RBV)                                                                                                    \
     hipLaunchKernelGGL((all_score_reduce_bf16_kernel<KSV, RBV>), grid, dim3(256), 0, ctx->stream, Eb, G.b, n, dr, n_rows, cps, want_lse, \
                        d_pm.as<float>(), d_pa.as<int32_t>(), d_ps.as<float>())
-#define GG_BF16_WIDE(KSV, NRBV)                                                                                                                         \
-    do {                                                                                                                                               \
-        if (want_lse) hipLaunchKernelGGL((all_score_reduce_bf16_x16_kernel<KSV, NRBV, true>), grid, dim3(256), 0, ctx->stream, Eb, G.b, n, dr, n_rows, cps, \
-                                         d_pm.as<float>(), d_pa.as<int32_t>(), d_ps.as<float>(), d_ovf.as<int32_t>());                                   \
-        else hipLaunchKernelGGL((all_score_reduce_bf16_x16_kernel<KSV, NRBV, false>), grid, dim3(256), 0, ctx->stream, Eb, G.b, n, dr, n_rows, cps,        \
-                                d_pm.as<float>(), d_pa.as<int32_t>(), d_ps.as<float>(), d_ovf.as<int32_t>());                                           \
-    } while (0)
 #define GG_BF16_X32(KSV, RBV, NWV)                                                                                                                         \
     do {                                                                                                                                               \
         const size_t dyn = 4 * (KSV) * 1024 + 1024 + 256 * (NWV);                                                                                                   \
@@ -864,8 +668,13 @@ extern "C" int gg_all_score_reduce(gg_ctx *ctx, const int32_t *rows, int32_t n_r
                                d_pm.as<float>(), d_pa.as<int32_t>(), d_ps.as<float>(), d_ovf.as<int32_t>());                                             \
         }                                                                                                                                              \
     } while (0)
+#ifdef GG_K7_ABLATIONS  // (make EXTRA=-DGG_K7_ABLATIONS: the timing ablations of profiles/HISTORY.md, results WRONG)
         static const int k7dbg = getenv("GG_K7_DBG") ? atoi(getenv("GG_K7_DBG")) : 0;
-        if (wide && !x16 && k7dbg && KS == 16) {  // timing ablations (results wrong): the max / argmax consumer, one wavefront per SIMD
+#else
+        constexpr int k7dbg = 0;
+#endif
+        if (wide && k7dbg && KS == 16) {
+#ifdef GG_K7_ABLATIONS
             const size_t dyn = 4 * 16 * 1024 + 1024 + 256 * 4;
 #define GG_X32_DBG(D)                                                                                                                         \
     case D:                                                                                                                                   \
@@ -874,26 +683,20 @@ extern "C" int gg_all_score_reduce(gg_ctx *ctx, const int32_t *rows, int32_t n_r
                            d_pm.as<float>(), d_pa.as<int32_t>(), d_ps.as<float>(), d_ovf.as<int32_t>());                                        \
         break;
             switch (k7dbg) {
-                GG_X32_DBG(1) GG_X32_DBG(2) GG_X32_DBG(8) GG_X32_DBG(16) GG_X32_DBG(27) GG_X32_DBG(32) GG_X32_DBG(96) GG_X32_DBG(34)
+                GG_X32_DBG(1) GG_X32_DBG(2) GG_X32_DBG(4) GG_X32_DBG(8) GG_X32_DBG(16) GG_X32_DBG(27) GG_X32_DBG(128)
             }
 #undef GG_X32_DBG
-        } else if (wide && !x16) {  // (RBX above)
-            static const bool one_wave = getenv("GG_K7_NW4") != nullptr;  // (A/B: one wavefront per SIMD with 4 row blocks)
+#endif
+        } else if (wide) {
             if (KS <= 4) { GG_BF16_X32(4, 2, 8); }
             else if (KS <= 8) { GG_BF16_X32(8, 2, 8); }
             else if (KS <= 16) { if (one_wave) { GG_BF16_X32(16, 4, 4); } else { GG_BF16_X32(16, 2, 8); } }
             else { GG_BF16_X32(32, 1, 8); }
-        } else if (wide) {  // (NRBW above)
-            if (KS <= 4) { GG_BF16_WIDE(4, 6); }
-            else if (KS <= 8) { GG_BF16_WIDE(8, 5); }
-            else if (KS <= 16) { GG_BF16_WIDE(16, 4); }
-            else { GG_BF16_WIDE(32, 2); }
         } else if (KS <= 4) { GG_BF16_LAUNCH(4, 2); }
         else if (KS <= 8) { GG_BF16_LAUNCH(8, 2); }
         else if (KS <= 16) { GG_BF16_LAUNCH(16, 1); }
         else { GG_BF16_LAUNCH(32, 1); }
 #undef GG_BF16_LAUNCH
-#undef GG_BF16_WIDE
 #undef GG_BF16_X32
     }
     (void)hipEventRecord(ctx->ev1, ctx->stream);

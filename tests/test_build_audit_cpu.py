@@ -1,34 +1,31 @@
-"""The wide all-pairs kernel (graphgan_amd/csrc/all_score.hip, all_score_reduce_bf16_x16_kernel) holds data of hand-placed
-loads in registers the compiler believes are already written; the build audits the generated assembly for anything that
-touches such a register while its load is in flight (csrc/audit_inflight_regs.py).  This checks the auditor itself: the
-assembly of the current build passes, and a copy with one injected register read fails."""
+"""Build audits.  The wide all-pairs kernel (graphgan_amd/csrc/all_score.hip, all_score_reduce_bf16_x32_kernel) must keep its
+operands in registers: the build fails if an instantiation uses scratch (csrc/check_no_scratch.sh) -- checked here on the
+auditor itself: the remarks of the current build pass, a copy with one spilled instantiation fails.  And the product path
+never touches the oracle."""
 import os
 import re
 import subprocess
-import sys
 
 import pytest
 
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "graphgan_amd", "csrc")
-ASM = os.path.join(CSRC, "all_score.s")
-AUDIT = os.path.join(CSRC, "audit_inflight_regs.py")
+REMARKS = os.path.join(CSRC, "all_score.remarks")
+CHECK = os.path.join(CSRC, "check_no_scratch.sh")
 
 
-@pytest.mark.skipif(not os.path.exists(ASM), reason="all_score.s is written by the build (make -C graphgan_amd/csrc)")
-def test_auditor_accepts_the_build_and_rejects_a_touched_register(tmp_path):
-    ok = subprocess.run([sys.executable, AUDIT, ASM], capture_output=True, text=True)
+@pytest.mark.skipif(not os.path.exists(REMARKS), reason="all_score.remarks is written by the build (make -C graphgan_amd/csrc)")
+def test_scratch_check_accepts_the_build_and_rejects_a_spill(tmp_path):
+    ok = subprocess.run(["bash", CHECK, REMARKS], capture_output=True, text=True)
     assert ok.returncode == 0, ok.stderr
-    assert "8 instantiations" in ok.stdout
-    lines = open(ASM).read().split("\n")
-    start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN2gg32all_score_reduce_bf16_x16_kernelILi16ELi4ELb1E.*:", l))
-    header = next(i for i in range(start, len(lines)) if "Loop Header" in lines[i] or "Inner Loop" in lines[i])
-    load = [i for i in range(header, header + 3000) if "global_load_dwordx4" in lines[i] and "#ASMSTART" in lines[i - 1]][3]
-    reg = re.search(r"v\[(\d+):", lines[load]).group(1)
-    bad = lines[:load + 3] + ["\tv_mov_b32_e32 v250, v%s" % reg] + lines[load + 3:]
-    p = tmp_path / "bad.s"
-    p.write_text("\n".join(bad))
-    res = subprocess.run([sys.executable, AUDIT, str(p)], capture_output=True, text=True)
-    assert res.returncode != 0 and "in flight" in res.stderr
+    assert "no scratch, no spill" in ok.stdout
+    text = open(REMARKS).read()
+    m = re.search(r"(Function Name: _ZN2gg32all_score_reduce_bf16_x32_kernel.*?ScratchSize \[bytes/lane\]: )0", text, flags=re.S)
+    assert m
+    bad = text[:m.end() - 1] + "832" + text[m.end():]
+    p = tmp_path / "bad.remarks"
+    p.write_text(bad)
+    res = subprocess.run(["bash", CHECK, str(p)], capture_output=True, text=True)
+    assert res.returncode != 0 and "spills" in res.stderr
 
 
 def test_product_path_never_touches_the_oracle():
