@@ -425,8 +425,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
     // the next k-step waits for the fragment (the compiler waits with lgkmcnt(0) everywhere in this loop: an LDS-DMA request
     // in flight makes it treat the LDS counter as out of order).
     constexpr int SLOTS = KS * RB, ELEMS = 16 * RB, CS = SLOTS - RB;
-    Frag a_cur;
-    a_cur.q = ((const u32x4 *)b_cur)[lane];
+    // A fragments: a ring of PD + 1, k-step s + PD requested under the matrix instructions of k-step s (PD + 1 divides KS: the
+    // ring's indices are the same in every iteration).  (Measured: PD = 3 against 1 with two matrix instructions per k-step --
+    // the same, three alternating runs each; the second wavefront of the SIMD covers the LDS round trip.)
+    constexpr int PD = 1, RING = PD + 1;
+    Frag af[RING];
+#pragma unroll
+    for (int s = 0; s < PD; ++s) af[s].q = ((const u32x4 *)b_cur)[64 * s + lane];
     float epend = 0.f;  // exponential of the last element, not yet added (row block RB - 1 at a tile's start)
     float *const ring_dst = tid < 32 ? ring + tid : ring + 128 + tid;  // (every thread stores: no branch in the loop; 128 .. 128 + 64 NW: a dump)
     for (int tt = 0; tt <= n_tiles; tt += 2) {
@@ -441,7 +446,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                Frag a_nxt;
 #pragma unroll
                 for (int k = 0; k < RB; ++k) {
                     const int slot = s * RB + k;
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
                         if (DMA) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
                         else asm volatile("s_barrier" ::: "memory");
                     }
-                    acc[p][k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur.v, rf[k][s].v, acc[p][k], 0, 0, 0);
+                    acc[p][k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s % RING].v, rf[k][s].v, acc[p][k], 0, 0, 0);
                     if (k == 0) {
 #pragma unroll
                         for (int e = 3; e < ELEMS; e += 4) {  // quads whose last element was consumed during the previous k-step
@@ -459,8 +463,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
 #pragma unroll
                             for (int j = 0; j < 4; ++j) acc[p ^ 1][e >> 4][(e & 12) + j] = b[j];
                         }
-                        if (!(DBG & 8)) a_nxt.q = s + 1 < KS ? tl[64 * (s + 1)] : tl_next[0];
-                        else a_nxt.q = a_cur.q;
+                        if (!(DBG & 8)) af[(s + PD) % RING].q = s + PD < KS ? tl[64 * (s + PD)] : tl_next[64 * (s + PD - KS)];
                     }
                     if (DMA && k == (RB > 1 ? 1 : 0) && s >= KS / 2 && s < KS / 2 + G && stager && !(DBG & 3)) {
                         // tile t + 3 straight into the buffer tile t - 1 has left; lane l's 16 bytes land at M0 + 16 l
@@ -495,7 +498,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                a_cur = a_nxt;
             }
             unsigned char *const o = b_cur;
             b_cur = b_nxt;
