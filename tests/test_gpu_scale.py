@@ -93,9 +93,11 @@ def test_powerlaw_10m_device_trees_and_walks_bit_exact(ga):
     slots = np.arange(len(roots), dtype=np.int32)
     stride = dmax + 3
     nbr = nbr.copy()
+    wants = []
     for rnd, for_d in enumerate((True, False, True)):
         nw = deg[roots] if for_d else np.full(len(roots), 20, np.int32)
         want = orc.c_walk_sample(Ep, b, off, nbr, base, roots, slots, nw, for_d, 6, rnd, stride)
+        wants.append(want)
         got = eng.walk_sample(slots, nw, for_d, 6, rnd, stride=stride)
         assert np.array_equal(got["root_status"], want["root_status"])
         assert np.array_equal(got["path_len"], want["path_len"])
@@ -105,6 +107,23 @@ def test_powerlaw_10m_device_trees_and_walks_bit_exact(ga):
     assert want["hops"] > 1000 and want["nbr_reads"] > 20 * want["hops"]   # hub lists were sampled from
     _, tnbr, _ = eng.get_trees()
     assert np.array_equal(tnbr, nbr)  # Q3 mutation state
+    del tnbr, nbr
+    # round 6: the same three launches on LAZY trees (exact through a level, deeper children lists resolved by the walks; at this
+    # size the visited words of a slot come from global memory: bfs_order2_kernel<false, .., true>, lazy_resolve_kernel<false>):
+    # the oracle's walks again, bit for bit, Q3 state carried from launch to launch
+    eng.set_tree_mode(1)
+    eng.build_trees(roots, device=True)
+    st = eng.lazy_stats()
+    assert st["lazy"] and st["lazy_slots"] >= 3
+    for rnd, for_d in enumerate((True, False, True)):
+        nw = deg[roots] if for_d else np.full(len(roots), 20, np.int32)
+        want = wants[rnd]
+        got = eng.walk_sample(slots, nw, for_d, 6, rnd, stride=stride)
+        assert np.array_equal(got["root_status"], want["root_status"])
+        assert np.array_equal(got["path_len"], want["path_len"])
+        assert np.array_equal(got["samples"], want["samples"])
+        m = np.arange(stride)[None, :] < want["path_len"][:, None]
+        assert np.array_equal(got["paths"][m], want["paths"][m])
     eng.close()
 
 
