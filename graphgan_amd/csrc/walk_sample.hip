@@ -119,6 +119,7 @@ struct WalkArgs {
     int32_t g_multi;              // some adjacency list holds a node twice: first-occurrence tests needed
     int32_t *lz_list;             // [n_slots] launch items with claimed walks at this level, then [n_slots] claims per item (zero between launches)
     int32_t *t_order_w, *t_edge_w;  // the tree arrays, writable (pool appends)
+    int32_t lz_coop_min;          // adjacencies longer than this are resolved by the whole workgroup (GG_LZ_COOP_MIN)
     int32_t lz_budget;            // 256-entry scan batches one list may cost; a list that needs more sends its slot to the whole-tree rebuild (bounds a launch's tail)
     unsigned long long *lz_ctr;   // statistics: [depth] lists resolved at depth 0 / 1 / 2, [3] candidates judged, [4] 16-entry scan rounds, [5] most rounds of one list
 };
@@ -404,9 +405,19 @@ __device__ __forceinline__ void lz_flat_scan(const WalkArgs &a, const Bits &bits
 // FENCE: readers of the pair may run in the SAME kernel (the finisher's walks): the list is made visible before the pair that names
 // it.  The resolve kernel's readers are later kernels -- and an agent-scope release on this chip writes the XCD's L2 back
 // (buffer_wbl2) and invalidates it: per list, that was ~60 % of the resolve kernel's time.
-template <bool FENCE, class Bits>
+// COOP (the resolve kernel's big lists, adjacencies of > LZ_COOP_MIN entries): ALL wavefronts of the workgroup call this for the
+// same list; wavefront wv judges the 64-entry chunks wv, wv + NW, .. (each privately, as above), the children masks meet in LDS,
+// and every wavefront writes the children of its own chunks behind the prefix of the masks' popcounts.  A walk through a hub
+// costs its list one round of chunks per NW instead of one chunk after the other on ONE wavefront while the item's other 15 wait:
+// in a 12 ms launch of the resolve kernel an item (root) took 187 us, most of it such a list.
+constexpr int LZ_COOP_CHUNKS = 256, LZ_COOP_MIN = 256;  // (adjacencies up to 16 384 entries; longer ones stay with one wavefront)
+struct LzCoop {
+    unsigned long long kids[LZ_COOP_CHUNKS];
+    int work, fb, start;
+};
+template <bool FENCE, class Bits, bool COOP = false>
 __device__ __forceinline__ unsigned long long lazy_resolve_wave(const WalkArgs &a, const Bits &bits, LzWork *ws, int slot, int64_t tbase, int rank, int cur, int prev,
-                                                                int level, int lane) {
+                                                                int level, int lane, int wv = 0, int nw = 1, LzCoop *sh = nullptr) {
     // Every argument is wave-uniform; as scalars the loops below branch on scalar conditions.
     // NO "if (lane == 0)" BRANCHES in this function or around its call: inlined into the resolve kernel's loop over the listed
     // walks, the lane-0-only store of the pair at its end was merged with the loop's latch -- lane 0 LEFT the loop after its first
@@ -443,7 +454,7 @@ __device__ __forceinline__ unsigned long long lazy_resolve_wave(const WalkArgs &
     // candidates of the whole adjacency: what the list can hold at most -> its place in the pool
     int x0 = -1, ncand = 0;
     bool c0 = false;
-    if (!fallback) {
+    if (!fallback && !COOP) {
         c0 = candidate(e0 + lane, x0);
         ncand = (int)__popcll(__ballot(c0));
         for (int64_t b = e0 + 64; b < e1; b += 64) {
@@ -452,18 +463,13 @@ __device__ __forceinline__ unsigned long long lazy_resolve_wave(const WalkArgs &
         }
     }
     int start = 0;
-    if (depth <= 1 && ncand > 0) {
+    if (!COOP && depth <= 1 && ncand > 0) {
         start = __builtin_amdgcn_readfirstlane(atomicAdd(&a.lz_cursor[slot], lane == 0 ? ncand : 0));
         if ((long long)start + ncand > (long long)seg) fallback = true;  // the pool is full
     }
     int count = 0, work = 0;
-    if (!fallback && ncand > 0) {
-        for (int64_t b = e0; b < e1 && work <= a.lz_budget; b += 64) {
-            int x = x0;
-            bool c = c0;
-            if (b != e0) c = candidate(b + lane, x);
-            const unsigned long long m = __ballot(c);
-            if (m) {
+    // one 64-entry chunk of adj(cur) (lane's entry: candidate c, node x; m = ballot of c): which entries are children
+    auto judge = [&](int x, bool c, unsigned long long m) -> unsigned long long {
             // the candidates' adjacencies, one segment per lane
             int64_t xq = 0, xe = 0;
             if (c) { xq = a.rowptr[x]; xe = a.rowptr[x + 1]; }
@@ -518,13 +524,83 @@ __device__ __forceinline__ unsigned long long lazy_resolve_wave(const WalkArgs &
                     if (below_m & ~ws->mask[1]) fallback = true;  // a neighbour two levels below the exact ones' children: cur is no leaf
                 }
             }
-            if ((kids >> lane) & 1ull) {
-                const int64_t at = tbase + start + count + (int)__popcll(kids & ((1ull << lane) - 1ull));
-                a.t_order_w[at] = x;
-                a.t_edge_w[at] = (int32_t)(b + lane);
+            return kids;
+    };
+    if (!COOP) {
+        if (!fallback && ncand > 0) {
+            for (int64_t b = e0; b < e1 && work <= a.lz_budget; b += 64) {
+                int x = x0;
+                bool c = c0;
+                if (b != e0) c = candidate(b + lane, x);
+                const unsigned long long m = __ballot(c);
+                if (m) {
+                    const unsigned long long kids = judge(x, c, m);
+                    if ((kids >> lane) & 1ull) {
+                        const int64_t at = tbase + start + count + (int)__popcll(kids & ((1ull << lane) - 1ull));
+                        a.t_order_w[at] = x;
+                        a.t_edge_w[at] = (int32_t)(b + lane);
+                    }
+                    count += (int)__popcll(kids);
+                    wave_lds_sync();  // (the masks are read: the next round resets them)
+                }
             }
-            count += (int)__popcll(kids);
-            wave_lds_sync();  // (the masks are read: the next round resets them)
+        }
+    } else {
+        // this wavefront's chunks; every value that decides a branch below is workgroup-uniform or private to the wavefront
+        const int n_chunks = (int)((e1 - e0 + 63) >> 6);
+        if (!fallback) {
+            for (int ch = wv; ch < n_chunks && work <= a.lz_budget; ch += nw) {
+                int x;
+                const bool c = candidate(e0 + 64 * (int64_t)ch + lane, x);
+                const unsigned long long m = __ballot(c);
+                unsigned long long kids = 0ull;
+                if (m) {
+                    kids = judge(x, c, m);
+                    wave_lds_sync();
+                }
+                sh->kids[ch] = kids;  // (every lane: the same word)
+            }
+        }
+        atomicAdd(&sh->work, lane == 0 ? work : 0);
+        if (fallback || work > a.lz_budget) sh->fb = 1;
+        __syncthreads();
+        work = sh->work;
+        fallback = sh->fb != 0;
+        // prefix of the chunks' children (every wavefront for itself: lane l sums chunks 4 l .. 4 l + 3)
+        int mine[4], tot4 = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mine[k] = 4 * lane + k < n_chunks ? (int)__popcll(sh->kids[4 * lane + k]) : 0;
+            tot4 += mine[k];
+        }
+        const int incl = wave_incl_scan_i32(tot4);
+        count = __builtin_amdgcn_readlane(incl, 63);
+        if (!fallback && depth <= 1 && count > 0) {
+            if (wv == 0) {
+                const int st = __builtin_amdgcn_readfirstlane(atomicAdd(&a.lz_cursor[slot], lane == 0 ? count : 0));
+                sh->start = st;  // (every lane: the same word)
+            }
+            __syncthreads();
+            start = sh->start;
+            if ((long long)start + count > (long long)seg) fallback = true;  // the pool is full
+            if (!fallback) {
+                ws->pre[lane] = incl - tot4;  // children in front of chunk 4 lane
+                wave_lds_sync();
+                for (int ch = wv; ch < n_chunks; ch += nw) {
+                    const unsigned long long kids = sh->kids[ch];
+                    if (kids) {
+                        int x;
+                        (void)candidate(e0 + 64 * (int64_t)ch + lane, x);
+                        int off = ws->pre[ch >> 2];
+                        for (int k = 0; k < (ch & 3); ++k) off += (int)__popcll(sh->kids[(ch & ~3) + k]);
+                        if ((kids >> lane) & 1ull) {
+                            const int64_t at = tbase + start + off + (int)__popcll(kids & ((1ull << lane) - 1ull));
+                            a.t_order_w[at] = x;
+                            a.t_edge_w[at] = (int32_t)(e0 + 64 * (int64_t)ch + lane);
+                        }
+                    }
+                }
+                wave_lds_sync();
             }
         }
     }
@@ -538,12 +614,13 @@ __device__ __forceinline__ unsigned long long lazy_resolve_wave(const WalkArgs &
         a.ctr[CTR_LZ_FB] = 1ull;
     }
     if (a.lz_ctr) {  // (GG_LZ_STATS=1: same-address atomics of every list of the launch -- ~40 ms per 16 384 roots)
-        const unsigned long long one = lane == 0 ? 1ull : 0ull;
+        const unsigned long long one = (lane == 0 && wv == 0) ? 1ull : 0ull;
         atomicAdd(&a.lz_ctr[depth < 0 ? 0 : depth > 2 ? 2 : depth], one);
         atomicAdd(&a.lz_ctr[3], one * (unsigned long long)ncand);
         atomicAdd(&a.lz_ctr[4], one * (unsigned long long)work);
         atomicMax(&a.lz_ctr[5], (unsigned long long)work);
         atomicMax(&a.lz_ctr[6], (unsigned long long)(e1 - e0));
+        if (COOP) atomicAdd(&a.lz_ctr[7], one);  // lists resolved by a whole workgroup
     }
     const unsigned long long v = lz_make(start, (unsigned long long)count, a.lz_stamp);
     if (FENCE) __threadfence();  // the list before the pair that names it
@@ -1168,8 +1245,10 @@ __global__ __launch_bounds__(LZ_T) void lazy_resolve_kernel(const WalkArgs a) {
     extern __shared__ uint32_t lz_lds[];  // [lz_words] when LDS_BITS
     __shared__ int32_t s_list[LZ_LIST];
     __shared__ LzWork s_ws[LZ_T / 64];
-    __shared__ int s_item, s_n, s_next;
-    const int tid = threadIdx.x, lane = tid & 63;
+    __shared__ int s_item, s_n, s_next, s_nbig;
+    __shared__ int32_t s_big[LZ_LIST];  // listed walks whose node has a long adjacency: resolved by the whole workgroup (LzCoop)
+    __shared__ LzCoop s_coop;
+    const int tid = threadIdx.x, lane = tid & 63, wvi = __builtin_amdgcn_readfirstlane(tid >> 6);
     LzWork *const ws = &s_ws[tid >> 6];
     for (;;) {
         if (tid == 0) {
@@ -1179,6 +1258,7 @@ __global__ __launch_bounds__(LZ_T) void lazy_resolve_kernel(const WalkArgs a) {
             s_item = it;
             s_n = 0;
             s_next = 0;
+            s_nbig = 0;
         }
         __syncthreads();
         const int item = s_item;
@@ -1214,15 +1294,34 @@ __global__ __launch_bounds__(LZ_T) void lazy_resolve_kernel(const WalkArgs a) {
                     if (i >= n) break;
                     if (a.exp & 4096) continue;
                     const int64_t w = w0 + s_list[i];
+                    const int cur = __builtin_amdgcn_readfirstlane(a.st_cur[w]);
+                    const int64_t deg = a.rowptr[cur + 1] - a.rowptr[cur];
+                    if (deg > a.lz_coop_min && deg <= 64 * LZ_COOP_CHUNKS && !(a.exp & 131072)) {  // (GG_WALK_EXPERIMENT & 131072: every list by one wavefront)
+                        const int j = __builtin_amdgcn_readfirstlane(atomicAdd(&s_nbig, lane == 0 ? 1 : 0));
+                        s_big[j] = s_list[i];  // (every lane: the same word)
+                    } else {
+                        const int4 sc2 = a.st_const2[w];
+                        const int64_t tbase = ((int64_t)sc2.y << 32) | (unsigned)sc2.x;
+                        if (LDS_BITS) (void)lazy_resolve_wave<false>(a, LzBitsLds{lz_lds, a.lz_bm + (size_t)slot * a.lz_words}, ws, slot, tbase, a.st_rank[w], cur, a.st_prev[w], a.level, lane);
+                        else (void)lazy_resolve_wave<false>(a, LzBitsGlobal{a.lz_bm + (size_t)slot * a.lz_words}, ws, slot, tbase, a.st_rank[w], cur, a.st_prev[w], a.level, lane);
+                    }
+                }
+                __syncthreads();
+                const int nbig = s_nbig;
+                for (int j = 0; j < nbig; ++j) {  // the long lists: all wavefronts on one list
+                    if (tid == 0) { s_coop.work = 0; s_coop.fb = 0; s_coop.start = 0; }
+                    __syncthreads();
+                    const int64_t w = w0 + s_big[j];
                     const int4 sc2 = a.st_const2[w];
                     const int64_t tbase = ((int64_t)sc2.y << 32) | (unsigned)sc2.x;
-                    if (LDS_BITS) (void)lazy_resolve_wave<false>(a, LzBitsLds{lz_lds, a.lz_bm + (size_t)slot * a.lz_words}, ws, slot, tbase, a.st_rank[w], a.st_cur[w], a.st_prev[w], a.level, lane);
-                    else (void)lazy_resolve_wave<false>(a, LzBitsGlobal{a.lz_bm + (size_t)slot * a.lz_words}, ws, slot, tbase, a.st_rank[w], a.st_cur[w], a.st_prev[w], a.level, lane);
+                    if (LDS_BITS) (void)lazy_resolve_wave<false, LzBitsLds, true>(a, LzBitsLds{lz_lds, a.lz_bm + (size_t)slot * a.lz_words}, ws, slot, tbase, a.st_rank[w], a.st_cur[w], a.st_prev[w], a.level, lane, wvi, LZ_T / 64, &s_coop);
+                    else (void)lazy_resolve_wave<false, LzBitsGlobal, true>(a, LzBitsGlobal{a.lz_bm + (size_t)slot * a.lz_words}, ws, slot, tbase, a.st_rank[w], a.st_cur[w], a.st_prev[w], a.level, lane, wvi, LZ_T / 64, &s_coop);
+                    __syncthreads();
                 }
             }
             __syncthreads();  // (everyone is through with the list and the LDS words)
             if (found <= LZ_LIST) break;
-            if (tid == 0) { s_n = 0; s_next = 0; }
+            if (tid == 0) { s_n = 0; s_next = 0; s_nbig = 0; }
             __syncthreads();
         }
     }
@@ -1770,10 +1869,11 @@ __global__ void dc_finish_kernel(const WalkArgs a, int64_t *words, int n_levels)
 static void launch_lazy_resolve(gg_ctx *ctx, const WalkArgs &x, hipStream_t st) {
     const size_t lds = sizeof(uint32_t) * (size_t)x.lz_words;
     const bool no_lds = getenv("GG_LZ_NO_LDS") != nullptr;  // (tests: the path of graphs whose visited words do not fit the LDS)
-    if (!no_lds && lds + sizeof(LzWork) * (LZ_T / 64) + sizeof(int32_t) * LZ_LIST + 256 <= 160 * 1024) {
+    const size_t lds_static = sizeof(LzWork) * (LZ_T / 64) + 2 * sizeof(int32_t) * LZ_LIST + sizeof(LzCoop) + 256;  // (the kernel's __shared__ arrays)
+    if (!no_lds && lds + lds_static <= 160 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void *)lazy_resolve_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 130 * 1024);
+            if (hipFuncSetAttribute((const void *)lazy_resolve_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - lds_static)) != hipSuccess) (void)hipGetLastError();
             attr_set = true;
         }
         hipLaunchKernelGGL(lazy_resolve_kernel<true>, dim3((unsigned)std::min<int64_t>(x.n_slots, ctx->n_cus)), dim3(LZ_T), lds, st, x);
@@ -2076,12 +2176,14 @@ int launch_walk_sample(gg_ctx *ctx, int32_t n_slots, int64_t total_walks, int fo
         a.g_multi = ctx->g_multi ? 1 : 0;
         a.lz_list = ctx->lz_list.as<int32_t>();
         {
-            static const bool stats_env = getenv("GG_LZ_STATS") != nullptr;
+            const bool stats_env = getenv("GG_LZ_STATS") != nullptr;  // (read per launch: tests switch it)
             a.lz_ctr = stats_env ? ctx->dev_ctr + 1500 : nullptr;  // (behind the launches' counter words; zeroed by the build)
         }
         {
             static const int budget_env = getenv("GG_LZ_BUDGET") ? atoi(getenv("GG_LZ_BUDGET")) : 2048;
             a.lz_budget = budget_env > 0 ? budget_env : 0x7fffffff;
+            const int coop_env = getenv("GG_LZ_COOP_MIN") ? atoi(getenv("GG_LZ_COOP_MIN")) : LZ_COOP_MIN;  // (read per launch: tests switch it)
+            a.lz_coop_min = std::max(64, coop_env);
         }
     }
     GG_HIP(ctx, ctx->fin_list.reserve(sizeof(int32_t) * (size_t)(total_walks + 1)));

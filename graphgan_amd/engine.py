@@ -198,7 +198,7 @@ class Engine:
         self._ck(lib.gg_lazy_stats(self._ctx, _ptr(out)))
         return dict(lazy=bool(out[0]), min_level=int(out[1]), fallback_roots=int(out[2]), fallback_rounds=int(out[3]), exact_nodes=int(out[4]),
                     pool_entries=int(out[5]), lazy_slots=int(out[6]), max_level=int(out[7]), resolved=[int(x) for x in out[8:11]],
-                    candidates=int(out[11]), scan_rounds=int(out[12]), max_rounds=int(out[13]), max_degree_resolved=int(out[14]),
+                    candidates=int(out[11]), scan_rounds=int(out[12]), max_rounds=int(out[13]), max_degree_resolved=int(out[14]), coop_lists=int(out[15]),
                     slots_by_level=[int(x) for x in out[16:24]])
 
     def get_lazy_trees(self):

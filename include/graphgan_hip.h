@@ -173,7 +173,7 @@ int gg_build_trees_device(gg_ctx *ctx, const int32_t *roots, int32_t n_roots);
  * gg_lazy_stats: out24 = {resident trees are lazy, smallest exact level of the lazy slots, slots rebuilt whole so far, launches
  * repeated for it, exact nodes the BFS wrote, pool entries reserved by resolutions, lazy slots, deepest exact level; of the
  * resident build: lists resolved at depth 0 / 1 / 2, candidates judged, 16-entry scan rounds, most rounds of one list, longest
- * adjacency resolved, 0; lazy slots whose exact level is 0 .. 7}.
+ * adjacency resolved, lists resolved by a whole workgroup (long adjacencies); lazy slots whose exact level is 0 .. 7}.
  * gg_get_lazy_trees (tests): the raw arrays -- info4[slot] = {first rank without a built list, exact ranks, their level,
  * capacity of the segment}, base[slot], then order / cstart / edge / pair over *n_entries entries (cstart: + n_roots). */
 int gg_set_tree_mode(gg_ctx *ctx, int32_t mode, int64_t node_cap);

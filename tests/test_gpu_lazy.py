@@ -17,14 +17,19 @@ def ga():
     return graphgan_amd
 
 
-@pytest.fixture(params=["levels", "finisher", "hybrid2", "levels_global_bits"])
+@pytest.fixture(params=["levels", "finisher", "hybrid2", "levels_global_bits", "levels_coop", "levels_coop_global_bits"])
 def walk_mode(request, monkeypatch):
     """The decompositions of the sampler a lazy tree must serve: the level pipeline with the resolve kernel between the two
     halves of the advance kernel (visited words of the slot in LDS; "levels_global_bits": read from the index in global memory,
-    the path of graphs above ~1.2 M nodes), the per-walk finisher alone (it resolves inline), and two levels + the finisher."""
+    the path of graphs above ~1.2 M nodes), the per-walk finisher alone (it resolves inline), and two levels + the finisher.
+    "levels_coop*": every adjacency of more than 64 entries is resolved by the whole workgroup (default: more than 256 -- on
+    these small graphs that path would hardly run)."""
     monkeypatch.setenv("GG_WALK_LEVELS", {"finisher": "0", "hybrid2": "2"}.get(request.param, "64"))
-    if request.param == "levels_global_bits":
+    if request.param.endswith("global_bits"):
         monkeypatch.setenv("GG_LZ_NO_LDS", "1")
+    if "coop" in request.param:
+        monkeypatch.setenv("GG_LZ_COOP_MIN", "64")
+        monkeypatch.setenv("GG_LZ_STATS", "1")
     return request.param
 
 
@@ -156,6 +161,8 @@ def test_powerlaw_lazy_bit_exact(ga, walk_mode, monkeypatch):
     hops, resolved, st = run_lazy(ga, n, rowptr, col, roots, E, b, rounds=4, seed=77, node_cap=6000, monkeypatch=monkeypatch)
     assert resolved > 3000
     assert st["lazy_slots"] + st["fallback_roots"] == len(roots) and st["lazy_slots"] > len(roots) // 2
+    if "coop" in walk_mode:
+        assert st["coop_lists"] > 100  # hubs' lists went through the workgroup path (and every one of them equals the whole tree's)
 
 
 def test_lazy_arena_overflow_rebuilds_the_batch_whole(ga, monkeypatch):
