@@ -1237,8 +1237,10 @@ __global__ void level_expand_kernel(const WalkArgs a) {
 // LAZY: the children lists the walks of this level were claimed for ("LAZY RESOLUTION").  One workgroup per launch item (a root
 // slot and its walks) at a time, items from a ticket: the claimed walks of the item (st_alive == 2) are listed in LDS, the slot's
 // visited words are copied into LDS (LDS_BITS: graphs up to ~1.2 M nodes; else the tests read the index in global memory), and
-// the workgroup's wavefronts take one listed walk each until the list is empty.  Runs whatever the launch's flags say: a claim
-// that stayed unresolved would stall every later reader of the pair.
+// the workgroup's wavefronts take one listed walk each until the list is empty -- except walks that stand on a node with a LONG
+// adjacency (> lz_coop_min entries: a hub): those are set aside and resolved afterwards by ALL wavefronts together, chunk by
+// chunk (lazy_resolve_wave<.., .., COOP>).  Runs whatever the launch's flags say: a claim that stayed unresolved would stall
+// every later reader of the pair.
 constexpr int LZ_T = 1024, LZ_LIST = 1024;
 template <bool LDS_BITS>
 __global__ __launch_bounds__(LZ_T) void lazy_resolve_kernel(const WalkArgs a) {
