@@ -1006,6 +1006,12 @@ def test_all_score_streamed_consumer(ga, n, d, precision):
         assert np.array_equal(wide["max"], narrow["max"]) and np.array_equal(wide["argmax"], narrow["argmax"])
         assert np.allclose(wide["logsumexp"], narrow["logsumexp"], rtol=1e-5, atol=1e-5)
         assert np.array_equal(wide["argmax"][rows], res["argmax"])
+        # ... and for a LIST of >= 512 requested rows (the bench's call: the row ids go through the kernel's index array;
+        # a last row tile that is not full)
+        some = np.random.RandomState(8).permutation(n)[:523].astype(np.int32)
+        listed = eng.all_score_reduce(some, precision=precision)
+        assert np.array_equal(listed["max"], narrow["max"][some]) and np.array_equal(listed["argmax"], narrow["argmax"][some])
+        assert np.allclose(listed["logsumexp"], narrow["logsumexp"][some], rtol=1e-5, atol=1e-5)
     eng.close()
 
 
