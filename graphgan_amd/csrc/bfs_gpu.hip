@@ -89,7 +89,7 @@ struct BfsArgs {
     int64_t *base_w;           // [slots]   LAZY: t_base, written here
     int32_t *lz_flag;          // [slots]
     int lz_easy, lz_limit_easy;  // levels 1 .. lz_easy are expanded while they fit lz_limit_easy (>= the root's own limit)
-    int lz_ablate;             // GG_LZ_ABLATE (timing only, results WRONG): 1 = no rank scatter, 2 = no copy out of the scratch tree, 4 = no visited index
+    int lz_ablate;             // GG_LZ_ABLATE (timing only, results WRONG): 1 = no rank scatter, 2 = no copy out of the scratch tree, 4 = no visited index; 8 (results right) = the ranks' indices from the index in global memory instead of LDS
 };
 
 __device__ __forceinline__ int lanes_below(unsigned long long m) {  // popcount of m restricted to the lanes below this one
@@ -751,7 +751,7 @@ __device__ __forceinline__ int sparse_fathers(unsigned long long *sph, lds_u32_t
 // needs: the visited set of the exact levels with a popcount index, and the BFS rank of every member by that index.
 template <bool LDS_BM, bool INSTR, bool LAZY = false>
 __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
-    extern __shared__ uint32_t lds_bm[];              // [bm_words] when LDS_BM
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_bm[];  // [bm_words, rounded up to 16] when LDS_BM
     __shared__ uint32_t e0s[B2_NB];                   // first CSR entry of each window node (of the segment, for a partial node)
     __shared__ uint16_t soff[B2_NB + 2];              // first quad of each window node; [nb] = quads of the window
     __shared__ uint16_t degs[B2_NB];                  // adjacency entries of each window node (of the segment)
@@ -1382,9 +1382,12 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
 #pragma unroll
                 for (int i = 0; i < B2_WAVES; ++i)
                     if (i < wv) run += wtot[0][i];
+                // (members below every 16th word stay in LDS -- the windows' quad map is free now -- for the ranks' indices below)
+                const bool coarse = LDS_BM && (W + 15) / 16 <= B2_SLOTS / 2 && !(a.lz_ablate & 8);
                 for (int i = w0; i < w1; ++i) {
                     const uint32_t wd = LDS_BM ? bm[i] : ldu(&bm[i]);
                     zb[i] = make_uint2(wd, (uint32_t)run);
+                    if (coarse && (i & 15) == 0) scratch[i >> 4] = (uint32_t)run;
                     run += (int)__popc(wd);
                 }
                 __syncthreads();  // (the index has landed: the ranks below read it back)
@@ -1400,6 +1403,28 @@ __global__ __launch_bounds__(B2_T) void bfs_order2_kernel(const BfsArgs a) {
                     unsigned long long wq[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) vv[u] = i0 + u * B2_T < tail ? ldi(&order[i0 + u * B2_T]) : -1;
+                    if (coarse) {
+                        // the index from LDS: members below the node's 16-word block + popcounts of the block's words in front of its
+                        // own (four 16-byte reads).  (From the index in global memory this was 88 k random 8-byte reads per root --
+                        // 2.8 MB of sectors, more than everything else the block moves.)
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            if (vv[u] < 0) continue;
+                            const int w = vv[u] >> 5, nb = w & 15;
+                            const uint4 *const b4 = reinterpret_cast<const uint4 *>(bm + (w & ~15));
+                            const uint4 q0 = b4[0], q1 = b4[1], q2 = b4[2], q3 = b4[3];
+                            const uint32_t ww[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+                            int idx = (int)scratch[w >> 4];
+                            uint32_t wd = 0u;
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) {
+                                idx += k < nb ? (int)__popc(ww[k]) : 0;
+                                wd = k == nb ? ww[k] : wd;
+                            }
+                            idxs[i0 + u * B2_T] = idx + (int)__popc(wd & ((1u << (vv[u] & 31)) - 1u));
+                        }
+                        continue;
+                    }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) wq[u] = vv[u] >= 0 ? ldq(reinterpret_cast<const unsigned long long *>(zb + (vv[u] >> 5))) : 0ull;
 #pragma unroll
@@ -1562,7 +1587,7 @@ static int bfs_run(gg_ctx *ctx, BfsArgs &a, int n_items, bool lazy, int32_t *sta
         (void)hipMemsetAsync(gkey.p, 0xFF, gkey.bytes, ctx->stream);  // the buffer without passing here again); the kernel restores every word it uses
     (void)hipEventRecord(ctx->ev0, ctx->stream);
     if (!v1) {
-        const size_t dyn = lds_bm ? (size_t)bm_words * 4 : 0;
+        const size_t dyn = lds_bm ? (size_t)((bm_words + 15) & ~15) * 4 : 0;  // (rounded up: the lazy finalize reads 16-word blocks)
         const bool instr = prof || a.exp != 0;
         const void *fn = lazy ? (lds_bm ? (const void *)bfs_order2_kernel<true, false, true> : (const void *)bfs_order2_kernel<false, false, true>)
                          : lds_bm ? (instr ? (const void *)bfs_order2_kernel<true, true> : (const void *)bfs_order2_kernel<true, false>)
@@ -1578,7 +1603,7 @@ static int bfs_run(gg_ctx *ctx, BfsArgs &a, int n_items, bool lazy, int32_t *sta
         else if (instr) hipLaunchKernelGGL((bfs_order2_kernel<false, true>), dim3(grid), dim3(B2_T), 0, ctx->stream, a);
         else hipLaunchKernelGGL((bfs_order2_kernel<false, false>), dim3(grid), dim3(B2_T), 0, ctx->stream, a);
     } else if (lds_bm) {
-        const size_t dyn = (size_t)bm_words * 4;
+        const size_t dyn = (size_t)((bm_words + 15) & ~15) * 4;
         const bool instr = prof || a.exp != 0;
         const void *fn = instr ? (const void *)bfs_order_kernel<true, true> : (const void *)bfs_order_kernel<true, false>;
         e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
