@@ -38,7 +38,8 @@ def demangle(names):
 def audit(path):
     with tempfile.TemporaryDirectory() as td:
         asm = os.path.join(td, "k.s")
-        r = subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + ["-o", asm, path], capture_output=True, text=True)
+        extra = ["-mllvm", "-amdgpu-mfma-vgpr-form", "-mllvm", "-pragma-unroll-threshold=200000"] if path.endswith("all_score.hip") else []  # (K7FLAGS of the Makefile)
+        r = subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + extra + ["-o", asm, path], capture_output=True, text=True)
         if r.returncode != 0:
             print("%s: does not compile stand-alone (%s)" % (os.path.relpath(path, ROOT), r.stderr.strip().split("\n")[-1][:120]))
             return
